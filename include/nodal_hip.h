@@ -1,0 +1,133 @@
+/*
+ * nodal_hip.h -- C ABI of libnodal_hip.so: MI355X (gfx950) assembly of the
+ * modified-nodal-analysis system G x = A and its dense / sparse solve.
+ *
+ * The reference (EnricoMiccoli/nodal v1.3.0) has no FFI layer; its seam is the
+ * Python pair Circuit.build_model / Circuit.solve.  Each entry point below
+ * names the reference code it replaces (file:line into the reference tree).
+ * The host-side mirror of the reference API that calls these through ctypes is
+ * nodal_amd/circuit.py; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns a nodal_status (0 = OK); no exception crosses;
+ *   - the caller owns all host buffers; the opaque handle owns device memory;
+ *   - one handle per (device, stream); thread-compatible, not thread-safe;
+ *   - node indices are int32, -1 means "lead is the ground node";
+ *   - unknown vector layout: x[0:K] node potentials in nodenum order,
+ *     x[K:K+B] branch currents in anomnum order (reference nodal/nodal.py:405-408).
+ */
+#ifndef NODAL_HIP_H
+#define NODAL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nodal_ctx *nodal_handle;
+
+typedef enum {
+    NODAL_OK = 0,
+    NODAL_E_INVALID = 1,          /* bad argument / call order                      */
+    NODAL_E_HIP = 2,              /* a HIP runtime call failed (see nodal_last_error) */
+    NODAL_E_ZERO_RESISTANCE = 3,  /* -> ValueError   (reference nodal/models.py:14-17) */
+    NODAL_E_STAMP_COLLISION = 4,  /* -> AssertionError (reference nodal/models.py:43,47,
+                                      66,70,168,172,176,193,197: `assert G[i, j] == 0`) */
+    NODAL_E_SINGULAR = 5,         /* exact zero pivot / non-finite solution          */
+    NODAL_E_NOMEM = 6,
+    NODAL_E_UNSUPPORTED = 7
+} nodal_status;
+
+/* component type codes of the `type` column (nodal_amd/constants.py TYPE_CODE).
+ * VCCS rows carry NODAL_T_VCVS: the reference dispatches them to write_VCVS
+ * (reference nodal/nodal.py:377-378). */
+enum { NODAL_T_R = 0, NODAL_T_A = 1, NODAL_T_E = 2, NODAL_T_VCVS = 3,
+       NODAL_T_CCVS = 4, NODAL_T_CCCS = 5 };
+
+/* sparse solver selection for nodal_solve_sparse */
+enum { NODAL_SPARSE_AUTO = 0, NODAL_SPARSE_PCG = 1, NODAL_SPARSE_DENSIFY = 2,
+       NODAL_SPARSE_LU = 3 };
+
+/* ---- lifetime ---------------------------------------------------------- */
+int nodal_create(int device_id, nodal_handle *out);
+int nodal_destroy(nodal_handle h);
+const char *nodal_last_error(nodal_handle h);
+/* library / build identification, e.g. "nodal_hip 0.1 gfx950" */
+const char *nodal_version(void);
+
+/* ---- component table (replaces the per-component Python objects read by
+ *      Circuit.build_model, reference nodal/nodal.py:338-368) --------------
+ * Copies the structure-of-arrays table to HBM.  K = nums["kcl"], B = nums["be"]. */
+int nodal_upload_components(nodal_handle h, int64_t ncomp,
+                            const uint8_t *type, const double *value,
+                            const int32_t *a, const int32_t *b,
+                            const int32_t *c, const int32_t *d,
+                            const int32_t *drv, const int32_t *k,
+                            int32_t K, int32_t B);
+
+/* Replace the value column only (same topology): `batch` members, row-major
+ * [batch][ncomp].  Used for value sweeps (BASELINE.json config 4). */
+int nodal_upload_values(nodal_handle h, int32_t batch, const double *values);
+
+/* ---- assembly (replaces Circuit.build_model + models.write_*, reference
+ *      nodal/nodal.py:338-398, nodal/models.py:13-214) ---------------------
+ * symbolic: sparsity pattern (CSR, sorted columns) + ordered contribution
+ *           lists; depends on topology only, reusable across a value sweep.
+ * numeric : folds every matrix / rhs entry's contributions in component order
+ *           (bit-identical to the reference's sequential += / = stamping) for
+ *           batch member `member` (0 when no batch was uploaded).
+ * On NODAL_E_ZERO_RESISTANCE / NODAL_E_STAMP_COLLISION, *bad_component (may be
+ * NULL) receives the table row of the first offending component. */
+int nodal_assemble_symbolic(nodal_handle h);
+int nodal_assemble_numeric(nodal_handle h, int32_t member, int64_t *bad_component);
+
+/* sizes after symbolic assembly */
+int nodal_get_sizes(nodal_handle h, int64_t *n, int64_t *nnz, int64_t *ncontrib);
+
+/* ---- export for parity / debugging (what the reference exposes as
+ *      Circuit.G, Circuit.A; reference nodal/nodal.py:311,396-398) --------- */
+int nodal_export_csr(nodal_handle h, int32_t *indptr, int32_t *indices,
+                     double *data, double *rhs);
+/* row-major n x n, as numpy's Circuit.G */
+int nodal_export_dense(nodal_handle h, double *G, double *rhs);
+
+/* ---- solve (replaces Circuit.solve, reference nodal/nodal.py:313-336) ----
+ * dense : LU with partial (row) pivoting, as LAPACK dgesv behind
+ *         np.linalg.solve (reference nodal/nodal.py:327).  *info > 0: U(info,info)
+ *         is exactly zero -> status NODAL_E_SINGULAR (host maps it to LinAlgError /
+ *         UnconnectedCircuitError as reference nodal/nodal.py:328-335).
+ * sparse: replaces scipy.sparse.linalg.spsolve (reference nodal/nodal.py:325).
+ *         On a singular system x is filled with NaN, *info > 0 and the status is
+ *         NODAL_OK: the reference's sparse path warns and returns NaNs, it does
+ *         not raise.
+ * x may be NULL to leave the solution on the device (nodal_download_x). */
+int nodal_solve_dense(nodal_handle h, double *x, int32_t *info);
+int nodal_solve_sparse(nodal_handle h, int32_t method, double *x, int32_t *info,
+                       int32_t *iters, double *resid);
+int nodal_download_x(nodal_handle h, double *x);
+
+/* scaled residual ||G x - A||_inf / (||G||_inf ||x||_inf + ||A||_inf) of the
+ * solution currently on the device, computed on the device from the CSR form */
+int nodal_residual(nodal_handle h, double *scaled_residual);
+
+/* ---- whole-path entry for resident inputs --------------------------------
+ * symbolic + numeric (member) + solve, nothing copied to the host.
+ * dense != 0 selects the dense path.  Used by bench.py's timed region. */
+int nodal_run(nodal_handle h, int32_t dense, int32_t member, int32_t reuse_symbolic,
+              int32_t *info);
+
+/* ---- timing of the last call, measured with HIP events on the handle's
+ *      stream: milliseconds spent in [symbolic, numeric, factor/solve] ----- */
+int nodal_last_timings(nodal_handle h, double *ms3);
+/* HIP-event duration (ms) and launch count of the dominant kernel class of the
+ * last solve (SpMV for the iterative path, trailing GEMM update for dense LU) */
+int nodal_last_kernel_stats(nodal_handle h, double *ms_total, int64_t *launches,
+                            double *alg_bytes_or_flops);
+
+int nodal_synchronize(nodal_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NODAL_HIP_H */

@@ -1,0 +1,198 @@
+"""ctypes binding of libnodal_hip.so (include/nodal_hip.h).
+
+There is no CPU fallback: if the library is missing, or no MI355X is visible
+when a handle is created, this raises.  The library itself is loadable on a
+machine without a GPU (symbol checks only).
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnodal_hip.so")
+
+OK, E_INVALID, E_HIP, E_ZERO_RESISTANCE, E_STAMP_COLLISION, E_SINGULAR, E_NOMEM, \
+    E_UNSUPPORTED = range(8)
+SPARSE_AUTO, SPARSE_PCG, SPARSE_DENSIFY, SPARSE_LU = range(4)
+
+_p = C.POINTER
+_i32p, _i64p, _f64p, _u8p = _p(C.c_int32), _p(C.c_int64), _p(C.c_double), _p(C.c_uint8)
+
+# name -> (restype, argtypes); every symbol include/nodal_hip.h declares
+SIGNATURES = {
+    "nodal_version": (C.c_char_p, []),
+    "nodal_create": (C.c_int, [C.c_int, _p(C.c_void_p)]),
+    "nodal_destroy": (C.c_int, [C.c_void_p]),
+    "nodal_last_error": (C.c_char_p, [C.c_void_p]),
+    "nodal_upload_components": (C.c_int, [C.c_void_p, C.c_int64, _u8p, _f64p, _i32p, _i32p,
+                                          _i32p, _i32p, _i32p, _i32p, C.c_int32, C.c_int32]),
+    "nodal_upload_values": (C.c_int, [C.c_void_p, C.c_int32, _f64p]),
+    "nodal_assemble_symbolic": (C.c_int, [C.c_void_p]),
+    "nodal_assemble_numeric": (C.c_int, [C.c_void_p, C.c_int32, _i64p]),
+    "nodal_get_sizes": (C.c_int, [C.c_void_p, _i64p, _i64p, _i64p]),
+    "nodal_export_csr": (C.c_int, [C.c_void_p, _i32p, _i32p, _f64p, _f64p]),
+    "nodal_export_dense": (C.c_int, [C.c_void_p, _f64p, _f64p]),
+    "nodal_solve_dense": (C.c_int, [C.c_void_p, _f64p, _i32p]),
+    "nodal_solve_sparse": (C.c_int, [C.c_void_p, C.c_int32, _f64p, _i32p, _i32p, _f64p]),
+    "nodal_download_x": (C.c_int, [C.c_void_p, _f64p]),
+    "nodal_residual": (C.c_int, [C.c_void_p, _f64p]),
+    "nodal_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _i32p]),
+    "nodal_last_timings": (C.c_int, [C.c_void_p, _f64p]),
+    "nodal_last_kernel_stats": (C.c_int, [C.c_void_p, _f64p, _i64p, _f64p]),
+    "nodal_synchronize": (C.c_int, [C.c_void_p]),
+}
+
+_lib = None
+
+
+class NodalHipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"libnodal_hip status {status}: {message}")
+        self.status = status
+
+
+def load():
+    """Load libnodal_hip.so and set the prototypes.  Raises OSError with build
+    instructions when the library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError(
+                f"{LIB_PATH} not found: build it with `make` (or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`) -- "
+                "nodal_amd has no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _ptr(arr, ctype):
+    return arr.ctypes.data_as(_p(ctype))
+
+
+class Handle:
+    """Owns one nodal_handle (device memory + stream) on `device`."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self._h = C.c_void_p()
+        status = self.lib.nodal_create(device, C.byref(self._h))
+        if status != OK:
+            raise NodalHipError(
+                status, f"nodal_create(device={device}) failed: no usable MI355X "
+                "(HIP device) is visible; nodal_amd has no CPU fallback")
+        self.n = self.nnz = self.ncontrib = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.nodal_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, status, allow=()):
+        if status != OK and status not in allow:
+            raise NodalHipError(status, self.lib.nodal_last_error(self._h).decode())
+        return status
+
+    # -- table ------------------------------------------------------------
+    def upload(self, table):
+        cols = [np.ascontiguousarray(getattr(table, n)) for n in
+                ("type", "value", "a", "b", "c", "d", "drv", "k")]
+        self._keep = cols
+        t, v, a, b, c, d, drv, k = cols
+        self._check(self.lib.nodal_upload_components(
+            self._h, table.ncomp, _ptr(t, C.c_uint8), _ptr(v, C.c_double),
+            _ptr(a, C.c_int32), _ptr(b, C.c_int32), _ptr(c, C.c_int32), _ptr(d, C.c_int32),
+            _ptr(drv, C.c_int32), _ptr(k, C.c_int32), table.K, table.B))
+
+    def upload_values(self, values):
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        assert values.ndim == 2
+        self._check(self.lib.nodal_upload_values(self._h, values.shape[0], _ptr(values, C.c_double)))
+
+    # -- assembly ---------------------------------------------------------
+    def assemble_symbolic(self):
+        self._check(self.lib.nodal_assemble_symbolic(self._h))
+        n, nnz, nc = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self.lib.nodal_get_sizes(self._h, C.byref(n), C.byref(nnz), C.byref(nc)))
+        self.n, self.nnz, self.ncontrib = n.value, nnz.value, nc.value
+
+    def assemble_numeric(self, member=0):
+        """Returns (status, bad_component): status is OK, E_ZERO_RESISTANCE or
+        E_STAMP_COLLISION."""
+        bad = C.c_int64(-1)
+        status = self._check(self.lib.nodal_assemble_numeric(self._h, member, C.byref(bad)),
+                             allow=(E_ZERO_RESISTANCE, E_STAMP_COLLISION))
+        return status, bad.value
+
+    def export_csr(self, values=True):
+        indptr = np.empty(self.n + 1, dtype=np.int32)
+        indices = np.empty(self.nnz, dtype=np.int32)
+        data = np.empty(self.nnz, dtype=np.float64) if values else None
+        rhs = np.empty(self.n, dtype=np.float64) if values else None
+        self._check(self.lib.nodal_export_csr(
+            self._h, _ptr(indptr, C.c_int32), _ptr(indices, C.c_int32),
+            _ptr(data, C.c_double) if values else None,
+            _ptr(rhs, C.c_double) if values else None))
+        return indptr, indices, data, rhs
+
+    def export_dense(self):
+        G = np.empty((self.n, self.n), dtype=np.float64)
+        rhs = np.empty(self.n, dtype=np.float64)
+        self._check(self.lib.nodal_export_dense(self._h, _ptr(G, C.c_double), _ptr(rhs, C.c_double)))
+        return G, rhs
+
+    # -- solve ------------------------------------------------------------
+    def solve_dense(self, download=True):
+        """Returns (x or None, info).  info > 0: exact zero pivot (singular)."""
+        x = np.empty(self.n, dtype=np.float64) if download else None
+        info = C.c_int32(0)
+        self._check(self.lib.nodal_solve_dense(
+            self._h, _ptr(x, C.c_double) if download else None, C.byref(info)),
+            allow=(E_SINGULAR,))
+        return x, info.value
+
+    def solve_sparse(self, method=SPARSE_AUTO, download=True):
+        """Returns (x or None, info, iterations, relative residual)."""
+        x = np.empty(self.n, dtype=np.float64) if download else None
+        info, iters, resid = C.c_int32(0), C.c_int32(0), C.c_double(0)
+        self._check(self.lib.nodal_solve_sparse(
+            self._h, method, _ptr(x, C.c_double) if download else None,
+            C.byref(info), C.byref(iters), C.byref(resid)))
+        return x, info.value, iters.value, resid.value
+
+    def download_x(self):
+        x = np.empty(self.n, dtype=np.float64)
+        self._check(self.lib.nodal_download_x(self._h, _ptr(x, C.c_double)))
+        return x
+
+    def residual(self):
+        r = C.c_double(0)
+        self._check(self.lib.nodal_residual(self._h, C.byref(r)))
+        return r.value
+
+    def run(self, dense, member=0, reuse_symbolic=False):
+        info = C.c_int32(0)
+        self._check(self.lib.nodal_run(self._h, int(dense), member, int(reuse_symbolic),
+                                       C.byref(info)), allow=(E_SINGULAR,))
+        return info.value
+
+    def timings(self):
+        ms = (C.c_double * 3)()
+        self._check(self.lib.nodal_last_timings(self._h, ms))
+        return list(ms)
+
+    def kernel_stats(self):
+        ms, launches, alg = C.c_double(0), C.c_int64(0), C.c_double(0)
+        self._check(self.lib.nodal_last_kernel_stats(self._h, C.byref(ms), C.byref(launches),
+                                                     C.byref(alg)))
+        return ms.value, launches.value, alg.value
+
+    def synchronize(self):
+        self._check(self.lib.nodal_synchronize(self._h))

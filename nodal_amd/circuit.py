@@ -1,0 +1,156 @@
+"""Circuit and Solution: the reference's Python seam over the HIP hot path.
+
+Mirrors reference nodal/nodal.py:299-434 (`Circuit(netlist, sparse=False)`,
+`.solve()`, `Solution`) with the same names, argument meaning and error
+behaviour.  What the reference does with numpy/scipy on the host happens here
+on an MI355X through libnodal_hip.so:
+
+    Circuit.__init__ -> build_model -> lowering.lower (host, strings -> table)
+                                    -> nodal_upload_components
+                                    -> nodal_assemble_symbolic / _numeric  (HIP)
+    Circuit.solve    -> nodal_solve_dense | nodal_solve_sparse            (HIP)
+
+`Circuit.G` / `Circuit.A` are exported from the device on first access (numpy
+array for the dense path, scipy CSR for the sparse path) so that code written
+against the reference's attributes keeps working without paying a device->host
+copy on the hot path.
+"""
+
+import logging
+import os
+import warnings
+
+import numpy as np
+
+from . import _ffi
+from . import constants as c
+from .lowering import lower
+from .netlist import Netlist, UnconnectedCircuitError, is_connected
+
+try:  # same warning class the reference's spsolve call emits
+    from scipy.sparse.linalg import MatrixRankWarning
+except Exception:  # pragma: no cover - scipy is optional at run time
+    class MatrixRankWarning(UserWarning):
+        pass
+
+
+def default_device():
+    return int(os.environ.get("NODAL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+class Circuit:
+    """Builds the linear system G e = A of a Netlist on the GPU.
+
+    Attributes: netlist, sparse, G, A, currents (reference nodal/nodal.py:306-311).
+    """
+
+    def __init__(self, netlist, sparse=False, device=None):
+        if not isinstance(netlist, Netlist):
+            raise TypeError("Input isn't a netlist")
+        self.netlist = netlist
+        self.sparse = sparse
+        self._device = default_device() if device is None else device
+        self._handle = None
+        self._G = self._A = None
+        self.currents = self.build_model()
+
+    # -- assembly ----------------------------------------------------------
+    def build_model(self):
+        """Lower the netlist, upload the component table and assemble G, A on
+        the device (reference nodal/nodal.py:338-398).  Returns `currents`."""
+        nl = self.netlist
+        table = lower(nl)
+        self.table = table
+        if table.first_error is not None:
+            row, exc, probe = table.first_error
+            # the reference would have hit an earlier stamp collision first
+            prefix = table.truncated(row + (1 if probe else 0))
+            if prefix.ncomp:
+                self._assemble(prefix)
+            raise exc
+        self._assemble(table)
+        comps = nl.components
+        return [key for key in nl.component_keys if comps[key].type in c.NODE_TYPES_ANOM]
+
+    def _assemble(self, table):
+        if self._handle is None:
+            self._handle = _ffi.Handle(self._device)
+        h = self._handle
+        h.upload(table)
+        h.assemble_symbolic()
+        status, bad = h.assemble_numeric(0)
+        if status == _ffi.E_ZERO_RESISTANCE:
+            raise ValueError("Model error: resistors can't have null resistance")
+        if status == _ffi.E_STAMP_COLLISION:
+            raise AssertionError  # the reference's bare `assert G[i, j] == 0`
+
+    # -- reference attributes, exported lazily -------------------------------
+    @property
+    def G(self):
+        if self._G is None:
+            h = self._handle
+            if self.sparse:
+                indptr, indices, data, rhs = h.export_csr()
+                import scipy.sparse as spsp
+                self._G = spsp.csr_matrix((data, indices, indptr), shape=(h.n, h.n))
+                self._A = rhs
+            else:
+                self._G, self._A = h.export_dense()
+        return self._G
+
+    @property
+    def A(self):
+        if self._A is None:
+            self._A = self._handle.export_csr()[3]
+        return self._A
+
+    # -- solve ---------------------------------------------------------------
+    def solve(self):
+        """Solve G e = A on the device (reference nodal/nodal.py:313-336).
+
+        Raises numpy.linalg.LinAlgError when the dense system is singular and
+        the circuit is connected, UnconnectedCircuitError when it is not.  The
+        sparse path never raises on a singular matrix: like the reference's
+        spsolve call it warns (MatrixRankWarning) and returns NaNs."""
+        h = self._handle
+        if self.sparse:
+            e, info, self.iterations, self.relative_residual = h.solve_sparse()
+            if info > 0:
+                warnings.warn("Matrix is exactly singular", MatrixRankWarning, stacklevel=2)
+        else:
+            e, info = h.solve_dense()
+            if info > 0:
+                if not is_connected(self.netlist):
+                    logging.error("Model error: unconnected circuit")
+                    raise UnconnectedCircuitError
+                logging.error("Model error: matrix is singular")
+                raise np.linalg.LinAlgError("Singular matrix")
+        return Solution(e, self.netlist, self.currents)
+
+    def scaled_residual(self):
+        """||G x - A||_inf / (||G||_inf ||x||_inf + ||A||_inf) of the last
+        solution, computed on the device."""
+        return self._handle.residual()
+
+
+class Solution:
+    """Result of Circuit.solve(): `result[0:K]` node potentials in nodenum
+    order, `result[K:K+B]` branch currents in anomnum order; printable
+    (reference nodal/nodal.py:401-434)."""
+
+    def __init__(self, result, netlist, currents):
+        self.result = result
+        self.nodenum = netlist.nodenum
+        self.nums = netlist.nums
+        self.currents = currents
+        self.ground = netlist.ground
+        self.anomnum = netlist.anomnum
+
+    def __str__(self):
+        lines = [f"Ground node: {self.ground}"]
+        for name in sorted(self.nodenum):
+            lines.append(f"e({name}) \t= {self.result[self.nodenum[name]]}")
+        offset = self.nums["kcl"]
+        for name in sorted(self.anomnum):
+            lines.append(f"i({name}) \t= {self.result[offset + self.anomnum[name]]}")
+        return "\n".join(lines)

@@ -1,0 +1,279 @@
+// extern "C" entry points of libnodal_hip.so (see include/nodal_hip.h).
+#include "ctx.h"
+
+int dense_prepare(nodal_ctx *h);  // sparse.hip
+
+namespace {
+
+struct DeviceGuard {
+    explicit DeviceGuard(nodal_ctx *h) { (void)hipSetDevice(h->device); }
+};
+
+template <class T>
+int upload(nodal_ctx *h, DevBuf &buf, const T *src, int64_t count) {
+    NODAL_HIP_TRY(h, buf.reserve((size_t)count * sizeof(T) + 16));
+    if (count > 0)
+        NODAL_HIP_TRY(h, hipMemcpyAsync(buf.p, src, (size_t)count * sizeof(T),
+                                        hipMemcpyHostToDevice, h->stream));
+    return NODAL_OK;
+}
+
+double elapsed(nodal_ctx *h, int a, int b) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, h->ev[a], h->ev[b]) != hipSuccess) return 0.0;
+    return ms;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *nodal_version(void) { return "nodal_hip 0.1 gfx950"; }
+
+int nodal_create(int device_id, nodal_handle *out) {
+    if (!out) return NODAL_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device_id < 0 || device_id >= count)
+        return NODAL_E_HIP;
+    nodal_ctx *h = new nodal_ctx();
+    h->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return NODAL_E_HIP;
+    }
+    for (auto &e : h->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete h;
+            return NODAL_E_HIP;
+        }
+    *out = h;
+    return NODAL_OK;
+}
+
+int nodal_destroy(nodal_handle h) {
+    if (!h) return NODAL_OK;
+    DeviceGuard g(h);
+    (void)hipStreamSynchronize(h->stream);
+    DevBuf *bufs[] = {&h->type, &h->value, &h->a, &h->b, &h->c, &h->d, &h->drv, &h->k,
+                      &h->values_batch, &h->indptr, &h->indices, &h->rowidx, &h->cptr,
+                      &h->contrib, &h->rhs_row, &h->rhs_cptr, &h->rhs_contrib, &h->diag_pos,
+                      &h->data, &h->rhs, &h->status, &h->x, &h->dense, &h->piv, &h->work,
+                      &h->work2, &h->solver};
+    for (DevBuf *b : bufs) b->release();
+    for (auto &e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return NODAL_OK;
+}
+
+const char *nodal_last_error(nodal_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int nodal_upload_components(nodal_handle h, int64_t ncomp, const uint8_t *type,
+                            const double *value, const int32_t *a, const int32_t *b,
+                            const int32_t *c, const int32_t *d, const int32_t *drv,
+                            const int32_t *k, int32_t K, int32_t B) {
+    if (!h || ncomp < 0 || K < 0 || B < 0) return NODAL_E_INVALID;
+    if (ncomp > 0 && (!type || !value || !a || !b || !c || !d || !drv || !k))
+        return nodal_fail(h, NODAL_E_INVALID, "null component column");
+    DeviceGuard g(h);
+    // validate indices on the host: a kernel must never see an out-of-range node
+    const int64_t n = (int64_t)K + B;
+    for (int64_t i = 0; i < ncomp; ++i) {
+        const bool ok = type[i] <= NODAL_T_CCCS && a[i] >= -1 && a[i] < K && b[i] >= -1 &&
+                        b[i] < K && c[i] >= -1 && c[i] < K && d[i] >= -1 && d[i] < K &&
+                        drv[i] >= -1 && drv[i] < ncomp && k[i] >= -1 && k[i] < B &&
+                        ((type[i] >= NODAL_T_E) == (k[i] >= 0));
+        if (!ok) return nodal_fail(h, NODAL_E_INVALID, "component table row out of range");
+    }
+    h->have_table = h->have_symbolic = h->have_numeric = h->have_x = false;
+    h->ncomp = ncomp;
+    h->K = K;
+    h->B = B;
+    h->n = n;
+    h->batch = 0;
+    NODAL_TRY(upload(h, h->type, type, ncomp));
+    NODAL_TRY(upload(h, h->value, value, ncomp));
+    NODAL_TRY(upload(h, h->a, a, ncomp));
+    NODAL_TRY(upload(h, h->b, b, ncomp));
+    NODAL_TRY(upload(h, h->c, c, ncomp));
+    NODAL_TRY(upload(h, h->d, d, ncomp));
+    NODAL_TRY(upload(h, h->drv, drv, ncomp));
+    NODAL_TRY(upload(h, h->k, k, ncomp));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->have_table = true;
+    return NODAL_OK;
+}
+
+int nodal_upload_values(nodal_handle h, int32_t batch, const double *values) {
+    if (!h || !h->have_table || batch < 1 || !values) return NODAL_E_INVALID;
+    DeviceGuard g(h);
+    NODAL_TRY(upload(h, h->values_batch, values, (int64_t)batch * h->ncomp));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->batch = batch;
+    h->have_numeric = h->have_x = false;
+    return NODAL_OK;
+}
+
+int nodal_assemble_symbolic(nodal_handle h) {
+    if (!h) return NODAL_E_INVALID;
+    DeviceGuard g(h);
+    NODAL_HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
+    int s = stamp_symbolic(h);
+    NODAL_HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
+    NODAL_HIP_TRY(h, hipEventSynchronize(h->ev[1]));
+    h->ms[0] = elapsed(h, 0, 1);
+    return s;
+}
+
+int nodal_assemble_numeric(nodal_handle h, int32_t member, int64_t *bad_component) {
+    if (!h) return NODAL_E_INVALID;
+    DeviceGuard g(h);
+    NODAL_HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
+    int s = stamp_numeric(h, member, bad_component);
+    NODAL_HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
+    NODAL_HIP_TRY(h, hipEventSynchronize(h->ev[1]));
+    h->ms[1] = elapsed(h, 0, 1);
+    return s;
+}
+
+int nodal_get_sizes(nodal_handle h, int64_t *n, int64_t *nnz, int64_t *ncontrib) {
+    if (!h || !h->have_symbolic) return NODAL_E_INVALID;
+    if (n) *n = h->n;
+    if (nnz) *nnz = h->nnz;
+    if (ncontrib) *ncontrib = h->ncontrib;
+    return NODAL_OK;
+}
+
+int nodal_export_csr(nodal_handle h, int32_t *indptr, int32_t *indices, double *data,
+                     double *rhs) {
+    if (!h || !h->have_symbolic) return NODAL_E_INVALID;
+    DeviceGuard g(h);
+    hipStream_t st = h->stream;
+    if (indptr)
+        NODAL_HIP_TRY(h, hipMemcpyAsync(indptr, h->indptr.p, (size_t)(h->n + 1) * 4,
+                                        hipMemcpyDeviceToHost, st));
+    if (indices && h->nnz)
+        NODAL_HIP_TRY(h, hipMemcpyAsync(indices, h->indices.p, (size_t)h->nnz * 4,
+                                        hipMemcpyDeviceToHost, st));
+    if (data || rhs) {
+        if (!h->have_numeric) return nodal_fail(h, NODAL_E_INVALID, "assemble_numeric not called");
+        if (data && h->nnz)
+            NODAL_HIP_TRY(h, hipMemcpyAsync(data, h->data.p, (size_t)h->nnz * 8,
+                                            hipMemcpyDeviceToHost, st));
+        if (rhs && h->n)
+            NODAL_HIP_TRY(h, hipMemcpyAsync(rhs, h->rhs.p, (size_t)h->n * 8,
+                                            hipMemcpyDeviceToHost, st));
+    }
+    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    return NODAL_OK;
+}
+
+int nodal_export_dense(nodal_handle h, double *G, double *rhs) {
+    if (!h || !h->have_numeric) return NODAL_E_INVALID;
+    DeviceGuard g(h);
+    const int64_t n = h->n;
+    if (G && n) {
+        NODAL_HIP_TRY(h, h->dense.reserve((size_t)n * (size_t)(n + 1) * 8 + 64));
+        NODAL_TRY(stamp_to_dense(h, h->dense.as<double>(), false));
+        NODAL_HIP_TRY(h, hipMemcpyAsync(G, h->dense.p, (size_t)n * n * 8, hipMemcpyDeviceToHost,
+                                        h->stream));
+    }
+    if (rhs && n)
+        NODAL_HIP_TRY(h, hipMemcpyAsync(rhs, h->rhs.p, (size_t)n * 8, hipMemcpyDeviceToHost,
+                                        h->stream));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NODAL_OK;
+}
+
+int nodal_download_x(nodal_handle h, double *x) {
+    if (!h || !h->have_x || !x) return NODAL_E_INVALID;
+    DeviceGuard g(h);
+    if (h->n)
+        NODAL_HIP_TRY(h, hipMemcpyAsync(x, h->x.p, (size_t)h->n * 8, hipMemcpyDeviceToHost,
+                                        h->stream));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NODAL_OK;
+}
+
+int nodal_solve_dense(nodal_handle h, double *x, int32_t *info) {
+    if (!h || !info) return NODAL_E_INVALID;
+    if (!h->have_numeric) return nodal_fail(h, NODAL_E_INVALID, "assemble_numeric not called");
+    DeviceGuard g(h);
+    *info = 0;
+    h->have_x = false;
+    NODAL_HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
+    if (h->n > 0) {
+        NODAL_TRY(dense_prepare(h));
+        NODAL_TRY(dense_factor_solve(h, info));
+    }
+    NODAL_HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
+    NODAL_HIP_TRY(h, hipEventSynchronize(h->ev[1]));
+    h->ms[2] = elapsed(h, 0, 1);
+    if (*info > 0) return nodal_fail(h, NODAL_E_SINGULAR, "singular matrix: exact zero pivot");
+    h->have_x = true;
+    if (x) return nodal_download_x(h, x);
+    return NODAL_OK;
+}
+
+int nodal_solve_sparse(nodal_handle h, int32_t method, double *x, int32_t *info, int32_t *iters,
+                       double *resid) {
+    if (!h || !info) return NODAL_E_INVALID;
+    DeviceGuard g(h);
+    int32_t it = 0;
+    double rs = 0;
+    NODAL_HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
+    int s = sparse_solve(h, method, info, &it, &rs);
+    NODAL_HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
+    NODAL_HIP_TRY(h, hipEventSynchronize(h->ev[1]));
+    h->ms[2] = elapsed(h, 0, 1);
+    if (iters) *iters = it;
+    if (resid) *resid = rs;
+    if (s != NODAL_OK) return s;
+    if (x) return nodal_download_x(h, x);
+    return NODAL_OK;
+}
+
+int nodal_residual(nodal_handle h, double *scaled_residual) {
+    if (!h || !scaled_residual) return NODAL_E_INVALID;
+    DeviceGuard g(h);
+    return sparse_residual(h, scaled_residual);
+}
+
+int nodal_run(nodal_handle h, int32_t dense, int32_t member, int32_t reuse_symbolic,
+              int32_t *info) {
+    if (!h || !info) return NODAL_E_INVALID;
+    DeviceGuard g(h);
+    if (!(reuse_symbolic && h->have_symbolic)) NODAL_TRY(nodal_assemble_symbolic(h));
+    NODAL_TRY(nodal_assemble_numeric(h, member, nullptr));
+    if (dense) return nodal_solve_dense(h, nullptr, info);
+    return nodal_solve_sparse(h, NODAL_SPARSE_AUTO, nullptr, info, nullptr, nullptr);
+}
+
+int nodal_last_timings(nodal_handle h, double *ms3) {
+    if (!h || !ms3) return NODAL_E_INVALID;
+    ms3[0] = h->ms[0];
+    ms3[1] = h->ms[1];
+    ms3[2] = h->ms[2];
+    return NODAL_OK;
+}
+
+int nodal_last_kernel_stats(nodal_handle h, double *ms_total, int64_t *launches,
+                            double *alg_bytes_or_flops) {
+    if (!h) return NODAL_E_INVALID;
+    if (ms_total) *ms_total = h->kern_ms;
+    if (launches) *launches = h->kern_launches;
+    if (alg_bytes_or_flops) *alg_bytes_or_flops = h->kern_alg;
+    return NODAL_OK;
+}
+
+int nodal_synchronize(nodal_handle h) {
+    if (!h) return NODAL_E_INVALID;
+    DeviceGuard g(h);
+    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NODAL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+// Internal context of libnodal_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/nodal_hip.h"
+
+// A device allocation that grows on demand and is reused across calls, so the
+// launch path never calls hipMalloc once sizes have settled.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + (bytes >> 3) + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct nodal_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // ---- component table (HBM, structure of arrays) ----
+    int64_t ncomp = 0;
+    int32_t K = 0, B = 0;
+    int64_t n = 0;
+    DevBuf type, value, a, b, c, d, drv, k;
+    DevBuf values_batch;  // [batch][ncomp] doubles
+    int32_t batch = 0;
+    bool have_table = false;
+
+    // ---- symbolic assembly results ----
+    bool have_symbolic = false;
+    int64_t nnz = 0;        // matrix entries
+    int64_t ncontrib = 0;   // matrix contributions
+    int64_t nrhs = 0;       // rhs entries (rows with at least one contribution)
+    int64_t nrhs_contrib = 0;
+    DevBuf indptr;          // i32[n+1]
+    DevBuf indices;         // i32[nnz]  (sorted inside each row)
+    DevBuf rowidx;          // i32[nnz]  row of each entry (COO companion)
+    DevBuf cptr;            // i32[nnz+1] contribution run of each entry
+    DevBuf contrib;         // u32[ncontrib] comp<<3 | slot, in fold order
+    DevBuf rhs_row;         // i32[nrhs]
+    DevBuf rhs_cptr;        // i32[nrhs+1]
+    DevBuf rhs_contrib;     // u32[nrhs_contrib]
+    DevBuf diag_pos;        // i32[n] position of (i,i) in CSR or -1
+
+    // ---- numeric assembly results ----
+    bool have_numeric = false;
+    DevBuf data;            // f64[nnz]
+    DevBuf rhs;             // f64[n]
+    DevBuf status;          // i64[4] device-side error words
+
+    // ---- solve ----
+    DevBuf x;               // f64[n]
+    bool have_x = false;
+    DevBuf dense;           // f64[n*n] column-major working copy for LU
+    DevBuf piv;             // i32[n]
+    DevBuf work;            // scratch (scans, sorts, solver vectors)
+    DevBuf work2;
+    DevBuf solver;          // persistent solver vectors
+
+    // ---- timing ----
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double ms[3] = {0, 0, 0};
+    double kern_ms = 0;
+    int64_t kern_launches = 0;
+    double kern_alg = 0;
+};
+
+#define NODAL_HIP_TRY(h, expr)                                                   \
+    do {                                                                         \
+        hipError_t _e = (expr);                                                  \
+        if (_e != hipSuccess) {                                                  \
+            char _buf[512];                                                      \
+            snprintf(_buf, sizeof _buf, "%s failed at %s:%d: %s", #expr, __FILE__, \
+                     __LINE__, hipGetErrorString(_e));                           \
+            (h)->err = _buf;                                                     \
+            return _e == hipErrorOutOfMemory ? NODAL_E_NOMEM : NODAL_E_HIP;      \
+        }                                                                        \
+    } while (0)
+
+#define NODAL_TRY(expr)                  \
+    do {                                 \
+        int _s = (expr);                 \
+        if (_s != NODAL_OK) return _s;   \
+    } while (0)
+
+static inline int nodal_fail(nodal_ctx *h, int code, const char *msg) {
+    h->err = msg;
+    return code;
+}
+
+// ---- device-wide primitives (scan.hip) ----
+// exclusive prefix sum of n uint32 values; out may alias in; total (optional,
+// device pointer) receives the grand total.  `tmp` must hold scan_tmp_bytes(n).
+size_t scan_tmp_bytes(int64_t n);
+int scan_exclusive_u32(nodal_ctx *h, const uint32_t *in, uint32_t *out, int64_t n,
+                       uint32_t *total_dev, void *tmp);
+
+// ---- stamping (stamp.hip) ----
+int stamp_symbolic(nodal_ctx *h);
+int stamp_numeric(nodal_ctx *h, int32_t member, int64_t *bad_component);
+int stamp_to_dense(nodal_ctx *h, double *G_dev, bool col_major);
+
+// ---- dense LU (dense_lu.hip) ----
+int dense_factor_solve(nodal_ctx *h, int32_t *info);
+
+// ---- sparse solvers (sparse_*.hip) ----
+int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, double *resid);
+int sparse_residual(nodal_ctx *h, double *scaled);

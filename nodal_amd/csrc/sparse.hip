@@ -1,0 +1,438 @@
+// Sparse path of Circuit.solve (replaces scipy.sparse.linalg.spsolve,
+// reference nodal/nodal.py:325) on the CSR matrix built by stamp.hip.
+//
+//   * B == 0 (resistors and current sources only): G is a symmetric weighted
+//     graph Laplacian plus ground conductances -> preconditioned conjugate
+//     gradients in fp64.  Three kernels per iteration, no atomics, no host
+//     round trip: dot products are block partials that the NEXT kernel's
+//     prologue reduces (every workgroup redundantly, in a fixed order, so the
+//     result is deterministic).  The SpMV gives each row to a sub-wave group of
+//     LPR lanes and reduces with wavefront shuffles.
+//   * otherwise (branch equations present: zero diagonals, non-symmetric): small
+//     systems are scattered into a dense column-major panel and factorised by
+//     the dense LU (dense_lu.hip); large ones need the sparse LU (sparse_lu.hip).
+//
+// Singular systems: x is filled with NaN and info > 0, without an error status,
+// because the reference's sparse path warns and returns NaNs (SURVEY.md section 0
+// quirk 3).
+#include "ctx.h"
+
+int dense_fill_nan(nodal_ctx *h, double *x, int64_t n);
+
+namespace {
+
+constexpr int TB = 256;
+constexpr int MAX_PARTIALS = 1024;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// sum of one value per thread over the workgroup; valid in every thread
+__device__ __forceinline__ double block_sum(double v) {
+    __shared__ double ws[TB / 64];
+    __syncthreads();
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < TB / 64; ++w) s += ws[w];
+    return s;
+}
+
+// every workgroup reduces the same partial array in the same order
+__device__ __forceinline__ double reduce_partials(const double *__restrict__ part, int count) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += TB) s += part[i];
+    return block_sum(s);
+}
+
+template <int LPR>
+__device__ __forceinline__ double row_dot(const int32_t *__restrict__ indptr,
+                                          const int32_t *__restrict__ indices,
+                                          const double *__restrict__ data,
+                                          const double *__restrict__ x, int64_t row, int sub) {
+    double s = 0.0;
+    const int32_t e1 = indptr[row + 1];
+    for (int32_t e = indptr[row] + sub; e < e1; e += LPR) s = fma(data[e], x[indices[e]], s);
+#pragma unroll
+    for (int off = LPR >> 1; off > 0; off >>= 1) s += __shfl_down(s, off, LPR);
+    return s;  // valid in sub == 0
+}
+
+// y = A x
+template <int LPR>
+__global__ __launch_bounds__(TB) void spmv_kernel(const int32_t *__restrict__ indptr,
+                                                  const int32_t *__restrict__ indices,
+                                                  const double *__restrict__ data,
+                                                  const double *__restrict__ x,
+                                                  double *__restrict__ y, int64_t n) {
+    const int sub = threadIdx.x % LPR;
+    const int64_t rows_per_pass = (int64_t)gridDim.x * (TB / LPR);
+    const int64_t passes = (n + rows_per_pass - 1) / rows_per_pass;
+    for (int64_t it = 0; it < passes; ++it) {
+        const int64_t row = it * rows_per_pass + (int64_t)blockIdx.x * (TB / LPR) + threadIdx.x / LPR;
+        const bool live = row < n;
+        const double s = live ? row_dot<LPR>(indptr, indices, data, x, row, sub) : 0.0;
+        if (live && sub == 0) y[row] = s;
+    }
+}
+
+// scalars kept on the device (doubles)
+enum { S_RZ0 = 0, S_RZ1 = 1, S_RR = 2, S_BB = 3, S_PAP = 4, S_FLAG = 5, S_COUNT = 8 };
+
+// z = r * dinv (r = b, x = 0), partials of r.z and r.r
+__global__ __launch_bounds__(TB) void pcg_init(const double *__restrict__ b,
+                                               const double *__restrict__ dinv,
+                                               double *__restrict__ x, double *__restrict__ r,
+                                               double *__restrict__ z, double *__restrict__ part_rz,
+                                               double *__restrict__ part_rr, int64_t n) {
+    double srz = 0.0, srr = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        const double ri = b[i];
+        const double zi = ri * dinv[i];
+        x[i] = 0.0;
+        r[i] = ri;
+        z[i] = zi;
+        srz = fma(ri, zi, srz);
+        srr = fma(ri, ri, srr);
+    }
+    srz = block_sum(srz);
+    srr = block_sum(srr);
+    if (threadIdx.x == 0) {
+        part_rz[blockIdx.x] = srz;
+        part_rr[blockIdx.x] = srr;
+    }
+}
+
+// K1: rz_new from partials; beta = rz_new / rz_old; p = z + beta p
+__global__ __launch_bounds__(TB) void pcg_direction(const double *__restrict__ z,
+                                                    double *__restrict__ p,
+                                                    const double *__restrict__ part_rz,
+                                                    const double *__restrict__ part_rr,
+                                                    int nparts, double *__restrict__ sc, int iter,
+                                                    int64_t n) {
+    const double rz_new = reduce_partials(part_rz, nparts);
+    const double rr = reduce_partials(part_rr, nparts);
+    const double rz_old = iter > 0 ? sc[(iter - 1) & 1] : 1.0;
+    const double beta = iter > 0 ? rz_new / rz_old : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc[iter & 1] = rz_new;
+        sc[S_RR] = rr;
+        if (iter == 0) sc[S_BB] = rr;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        p[i] = iter > 0 ? fma(beta, p[i], z[i]) : z[i];
+}
+
+// K2: Ap = A p, partials of p.Ap
+template <int LPR>
+__global__ __launch_bounds__(TB) void pcg_spmv(const int32_t *__restrict__ indptr,
+                                               const int32_t *__restrict__ indices,
+                                               const double *__restrict__ data,
+                                               const double *__restrict__ p,
+                                               double *__restrict__ Ap,
+                                               double *__restrict__ part_pap, int64_t n) {
+    const int sub = threadIdx.x % LPR;
+    const int64_t rows_per_pass = (int64_t)gridDim.x * (TB / LPR);
+    const int64_t passes = (n + rows_per_pass - 1) / rows_per_pass;
+    double acc = 0.0;
+    for (int64_t it = 0; it < passes; ++it) {
+        const int64_t row = it * rows_per_pass + (int64_t)blockIdx.x * (TB / LPR) + threadIdx.x / LPR;
+        const bool live = row < n;
+        const double s = live ? row_dot<LPR>(indptr, indices, data, p, row, sub) : 0.0;
+        if (live && sub == 0) {
+            Ap[row] = s;
+            acc = fma(p[row], s, acc);
+        }
+    }
+    acc = block_sum(acc);
+    if (threadIdx.x == 0) part_pap[blockIdx.x] = acc;
+}
+
+// K3: alpha = rz / pAp; x += alpha p; r -= alpha Ap; z = r dinv; partials r.z, r.r
+__global__ __launch_bounds__(TB) void pcg_update(double *__restrict__ x, double *__restrict__ r,
+                                                 double *__restrict__ z,
+                                                 const double *__restrict__ p,
+                                                 const double *__restrict__ Ap,
+                                                 const double *__restrict__ dinv,
+                                                 const double *__restrict__ part_pap,
+                                                 double *__restrict__ part_rz,
+                                                 double *__restrict__ part_rr, int nparts,
+                                                 double *__restrict__ sc, int iter, int64_t n) {
+    const double pap = reduce_partials(part_pap, nparts);
+    const double rz = sc[iter & 1];
+    // breakdown (indefinite or singular G): freeze the iteration, raise the flag
+    const bool bad = !(pap > 0.0) && rz != 0.0;
+    const double alpha = (pap > 0.0) ? rz / pap : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc[S_PAP] = pap;
+        if (bad) sc[S_FLAG] = 1.0;
+    }
+    double srz = 0.0, srr = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        x[i] = fma(alpha, p[i], x[i]);
+        const double ri = fma(-alpha, Ap[i], r[i]);
+        const double zi = ri * dinv[i];
+        r[i] = ri;
+        z[i] = zi;
+        srz = fma(ri, zi, srz);
+        srr = fma(ri, ri, srr);
+    }
+    srz = block_sum(srz);
+    srr = block_sum(srr);
+    if (threadIdx.x == 0) {
+        part_rz[blockIdx.x] = srz;
+        part_rr[blockIdx.x] = srr;
+    }
+}
+
+// dinv = 1 / diag(G); flag rows whose diagonal is missing or not positive
+__global__ __launch_bounds__(TB) void jacobi_setup(const int32_t *__restrict__ diag_pos,
+                                                   const double *__restrict__ data,
+                                                   double *__restrict__ dinv,
+                                                   double *__restrict__ sc, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        const int32_t e = diag_pos[i];
+        const double d = e >= 0 ? data[e] : 0.0;
+        if (!(d > 0.0)) sc[S_FLAG] = 2.0;  // benign race: every writer stores the same value
+        dinv[i] = d > 0.0 ? 1.0 / d : 1.0;
+    }
+}
+
+__device__ __forceinline__ void atomic_max_nonneg(double *addr, double v) {
+    // non-negative doubles order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+// out[0] = max_i |(A x - b)_i|, out[1] = max row sum |A|, out[2] = max|x|, out[3] = max|b|
+// NaNs anywhere in x poison out[0] via out[4].
+template <int LPR>
+__global__ __launch_bounds__(TB) void residual_kernel(const int32_t *__restrict__ indptr,
+                                                      const int32_t *__restrict__ indices,
+                                                      const double *__restrict__ data,
+                                                      const double *__restrict__ x,
+                                                      const double *__restrict__ b,
+                                                      double *__restrict__ out, int64_t n) {
+    const int sub = threadIdx.x % LPR;
+    const int64_t rows_per_pass = (int64_t)gridDim.x * (TB / LPR);
+    const int64_t passes = (n + rows_per_pass - 1) / rows_per_pass;
+    for (int64_t it = 0; it < passes; ++it) {
+        const int64_t row = it * rows_per_pass + (int64_t)blockIdx.x * (TB / LPR) + threadIdx.x / LPR;
+        const bool live = row < n;
+        double s = 0.0, an = 0.0;
+        if (live) {
+            const int32_t e1 = indptr[row + 1];
+            for (int32_t e = indptr[row] + sub; e < e1; e += LPR) {
+                s = fma(data[e], x[indices[e]], s);
+                an += fabs(data[e]);
+            }
+        }
+#pragma unroll
+        for (int off = LPR >> 1; off > 0; off >>= 1) {
+            s += __shfl_down(s, off, LPR);
+            an += __shfl_down(an, off, LPR);
+        }
+        if (live && sub == 0) {
+            const double res = fabs(s - b[row]);
+            if (res != res || x[row] != x[row]) out[4] = 1.0;
+            else {
+                atomic_max_nonneg(&out[0], res);
+                atomic_max_nonneg(&out[2], fabs(x[row]));
+            }
+            atomic_max_nonneg(&out[1], an);
+            atomic_max_nonneg(&out[3], fabs(b[row]));
+        }
+    }
+}
+
+int lanes_per_row(nodal_ctx *h) {
+    const double avg = h->n > 0 ? (double)h->nnz / (double)h->n : 1.0;
+    int lpr = 2;
+    while (lpr < 64 && lpr < avg) lpr <<= 1;
+    return lpr;
+}
+
+unsigned grid_rows(int64_t n, int lpr) {
+    int64_t g = (n * lpr + TB - 1) / TB;
+    if (g < 1) g = 1;
+    return (unsigned)(g > MAX_PARTIALS ? MAX_PARTIALS : g);
+}
+
+#define DISPATCH_LPR(lpr, CALL)          \
+    switch (lpr) {                       \
+    case 2: { constexpr int L = 2; CALL; } break;   \
+    case 4: { constexpr int L = 4; CALL; } break;   \
+    case 8: { constexpr int L = 8; CALL; } break;   \
+    case 16: { constexpr int L = 16; CALL; } break; \
+    case 32: { constexpr int L = 32; CALL; } break; \
+    default: { constexpr int L = 64; CALL; } break; \
+    }
+
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int pcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
+    const int64_t n = h->n;
+    hipStream_t st = h->stream;
+    const size_t vec = align_up((size_t)n * 8);
+    // solver layout: r | z | p | Ap | dinv | partials 3 x MAX | scalars
+    NODAL_HIP_TRY(h, h->solver.reserve(5 * vec + 3 * MAX_PARTIALS * 8 + 256));
+    char *base = h->solver.as<char>();
+    double *r = reinterpret_cast<double *>(base);
+    double *z = reinterpret_cast<double *>(base + vec);
+    double *p = reinterpret_cast<double *>(base + 2 * vec);
+    double *Ap = reinterpret_cast<double *>(base + 3 * vec);
+    double *dinv = reinterpret_cast<double *>(base + 4 * vec);
+    double *part_rz = reinterpret_cast<double *>(base + 5 * vec);
+    double *part_rr = part_rz + MAX_PARTIALS;
+    double *part_pap = part_rr + MAX_PARTIALS;
+    double *sc = part_pap + MAX_PARTIALS;
+    double *x = h->x.as<double>();
+    const int32_t *indptr = h->indptr.as<int32_t>();
+    const int32_t *indices = h->indices.as<int32_t>();
+    const double *data = h->data.as<double>();
+    const double *b = h->rhs.as<double>();
+
+    const int lpr = lanes_per_row(h);
+    const unsigned gv = grid_rows(n, 1);     // vector kernels
+    const unsigned gs = grid_rows(n, lpr);   // spmv kernels
+    const int nparts_v = (int)gv, nparts_s = (int)gs;
+
+    NODAL_HIP_TRY(h, hipMemsetAsync(sc, 0, S_COUNT * 8, st));
+    jacobi_setup<<<gv, TB, 0, st>>>(h->diag_pos.as<int32_t>(), data, dinv, sc, n);
+    pcg_init<<<gv, TB, 0, st>>>(b, dinv, x, r, z, part_rz, part_rr, n);
+    NODAL_HIP_TRY(h, hipGetLastError());
+
+    const double tol = 1e-13;
+    const int64_t maxit = 20 * (int64_t)(n < 1000 ? 1000 : n);
+    const int check = 50;
+    double hs[S_COUNT];
+    int64_t it = 0;
+    int status = 0;  // 0 running, 1 converged, 2 breakdown, 3 maxit
+    hipEvent_t e0 = h->ev[2], e1 = h->ev[3];
+    h->kern_ms = 0;
+    h->kern_launches = 0;
+    while (status == 0) {
+        for (int c = 0; c < check; ++c, ++it) {
+            pcg_direction<<<gv, TB, 0, st>>>(z, p, part_rz, part_rr, nparts_v, sc, (int)it, n);
+            const bool timed = (c == check - 1);
+            if (timed) NODAL_HIP_TRY(h, hipEventRecord(e0, st));
+            DISPATCH_LPR(lpr, (pcg_spmv<L><<<gs, TB, 0, st>>>(indptr, indices, data, p, Ap, part_pap, n)));
+            if (timed) NODAL_HIP_TRY(h, hipEventRecord(e1, st));
+            pcg_update<<<gv, TB, 0, st>>>(x, r, z, p, Ap, dinv, part_pap, part_rz, part_rr,
+                                          nparts_s, sc, (int)it, n);
+        }
+        NODAL_HIP_TRY(h, hipGetLastError());
+        NODAL_HIP_TRY(h, hipMemcpyAsync(hs, sc, S_COUNT * 8, hipMemcpyDeviceToHost, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+            h->kern_ms += ms;
+            h->kern_launches += 1;
+        }
+        // sc[S_RR] is |r|^2 as of the direction kernel of the last iteration
+        if (hs[S_FLAG] != 0.0) status = 2;
+        else if (!(hs[S_RR] == hs[S_RR])) status = 2;
+        else if (hs[S_BB] == 0.0 || hs[S_RR] <= tol * tol * hs[S_BB]) status = 1;
+        else if (it >= maxit) status = 3;
+    }
+    *iters = (int32_t)it;
+    *resid = hs[S_BB] > 0 ? sqrt(hs[S_RR] / hs[S_BB]) : 0.0;
+    // algorithmic bytes of one SpMV launch: matrix once, x and y once
+    h->kern_alg = 12.0 * (double)h->nnz + 4.0 * (double)(n + 1) + 16.0 * (double)n;
+    if (status == 2) return -1;  // not SPD / singular: caller falls back
+    *info = 0;
+    return NODAL_OK;
+}
+
+__global__ __launch_bounds__(TB) void copy_rhs_column(const double *__restrict__ rhs,
+                                                      double *__restrict__ col, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        col[i] = rhs[i];
+}
+
+}  // namespace
+
+int dense_prepare(nodal_ctx *h) {
+    const int64_t n = h->n;
+    NODAL_HIP_TRY(h, h->dense.reserve((size_t)n * (size_t)(n + 1) * 8 + 64));
+    NODAL_TRY(stamp_to_dense(h, h->dense.as<double>(), true));
+    if (n > 0) {
+        copy_rhs_column<<<grid_rows(n, 1), TB, 0, h->stream>>>(h->rhs.as<double>(),
+                                                              h->dense.as<double>() + n * n, n);
+        NODAL_HIP_TRY(h, hipGetLastError());
+    }
+    return NODAL_OK;
+}
+
+int sparse_lu_solve(nodal_ctx *h, int32_t *info);  // sparse_lu.hip
+
+int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, double *resid) {
+    if (!h->have_numeric) return nodal_fail(h, NODAL_E_INVALID, "assemble_numeric not called");
+    const int64_t n = h->n;
+    *info = 0;
+    *iters = 0;
+    *resid = 0.0;
+    h->have_x = false;
+    if (n == 0) {
+        h->have_x = true;
+        return NODAL_OK;
+    }
+    const int64_t densify_max = 16384;
+    if (method == NODAL_SPARSE_AUTO) {
+        if (h->B == 0 && n > 64) method = NODAL_SPARSE_PCG;
+        else method = n <= densify_max ? NODAL_SPARSE_DENSIFY : NODAL_SPARSE_LU;
+    }
+    if (method == NODAL_SPARSE_PCG) {
+        int s = pcg_solve(h, info, iters, resid);
+        if (s == NODAL_OK) {
+            h->have_x = true;
+            return NODAL_OK;
+        }
+        if (s > 0) return s;
+        // breakdown: negative resistances or a singular / disconnected network
+        method = n <= densify_max ? NODAL_SPARSE_DENSIFY : NODAL_SPARSE_LU;
+    }
+    if (method == NODAL_SPARSE_DENSIFY) {
+        NODAL_TRY(dense_prepare(h));
+        NODAL_TRY(dense_factor_solve(h, info));
+    } else if (method == NODAL_SPARSE_LU) {
+        NODAL_TRY(sparse_lu_solve(h, info));
+    } else {
+        return nodal_fail(h, NODAL_E_INVALID, "unknown sparse method");
+    }
+    if (*info > 0) NODAL_TRY(dense_fill_nan(h, h->x.as<double>(), n));
+    h->have_x = true;
+    return NODAL_OK;
+}
+
+int sparse_residual(nodal_ctx *h, double *scaled) {
+    if (!h->have_numeric || !h->have_x)
+        return nodal_fail(h, NODAL_E_INVALID, "no assembled system / solution on the device");
+    const int64_t n = h->n;
+    if (n == 0) {
+        *scaled = 0.0;
+        return NODAL_OK;
+    }
+    NODAL_HIP_TRY(h, h->status.reserve(64));
+    double *out = h->status.as<double>();
+    NODAL_HIP_TRY(h, hipMemsetAsync(out, 0, 40, h->stream));
+    const int lpr = lanes_per_row(h);
+    DISPATCH_LPR(lpr, (residual_kernel<L><<<grid_rows(n, lpr), TB, 0, h->stream>>>(
+                          h->indptr.as<int32_t>(), h->indices.as<int32_t>(), h->data.as<double>(),
+                          h->x.as<double>(), h->rhs.as<double>(), out, n)));
+    NODAL_HIP_TRY(h, hipGetLastError());
+    double o[5];
+    NODAL_HIP_TRY(h, hipMemcpyAsync(o, out, 40, hipMemcpyDeviceToHost, h->stream));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (o[4] != 0.0) {
+        *scaled = __builtin_nan("");
+        return NODAL_OK;
+    }
+    const double den = o[1] * o[2] + o[3];
+    *scaled = den > 0 ? o[0] / den : 0.0;
+    return NODAL_OK;
+}

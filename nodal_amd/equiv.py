@@ -1,0 +1,67 @@
+"""Equivalent resistance between two nodes, and the `nodal-resistance [-s] FILE`
+command line entry (reference nodal/equiv.py:22-85)."""
+
+import argparse
+import sys
+from copy import deepcopy
+
+import nodal_amd as n
+
+parser = argparse.ArgumentParser(
+    description="Calculate equivalent resistance using nodal analysis"
+    "\n"
+    "Label nodes as '1' and 'g' to mark where to connect to the network."
+)
+parser.add_argument("netlist_path", metavar="FILE", help="csv file describing the resistive network")
+parser.add_argument("-s", "--sparse", action="store_true", help="use a sparse matrix")
+
+
+def check_resistive(netlist):
+    """True iff every component of the netlist is a resistor."""
+    return all(comp.type == "R" for comp in netlist.components.values())
+
+
+def equivalent_resistance(netlist, a, b, sparse=False):
+    """Resistance seen between nodes `a` and `b`: drive 1 A from b to a, solve,
+    return e(a) - e(b) (reference nodal/equiv.py:31-61).
+
+    Raises ValueError if the netlist holds anything but resistors and KeyError if
+    a node is unknown.  As in the reference the probe source is named "a1", node
+    numbering is not recomputed, and a node counts as grounded only if it is
+    literally labelled "g"."""
+    if not check_resistive(netlist):
+        raise ValueError("Network is not resistive")
+    for node in (a, b):
+        if node not in netlist.nodenum and node != netlist.ground:
+            raise KeyError(f"Node `{node}` not found in netlist")
+    probed = deepcopy(netlist)
+    probed.process_component(["a1", "A", "1", a, b])
+    solution = n.Circuit(probed, sparse=sparse).solve()
+    potential = [0, 0]
+    for i, node in enumerate((a, b)):
+        if node != "g":
+            potential[i] = solution.result[solution.nodenum[node]]
+    return potential[0] - potential[1]
+
+
+def main(argv=None):
+    args = parser.parse_args(argv)
+    try:
+        netlist = n.Netlist(args.netlist_path)
+    except FileNotFoundError:
+        sys.exit(1)
+    try:
+        r = equivalent_resistance(netlist, "1", "g", sparse=args.sparse)
+    except ValueError:
+        print("Invalid netlist\n")
+        print("Resistors are the only component allowed in the circuit")
+        sys.exit(1)
+    except KeyError as e:
+        print("Invalid netlist\n")
+        print(e.args[0])
+        sys.exit(1)
+    print(f"R = {r}")
+
+
+if __name__ == "__main__":
+    main()

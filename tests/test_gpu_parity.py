@@ -1,0 +1,324 @@
+"""Parity of the HIP path (through the C ABI) with the reference's golden
+vectors and with the oracle.  Integer outputs and G / A are compared bit-exactly;
+solutions norm-wise over the whole vector:
+max|x - x_ref| / max|x_ref| <= 1e-9, plus the scaled residual."""
+import io
+import random
+import warnings
+
+import numpy as np
+import pytest
+
+import nodal_amd as n
+from nodal_amd import _ffi, equiv
+from nodal_amd import generators as gen
+from nodal_amd.circuit import MatrixRankWarning
+from nodal_amd.lowering import lower
+from oracle import nodal_oracle as oracle
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+CASES = [c for c in load_golden("cases.json") if "parse_error" not in c]
+SYNTH = load_golden("synth.json")
+LARGE = load_golden("synth_large.json")
+EQUIV = load_golden("equiv.json")
+TOL = 1e-9  # north_star: 1e-9 rel-tol fp64, norm-wise
+EXC = {"ValueError": ValueError, "KeyError": KeyError, "AssertionError": AssertionError,
+       "AttributeError": AttributeError, "NotImplementedError": NotImplementedError,
+       "LinAlgError": np.linalg.LinAlgError, "ZeroDivisionError": ZeroDivisionError,
+       "UnconnectedCircuitError": n.UnconnectedCircuitError}
+
+
+def parse(case):
+    if case.get("raw_text") is not None:
+        import csv
+        return n.Netlist.from_rows(csv.reader(io.StringIO(case["raw_text"]), skipinitialspace=True))
+    return n.Netlist.from_rows(case["rows"])
+
+
+def normwise(x, ref):
+    x, ref = np.asarray(x, float), np.asarray(ref, float)
+    scale = np.abs(ref).max()
+    return np.abs(x - ref).max() / (scale if scale > 0 else 1.0)
+
+
+def ref_dense_G(case, n_):
+    ii, jj, vv = case["G_coo"]
+    G = np.zeros((n_, n_))
+    G[ii, jj] = vv
+    return G
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+@pytest.mark.parametrize("mode", ["dense", "sparse"])
+def test_golden_case(case, mode):
+    nl = parse(case)
+    want = case[mode]
+    sparse = mode == "sparse"
+    stamping_error = "error" in want and want["error"]["type"] not in (
+        "LinAlgError", "UnconnectedCircuitError")
+    if stamping_error:
+        with pytest.raises(EXC[want["error"]["type"]]) as info:
+            n.Circuit(nl, sparse=sparse)
+        assert [str(a) for a in info.value.args] == want["error"]["args"]
+        return
+    circ = n.Circuit(nl, sparse=sparse)
+    assert circ.currents == case["currents"]
+    nn = nl.nums["kcl"] + nl.nums["be"]
+    G = circ.G.toarray() if sparse else circ.G
+    assert np.array_equal(G, ref_dense_G(case, nn))  # bit-exact stamping
+    assert np.asarray(circ.A).tolist() == case["A"]
+    if "error" in want:
+        with pytest.raises(EXC[want["error"]["type"]]):
+            circ.solve()
+        return
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        sol = circ.solve()
+    ref_x = np.array(want["x"])
+    if np.isnan(ref_x).any():
+        assert np.isnan(sol.result).all()
+        assert any(issubclass(i.category, MatrixRankWarning) for i in w)
+        return
+    assert normwise(sol.result, ref_x) <= TOL
+    if nn:
+        assert circ.scaled_residual() <= 1e-14
+    # printed form: same lines, same names, values parsed numerically
+    got, exp = str(sol).split("\n"), want["str"].split("\n")
+    assert got[0] == exp[0] and len(got) == len(exp)
+    for g_line, e_line in zip(got[1:], exp[1:]):
+        assert g_line.split("\t= ")[0] == e_line.split("\t= ")[0]
+
+
+def rows_of(genspec):
+    kind = genspec[0]
+    if kind == "grid":
+        return list(gen.grid_rows(genspec[1]))
+    if kind == "cfg4":
+        return list(gen.grid_rows(genspec[1], gen.cfg4_values(genspec[2], genspec[1])))
+    return gen.cfg5_rows(genspec[1], genspec[2])
+
+
+@pytest.mark.parametrize("case", SYNTH, ids=[c["name"] for c in SYNTH])
+def test_synthetic_sparse(case):
+    nl = n.Netlist.from_rows(rows_of(case["gen"]))
+    circ = n.Circuit(nl, sparse=True)
+    G = circ.G
+    G.eliminate_zeros()
+    assert G.nnz == case["nnz"]
+    assert float(np.abs(G.data).sum()) == case["G_abs_sum"]
+    assert float(np.asarray(circ.A).sum()) == case["A_sum"]
+    Go, Ao = oracle.assemble_fast(lower(nl))
+    assert (abs(G - Go)).nnz == 0 and np.array_equal(circ.A, Ao)  # bit-exact vs oracle
+    sol = circ.solve()
+    idx = case["x_idx"]
+    assert normwise(sol.result[idx], case["x_sparse_samples"]) <= TOL
+    assert abs(np.abs(sol.result).max() - case["x_sparse_absmax"]) <= TOL * case["x_sparse_absmax"]
+    assert circ.scaled_residual() <= 1e-13
+    if "x_sparse" in case:
+        assert normwise(sol.result, case["x_sparse"]) <= TOL
+
+
+@pytest.mark.parametrize("case", [c for c in SYNTH if c["nums"]["kcl"] < 5000],
+                         ids=[c["name"] for c in SYNTH if c["nums"]["kcl"] < 5000])
+def test_synthetic_dense(case):
+    nl = n.Netlist.from_rows(rows_of(case["gen"]))
+    circ = n.Circuit(nl, sparse=False)
+    sol = circ.solve()
+    idx = case["x_idx"]
+    assert normwise(sol.result[idx], case["x_dense_samples"]) <= TOL
+    assert circ.scaled_residual() <= 1e-14
+
+
+def test_cfg2_grid100_dense_full_size():
+    """BASELINE.json config 2: 100 x 100 grid, dense G, fp64."""
+    case = next(c for c in SYNTH if c["name"] == "grid(100)")
+    nl = n.Netlist.from_rows(gen.grid_rows(100))
+    circ = n.Circuit(nl, sparse=False)
+    sol = circ.solve()
+    assert normwise(sol.result[case["x_idx"]], case["x_sparse_samples"]) <= TOL
+    assert abs(sol.result[nl.nodenum["1"]] - case["e1"]) <= TOL * case["e1"]
+    assert circ.scaled_residual() <= 1e-14
+
+
+@pytest.mark.parametrize("name", ["grid(316)", "grid(1000)"])
+def test_cfg3_large_grid_sparse(name):
+    """BASELINE.json config 3 at full size, checked against samples of the
+    reference's own solution and size-independent properties."""
+    case = next(c for c in LARGE if c["name"] == name)
+    N = case["gen"][1]
+    table = gen.grid_table(N)
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.nnz == case["nnz"] and h.n == case["nums"]["kcl"]
+    status, _ = h.assemble_numeric()
+    assert status == _ffi.OK
+    indptr, indices, data, rhs = h.export_csr()
+    assert float(np.abs(data).sum()) == case["G_abs_sum"]
+    assert float(rhs.sum()) == case["A_sum"] and np.count_nonzero(rhs) == case["A_nnz"]
+    assert (np.diff(indptr) > 0).all()
+    x, info, iters, relres = h.solve_sparse()
+    assert info == 0
+    assert normwise(x[case["x_idx"]], case["x_sparse_samples"]) <= TOL
+    assert abs(x[0] - case["e1"]) <= TOL * case["e1"]  # R_eq(corner, corner)
+    assert abs(x.sum() - case["x_sparse_sum"]) <= TOL * abs(case["x_sparse_sum"]) * 10
+    assert h.residual() <= 1e-13
+    # physics: all potentials lie between ground (0) and the driven node
+    assert x.min() > 0 and x.argmax() == 0
+    h.close()
+
+
+def test_equivalent_resistance_golden():
+    for case in EQUIV:
+        if "gen" in case:
+            nl = n.Netlist.from_rows(list(gen.grid_rows(case["gen"][1]))[:-1])
+        else:
+            nl = n.Netlist.from_rows(case["rows"])
+        if "error" in case:
+            with pytest.raises(EXC[case["error"]["type"]]):
+                equiv.equivalent_resistance(nl, case["a"], case["b"])
+            continue
+        for sparse in (False, True):
+            r = equiv.equivalent_resistance(nl, case["a"], case["b"], sparse=sparse)
+            want = case["sparse" if sparse else "dense"]
+            assert abs(r - want) <= TOL * abs(want), (case["name"], sparse, r, want)
+
+
+def test_reference_resistance_tests_exact():
+    """reference tests.py:24-29 asserts exact equality for resistive_{1,2,3}."""
+    want = {"doc/resistive_1": 2.0, "doc/resistive_2": 1.0, "doc/resistive_3": 1.0}
+    for case in EQUIV:
+        if case["name"] in want and case["a"] == "1" and case["b"] == "g" and "error" not in case:
+            r = equiv.equivalent_resistance(n.Netlist.from_rows(case["rows"]), "1", "g")
+            assert r == want[case["name"]], (case["name"], r)
+
+
+def random_netlist(rng, nodes, extra):
+    """Connected random resistor network with a few sources of every kind."""
+    labels = [str(i) for i in range(1, nodes)] + ["g"]
+    rows = []
+    for i in range(1, nodes):  # spanning tree keeps it connected
+        j = rng.randrange(0, i)
+        rows.append([f"r{len(rows)}", "R", repr(rng.uniform(0.5, 20)), labels[i], labels[j]])
+    for _ in range(extra):
+        a, b = rng.sample(labels, 2)
+        rows.append([f"r{len(rows)}", "R", repr(rng.uniform(0.5, 20)), a, b])
+    res = [r for r in rows]
+    for s in range(3):
+        a, b = rng.sample(labels, 2)
+        rows.append([f"a{s}", "A", repr(rng.uniform(-2, 2)), a, b])
+    fresh = 0
+    for s in range(2):
+        fresh += 1
+        a = f"x{fresh}"
+        rows.append([f"e{s}", "E", repr(rng.uniform(-5, 5)), a, rng.choice(labels)])
+        rows.append([f"rx{fresh}", "R", "2", a, rng.choice(labels)])
+    for s in range(2):
+        drv = rng.choice(res)
+        fresh += 1
+        a = f"x{fresh}"
+        rows.append([f"h{s}", "CCVS", repr(rng.uniform(0.1, 0.9)), a, "g", drv[3], drv[4], drv[0]])
+        rows.append([f"rx{fresh}", "R", "3", a, rng.choice(labels)])
+        drv = rng.choice(res)
+        rows.append([f"f{s}", "CCCS", repr(rng.uniform(0.1, 0.9)), rng.choice(labels[:-1]), "g",
+                     drv[4], drv[3], drv[0]])
+        fresh += 1
+        a = f"x{fresh}"
+        c_, d_ = rng.sample(labels, 2)
+        rows.append([f"v{s}", rng.choice(["VCVS", "VCCS"]), repr(rng.uniform(0.1, 0.9)), a, "g", c_, d_])
+        rows.append([f"rx{fresh}", "R", "4", a, rng.choice(labels)])
+    rng.shuffle(rows)
+    return rows
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_circuits_against_oracle(seed):
+    rng = random.Random(seed)
+    rows = random_netlist(rng, rng.choice([5, 17, 60, 200]), rng.randrange(3, 80))
+    nl = n.Netlist.from_rows(rows)
+    for sparse in (False, True):
+        try:
+            Go, Ao, cur = oracle.build_model(nl, sparse)
+        except AssertionError:
+            with pytest.raises(AssertionError):
+                n.Circuit(nl, sparse=sparse)
+            continue
+        circ = n.Circuit(nl, sparse=sparse)
+        assert circ.currents == cur
+        G = circ.G.toarray() if sparse else circ.G
+        assert np.array_equal(G, Go.toarray() if sparse else Go)
+        assert np.array_equal(circ.A, Ao)
+        xo, _ = oracle.solve(Go, Ao, sparse)
+        x = circ.solve().result
+        if np.isfinite(xo).all() and np.linalg.cond(G) < 1e8:
+            assert normwise(x, xo) <= TOL
+
+
+def test_hub_node_long_row_sorts():
+    """A node with thousands of stamps exercises the LDS and global-memory row
+    sorts of the symbolic phase; G must still be bit-exact."""
+    rng = random.Random(7)
+    rows = []
+    for i in range(3000):
+        rows.append([f"r{i}", "R", repr(rng.uniform(0.5, 2)), "hub", str(i)])
+        rows.append([f"q{i}", "R", repr(rng.uniform(0.5, 2)), str(i), "g"])
+    for i in range(600):  # a second, medium-sized hub
+        rows.append([f"m{i}", "R", repr(rng.uniform(0.5, 2)), "hub2", str(i)])
+    rows.append(["a1", "A", "1", "hub", "g"])
+    rng.shuffle(rows)
+    nl = n.Netlist.from_rows(rows)
+    circ = n.Circuit(nl, sparse=True)
+    Go, Ao = oracle.assemble_fast(lower(nl))
+    assert (abs(circ.G - Go)).nnz == 0 and np.array_equal(circ.A, Ao)
+    x = circ.solve().result
+    xo, _ = oracle.solve(Go.tocsr(), Ao, True)
+    assert normwise(x, xo) <= TOL
+
+
+def test_value_sweep_batch_reuses_symbolic():
+    """BASELINE.json config 4 in miniature: one topology, per-member values."""
+    N, members = 10, 4
+    table = gen.grid_table(N)
+    vals = np.ones((members, table.ncomp))
+    for b in range(members):
+        vals[b, :-1] = gen.cfg4_values(b, N)
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    h.upload_values(vals)
+    for b in range(members):
+        assert h.assemble_numeric(b)[0] == _ffi.OK
+        indptr, indices, data, rhs = h.export_csr()
+        Go, Ao = oracle.assemble_fast(gen.grid_table(N, vals[b, :-1]))
+        Go.sort_indices()
+        assert np.array_equal(indptr, Go.indptr) and np.array_equal(indices, Go.indices)
+        assert np.array_equal(data, Go.data) and np.array_equal(rhs, Ao)
+        x, info, _, _ = h.solve_sparse()
+        xo, _ = oracle.solve(Go, Ao, True)
+        assert info == 0 and normwise(x, xo) <= TOL
+    h.close()
+
+
+def test_cli_scripts(tmp_path, capsys):
+    from nodal_amd import solver
+    case = next(c for c in CASES if c["name"] == "doc/1.6.1")
+    path = tmp_path / "c.csv"
+    gen.write_csv(case["rows"], str(path))
+    for flags in ([], ["-s"]):
+        solver.main(flags + [str(path)])
+        out = capsys.readouterr().out
+        assert out.startswith("Ground node: g\ne(1) \t= 2.0\ne(2) \t= -1.0\ne(4) \t= 8.0\n")
+    case = next(c for c in CASES if c["name"] == "doc/resistive_1")
+    gen.write_csv(case["rows"], str(path))
+    equiv.main([str(path)])
+    assert capsys.readouterr().out == "R = 2.0\n"
+    with pytest.raises(SystemExit) as e:
+        solver.main([str(tmp_path / "missing.csv")])
+    assert e.value.code == 1
+    case = next(c for c in CASES if c["name"] == "doc/unconnected_1")
+    gen.write_csv(case["rows"], str(path))
+    with pytest.raises(SystemExit) as e:
+        solver.main([str(path)])
+    assert e.value.code == 1
