@@ -5,8 +5,10 @@ when a handle is created, this raises.  The library itself is loadable on a
 machine without a GPU (symbol checks only).
 """
 
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -45,6 +47,13 @@ SIGNATURES = {
 }
 
 _lib = None
+_live = weakref.WeakSet()  # handles still open; closed before the HIP runtime unloads
+
+
+@atexit.register
+def _close_all():
+    for h in list(_live):
+        h.close()
 
 
 class NodalHipError(RuntimeError):
@@ -87,6 +96,7 @@ class Handle:
                 status, f"nodal_create(device={device}) failed: no usable MI355X "
                 "(HIP device) is visible; nodal_amd has no CPU fallback")
         self.n = self.nnz = self.ncontrib = 0
+        _live.add(self)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -119,6 +129,9 @@ class Handle:
     # -- assembly ---------------------------------------------------------
     def assemble_symbolic(self):
         self._check(self.lib.nodal_assemble_symbolic(self._h))
+        self._refresh_sizes()
+
+    def _refresh_sizes(self):
         n, nnz, nc = C.c_int64(), C.c_int64(), C.c_int64()
         self._check(self.lib.nodal_get_sizes(self._h, C.byref(n), C.byref(nnz), C.byref(nc)))
         self.n, self.nnz, self.ncontrib = n.value, nnz.value, nc.value
@@ -181,6 +194,7 @@ class Handle:
         info = C.c_int32(0)
         self._check(self.lib.nodal_run(self._h, int(dense), member, int(reuse_symbolic),
                                        C.byref(info)), allow=(E_SINGULAR,))
+        self._refresh_sizes()
         return info.value
 
     def timings(self):

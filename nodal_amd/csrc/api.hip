@@ -64,6 +64,7 @@ int nodal_destroy(nodal_handle h) {
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : h->evpool) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return NODAL_OK;

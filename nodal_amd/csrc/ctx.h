@@ -84,6 +84,7 @@ struct nodal_ctx {
     double kern_ms = 0;
     int64_t kern_launches = 0;
     double kern_alg = 0;
+    std::vector<hipEvent_t> evpool;  // HIP-event pairs around the dominant kernel
 };
 
 #define NODAL_HIP_TRY(h, expr)                                                   \

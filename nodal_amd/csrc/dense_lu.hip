@@ -243,6 +243,16 @@ int dense_factor_solve(nodal_ctx *h, int32_t *info) {
     int32_t *dinfo = piv + n;  // one spare word after the pivots
     NODAL_HIP_TRY(h, hipMemsetAsync(dinfo, 0, 4, st));
 
+    // HIP-event pairs around every trailing-update launch (the dominant kernel)
+    const size_t npanels = (size_t)((n + NB - 1) / NB);
+    while (h->evpool.size() < 2 * npanels) {
+        hipEvent_t e;
+        NODAL_HIP_TRY(h, hipEventCreate(&e));
+        h->evpool.push_back(e);
+    }
+    size_t timed = 0;
+    double flops = 0;
+
     for (int64_t j0 = 0; j0 < n; j0 += NB) {
         const int64_t j1 = j0 + NB < n ? j0 + NB : n;
         for (int64_t c = j0; c < j1; ++c) {
@@ -256,7 +266,11 @@ int dense_factor_solve(nodal_ctx *h, int32_t *info) {
         lu_trsm<<<blocks_for(ncols - j1, 256), 256, 0, st>>>(A, lda, ncols, (int)j0, (int)j1);
         if (j1 < n) {
             dim3 grid((unsigned)((n - j1 + 63) / 64), (unsigned)((ncols - j1 + 63) / 64));
+            NODAL_HIP_TRY(h, hipEventRecord(h->evpool[2 * timed], st));
             lu_gemm<<<grid, 256, 0, st>>>(A, n, lda, ncols, (int)j0, (int)j1);
+            NODAL_HIP_TRY(h, hipEventRecord(h->evpool[2 * timed + 1], st));
+            ++timed;
+            flops += 2.0 * (double)(j1 - j0) * (double)(n - j1) * (double)(ncols - j1);
         }
         NODAL_HIP_TRY(h, hipGetLastError());
     }
@@ -274,5 +288,13 @@ int dense_factor_solve(nodal_ctx *h, int32_t *info) {
     NODAL_HIP_TRY(h, hipMemcpyAsync(&hinfo, dinfo, 4, hipMemcpyDeviceToHost, st));
     NODAL_HIP_TRY(h, hipStreamSynchronize(st));
     *info = hinfo;
+    h->kern_ms = 0;
+    for (size_t i = 0; i < timed; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, h->evpool[2 * i], h->evpool[2 * i + 1]) == hipSuccess)
+            h->kern_ms += ms;
+    }
+    h->kern_launches = (int64_t)timed;
+    h->kern_alg = timed ? flops / (double)timed : 0.0;  // average flops per launch
     return NODAL_OK;
 }

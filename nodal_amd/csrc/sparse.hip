@@ -118,7 +118,7 @@ __global__ __launch_bounds__(TB) void pcg_direction(const double *__restrict__ z
     const double rz_new = reduce_partials(part_rz, nparts);
     const double rr = reduce_partials(part_rr, nparts);
     const double rz_old = iter > 0 ? sc[(iter - 1) & 1] : 1.0;
-    const double beta = iter > 0 ? rz_new / rz_old : 0.0;
+    const double beta = (iter > 0 && rz_old != 0.0) ? rz_new / rz_old : 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         sc[iter & 1] = rz_new;
         sc[S_RR] = rr;
