@@ -127,6 +127,18 @@ int nodal_last_kernel_stats(nodal_handle h, double *ms_total, int64_t *launches,
 
 int nodal_synchronize(nodal_handle h);
 
+/* ---- options -------------------------------------------------------------
+ * NODAL_OPT_FORCE_PIVOTING (0/1): dense LU always searches pivots, even on
+ *   passive networks (column diagonally dominant G) where it provably never swaps. */
+enum { NODAL_OPT_FORCE_PIVOTING = 1 };
+int nodal_set_option(nodal_handle h, int32_t option, int32_t value);
+
+/* ---- testing hooks (not part of the reference-facing surface) -------------
+ * C[M x N] -= A[M x K] * B[K x N] on the device with the LU's trailing-update
+ * kernel; host buffers, column-major, leading dimensions M, K, M. */
+int nodal_debug_gemm(nodal_handle h, int32_t M, int32_t N, int32_t K, const double *A,
+                     const double *B, double *C);
+
 #ifdef __cplusplus
 }
 #endif

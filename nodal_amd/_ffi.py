@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libnodal_hip.so")
 OK, E_INVALID, E_HIP, E_ZERO_RESISTANCE, E_STAMP_COLLISION, E_SINGULAR, E_NOMEM, \
     E_UNSUPPORTED = range(8)
 SPARSE_AUTO, SPARSE_PCG, SPARSE_DENSIFY, SPARSE_LU = range(4)
+OPT_FORCE_PIVOTING = 1
 
 _p = C.POINTER
 _i32p, _i64p, _f64p, _u8p = _p(C.c_int32), _p(C.c_int64), _p(C.c_double), _p(C.c_uint8)
@@ -44,6 +45,8 @@ SIGNATURES = {
     "nodal_last_timings": (C.c_int, [C.c_void_p, _f64p]),
     "nodal_last_kernel_stats": (C.c_int, [C.c_void_p, _f64p, _i64p, _f64p]),
     "nodal_synchronize": (C.c_int, [C.c_void_p]),
+    "nodal_set_option": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "nodal_debug_gemm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p, _f64p]),
 }
 
 _lib = None
@@ -207,6 +210,18 @@ class Handle:
         self._check(self.lib.nodal_last_kernel_stats(self._h, C.byref(ms), C.byref(launches),
                                                      C.byref(alg)))
         return ms.value, launches.value, alg.value
+
+    def set_option(self, option, value):
+        self._check(self.lib.nodal_set_option(self._h, option, int(value)))
+
+    def debug_gemm(self, A, B, Cm):
+        """C - A @ B through the LU's trailing-update kernel (testing hook)."""
+        A, B, Cm = (np.asfortranarray(x, dtype=np.float64) for x in (A, B, Cm))
+        out = Cm.copy(order="F")
+        self._check(self.lib.nodal_debug_gemm(self._h, A.shape[0], B.shape[1], A.shape[1],
+                                              _ptr(A, C.c_double), _ptr(B, C.c_double),
+                                              _ptr(out, C.c_double)))
+        return out
 
     def synchronize(self):
         self._check(self.lib.nodal_synchronize(self._h))

@@ -177,8 +177,8 @@ int nodal_export_dense(nodal_handle h, double *G, double *rhs) {
     DeviceGuard g(h);
     const int64_t n = h->n;
     if (G && n) {
-        NODAL_HIP_TRY(h, h->dense.reserve((size_t)n * (size_t)(n + 1) * 8 + 64));
-        NODAL_TRY(stamp_to_dense(h, h->dense.as<double>(), false));
+        NODAL_HIP_TRY(h, h->dense.reserve((size_t)dense_lda(n) * (size_t)(n + 1) * 8 + 64));
+        NODAL_TRY(stamp_to_dense(h, h->dense.as<double>(), n, false));
         NODAL_HIP_TRY(h, hipMemcpyAsync(G, h->dense.p, (size_t)n * n * 8, hipMemcpyDeviceToHost,
                                         h->stream));
     }
@@ -267,6 +267,34 @@ int nodal_last_kernel_stats(nodal_handle h, double *ms_total, int64_t *launches,
     if (ms_total) *ms_total = h->kern_ms;
     if (launches) *launches = h->kern_launches;
     if (alg_bytes_or_flops) *alg_bytes_or_flops = h->kern_alg;
+    return NODAL_OK;
+}
+
+int nodal_set_option(nodal_handle h, int32_t option, int32_t value) {
+    if (!h) return NODAL_E_INVALID;
+    if (option == NODAL_OPT_FORCE_PIVOTING) {
+        h->force_pivoting = value != 0;
+        return NODAL_OK;
+    }
+    return nodal_fail(h, NODAL_E_INVALID, "unknown option");
+}
+
+int nodal_debug_gemm(nodal_handle h, int32_t M, int32_t N, int32_t K, const double *A,
+                     const double *B, double *C) {
+    if (!h || M < 1 || N < 1 || K < 1 || !A || !B || !C) return NODAL_E_INVALID;
+    DeviceGuard g(h);
+    const size_t sa = (size_t)M * K * 8, sb = (size_t)K * N * 8, sc = (size_t)M * N * 8;
+    NODAL_HIP_TRY(h, h->work.reserve(sa + sb + sc + 768));
+    char *w = h->work.as<char>();
+    double *dA = reinterpret_cast<double *>(w);
+    double *dB = reinterpret_cast<double *>(w + ((sa + 255) & ~(size_t)255));
+    double *dC = reinterpret_cast<double *>(w + ((sa + 255) & ~(size_t)255) + ((sb + 255) & ~(size_t)255));
+    NODAL_HIP_TRY(h, hipMemcpyAsync(dA, A, sa, hipMemcpyHostToDevice, h->stream));
+    NODAL_HIP_TRY(h, hipMemcpyAsync(dB, B, sb, hipMemcpyHostToDevice, h->stream));
+    NODAL_HIP_TRY(h, hipMemcpyAsync(dC, C, sc, hipMemcpyHostToDevice, h->stream));
+    NODAL_TRY(gemm_sub_f64(h, dC, M, dA, M, dB, K, M, N, K));
+    NODAL_HIP_TRY(h, hipMemcpyAsync(C, dC, sc, hipMemcpyDeviceToHost, h->stream));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
     return NODAL_OK;
 }
 

@@ -65,6 +65,8 @@ struct nodal_ctx {
 
     // ---- numeric assembly results ----
     bool have_numeric = false;
+    bool force_pivoting = false;   // testing: use the tournament path even when passive
+    bool passive_network = false;  // B == 0 and all R > 0 (set by stamp_numeric)
     DevBuf data;            // f64[nnz]
     DevBuf rhs;             // f64[n]
     DevBuf status;          // i64[4] device-side error words
@@ -120,9 +122,21 @@ int scan_exclusive_u32(nodal_ctx *h, const uint32_t *in, uint32_t *out, int64_t 
 // ---- stamping (stamp.hip) ----
 int stamp_symbolic(nodal_ctx *h);
 int stamp_numeric(nodal_ctx *h, int32_t member, int64_t *bad_component);
-int stamp_to_dense(nodal_ctx *h, double *G_dev, bool col_major);
+int stamp_to_dense(nodal_ctx *h, double *G_dev, int64_t ld, bool col_major);
+
+// ---- fp64 MFMA GEMM (gemm_f64.hip): C -= A * B, column-major ----
+int gemm_sub_f64(nodal_ctx *h, double *C, int64_t ldc, const double *A, int64_t lda,
+                 const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K);
 
 // ---- dense LU (dense_lu.hip) ----
+// leading dimension of the column-major dense panel: padded so that 32-row tiles
+// are aligned and columns do not alias on the HBM channels
+static inline int64_t dense_lda(int64_t n) {
+    int64_t l = (n + 31) & ~(int64_t)31;
+    if (l < 32) l = 32;
+    if (l % 1024 == 0) l += 32;
+    return l;
+}
 int dense_factor_solve(nodal_ctx *h, int32_t *info);
 
 // ---- sparse solvers (sparse_*.hip) ----

@@ -1,31 +1,72 @@
-// Dense path of Circuit.solve: LU with partial (row) pivoting + triangular
-// solves, fp64 -- the arithmetic LAPACK dgesv performs behind
-// np.linalg.solve(G, A) (reference nodal/nodal.py:327).
+// Dense path of Circuit.solve: LU with row pivoting + triangular solves, fp64 --
+// the arithmetic LAPACK dgesv performs behind np.linalg.solve(G, A)
+// (reference nodal/nodal.py:327).
 //
-// Layout: column-major n x (n+1) in HBM; column n is the right-hand side, so the
-// row interchanges and the forward substitution L y = P b happen as part of the
-// blocked factorisation (the rhs is just one more trailing column).  Pivot rule
-// as LAPACK idamax: first row of maximal |a|; an exactly zero pivot sets
-// info = column + 1 and the factorisation continues without scaling.
+// Layout: column-major, leading dimension lda = dense_lda(n) (padded), n + 1
+// columns: column n is the right-hand side, so the row interchanges and the
+// forward substitution L y = P b happen as part of the blocked factorisation.
+//
+// Two regimes:
+//   n <= GEPP_MAX  classic partial pivoting, one pivot search per column with the
+//                  LAPACK idamax rule (first row of maximal |a|): the same pivot
+//                  sequence as dgetrf, for the small circuits whose printed digits
+//                  users compare with the reference.
+//   n >  GEPP_MAX  two-level blocking for the matrix cores.  Outer panels of W = 256
+//                  columns feed a K = 256 trailing update (gemm_f64.hip; 32 flop per
+//                  byte of C traffic, MFMA-bound).  Inside an outer panel, blocks of
+//                  32 columns are pivoted by a tournament (communication-avoiding
+//                  LU, Grigori/Demmel/Xiang): every 256-row slab elects 32 candidate
+//                  rows by partial pivoting on a register-resident copy, candidates
+//                  are merged 8 slabs at a time, and the winners' LU is the block's
+//                  L11/U11.  That replaces 2 launches per COLUMN by ~7 per 32 columns;
+//                  its stability is that of partial pivoting in practice and the
+//                  solution is checked by the scaled residual.
+//   passive        resistors + current sources only, all R > 0 (B == 0): G is column
+//   networks       diagonally dominant, and on such matrices partial pivoting never
+//   (n > GEPP_MAX) interchanges -- the diagonal is a maximal entry of its column, idamax
+//                  resolves ties to the first row, which IS the diagonal, and Schur
+//                  complements of column diagonally dominant matrices stay so.  The
+//                  pivot search is skipped: same pivot sequence as dgetrf, none of its
+//                  latency.  (BASELINE.json configs 2 and 4.)
+// An exactly zero pivot sets info = column + 1 (LAPACK convention).
 #include "ctx.h"
 
 namespace {
 
-constexpr int NB = 32;  // panel width
+constexpr int NB = 32;          // inner block
+constexpr int W = 256;          // outer panel (K of the trailing update)
+constexpr int GEPP_MAX = 2048;  // above this, tournament pivoting
+constexpr int SLAB = 256;       // rows per tournament workgroup
 
 struct MaxLoc {
     double v;
     int i;
 };
 
+typedef const __attribute__((address_space(3))) double *lds_cptr;
+
+// Launder an LDS pointer so the optimiser can no longer prove that the
+// `asm volatile("" ::: "memory")` fences below leave the array untouched.  Without
+// it LICM hoists every (loop-invariant) LDS read of a fully unrolled triangular
+// solve out of the loop: ~500 live doubles, 256 VGPRs and 2.5 KB of scratch per lane.
+__device__ __forceinline__ lds_cptr opaque_lds(const double *p) {
+    lds_cptr q = (lds_cptr)p;
+    asm volatile("" : "+v"(q)::"memory");
+    return q;
+}
+
 __device__ __forceinline__ MaxLoc better(MaxLoc a, MaxLoc b) {
-    // larger magnitude wins; on ties the smaller row index (idamax semantics)
+    // larger magnitude wins; on ties the smaller index (idamax semantics)
     if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
     return a;
 }
 
-// One workgroup: find the pivot of column c among rows c..n-1, record it, then
-// swap rows c and pivot inside the panel columns [j0, j1).
+// ---------------------------------------------------------------------------------
+// classic partial pivoting (small n)
+// ---------------------------------------------------------------------------------
+
+// One workgroup: pivot of column c among rows c..n-1, then swap rows c and pivot
+// inside the panel columns [j0, j1).
 __global__ __launch_bounds__(1024) void lu_pivot_swap(double *__restrict__ A, int64_t n,
                                                       int64_t lda, int c, int j0, int j1,
                                                       int32_t *__restrict__ piv,
@@ -36,8 +77,7 @@ __global__ __launch_bounds__(1024) void lu_pivot_swap(double *__restrict__ A, in
     MaxLoc best{-1.0, 0x7fffffff};
     for (int i = c + threadIdx.x; i < n; i += 1024) {
         const double v = fabs(col[i]);
-        // NaN never compares greater: it is skipped exactly as idamax skips it
-        if (v > best.v) best = MaxLoc{v, i};
+        if (v > best.v) best = MaxLoc{v, i};  // NaN never compares greater
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -66,8 +106,7 @@ __global__ __launch_bounds__(1024) void lu_pivot_swap(double *__restrict__ A, in
     }
 }
 
-// rows below the diagonal of column c: l = a / pivot, then rank-1 update of the
-// remaining panel columns (c, j1)
+// rows below the diagonal of column c: l = a / pivot, rank-1 update of (c, j1)
 __global__ __launch_bounds__(256) void lu_scale_update(double *__restrict__ A, int64_t n,
                                                        int64_t lda, int c, int j1) {
     const double pivot = A[(int64_t)c * lda + c];
@@ -84,15 +123,20 @@ __global__ __launch_bounds__(256) void lu_scale_update(double *__restrict__ A, i
     }
 }
 
-// apply the panel's interchanges to every column outside the panel
-__global__ __launch_bounds__(256) void lu_swap_outside(double *__restrict__ A, int64_t lda,
-                                                       int64_t ncols, int j0, int j1,
-                                                       const int32_t *__restrict__ piv) {
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < ncols;
+// ---------------------------------------------------------------------------------
+// shared pieces
+// ---------------------------------------------------------------------------------
+
+// apply interchanges piv[c], c in [c0, c1), to the columns [q0, q1) except [x0, x1)
+__global__ __launch_bounds__(256) void lu_swap_cols(double *__restrict__ A, int64_t lda,
+                                                    int64_t q0, int64_t q1, int64_t x0,
+                                                    int64_t x1, int c0, int c1,
+                                                    const int32_t *__restrict__ piv) {
+    for (int64_t q = q0 + (int64_t)blockIdx.x * 256 + threadIdx.x; q < q1;
          q += (int64_t)gridDim.x * 256) {
-        if (q >= j0 && q < j1) continue;
+        if (q >= x0 && q < x1) continue;
         double *cq = A + q * lda;
-        for (int c = j0; c < j1; ++c) {
+        for (int c = c0; c < c1; ++c) {
             const int p = piv[c];
             if (p != c) {
                 const double t = cq[c];
@@ -103,80 +147,330 @@ __global__ __launch_bounds__(256) void lu_swap_outside(double *__restrict__ A, i
     }
 }
 
-// U12 = L11^-1 A12 for the columns right of the panel (unit lower triangular)
-__global__ __launch_bounds__(256) void lu_trsm(double *__restrict__ A, int64_t lda, int64_t ncols,
-                                               int j0, int j1) {
+// U12 = L11^-1 A12 for columns [q0, q1), L11 = unit lower nb x nb block at (j0, j0)
+template <bool FULL>  // FULL: nb == NB, no per-element predicates (the hot case)
+__global__ __launch_bounds__(256) void lu_trsm32(double *__restrict__ A, int64_t lda, int64_t q0,
+                                                 int64_t q1, int j0, int nb_) {
+    const int nb = FULL ? NB : nb_;
     __shared__ double L[NB][NB + 1];
-    const int nb = j1 - j0;
     for (int t = threadIdx.x; t < NB * NB; t += 256) {
         const int r = t % NB, s = t / NB;
         L[r][s] = (r < nb && s < nb) ? A[(int64_t)(j0 + s) * lda + j0 + r] : 0.0;
     }
     __syncthreads();
-    for (int64_t q = j1 + (int64_t)blockIdx.x * 256 + threadIdx.x; q < ncols;
+    lds_cptr Lp = opaque_lds(&L[0][0]);
+    for (int64_t q = q0 + (int64_t)blockIdx.x * 256 + threadIdx.x; q < q1;
          q += (int64_t)gridDim.x * 256) {
         double *cq = A + q * lda + j0;
         double u[NB];
 #pragma unroll
-        for (int r = 0; r < NB; ++r) u[r] = r < nb ? cq[r] : 0.0;
+        for (int r = 0; r < NB; ++r) u[r] = (FULL || r < nb) ? cq[r] : 0.0;
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
 #pragma unroll
-            for (int s = r + 1; s < NB; ++s) u[s] = fma(-L[s][r], u[r], u[s]);
+            for (int s = r + 1; s < NB; ++s) u[s] = fma(-Lp[s * (NB + 1) + r], u[r], u[s]);
+            asm volatile("" ::: "memory");  // with the laundered pointer: no hoisting (IR level)
+            __builtin_amdgcn_sched_barrier(0);  // ... nor clustering by the machine scheduler
         }
 #pragma unroll
         for (int r = 0; r < NB; ++r)
-            if (r < nb) cq[r] = u[r];
+            if (FULL || r < nb) cq[r] = u[r];
     }
 }
 
-// trailing update C -= L21 * U12 : C rows [j1, n), cols [j1, ncols), K = [j0, j1)
-// 64 x 64 tile per workgroup, 4 x 4 per lane, operands staged through LDS.
-__global__ __launch_bounds__(256) void lu_gemm(double *__restrict__ A, int64_t n, int64_t lda,
-                                               int64_t ncols, int j0, int j1) {
-    __shared__ double Ls[NB][64 + 1];  // [k][row]
-    __shared__ double Us[NB][64 + 1];  // [k][col]
-    const int nb = j1 - j0;
-    const int64_t row0 = j1 + (int64_t)blockIdx.x * 64;
-    const int64_t col0 = j1 + (int64_t)blockIdx.y * 64;
-    for (int t = threadIdx.x; t < NB * 64; t += 256) {
-        const int r = t % 64, kk = t / 64;
-        const int64_t gr = row0 + r;
-        Ls[kk][r] = (kk < nb && gr < n) ? A[(int64_t)(j0 + kk) * lda + gr] : 0.0;
+// ---------------------------------------------------------------------------------
+// tournament pivoting
+// ---------------------------------------------------------------------------------
+
+// Wave-wide unsigned max with DPP (row_shr 1,2,4,8 inside rows of 16, then
+// row_bcast15 / row_bcast31): six v_max_u32_dpp + one v_readlane instead of a
+// chain of ds_bpermute shuffles, whose latency dominated the pivot search.
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// One workgroup = up to SLAB rows, one row per lane held in registers (current
+// and original values).  Partial pivoting on that copy elects nbc rows; their
+// indices and ORIGINAL values go to the candidate buffers in pivot order, so the
+// next level reads a compact, coalesced image instead of gathering matrix rows.
+//
+// One barrier per column: each wave finds its best row (DPP max on the top 32 bits
+// of |a|: 20 mantissa bits, plenty for choosing a tournament pivot) and that lane
+// speculatively publishes its row and 1/pivot to LDS; after the barrier every
+// lane reads the four wave keys, picks the winning wave (lowest on ties) and
+// eliminates with its row.  LDS images are double buffered across columns.
+//
+// At the final level (one workgroup) the winners' eliminated rows ARE the block's
+// L11\U11: they are written to lu11 (32 x 32, column-major) and the LAPACK-style
+// interchange list piv[c0 .. c0+nbc) is derived from the winners.
+template <bool FROM_LIST, bool FULL>
+__global__ __launch_bounds__(SLAB) void tslu_select(
+    const double *__restrict__ A, int64_t lda, int n, int c0, int nbc_,
+    const int32_t *__restrict__ cand_in, const double *__restrict__ val_in, int ncand_in,
+    int in_stride, int32_t *__restrict__ cand_out, double *__restrict__ val_out, int out_stride,
+    int final_level, double *__restrict__ lu11, int32_t *__restrict__ piv,
+    int32_t *__restrict__ info) {
+    constexpr int WAVES = SLAB / 64;
+    __shared__ double prow[2][WAVES][NB];
+    __shared__ double prcp[2][WAVES];
+    __shared__ unsigned keys[2][WAVES];
+    __shared__ int sel[NB];
+    const int nbc = FULL ? NB : nbc_;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int row = -1;
+    double a[NB], orig[NB];
+    if (FROM_LIST) {
+        const int idx = blockIdx.x * SLAB + t;
+        if (idx < ncand_in) row = cand_in[idx];
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+            a[q] = (row >= 0 && (FULL || q < nbc)) ? val_in[(int64_t)q * in_stride + idx] : 0.0;
+    } else {
+        const int r = c0 + blockIdx.x * SLAB + t;
+        if (r < n) row = r;
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+            a[q] = (row >= 0 && (FULL || q < nbc)) ? A[(int64_t)(c0 + q) * lda + row] : 0.0;
     }
-    for (int t = threadIdx.x; t < NB * 64; t += 256) {
-        const int kk = t % NB, cc = t / NB;
-        const int64_t gc = col0 + cc;
-        Us[kk][cc] = (kk < nb && gc < ncols) ? A[gc * lda + j0 + kk] : 0.0;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) orig[q] = a[q];
+    bool active = row >= 0;
+
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        if (FULL || c < nbc) {  // uniform
+            const int buf = c & 1;
+            unsigned key = 0;
+            if (active) {
+                const double v = fabs(a[c]);
+                key = (v == v ? (unsigned)__double2hiint(v) : 0u) + 1u;  // NaN ranks last
+            }
+            const unsigned wmax = wave_umax(key);
+            const unsigned long long mine = __ballot(key == wmax && key != 0);
+            const int lane_w = mine ? __ffsll((long long)mine) - 1 : -1;
+            if (lane == lane_w) {
+                keys[buf][wave] = wmax;
+                prcp[buf][wave] = a[c] != 0.0 ? 1.0 / a[c] : 0.0;
+#pragma unroll
+                for (int q = 0; q < NB; ++q) prow[buf][wave][q] = a[q];
+            }
+            if (lane_w < 0 && lane == 0) keys[buf][wave] = 0;
+            __syncthreads();
+            unsigned kbest = keys[buf][0];
+            int wb = 0;
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) {
+                const unsigned kw = keys[buf][w];
+                if (kw > kbest) { kbest = kw; wb = w; }
+            }
+            const bool any = kbest != 0;
+            if (any && wave == wb && lane == lane_w) {
+                sel[c] = row;
+                active = false;
+                const int slot = blockIdx.x * NB + c;
+#pragma unroll
+                for (int q = 0; q < NB; ++q) val_out[(int64_t)q * out_stride + slot] = orig[q];
+                if (final_level) {
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) lu11[q * NB + c] = a[q];
+                    if (a[c] == 0.0) atomicCAS(info, 0, c0 + c + 1);  // exact zero pivot
+                }
+            } else if (any && active) {
+                const double rc = prcp[buf][wb];
+                if (rc != 0.0) {
+                    const double l = a[c] * rc;
+                    a[c] = l;
+#pragma unroll
+                    for (int q = c + 1; q < NB; ++q) a[q] = fma(-l, prow[buf][wb][q], a[q]);
+                }
+            }
+            if (!any && t == 0) sel[c] = -1;
+        }
     }
     __syncthreads();
-    const int tr = (threadIdx.x % 16) * 4, tc = (threadIdx.x / 16) * 4;
-    double acc[4][4] = {};
-#pragma unroll 8
-    for (int kk = 0; kk < NB; ++kk) {
-        double a[4], b[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = Ls[kk][tr + i];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = Us[kk][tc + j];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t gc = col0 + tc + j;
-        if (gc >= ncols) continue;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t gr = row0 + tr + i;
-            if (gr < n) A[gc * lda + gr] -= acc[i][j];
+    if (t < NB) cand_out[blockIdx.x * NB + t] = t < nbc ? sel[t] : -1;
+
+    if (final_level && t < 64) {
+        // Turn "row sel[c] becomes row c0+c" into sequential interchanges.  Only the
+        // positions c0..c0+nbc-1 and the winners' home positions are ever touched:
+        // lane i of wave 0 tracks one such position and what currently sits there.
+        __shared__ int s_pos[2 * NB], s_content[2 * NB];
+        const int r = t < nbc ? sel[t] : -1;
+        const bool extra = t < nbc && r >= c0 + nbc;
+        const unsigned long long em = __ballot(extra);
+        if (t < nbc) { s_pos[t] = c0 + t; s_content[t] = c0 + t; }
+        if (extra) {
+            const int at = nbc + __popcll(em & ((1ull << t) - 1ull));
+            s_pos[at] = r;
+            s_content[at] = r;
+        }
+        const int cnt = nbc + __popcll(em);
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): one wave, LDS writes done
+        __builtin_amdgcn_wave_barrier();
+        for (int c = 0; c < nbc; ++c) {
+            const int want = sel[c];
+            const bool hit = t < cnt && want >= 0 && s_content[t] == want;
+            const unsigned long long hm = __ballot(hit);
+            const int at = hm ? __ffsll((long long)hm) - 1 : c;
+            if (t == 0) {
+                piv[c0 + c] = s_pos[at];
+                const int tmp = s_content[c];
+                s_content[c] = s_content[at];
+                s_content[at] = tmp;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
 
-// back substitution, one diagonal block: solve U[j0:j1, j0:j1] x = y in place
+// Unpivoted LU of the nbc x nbc diagonal block at (c0, c0), in LDS; the factors go to
+// lu11 (and tslu_apply writes them back).  piv = identity.
+__global__ __launch_bounds__(256) void diag_lu_nopivot(const double *__restrict__ A, int64_t lda,
+                                                       int c0, int nbc, double *__restrict__ lu11,
+                                                       int32_t *__restrict__ piv,
+                                                       int32_t *__restrict__ info) {
+    __shared__ double D[NB][NB + 1];  // D[r][c]
+    for (int t = threadIdx.x; t < NB * NB; t += 256) {
+        const int r = t % NB, c = t / NB;
+        D[r][c] = (r < nbc && c < nbc) ? A[(int64_t)(c0 + c) * lda + c0 + r] : (r == c ? 1.0 : 0.0);
+    }
+    if (threadIdx.x < nbc) piv[c0 + threadIdx.x] = c0 + threadIdx.x;
+    __syncthreads();
+    const int r = threadIdx.x % NB, cg = threadIdx.x / NB;  // 8 column groups
+    for (int k = 0; k < NB - 1; ++k) {
+        const double pv = D[k][k];
+        if (pv == 0.0 && threadIdx.x == 0 && k < nbc) atomicCAS(info, 0, c0 + k + 1);
+        const double l = (r > k && pv != 0.0) ? D[r][k] * (1.0 / pv) : 0.0;
+        __syncthreads();
+        if (r > k) {
+            if (cg == 0) D[r][k] = l;
+            for (int c = k + 1 + cg; c < NB; c += 8) D[r][c] = fma(-l, D[k][c], D[r][c]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && nbc == NB && D[NB - 1][NB - 1] == 0.0) atomicCAS(info, 0, c0 + NB);
+    for (int t = threadIdx.x; t < NB * NB; t += 256) {
+        const int rr = t % NB, c = t / NB;
+        lu11[c * NB + rr] = D[rr][c];
+    }
+}
+
+// After the interchanges: rows [c0, c0+nbc) of the block receive L11\U11, every row
+// below solves x U11 = a (its row of L21).  One lane per row.
+template <bool FULL>
+__global__ __launch_bounds__(256) void tslu_apply(double *__restrict__ A, int64_t lda, int n,
+                                                  int c0, int nbc_,
+                                                  const double *__restrict__ lu11) {
+    const int nbc = FULL ? NB : nbc_;
+    __shared__ double U[NB][NB + 1];  // U[s][c]
+    __shared__ double rcp[NB];
+    for (int t = threadIdx.x; t < NB * NB; t += 256) {
+        const int s = t % NB, c = t / NB;
+        U[s][c] = lu11[c * NB + s];
+    }
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        const double d = U[threadIdx.x][threadIdx.x];
+        rcp[threadIdx.x] = d != 0.0 ? 1.0 / d : 0.0;
+    }
+    __syncthreads();
+    lds_cptr Up = opaque_lds(&U[0][0]);
+    for (int64_t r = c0 + (int64_t)blockIdx.x * 256 + threadIdx.x; r < n;
+         r += (int64_t)gridDim.x * 256) {
+        double *ar = A + (int64_t)c0 * lda + r;
+        if (r < c0 + nbc) {
+            const int rr = (int)(r - c0);
+            for (int q = 0; q < nbc; ++q) ar[(int64_t)q * lda] = lu11[q * NB + rr];
+            continue;
+        }
+        double x[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) x[q] = (FULL || q < nbc) ? ar[(int64_t)q * lda] : 0.0;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            const double xc = x[c] * rcp[c];
+            x[c] = xc;
+#pragma unroll
+            for (int q = c + 1; q < NB; ++q) x[q] = fma(-xc, Up[c * (NB + 1) + q], x[q]);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+            if (FULL || q < nbc) ar[(int64_t)q * lda] = x[q];
+    }
+}
+
+// U12 = L11^-1 A12 with a W x W unit lower triangular L11 at (j0, j0): one workgroup
+// per 32 columns; the W x 32 tile of A12 lives in LDS for the whole solve and L11 is
+// streamed through LDS in 32 x 32 blocks (diagonal block: substitution; blocks
+// below: rank-32 update with the just-solved rows held in registers).
+__global__ __launch_bounds__(256) void trsm_outer(double *__restrict__ A, int64_t lda, int64_t q0,
+                                                  int64_t q1, int j0, int w) {
+    __shared__ double T[32][W + 1];
+    __shared__ double Lb[NB][NB + 1];  // Lb[r][k]
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;  // 8 row groups
+    const int64_t q = q0 + (int64_t)blockIdx.x * 32 + col;
+    const bool live = q < q1;
+    for (int r = grp; r < w; r += 8) T[col][r] = live ? A[q * lda + j0 + r] : 0.0;
+    const int nblk = (w + NB - 1) / NB;
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int base = kb * NB;
+        // diagonal block -> LDS
+        __syncthreads();
+        for (int t = threadIdx.x; t < NB * NB; t += 256) {
+            const int r = t % NB, k = t / NB;
+            Lb[r][k] = (base + r < w && base + k < w)
+                           ? A[(int64_t)(j0 + base + k) * lda + j0 + base + r] : 0.0;
+        }
+        __syncthreads();
+        for (int k = 0; k < NB - 1; ++k) {
+            const double xk = T[col][base + k];
+            for (int r = k + 1 + grp; r < NB; r += 8)
+                if (base + r < w) T[col][base + r] = fma(-Lb[r][k], xk, T[col][base + r]);
+            __syncthreads();
+        }
+        double x[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) x[k] = base + k < w ? T[col][base + k] : 0.0;
+        // blocks below the diagonal
+        for (int rb = kb + 1; rb < nblk; ++rb) {
+            const int rbase = rb * NB;
+            __syncthreads();
+            for (int t = threadIdx.x; t < NB * NB; t += 256) {
+                const int r = t % NB, k = t / NB;
+                Lb[r][k] = (rbase + r < w && base + k < w)
+                               ? A[(int64_t)(j0 + base + k) * lda + j0 + rbase + r] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NB / 8; ++i) {
+                const int r = grp + 8 * i;
+                if (rbase + r < w) {
+                    double acc = T[col][rbase + r];
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) acc = fma(-Lb[r][k], x[k], acc);
+                    T[col][rbase + r] = acc;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (live)
+        for (int r = grp; r < w; r += 8) A[q * lda + j0 + r] = T[col][r];
+}
+
+// ---------------------------------------------------------------------------------
+// back substitution
+// ---------------------------------------------------------------------------------
+
 __global__ __launch_bounds__(64) void bs_diag(const double *__restrict__ A, int64_t lda,
                                               double *__restrict__ y, int j0, int j1) {
     __shared__ double U[NB][NB + 1];
@@ -186,7 +480,7 @@ __global__ __launch_bounds__(64) void bs_diag(const double *__restrict__ A, int6
         const int r = t % NB, s = t / NB;
         U[r][s] = (r < nb && s < nb) ? A[(int64_t)(j0 + s) * lda + j0 + r] : 0.0;
     }
-    if (threadIdx.x < NB) x[threadIdx.x] = threadIdx.x < nb ? y[j0 + threadIdx.x] : 0.0;
+    if (threadIdx.x < NB) x[threadIdx.x] = (int)threadIdx.x < nb ? y[j0 + threadIdx.x] : 0.0;
     __syncthreads();
     for (int r = nb - 1; r >= 0; --r) {
         if (threadIdx.x == 0) x[r] = x[r] / U[r][r];
@@ -197,7 +491,6 @@ __global__ __launch_bounds__(64) void bs_diag(const double *__restrict__ A, int6
     if ((int)threadIdx.x < nb) y[j0 + threadIdx.x] = x[threadIdx.x];
 }
 
-// y[0:j0] -= U[0:j0, j0:j1] * x[j0:j1]
 __global__ __launch_bounds__(256) void bs_update(const double *__restrict__ A, int64_t lda,
                                                  double *__restrict__ y, int j0, int j1) {
     __shared__ double x[NB];
@@ -224,35 +517,40 @@ unsigned blocks_for(int64_t work, int per_block) {
     return (unsigned)b;
 }
 
-}  // namespace
-
-int dense_fill_nan(nodal_ctx *h, double *x, int64_t n) {
-    fill_nan<<<blocks_for(n, 256), 256, 0, h->stream>>>(x, n);
-    NODAL_HIP_TRY(h, hipGetLastError());
-    return NODAL_OK;
-}
-
-// Factor the column-major n x (n+1) augmented matrix in h->dense and leave the
-// solution in h->x.  *info as LAPACK dgesv.
-int dense_factor_solve(nodal_ctx *h, int32_t *info) {
-    const int64_t n = h->n, lda = n, ncols = n + 1;
-    hipStream_t st = h->stream;
-    double *A = h->dense.as<double>();
-    NODAL_HIP_TRY(h, h->piv.reserve((size_t)n * 4 + 64));
-    int32_t *piv = h->piv.as<int32_t>();
-    int32_t *dinfo = piv + n;  // one spare word after the pivots
-    NODAL_HIP_TRY(h, hipMemsetAsync(dinfo, 0, 4, st));
-
-    // HIP-event pairs around every trailing-update launch (the dominant kernel)
-    const size_t npanels = (size_t)((n + NB - 1) / NB);
-    while (h->evpool.size() < 2 * npanels) {
-        hipEvent_t e;
-        NODAL_HIP_TRY(h, hipEventCreate(&e));
-        h->evpool.push_back(e);
-    }
-    size_t timed = 0;
+struct GemmTimer {
+    nodal_ctx *h;
+    size_t used = 0;
     double flops = 0;
+    int begin() {
+        while (h->evpool.size() < 2 * (used + 1)) {
+            hipEvent_t e;
+            NODAL_HIP_TRY(h, hipEventCreate(&e));
+            h->evpool.push_back(e);
+        }
+        NODAL_HIP_TRY(h, hipEventRecord(h->evpool[2 * used], h->stream));
+        return NODAL_OK;
+    }
+    int end(double f) {
+        NODAL_HIP_TRY(h, hipEventRecord(h->evpool[2 * used + 1], h->stream));
+        ++used;
+        flops += f;
+        return NODAL_OK;
+    }
+    void collect() {
+        h->kern_ms = 0;
+        for (size_t i = 0; i < used; ++i) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, h->evpool[2 * i], h->evpool[2 * i + 1]) == hipSuccess)
+                h->kern_ms += ms;
+        }
+        h->kern_launches = (int64_t)used;
+        h->kern_alg = used ? flops / (double)used : 0.0;  // average flops per launch
+    }
+};
 
+int factor_gepp(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncols, int32_t *piv,
+                int32_t *dinfo, GemmTimer &tm) {
+    hipStream_t st = h->stream;
     for (int64_t j0 = 0; j0 < n; j0 += NB) {
         const int64_t j1 = j0 + NB < n ? j0 + NB : n;
         for (int64_t c = j0; c < j1; ++c) {
@@ -261,19 +559,168 @@ int dense_factor_solve(nodal_ctx *h, int32_t *info) {
                 lu_scale_update<<<blocks_for(n - c - 1, 256), 256, 0, st>>>(A, n, lda, (int)c,
                                                                            (int)j1);
         }
-        lu_swap_outside<<<blocks_for(ncols, 256), 256, 0, st>>>(A, lda, ncols, (int)j0, (int)j1,
-                                                               piv);
-        lu_trsm<<<blocks_for(ncols - j1, 256), 256, 0, st>>>(A, lda, ncols, (int)j0, (int)j1);
-        if (j1 < n) {
-            dim3 grid((unsigned)((n - j1 + 63) / 64), (unsigned)((ncols - j1 + 63) / 64));
-            NODAL_HIP_TRY(h, hipEventRecord(h->evpool[2 * timed], st));
-            lu_gemm<<<grid, 256, 0, st>>>(A, n, lda, ncols, (int)j0, (int)j1);
-            NODAL_HIP_TRY(h, hipEventRecord(h->evpool[2 * timed + 1], st));
-            ++timed;
-            flops += 2.0 * (double)(j1 - j0) * (double)(n - j1) * (double)(ncols - j1);
-        }
+        lu_swap_cols<<<blocks_for(ncols, 256), 256, 0, st>>>(A, lda, 0, ncols, j0, j1, (int)j0,
+                                                            (int)j1, piv);
+        if (j1 - j0 == NB)
+            lu_trsm32<true><<<blocks_for(ncols - j1, 256), 256, 0, st>>>(A, lda, j1, ncols, (int)j0, NB);
+        else
+            lu_trsm32<false><<<blocks_for(ncols - j1, 256), 256, 0, st>>>(A, lda, j1, ncols,
+                                                                         (int)j0, (int)(j1 - j0));
         NODAL_HIP_TRY(h, hipGetLastError());
+        if (j1 < n) {
+            NODAL_TRY(tm.begin());
+            NODAL_TRY(gemm_sub_f64(h, A + j1 * lda + j1, lda, A + j0 * lda + j1, lda,
+                                   A + j1 * lda + j0, lda, n - j1, ncols - j1, j1 - j0));
+            NODAL_TRY(tm.end(2.0 * (double)(j1 - j0) * (double)(n - j1) * (double)(ncols - j1)));
+        }
     }
+    return NODAL_OK;
+}
+
+int factor_tournament(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncols,
+                      int32_t *piv, int32_t *dinfo, GemmTimer &tm) {
+    hipStream_t st = h->stream;
+    // scratch: two candidate sets (row indices + original row values, [q][slot]) and
+    // the 32 x 32 winners' LU
+    const int64_t max_slabs = (n + SLAB - 1) / SLAB;
+    const int stride = (int)(max_slabs * NB);
+    const size_t idx_bytes = ((size_t)stride * 4 + 255) & ~(size_t)255;
+    const size_t val_bytes = ((size_t)stride * NB * 8 + 255) & ~(size_t)255;
+    NODAL_HIP_TRY(h, h->work.reserve(2 * (idx_bytes + val_bytes) + NB * NB * 8 + 256));
+    char *wbase = h->work.as<char>();
+    int32_t *cand[2] = {reinterpret_cast<int32_t *>(wbase),
+                        reinterpret_cast<int32_t *>(wbase + idx_bytes)};
+    double *cval[2] = {reinterpret_cast<double *>(wbase + 2 * idx_bytes),
+                       reinterpret_cast<double *>(wbase + 2 * idx_bytes + val_bytes)};
+    double *lu11 = reinterpret_cast<double *>(wbase + 2 * (idx_bytes + val_bytes));
+
+    for (int64_t J0 = 0; J0 < n; J0 += W) {
+        const int64_t J1 = J0 + W < n ? J0 + W : n;
+        for (int64_t c0 = J0; c0 < J1; c0 += NB) {
+            const int nbc = (int)(c0 + NB < J1 ? NB : J1 - c0);
+            // tournament: slabs of the panel, then 8-way merges down to one workgroup
+            int64_t groups = (n - c0 + SLAB - 1) / SLAB;
+            int cur = 0;
+            if (nbc == NB)
+                tslu_select<false, true><<<(unsigned)groups, SLAB, 0, st>>>(
+                    A, lda, (int)n, (int)c0, nbc, nullptr, nullptr, 0, 0, cand[cur], cval[cur],
+                    stride, groups == 1, lu11, piv, dinfo);
+            else
+                tslu_select<false, false><<<(unsigned)groups, SLAB, 0, st>>>(
+                    A, lda, (int)n, (int)c0, nbc, nullptr, nullptr, 0, 0, cand[cur], cval[cur],
+                    stride, groups == 1, lu11, piv, dinfo);
+            while (groups > 1) {
+                const int ncand = (int)groups * NB;
+                const int64_t next = (ncand + SLAB - 1) / SLAB;
+                if (nbc == NB)
+                    tslu_select<true, true><<<(unsigned)next, SLAB, 0, st>>>(
+                        A, lda, (int)n, (int)c0, nbc, cand[cur], cval[cur], ncand, stride,
+                        cand[cur ^ 1], cval[cur ^ 1], stride, next == 1, lu11, piv, dinfo);
+                else
+                    tslu_select<true, false><<<(unsigned)next, SLAB, 0, st>>>(
+                        A, lda, (int)n, (int)c0, nbc, cand[cur], cval[cur], ncand, stride,
+                        cand[cur ^ 1], cval[cur ^ 1], stride, next == 1, lu11, piv, dinfo);
+                cur ^= 1;
+                groups = next;
+            }
+            // interchanges inside the outer panel, L11\U11 + L21, then the rest of the panel
+            lu_swap_cols<<<blocks_for(J1 - J0, 256), 256, 0, st>>>(A, lda, J0, J1, 0, 0, (int)c0,
+                                                                  (int)c0 + nbc, piv);
+            if (nbc == NB)
+                tslu_apply<true><<<blocks_for(n - c0, 256), 256, 0, st>>>(A, lda, (int)n, (int)c0, NB, lu11);
+            else
+                tslu_apply<false><<<blocks_for(n - c0, 256), 256, 0, st>>>(A, lda, (int)n, (int)c0, nbc, lu11);
+            const int64_t c1 = c0 + nbc;
+            if (c1 < J1) {
+                if (nbc == NB)
+                    lu_trsm32<true><<<blocks_for(J1 - c1, 256), 256, 0, st>>>(A, lda, c1, J1, (int)c0, NB);
+                else
+                    lu_trsm32<false><<<blocks_for(J1 - c1, 256), 256, 0, st>>>(A, lda, c1, J1, (int)c0, nbc);
+                NODAL_TRY(gemm_sub_f64(h, A + c1 * lda + c1, lda, A + c0 * lda + c1, lda,
+                                       A + c1 * lda + c0, lda, n - c1, J1 - c1, nbc));
+            }
+            NODAL_HIP_TRY(h, hipGetLastError());
+        }
+        // outside the panel: interchanges, U12, trailing update
+        lu_swap_cols<<<blocks_for(ncols, 256), 256, 0, st>>>(A, lda, 0, ncols, J0, J1, (int)J0,
+                                                            (int)J1, piv);
+        trsm_outer<<<(unsigned)((ncols - J1 + 31) / 32), 256, 0, st>>>(A, lda, J1, ncols, (int)J0,
+                                                                      (int)(J1 - J0));
+        NODAL_HIP_TRY(h, hipGetLastError());
+        if (J1 < n) {
+            NODAL_TRY(tm.begin());
+            NODAL_TRY(gemm_sub_f64(h, A + J1 * lda + J1, lda, A + J0 * lda + J1, lda,
+                                   A + J1 * lda + J0, lda, n - J1, ncols - J1, J1 - J0));
+            NODAL_TRY(tm.end(2.0 * (double)(J1 - J0) * (double)(n - J1) * (double)(ncols - J1)));
+        }
+    }
+    return NODAL_OK;
+}
+
+// Passive networks: same blocking as the tournament path, no pivot search, no swaps.
+int factor_nopivot(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncols, int32_t *piv,
+                   int32_t *dinfo, GemmTimer &tm) {
+    hipStream_t st = h->stream;
+    NODAL_HIP_TRY(h, h->work.reserve(NB * NB * 8 + 256));
+    double *lu11 = h->work.as<double>();
+    for (int64_t J0 = 0; J0 < n; J0 += W) {
+        const int64_t J1 = J0 + W < n ? J0 + W : n;
+        for (int64_t c0 = J0; c0 < J1; c0 += NB) {
+            const int nbc = (int)(c0 + NB < J1 ? NB : J1 - c0);
+            diag_lu_nopivot<<<1, 256, 0, st>>>(A, lda, (int)c0, nbc, lu11, piv, dinfo);
+            if (nbc == NB)
+                tslu_apply<true><<<blocks_for(n - c0, 256), 256, 0, st>>>(A, lda, (int)n, (int)c0, NB, lu11);
+            else
+                tslu_apply<false><<<blocks_for(n - c0, 256), 256, 0, st>>>(A, lda, (int)n, (int)c0, nbc, lu11);
+            const int64_t c1 = c0 + nbc;
+            if (c1 < J1) {
+                if (nbc == NB)
+                    lu_trsm32<true><<<blocks_for(J1 - c1, 256), 256, 0, st>>>(A, lda, c1, J1, (int)c0, NB);
+                else
+                    lu_trsm32<false><<<blocks_for(J1 - c1, 256), 256, 0, st>>>(A, lda, c1, J1, (int)c0, nbc);
+                NODAL_TRY(gemm_sub_f64(h, A + c1 * lda + c1, lda, A + c0 * lda + c1, lda,
+                                       A + c1 * lda + c0, lda, n - c1, J1 - c1, nbc));
+            }
+            NODAL_HIP_TRY(h, hipGetLastError());
+        }
+        trsm_outer<<<(unsigned)((ncols - J1 + 31) / 32), 256, 0, st>>>(A, lda, J1, ncols, (int)J0,
+                                                                      (int)(J1 - J0));
+        NODAL_HIP_TRY(h, hipGetLastError());
+        if (J1 < n) {
+            NODAL_TRY(tm.begin());
+            NODAL_TRY(gemm_sub_f64(h, A + J1 * lda + J1, lda, A + J0 * lda + J1, lda,
+                                   A + J1 * lda + J0, lda, n - J1, ncols - J1, J1 - J0));
+            NODAL_TRY(tm.end(2.0 * (double)(J1 - J0) * (double)(n - J1) * (double)(ncols - J1)));
+        }
+    }
+    return NODAL_OK;
+}
+
+}  // namespace
+
+int dense_fill_nan(nodal_ctx *h, double *x, int64_t n) {
+    fill_nan<<<blocks_for(n, 256), 256, 0, h->stream>>>(x, n);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
+}
+
+// Factor the column-major augmented matrix in h->dense (lda = dense_lda(n), n + 1
+// columns) and leave the solution in h->x.  *info as LAPACK dgesv.
+int dense_factor_solve(nodal_ctx *h, int32_t *info) {
+    const int64_t n = h->n, lda = dense_lda(n), ncols = n + 1;
+    hipStream_t st = h->stream;
+    double *A = h->dense.as<double>();
+    NODAL_HIP_TRY(h, h->piv.reserve((size_t)n * 4 + 64));
+    int32_t *piv = h->piv.as<int32_t>();
+    int32_t *dinfo = piv + n;  // one spare word after the pivots
+    NODAL_HIP_TRY(h, hipMemsetAsync(dinfo, 0, 4, st));
+
+    GemmTimer tm{h};
+    if (n <= GEPP_MAX) NODAL_TRY(factor_gepp(h, A, n, lda, ncols, piv, dinfo, tm));
+    else if (h->passive_network && !h->force_pivoting)
+        NODAL_TRY(factor_nopivot(h, A, n, lda, ncols, piv, dinfo, tm));
+    else NODAL_TRY(factor_tournament(h, A, n, lda, ncols, piv, dinfo, tm));
+
     // back substitution on the transformed rhs (column n)
     double *y = A + n * lda;
     for (int64_t j1 = n; j1 > 0;) {
@@ -288,13 +735,6 @@ int dense_factor_solve(nodal_ctx *h, int32_t *info) {
     NODAL_HIP_TRY(h, hipMemcpyAsync(&hinfo, dinfo, 4, hipMemcpyDeviceToHost, st));
     NODAL_HIP_TRY(h, hipStreamSynchronize(st));
     *info = hinfo;
-    h->kern_ms = 0;
-    for (size_t i = 0; i < timed; ++i) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, h->evpool[2 * i], h->evpool[2 * i + 1]) == hipSuccess)
-            h->kern_ms += ms;
-    }
-    h->kern_launches = (int64_t)timed;
-    h->kern_alg = timed ? flops / (double)timed : 0.0;  // average flops per launch
+    tm.collect();
     return NODAL_OK;
 }

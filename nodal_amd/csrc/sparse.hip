@@ -357,12 +357,12 @@ __global__ __launch_bounds__(TB) void copy_rhs_column(const double *__restrict__
 }  // namespace
 
 int dense_prepare(nodal_ctx *h) {
-    const int64_t n = h->n;
-    NODAL_HIP_TRY(h, h->dense.reserve((size_t)n * (size_t)(n + 1) * 8 + 64));
-    NODAL_TRY(stamp_to_dense(h, h->dense.as<double>(), true));
+    const int64_t n = h->n, lda = dense_lda(n);
+    NODAL_HIP_TRY(h, h->dense.reserve((size_t)lda * (size_t)(n + 1) * 8 + 64));
+    NODAL_TRY(stamp_to_dense(h, h->dense.as<double>(), lda, true));
     if (n > 0) {
         copy_rhs_column<<<grid_rows(n, 1), TB, 0, h->stream>>>(h->rhs.as<double>(),
-                                                              h->dense.as<double>() + n * n, n);
+                                                              h->dense.as<double>() + n * lda, n);
         NODAL_HIP_TRY(h, hipGetLastError());
     }
     return NODAL_OK;

@@ -379,6 +379,7 @@ __global__ __launch_bounds__(TB) void fold_matrix(Table tb, const double *__rest
                 if (dr >= 0) Rd = value[dr];
             }
             if (t == NODAL_T_R && v == 0.0) note_min(&status[0], comp);
+            if (t == NODAL_T_R && !(v > 0.0)) status[2] = 1;  // not a passive network (benign race)
             unsigned flags;
             const double val = matrix_value(t, s, v, Rd, flags);
             if ((flags & F_ASSERT0) && x != 0.0) note_min(&status[1], comp);
@@ -409,12 +410,12 @@ __global__ __launch_bounds__(TB) void fold_rhs(Table tb, const double *__restric
 __global__ __launch_bounds__(TB) void scatter_dense(const int32_t *__restrict__ rowidx,
                                                     const int32_t *__restrict__ indices,
                                                     const double *__restrict__ data,
-                                                    double *__restrict__ G, int64_t n, int64_t nnz,
+                                                    double *__restrict__ G, int64_t ld, int64_t nnz,
                                                     bool col_major) {
     for (int64_t e = (int64_t)blockIdx.x * TB + threadIdx.x; e < nnz;
          e += (int64_t)gridDim.x * TB) {
         const int64_t r = rowidx[e], c = indices[e];
-        G[col_major ? c * n + r : r * n + c] = data[e];
+        G[col_major ? c * ld + r : r * ld + c] = data[e];
     }
 }
 
@@ -586,6 +587,7 @@ int stamp_numeric(nodal_ctx *h, int32_t member, int64_t *bad_component) {
         h->batch > 0 ? h->values_batch.as<double>() + (int64_t)member * h->ncomp : tb.value;
     unsigned long long *status = h->status.as<unsigned long long>();
     NODAL_HIP_TRY(h, hipMemsetAsync(status, 0xff, 16, st));
+    NODAL_HIP_TRY(h, hipMemsetAsync(status + 2, 0, 8, st));
     NODAL_HIP_TRY(h, hipMemsetAsync(h->rhs.p, 0, (size_t)h->n * 8, st));
     if (h->nnz > 0) {
         fold_matrix<<<grid_for(h->nnz), TB, 0, st>>>(tb, value, h->cptr.as<int32_t>(),
@@ -600,11 +602,14 @@ int stamp_numeric(nodal_ctx *h, int32_t member, int64_t *bad_component) {
                                                   h->rhs.as<double>(), h->nrhs);
         NODAL_HIP_TRY(h, hipGetLastError());
     }
-    unsigned long long st_host[2];
-    NODAL_HIP_TRY(h, hipMemcpyAsync(st_host, status, 16, hipMemcpyDeviceToHost, st));
+    unsigned long long st_host[3];
+    NODAL_HIP_TRY(h, hipMemcpyAsync(st_host, status, 24, hipMemcpyDeviceToHost, st));
     NODAL_HIP_TRY(h, hipStreamSynchronize(st));
     h->have_numeric = true;
     h->have_x = false;
+    // resistors and current sources only, every resistance positive: G is a column
+    // diagonally dominant M-matrix (used by the dense LU to skip the pivot search)
+    h->passive_network = (h->B == 0) && st_host[2] == 0;
     const unsigned long long none = ~0ull;
     if (st_host[0] != none || st_host[1] != none) {
         // the reference stops at the first offending component in file order
@@ -618,14 +623,14 @@ int stamp_numeric(nodal_ctx *h, int32_t member, int64_t *bad_component) {
     return NODAL_OK;
 }
 
-int stamp_to_dense(nodal_ctx *h, double *G_dev, bool col_major) {
+int stamp_to_dense(nodal_ctx *h, double *G_dev, int64_t ld, bool col_major) {
     if (!h->have_numeric) return nodal_fail(h, NODAL_E_INVALID, "assemble_numeric not called");
     const int64_t n = h->n;
-    NODAL_HIP_TRY(h, hipMemsetAsync(G_dev, 0, (size_t)n * n * 8, h->stream));
+    NODAL_HIP_TRY(h, hipMemsetAsync(G_dev, 0, (size_t)ld * n * 8, h->stream));
     if (h->nnz > 0) {
         scatter_dense<<<grid_for(h->nnz), TB, 0, h->stream>>>(h->rowidx.as<int32_t>(),
                                                              h->indices.as<int32_t>(),
-                                                             h->data.as<double>(), G_dev, n, h->nnz,
+                                                             h->data.as<double>(), G_dev, ld, h->nnz,
                                                              col_major);
         NODAL_HIP_TRY(h, hipGetLastError());
     }

@@ -1,0 +1,63 @@
+"""Kernel-level checks on the MI355X (through the C ABI testing hooks)."""
+import numpy as np
+import pytest
+
+from nodal_amd import _ffi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 16, 4), (128, 128, 16), (130, 70, 32), (257, 300, 128),
+                                   (1000, 513, 256), (64, 1, 20), (3, 5, 7)])
+def test_mfma_f64_gemm(M, N, K):
+    """fp64 MFMA fragment layout and edge handling, against numpy in fp64.
+    Asymmetric integer-valued data makes any row/col or k-order mix-up exact."""
+    rng = np.random.RandomState(M * 7 + N * 3 + K)
+    A = rng.randint(-8, 9, size=(M, K)).astype(float)
+    B = rng.randint(-8, 9, size=(K, N)).astype(float)
+    C = rng.randint(-8, 9, size=(M, N)).astype(float)
+    h = _ffi.Handle(0)
+    out = h.debug_gemm(A, B, C)
+    assert np.array_equal(out, C - A @ B)  # integers: exact
+    A, B, C = rng.randn(M, K), rng.randn(K, N), rng.randn(M, N)
+    out = h.debug_gemm(A, B, C)
+    ref = C - A @ B
+    assert np.abs(out - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()) * K
+    h.close()
+
+
+def test_dense_lu_paths_agree_on_passive_network():
+    """On a resistor-only network the dense LU skips the pivot search (partial
+    pivoting never interchanges on a column diagonally dominant matrix).  Forcing the
+    tournament-pivoted path must give the same solution and choose identity pivots."""
+    from nodal_amd import generators as gen
+    table = gen.grid_table(50)  # n = 2499 > GEPP_MAX: exercises the blocked paths
+    out = []
+    for force in (0, 1):
+        h = _ffi.Handle(0)
+        h.set_option(_ffi.OPT_FORCE_PIVOTING, force)
+        h.upload(table)
+        h.assemble_symbolic()
+        assert h.assemble_numeric()[0] == _ffi.OK
+        x, info = h.solve_dense()
+        assert info == 0 and h.residual() <= 1e-14
+        out.append(x)
+        h.close()
+    assert np.abs(out[0] - out[1]).max() <= 1e-12 * np.abs(out[0]).max()
+
+
+def test_dense_lu_tournament_on_general_matrix():
+    """cfg5 has zero diagonals and non-symmetric rows: the tournament path must pivot."""
+    from nodal_amd import generators as gen
+    from oracle import nodal_oracle as oracle
+    table = gen.cfg5_table(56)  # n ~ 3200
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    x, info = h.solve_dense()
+    assert info == 0 and h.residual() <= 1e-14
+    G, A = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(G.tocsr(), A, True)
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    h.close()
