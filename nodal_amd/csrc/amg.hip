@@ -1,0 +1,634 @@
+// Aggregation multigrid preconditioner for the sparse SPD path (passive networks:
+// G is a weighted graph Laplacian plus ground conductances, an M-matrix).
+//
+// Replaces -- together with the flexible CG driver below -- what
+// scipy.sparse.linalg.spsolve does for the reference (nodal/nodal.py:325) on large
+// resistor networks, where Jacobi-preconditioned CG needs ~5.5 sqrt(n) iterations.
+//
+// Setup (all on the device, deterministic):
+//   * aggregation by pairwise matching (Notay's AGMG idea): each free node proposes
+//     to its strongest free neighbour, (weight, symmetric edge hash) breaks ties the
+//     same way from both ends, mutual proposals are matched; leftovers join the
+//     aggregate of their strongest matched neighbour.  PASSES passes per level (the
+//     graph of pairs is matched again) give aggregates of ~10 nodes.
+//   * coarse matrices A_c = P^T A P (P piecewise constant) are formed by the same
+//     grouping pipeline as the stamping (group.h): tuples (agg[row], agg[col]) of the
+//     fine entries are bucketed, sorted and summed in a fixed order.
+//   * coarsening stops at <= COARSEST_MAX nodes; that matrix is inverted densely.
+// Cycle: unsmoothed aggregation needs the K-cycle for mesh-independent convergence
+// (V-cycle iteration counts grow with the number of levels): at every level the
+// coarse problem is solved by two steps of flexible CG preconditioned by the next
+// level's cycle.  One damped-Jacobi pre- and post-smoothing step, fused with the
+// residual / prolongation so a level visit costs three kernels.
+#include "group.h"
+
+namespace {
+
+using grp::grid_for;
+using grp::TB;
+
+constexpr int PASSES = 3;
+constexpr int MATCH_ROUNDS = 5;
+constexpr int COARSEST_MAX = 64;
+constexpr int MAX_LEVELS = 16;
+constexpr double OMEGA = 0.67;
+constexpr int DOT_BLOCKS = 128;  // partial sums per dot product
+
+struct Csr {
+    int64_t n = 0, nnz = 0;
+    const int32_t *indptr = nullptr, *indices = nullptr, *rowidx = nullptr;
+    const double *data = nullptr;
+};
+
+struct Level {
+    Csr A;
+    DevBuf indptr, indices, rowidx, data, diag_pos, cptr, contrib;  // owned (levels >= 1)
+    DevBuf dinv;
+    int64_t nc = 0;       // size of the next level
+    DevBuf agg;           // i32[n]: node -> aggregate
+    DevBuf memptr, mem;   // aggregate -> member nodes (ascending)
+    DevBuf vec;           // work vectors, see V_* below
+    DevBuf part;          // dot-product partials: 5 x DOT_BLOCKS
+    double *v(int which) const { return vec.as<double>() + (int64_t)which * ((A.n + 31) & ~31ll); }
+};
+enum { V_X = 0, V_R = 1, V_RC = 2, V_C1 = 3, V_C2 = 4, V_V1 = 5, V_V2 = 6, V_R2 = 7, V_COUNT = 8 };
+
+struct Hierarchy {
+    std::vector<Level *> levels;
+    DevBuf coarse_inv;  // dense inverse of the last level
+    bool coarse_direct = false;
+    ~Hierarchy() { clear(); }
+    void clear() {
+        for (Level *l : levels) {
+            DevBuf *bufs[] = {&l->indptr, &l->indices, &l->rowidx, &l->data, &l->diag_pos, &l->cptr,
+                              &l->contrib, &l->dinv, &l->agg, &l->memptr, &l->mem, &l->vec, &l->part};
+            for (DevBuf *b : bufs) b->release();
+            delete l;
+        }
+        levels.clear();
+        coarse_inv.release();
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// setup kernels
+// ---------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint64_t edge_hash(uint32_t a, uint32_t b) {
+    const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+    uint64_t h = lo * 0x9E3779B97F4A7C15ull + hi * 0xC2B2AE3D27D4EB4Full;
+    h ^= h >> 29;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 32;
+    return h;
+}
+
+// every free node proposes to its strongest free neighbour
+__global__ __launch_bounds__(TB) void match_propose(Csr A, const int32_t *__restrict__ match,
+                                                    int32_t *__restrict__ prop) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        int best = -1;
+        if (match[i] < 0) {
+            double bw = 0.0;
+            uint64_t bh = 0;
+            for (int32_t e = A.indptr[i]; e < A.indptr[i + 1]; ++e) {
+                const int j = A.indices[e];
+                const double w = -A.data[e];
+                if (j == i || !(w > 0.0) || match[j] >= 0) continue;
+                const uint64_t hh = edge_hash((uint32_t)i, (uint32_t)j);
+                if (w > bw || (w == bw && hh > bh)) { bw = w; bh = hh; best = j; }
+            }
+        }
+        prop[i] = best;
+    }
+}
+
+__global__ __launch_bounds__(TB) void match_confirm(int64_t n, const int32_t *__restrict__ prop,
+                                                    int32_t *__restrict__ match) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        const int j = prop[i];
+        if (j >= 0 && prop[j] == (int)i) match[i] = j;
+    }
+}
+
+// unmatched nodes join their strongest matched neighbour; leaders are flagged
+__global__ __launch_bounds__(TB) void match_join(Csr A, const int32_t *__restrict__ match,
+                                                 int32_t *__restrict__ join,
+                                                 uint32_t *__restrict__ leader) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        int best = -1;
+        if (match[i] < 0) {
+            double bw = 0.0;
+            uint64_t bh = 0;
+            for (int32_t e = A.indptr[i]; e < A.indptr[i + 1]; ++e) {
+                const int j = A.indices[e];
+                const double w = -A.data[e];
+                if (j == i || !(w > 0.0) || match[j] < 0) continue;
+                const uint64_t hh = edge_hash((uint32_t)i, (uint32_t)j);
+                if (w > bw || (w == bw && hh > bh)) { bw = w; bh = hh; best = j; }
+            }
+        }
+        join[i] = best;
+        const int m = match[i];
+        leader[i] = (m >= 0 ? (int)i < m : best < 0) ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(TB) void assign_aggregates(int64_t n, const int32_t *__restrict__ match,
+                                                        const int32_t *__restrict__ join,
+                                                        const uint32_t *__restrict__ lead_id,
+                                                        int32_t *__restrict__ agg) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        int rep = (int)i;
+        if (match[i] < 0 && join[i] >= 0) rep = join[i];  // joins a matched pair
+        const int m = match[rep];
+        if (m >= 0 && m < rep) rep = m;  // the pair's leader is its smaller index
+        agg[i] = (int32_t)lead_id[rep];
+    }
+}
+
+__global__ __launch_bounds__(TB) void compose_map(int64_t n, int32_t *__restrict__ agg,
+                                                  const int32_t *__restrict__ next) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        agg[i] = next[agg[i]];
+}
+
+// grouping enumerators (group.h)
+struct CoarseEntries {  // fine entry e -> (agg[row], agg[col])
+    static constexpr int SLOTS = 1;
+    const int32_t *rowidx, *indices, *agg;
+    int64_t nitems;
+    template <class F>
+    __device__ void for_each(int64_t e, F f) const {
+        f(0, agg[rowidx[e]], agg[indices[e]]);
+    }
+};
+struct Members {  // node i -> (agg[i], 0): one entry per aggregate, members ascending
+    static constexpr int SLOTS = 1;
+    const int32_t *agg;
+    int64_t nitems;
+    template <class F>
+    __device__ void for_each(int64_t i, F f) const {
+        f(0, agg[i], 0);
+    }
+};
+
+__global__ __launch_bounds__(TB) void sum_groups(const int32_t *__restrict__ cptr,
+                                                 const uint32_t *__restrict__ contrib,
+                                                 const double *__restrict__ fine,
+                                                 double *__restrict__ coarse, int64_t nent) {
+    for (int64_t e = (int64_t)blockIdx.x * TB + threadIdx.x; e < nent; e += (int64_t)gridDim.x * TB) {
+        double s = 0.0;
+        for (int32_t p = cptr[e]; p < cptr[e + 1]; ++p) s += fine[contrib[p] >> 3];
+        coarse[e] = s;
+    }
+}
+
+__global__ __launch_bounds__(TB) void unpack_members(const uint32_t *__restrict__ contrib,
+                                                     int32_t *__restrict__ mem, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        mem[i] = (int32_t)(contrib[i] >> 3);
+}
+
+__global__ __launch_bounds__(TB) void diag_inverse(Csr A, const int32_t *__restrict__ diag_pos,
+                                                   double *__restrict__ dinv,
+                                                   double *__restrict__ flag) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        const int32_t e = diag_pos[i];
+        const double d = e >= 0 ? A.data[e] : 0.0;
+        if (!(d > 0.0)) *flag = 2.0;  // benign race: every writer stores the same value
+        dinv[i] = d > 0.0 ? 1.0 / d : 1.0;
+    }
+}
+
+// dense inverse of the coarsest matrix (n <= COARSEST_MAX) by Gauss-Jordan in LDS;
+// SPD, so no pivoting.  A non-positive pivot (singular network) raises the flag.
+__global__ __launch_bounds__(256) void coarsest_inverse(Csr A, double *__restrict__ inv,
+                                                        double *__restrict__ flag) {
+    __shared__ double M[COARSEST_MAX][2 * COARSEST_MAX + 1];
+    const int n = (int)A.n;
+    for (int t = threadIdx.x; t < n * 2 * n; t += 256) {
+        const int r = t / (2 * n), c = t % (2 * n);
+        M[r][c] = (c >= n && c - n == r) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < n; r += 256)
+        for (int32_t e = A.indptr[r]; e < A.indptr[r + 1]; ++e) M[r][A.indices[e]] = A.data[e];
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        const double pv = M[k][k];
+        if (!(pv > 0.0)) {
+            if (threadIdx.x == 0) *flag = 3.0;
+            return;  // uniform: every thread reads the same pivot
+        }
+        const double rp = 1.0 / pv;
+        __syncthreads();
+        for (int c = threadIdx.x; c < 2 * n; c += 256) M[k][c] *= rp;
+        __syncthreads();
+        for (int t = threadIdx.x; t < n * 2 * n; t += 256) {
+            const int r = t / (2 * n), c = t % (2 * n);
+            if (r != k && c != k) M[r][c] = fma(-M[r][k], M[k][c], M[r][c]);
+        }
+        __syncthreads();
+        for (int r = threadIdx.x; r < n; r += 256)
+            if (r != k) M[r][k] = 0.0;
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < n * n; t += 256) inv[t] = M[t / n][n + t % n];
+}
+
+// ---------------------------------------------------------------------------------
+// cycle kernels
+// ---------------------------------------------------------------------------------
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ double block_sum(double v) {
+    __shared__ double ws[TB / 64];
+    __syncthreads();
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < TB / 64; ++w) s += ws[w];
+    return s;
+}
+
+__device__ __forceinline__ double reduce_partials(const double *__restrict__ part, int count) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += TB) s += part[i];
+    return block_sum(s);
+}
+
+// pre-smoothing from a zero guess, fused with the residual:
+//   x = w D^-1 b ;  r = b - A x          (x_j is recomputed from b_j on the fly)
+__global__ __launch_bounds__(TB) void smooth_residual(Csr A, const double *__restrict__ dinv,
+                                                      const double *__restrict__ b,
+                                                      double *__restrict__ x,
+                                                      double *__restrict__ r) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        double s = b[i];
+        for (int32_t e = A.indptr[i]; e < A.indptr[i + 1]; ++e) {
+            const int j = A.indices[e];
+            s = fma(-A.data[e], OMEGA * dinv[j] * b[j], s);
+        }
+        x[i] = OMEGA * dinv[i] * b[i];
+        r[i] = s;
+    }
+}
+
+// rc[I] = sum of r over the members of aggregate I (fixed order)
+__global__ __launch_bounds__(TB) void restrict_sum(int64_t nc, const int32_t *__restrict__ memptr,
+                                                   const int32_t *__restrict__ mem,
+                                                   const double *__restrict__ r,
+                                                   double *__restrict__ rc) {
+    for (int64_t I = (int64_t)blockIdx.x * TB + threadIdx.x; I < nc; I += (int64_t)gridDim.x * TB) {
+        double s = 0.0;
+        for (int32_t p = memptr[I]; p < memptr[I + 1]; ++p) s += r[mem[p]];
+        rc[I] = s;
+    }
+}
+
+// K-cycle coefficients from the five dot products of the two inner FCG steps
+struct KCoef { double s1, s2; };
+__device__ __forceinline__ KCoef kcycle_coefficients(const double *__restrict__ part, int nparts) {
+    if (nparts == 0) return KCoef{1.0, 0.0};  // plain V-cycle hand-over
+    const double rho1 = reduce_partials(part + 0 * DOT_BLOCKS, nparts);
+    const double alpha1 = reduce_partials(part + 1 * DOT_BLOCKS, nparts);
+    const double gamma = reduce_partials(part + 2 * DOT_BLOCKS, nparts);
+    const double beta = reduce_partials(part + 3 * DOT_BLOCKS, nparts);
+    const double alpha2 = reduce_partials(part + 4 * DOT_BLOCKS, nparts);
+    if (!(rho1 > 0.0)) return KCoef{0.0, 0.0};
+    const double rho2 = beta - gamma * gamma / rho1;
+    if (!(rho2 > 0.0)) return KCoef{alpha1 / rho1, 0.0};
+    return KCoef{alpha1 / rho1 - gamma * alpha2 / (rho1 * rho2), alpha2 / rho2};
+}
+
+// coarse correction + post-smoothing, fused:
+//   x' = x + P (s1 c1 + s2 c2) ;  out = x' + w D^-1 (b - A x')
+__global__ __launch_bounds__(TB) void prolong_smooth(Csr A, const double *__restrict__ dinv,
+                                                     const double *__restrict__ b,
+                                                     const double *__restrict__ x,
+                                                     const int32_t *__restrict__ agg,
+                                                     const double *__restrict__ c1,
+                                                     const double *__restrict__ c2,
+                                                     const double *__restrict__ part, int nparts,
+                                                     double *__restrict__ out) {
+    const KCoef k = kcycle_coefficients(part, nparts);
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        double s = b[i];
+        for (int32_t e = A.indptr[i]; e < A.indptr[i + 1]; ++e) {
+            const int j = A.indices[e];
+            const int J = agg[j];
+            const double xj = x[j] + k.s1 * c1[J] + (nparts ? k.s2 * c2[J] : 0.0);
+            s = fma(-A.data[e], xj, s);
+        }
+        const int I = agg[i];
+        const double xi = x[i] + k.s1 * c1[I] + (nparts ? k.s2 * c2[I] : 0.0);
+        out[i] = fma(OMEGA * dinv[i], s, xi);
+    }
+}
+
+// v = A c and the partial dot products c.v, c.u1 (and c.u2 when given)
+__global__ __launch_bounds__(TB) void spmv_dots(Csr A, const double *__restrict__ c,
+                                                double *__restrict__ v,
+                                                const double *__restrict__ u1,
+                                                const double *__restrict__ u2,
+                                                double *__restrict__ p_cv,
+                                                double *__restrict__ p_cu1,
+                                                double *__restrict__ p_cu2) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        double s = 0.0;
+        for (int32_t e = A.indptr[i]; e < A.indptr[i + 1]; ++e)
+            s = fma(A.data[e], c[A.indices[e]], s);
+        v[i] = s;
+        const double ci = c[i];
+        a0 = fma(ci, s, a0);
+        a1 = fma(ci, u1[i], a1);
+        if (u2) a2 = fma(ci, u2[i], a2);
+    }
+    a0 = block_sum(a0);
+    a1 = block_sum(a1);
+    a2 = block_sum(a2);
+    if (threadIdx.x == 0) {
+        p_cv[blockIdx.x] = a0;
+        p_cu1[blockIdx.x] = a1;
+        if (p_cu2) p_cu2[blockIdx.x] = a2;
+    }
+}
+
+// r2 = rc - (alpha1 / rho1) v1
+__global__ __launch_bounds__(TB) void second_residual(int64_t n, const double *__restrict__ rc,
+                                                      const double *__restrict__ v1,
+                                                      const double *__restrict__ part, int nparts,
+                                                      double *__restrict__ r2) {
+    const double rho1 = reduce_partials(part + 0 * DOT_BLOCKS, nparts);
+    const double alpha1 = reduce_partials(part + 1 * DOT_BLOCKS, nparts);
+    const double t = rho1 > 0.0 ? alpha1 / rho1 : 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        r2[i] = fma(-t, v1[i], rc[i]);
+}
+
+__global__ __launch_bounds__(TB) void dense_apply(int n, const double *__restrict__ inv,
+                                                  const double *__restrict__ b,
+                                                  double *__restrict__ out) {
+    for (int i = threadIdx.x; i < n; i += TB) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s = fma(inv[i * n + j], b[j], s);
+        out[i] = s;
+    }
+}
+
+__global__ __launch_bounds__(TB) void jacobi_apply(int64_t n, const double *__restrict__ dinv,
+                                                   const double *__restrict__ b,
+                                                   double *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        out[i] = dinv[i] * b[i];
+}
+
+unsigned dot_grid(int64_t n) {
+    const unsigned g = grid_for(n);
+    return g > DOT_BLOCKS ? DOT_BLOCKS : g;
+}
+
+// ---------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------
+
+// one pairwise-matching pass on graph A: agg (i32[n]) and the number of aggregates
+int matching_pass(nodal_ctx *h, const Csr &A, int32_t *agg, int64_t *nagg) {
+    hipStream_t st = h->stream;
+    const int64_t n = A.n;
+    const size_t a4 = ((size_t)n * 4 + 255) & ~(size_t)255;
+    // work layout: match | prop/join | leader/lead_id (n+1) | scan tmp
+    NODAL_HIP_TRY(h, h->work.reserve(3 * a4 + 512 + scan_tmp_bytes(n + 1)));
+    char *w = h->work.as<char>();
+    int32_t *match = reinterpret_cast<int32_t *>(w);
+    int32_t *prop = reinterpret_cast<int32_t *>(w + a4);
+    uint32_t *lead = reinterpret_cast<uint32_t *>(w + 2 * a4);
+    void *scan_tmp = w + 3 * a4 + 512;
+    NODAL_HIP_TRY(h, hipMemsetAsync(match, 0xff, (size_t)n * 4, st));
+    for (int r = 0; r < MATCH_ROUNDS; ++r) {
+        match_propose<<<grid_for(n), TB, 0, st>>>(A, match, prop);
+        match_confirm<<<grid_for(n), TB, 0, st>>>(n, prop, match);
+    }
+    match_join<<<grid_for(n), TB, 0, st>>>(A, match, prop, lead);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    NODAL_HIP_TRY(h, hipMemsetAsync(lead + n, 0, 4, st));
+    NODAL_TRY(scan_exclusive_u32(h, lead, lead, n + 1, nullptr, scan_tmp));
+    assign_aggregates<<<grid_for(n), TB, 0, st>>>(n, match, prop, lead, agg);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    uint32_t total = 0;
+    NODAL_HIP_TRY(h, hipMemcpyAsync(&total, lead + n, 4, hipMemcpyDeviceToHost, st));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    *nagg = total;
+    return NODAL_OK;
+}
+
+// A_c = P^T A P into the owned buffers of `out`
+int galerkin(nodal_ctx *h, const Csr &A, const int32_t *agg, int64_t nc, Level *out) {
+    CoarseEntries en{A.rowidx, A.indices, agg, A.nnz};
+    int64_t nent = 0, ncon = 0;
+    NODAL_TRY(grp::build_lists(h, en, nc, &nent, &ncon, out->indices, out->rowidx, out->cptr,
+                               out->contrib, &out->indptr, &out->diag_pos));
+    NODAL_HIP_TRY(h, out->data.reserve((size_t)nent * 8 + 8));
+    if (nent > 0) {
+        sum_groups<<<grid_for(nent), TB, 0, h->stream>>>(out->cptr.as<int32_t>(),
+                                                        out->contrib.as<uint32_t>(), A.data,
+                                                        out->data.as<double>(), nent);
+        NODAL_HIP_TRY(h, hipGetLastError());
+    }
+    out->A.n = nc;
+    out->A.nnz = nent;
+    out->A.indptr = out->indptr.as<int32_t>();
+    out->A.indices = out->indices.as<int32_t>();
+    out->A.rowidx = out->rowidx.as<int32_t>();
+    out->A.data = out->data.as<double>();
+    return NODAL_OK;
+}
+
+int finish_level(nodal_ctx *h, Level *l, const int32_t *diag_pos, double *flag) {
+    const int64_t n = l->A.n;
+    NODAL_HIP_TRY(h, l->dinv.reserve((size_t)n * 8 + 8));
+    diag_inverse<<<grid_for(n), TB, 0, h->stream>>>(l->A, diag_pos, l->dinv.as<double>(), flag);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    NODAL_HIP_TRY(h, l->vec.reserve((size_t)V_COUNT * (((size_t)n + 31) & ~(size_t)31) * 8 + 256));
+    NODAL_HIP_TRY(h, l->part.reserve(5 * DOT_BLOCKS * 8));
+    return NODAL_OK;
+}
+
+}  // namespace
+
+// ---- interface used by sparse.hip ------------------------------------------------
+
+void amg_destroy(nodal_ctx *h) {
+    delete static_cast<Hierarchy *>(h->amg);
+    h->amg = nullptr;
+}
+
+// Build the hierarchy for the CSR matrix of the context.  `flag` (device double) is
+// set non-zero if a diagonal or coarse pivot is not positive (not SPD).
+int amg_setup(nodal_ctx *h, double *flag) {
+    amg_destroy(h);
+    Hierarchy *H = new Hierarchy();
+    h->amg = H;
+    hipStream_t st = h->stream;
+
+    Level *l0 = new Level();
+    H->levels.push_back(l0);
+    l0->A.n = h->n;
+    l0->A.nnz = h->nnz;
+    l0->A.indptr = h->indptr.as<int32_t>();
+    l0->A.indices = h->indices.as<int32_t>();
+    l0->A.rowidx = h->rowidx.as<int32_t>();
+    l0->A.data = h->data.as<double>();
+    NODAL_TRY(finish_level(h, l0, h->diag_pos.as<int32_t>(), flag));
+
+    while ((int)H->levels.size() < MAX_LEVELS) {
+        Level *fine = H->levels.back();
+        const int64_t n = fine->A.n;
+        if (n <= COARSEST_MAX) break;
+        // PASSES matching passes; the intermediate pair graphs live in scratch levels
+        NODAL_HIP_TRY(h, fine->agg.reserve((size_t)n * 4 + 8));
+        int32_t *agg = fine->agg.as<int32_t>();
+        Level tmp[2];
+        Csr cur = fine->A;
+        int64_t nc = n;
+        DevBuf pass_map;
+        bool stalled = false;
+        Level *coarse = new Level();
+        for (int p = 0; p < PASSES; ++p) {
+            NODAL_HIP_TRY(h, pass_map.reserve((size_t)cur.n * 4 + 8));
+            int32_t *map = p == 0 ? agg : pass_map.as<int32_t>();
+            int64_t na = 0;
+            int s = matching_pass(h, cur, map, &na);
+            if (s != NODAL_OK) { delete coarse; return s; }
+            if (p == 0 && na > (int64_t)(0.8 * (double)n)) { stalled = true; break; }
+            if (p > 0) {
+                compose_map<<<grid_for(n), TB, 0, st>>>(n, agg, map);
+                NODAL_HIP_TRY(h, hipGetLastError());
+            }
+            const bool last = (p == PASSES - 1) || na <= COARSEST_MAX || na > (int64_t)(0.9 * (double)cur.n);
+            Level *dst = last ? coarse : &tmp[p & 1];
+            s = galerkin(h, cur, map, na, dst);
+            if (s != NODAL_OK) { delete coarse; return s; }
+            cur = dst->A;
+            nc = na;
+            if (last) break;
+        }
+        for (Level &t : tmp) {
+            DevBuf *bufs[] = {&t.indptr, &t.indices, &t.rowidx, &t.data, &t.diag_pos, &t.cptr, &t.contrib};
+            for (DevBuf *b : bufs) b->release();
+        }
+        pass_map.release();
+        if (stalled) { delete coarse; break; }
+        fine->nc = nc;
+        // aggregate -> members
+        {
+            Members en{agg, n};
+            int64_t nent = 0, ncon = 0;
+            DevBuf none, rowi;
+            int s = grp::build_lists(h, en, nc, &nent, &ncon, none, rowi, fine->memptr, fine->cptr,
+                                     nullptr, nullptr);
+            none.release();
+            rowi.release();
+            if (s != NODAL_OK) { delete coarse; return s; }
+            if (nent != nc || ncon != n) {
+                delete coarse;
+                return nodal_fail(h, NODAL_E_INVALID, "amg: empty aggregate");
+            }
+            NODAL_HIP_TRY(h, fine->mem.reserve((size_t)n * 4 + 8));
+            unpack_members<<<grid_for(n), TB, 0, st>>>(fine->cptr.as<uint32_t>(),
+                                                      fine->mem.as<int32_t>(), n);
+            NODAL_HIP_TRY(h, hipGetLastError());
+        }
+        H->levels.push_back(coarse);
+        NODAL_TRY(finish_level(h, coarse, coarse->diag_pos.as<int32_t>(), flag));
+    }
+
+    Level *last = H->levels.back();
+    H->coarse_direct = last->A.n <= COARSEST_MAX && H->levels.size() > 1;
+    if (H->coarse_direct) {
+        NODAL_HIP_TRY(h, H->coarse_inv.reserve((size_t)last->A.n * last->A.n * 8 + 8));
+        coarsest_inverse<<<1, 256, 0, st>>>(last->A, H->coarse_inv.as<double>(), flag);
+        NODAL_HIP_TRY(h, hipGetLastError());
+    }
+    return NODAL_OK;
+}
+
+int amg_num_levels(nodal_ctx *h) {
+    return h->amg ? (int)static_cast<Hierarchy *>(h->amg)->levels.size() : 0;
+}
+
+int64_t amg_level_size(nodal_ctx *h, int l) {
+    return static_cast<Hierarchy *>(h->amg)->levels[l]->A.n;
+}
+
+namespace {
+
+// out ~= A_l^-1 b
+int cycle(nodal_ctx *h, Hierarchy *H, int l, const double *b, double *out) {
+    hipStream_t st = h->stream;
+    Level *L = H->levels[l];
+    const int64_t n = L->A.n;
+    if (l == (int)H->levels.size() - 1) {
+        if (H->coarse_direct)
+            dense_apply<<<1, TB, 0, st>>>((int)n, H->coarse_inv.as<double>(), b, out);
+        else
+            jacobi_apply<<<grid_for(n), TB, 0, st>>>(n, L->dinv.as<double>(), b, out);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        return NODAL_OK;
+    }
+    Level *C = H->levels[l + 1];
+    const int64_t nc = C->A.n;
+    const double *dinv = L->dinv.as<double>();
+    double *x = L->v(V_X), *r = L->v(V_R);
+    double *rc = C->v(V_RC), *c1 = C->v(V_C1), *c2 = C->v(V_C2);
+    smooth_residual<<<grid_for(n), TB, 0, st>>>(L->A, dinv, b, x, r);
+    restrict_sum<<<grid_for(nc), TB, 0, st>>>(nc, L->memptr.as<int32_t>(), L->mem.as<int32_t>(), r, rc);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    int nparts = 0;
+    const bool coarse_is_last = (l + 1 == (int)H->levels.size() - 1);
+    if (coarse_is_last) {
+        NODAL_TRY(cycle(h, H, l + 1, rc, c1));  // direct coarse solve: one call is exact
+    } else {
+        // two flexible-CG steps on the coarse problem, preconditioned by its own cycle
+        double *v1 = C->v(V_V1), *v2 = C->v(V_V2), *r2 = C->v(V_R2);
+        double *part = C->part.as<double>();
+        const unsigned g = dot_grid(nc);
+        nparts = (int)g;
+        NODAL_TRY(cycle(h, H, l + 1, rc, c1));
+        spmv_dots<<<g, TB, 0, st>>>(C->A, c1, v1, rc, nullptr, part + 0 * DOT_BLOCKS,
+                                    part + 1 * DOT_BLOCKS, nullptr);
+        second_residual<<<grid_for(nc), TB, 0, st>>>(nc, rc, v1, part, nparts, r2);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        NODAL_TRY(cycle(h, H, l + 1, r2, c2));
+        spmv_dots<<<g, TB, 0, st>>>(C->A, c2, v2, v1, r2, part + 3 * DOT_BLOCKS,
+                                    part + 2 * DOT_BLOCKS, part + 4 * DOT_BLOCKS);
+        NODAL_HIP_TRY(h, hipGetLastError());
+    }
+    prolong_smooth<<<grid_for(n), TB, 0, st>>>(L->A, dinv, b, x, L->agg.as<int32_t>(), c1, c2,
+                                              C->part.as<double>(), nparts, out);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
+}
+
+}  // namespace
+
+// z ~= G^-1 r with one K-cycle
+int amg_apply(nodal_ctx *h, const double *r, double *z) {
+    Hierarchy *H = static_cast<Hierarchy *>(h->amg);
+    if (!H || H->levels.empty()) return nodal_fail(h, NODAL_E_INVALID, "amg_setup not called");
+    if (H->levels.size() == 1) {
+        jacobi_apply<<<grid_for(h->n), TB, 0, h->stream>>>(h->n, H->levels[0]->dinv.as<double>(), r, z);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        return NODAL_OK;
+    }
+    return cycle(h, H, 0, r, z);
+}

@@ -56,11 +56,12 @@ int nodal_destroy(nodal_handle h) {
     if (!h) return NODAL_OK;
     DeviceGuard g(h);
     (void)hipStreamSynchronize(h->stream);
+    amg_destroy(h);
     DevBuf *bufs[] = {&h->type, &h->value, &h->a, &h->b, &h->c, &h->d, &h->drv, &h->k,
                       &h->values_batch, &h->indptr, &h->indices, &h->rowidx, &h->cptr,
                       &h->contrib, &h->rhs_row, &h->rhs_cptr, &h->rhs_contrib, &h->diag_pos,
                       &h->data, &h->rhs, &h->status, &h->x, &h->dense, &h->piv, &h->work,
-                      &h->work2, &h->solver};
+                      &h->work2, &h->work3, &h->solver};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);

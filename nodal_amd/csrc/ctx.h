@@ -78,6 +78,7 @@ struct nodal_ctx {
     DevBuf piv;             // i32[n]
     DevBuf work;            // scratch (scans, sorts, solver vectors)
     DevBuf work2;
+    DevBuf work3;           // grouping: padded scratch for hub-row sorts
     DevBuf solver;          // persistent solver vectors
 
     // ---- timing ----
@@ -87,6 +88,11 @@ struct nodal_ctx {
     int64_t kern_launches = 0;
     double kern_alg = 0;
     std::vector<hipEvent_t> evpool;  // HIP-event pairs around the dominant kernel
+
+    void *amg = nullptr;  // multigrid hierarchy (amg.hip)
+    int32_t last_iterations = 0;
+    int32_t amg_levels = 0;
+    int64_t amg_min_n = 4096;  // below this the sparse SPD path uses Jacobi-CG
 };
 
 #define NODAL_HIP_TRY(h, expr)                                                   \
@@ -138,6 +144,13 @@ static inline int64_t dense_lda(int64_t n) {
     return l;
 }
 int dense_factor_solve(nodal_ctx *h, int32_t *info);
+
+// ---- aggregation multigrid preconditioner (amg.hip) ----
+int amg_setup(nodal_ctx *h, double *flag_dev);
+int amg_apply(nodal_ctx *h, const double *r, double *z);
+int amg_num_levels(nodal_ctx *h);
+int64_t amg_level_size(nodal_ctx *h, int level);
+void amg_destroy(nodal_ctx *h);
 
 // ---- sparse solvers (sparse_*.hip) ----
 int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, double *resid);

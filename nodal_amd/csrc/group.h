@@ -1,0 +1,354 @@
+// Deterministic grouping of (row, col, item) tuples into CSR entries -- the shared
+// machinery of the stamping (stamp.hip: items = component stamps) and of the
+// multigrid setup (amg.hip: items = fine-matrix entries mapped to aggregates).
+//
+//   1. an enumerator emits, per item, up to SLOTS tuples (row, col, slot);
+//   2. tuples are bucketed by row (integer histogram + exclusive scan) and every
+//      row bucket is sorted by key = col << 32 | item << 3 | slot, so the result
+//      does not depend on the order in which the atomics filled the bucket;
+//   3. runs of equal (row, col) become one entry: `cptr` delimits the run and
+//      `contrib` lists item << 3 | slot in ascending (item, slot) order -- the order
+//      in which a sequential program would have visited them.
+//
+// Enumerator concept:
+//   struct E { static constexpr int SLOTS; int64_t nitems;
+//              template <class F> __device__ void for_each(int64_t item, F f) const; }
+//   with f(int slot, int row, int col) called for every tuple of `item`.
+#pragma once
+#include "ctx.h"
+
+namespace {
+namespace grp {
+
+constexpr int TB = 256;
+constexpr unsigned MAX_GRID = 4096;
+
+inline unsigned grid_for(int64_t n) {
+    int64_t g = (n + TB - 1) / TB;
+    if (g < 1) g = 1;
+    return (unsigned)(g > MAX_GRID ? MAX_GRID : g);
+}
+
+template <class E>
+__global__ __launch_bounds__(TB) void count_rows(E en, uint32_t *__restrict__ rowcount) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < en.nitems;
+         i += (int64_t)gridDim.x * TB)
+        en.for_each(i, [&](int, int row, int) { atomicAdd(&rowcount[row], 1u); });
+}
+
+template <class E>
+__global__ __launch_bounds__(TB) void emit_tuples(E en, const uint32_t *__restrict__ rowstart,
+                                                  uint32_t *__restrict__ fill,
+                                                  uint64_t *__restrict__ skey,
+                                                  int32_t *__restrict__ srow) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < en.nitems;
+         i += (int64_t)gridDim.x * TB)
+        en.for_each(i, [&](int s, int row, int col) {
+            const uint32_t p = rowstart[row] + atomicAdd(&fill[row], 1u);
+            skey[p] = ((uint64_t)(uint32_t)col << 32) | ((uint64_t)i << 3) | (uint64_t)s;
+            srow[p] = row;
+        });
+}
+
+// ---- per-row sorts -------------------------------------------------------------
+
+template <int N>
+__device__ __forceinline__ void sort_network(uint64_t (&k)[N]) {
+#pragma unroll
+    for (int size = 2; size <= N; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int l = i ^ stride;
+                if (l > i) {
+                    const bool up = (i & size) == 0;
+                    const uint64_t lo = k[i] < k[l] ? k[i] : k[l];
+                    const uint64_t hi = k[i] < k[l] ? k[l] : k[i];
+                    k[i] = up ? lo : hi;
+                    k[l] = up ? hi : lo;
+                }
+            }
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void sort_short_row(uint64_t *seg, int len) {
+    uint64_t k[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) k[i] = i < len ? seg[i] : ~0ull;
+    sort_network<N>(k);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (i < len) seg[i] = k[i];
+}
+
+constexpr int SHORT_MAX = 16;
+constexpr int MEDIUM_MAX = 2048;
+
+// one lane per row; rows longer than SHORT_MAX are appended to work lists
+__global__ __launch_bounds__(TB) void sort_rows_short(const uint32_t *__restrict__ rowstart,
+                                                      uint64_t *__restrict__ skey, int64_t nrows,
+                                                      int32_t *__restrict__ medium_list,
+                                                      int32_t *__restrict__ long_list,
+                                                      uint32_t *__restrict__ list_counts) {
+    for (int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x; r < nrows;
+         r += (int64_t)gridDim.x * TB) {
+        const uint32_t s = rowstart[r];
+        const int len = (int)(rowstart[r + 1] - s);
+        if (len < 2) continue;
+        if (len <= 4) sort_short_row<4>(skey + s, len);
+        else if (len <= 8) sort_short_row<8>(skey + s, len);
+        else if (len <= SHORT_MAX) sort_short_row<16>(skey + s, len);
+        else if (len <= MEDIUM_MAX) medium_list[atomicAdd(&list_counts[0], 1u)] = (int32_t)r;
+        else long_list[atomicAdd(&list_counts[1], 1u)] = (int32_t)r;
+    }
+}
+
+// one workgroup per listed row, bitonic sort in LDS (len <= MEDIUM_MAX)
+__global__ __launch_bounds__(TB) void sort_rows_medium(const uint32_t *__restrict__ rowstart,
+                                                       uint64_t *__restrict__ skey,
+                                                       const int32_t *__restrict__ list,
+                                                       const uint32_t *__restrict__ list_counts) {
+    __shared__ uint64_t buf[MEDIUM_MAX];
+    const uint32_t count = list_counts[0];
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
+        const int32_t r = list[it];
+        const uint32_t s = rowstart[r];
+        const int len = (int)(rowstart[r + 1] - s);
+        int P = 32;
+        while (P < len) P <<= 1;
+        for (int i = threadIdx.x; i < P; i += TB) buf[i] = i < len ? skey[s + i] : ~0ull;
+        __syncthreads();
+        for (int size = 2; size <= P; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int i = threadIdx.x; i < P; i += TB) {
+                    const int l = i ^ stride;
+                    if (l > i) {
+                        const bool up = (i & size) == 0;
+                        const uint64_t x = buf[i], y = buf[l];
+                        if ((x > y) == up) { buf[i] = y; buf[l] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = threadIdx.x; i < len; i += TB) skey[s + i] = buf[i];
+        __syncthreads();
+    }
+}
+
+// one workgroup per listed row, bitonic sort through a padded global scratch
+// region [2*rowstart, 2*rowstart + P): regions of different rows are disjoint
+// because P < 2*len.  Only hub nodes with > MEDIUM_MAX stamps get here.
+__global__ __launch_bounds__(1024) void sort_rows_long(const uint32_t *__restrict__ rowstart,
+                                                       uint64_t *__restrict__ skey,
+                                                       uint64_t *__restrict__ scratch,
+                                                       const int32_t *__restrict__ list,
+                                                       const uint32_t *__restrict__ list_counts) {
+    const uint32_t count = list_counts[1];
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
+        const int32_t r = list[it];
+        const uint32_t s = rowstart[r];
+        const int64_t len = (int64_t)rowstart[r + 1] - s;
+        int64_t P = 1;
+        while (P < len) P <<= 1;
+        uint64_t *buf = scratch + 2 * (int64_t)s;
+        for (int64_t i = threadIdx.x; i < P; i += 1024) buf[i] = i < len ? skey[s + i] : ~0ull;
+        __syncthreads();
+        for (int64_t size = 2; size <= P; size <<= 1) {
+            for (int64_t stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int64_t i = threadIdx.x; i < P; i += 1024) {
+                    const int64_t l = i ^ stride;
+                    if (l > i) {
+                        const bool up = (i & size) == 0;
+                        const uint64_t x = buf[i], y = buf[l];
+                        if ((x > y) == up) { buf[i] = y; buf[l] = x; }
+                    }
+                }
+                __syncthreads();  // one workgroup: global writes are visible after the barrier
+            }
+        }
+        for (int64_t i = threadIdx.x; i < len; i += 1024) skey[s + i] = buf[i];
+        __syncthreads();
+    }
+}
+
+// ---- runs of equal (row, col) -> CSR entries -------------------------------------
+
+__global__ __launch_bounds__(TB) void mark_heads(const uint64_t *__restrict__ skey,
+                                                 const int32_t *__restrict__ srow,
+                                                 const uint32_t *__restrict__ rowstart,
+                                                 uint32_t *__restrict__ head, int64_t C) {
+    for (int64_t p = (int64_t)blockIdx.x * TB + threadIdx.x; p < C; p += (int64_t)gridDim.x * TB) {
+        const bool first = p == (int64_t)rowstart[srow[p]];
+        head[p] = (first || (skey[p] >> 32) != (skey[p - 1] >> 32)) ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(TB) void fill_entries(const uint64_t *__restrict__ skey,
+                                                   const int32_t *__restrict__ srow,
+                                                   const uint32_t *__restrict__ head,
+                                                   const uint32_t *__restrict__ eidx, int64_t C,
+                                                   int32_t *__restrict__ indices,
+                                                   int32_t *__restrict__ rowidx,
+                                                   int32_t *__restrict__ cptr,
+                                                   uint32_t *__restrict__ contrib,
+                                                   int32_t *__restrict__ diag_pos) {
+    for (int64_t p = (int64_t)blockIdx.x * TB + threadIdx.x; p < C; p += (int64_t)gridDim.x * TB) {
+        const uint64_t key = skey[p];
+        contrib[p] = (uint32_t)key;
+        if (head[p]) {
+            const uint32_t e = eidx[p];
+            const int32_t col = (int32_t)(key >> 32), row = srow[p];
+            if (indices) indices[e] = col;
+            rowidx[e] = row;
+            cptr[e] = (int32_t)p;
+            if (diag_pos && col == row) diag_pos[row] = (int32_t)e;
+        }
+    }
+}
+
+// indptr[r] = entry index of the first stamp of row r (eidx has C+1 values)
+__global__ __launch_bounds__(TB) void fill_indptr(const uint32_t *__restrict__ rowstart,
+                                                  const uint32_t *__restrict__ eidx,
+                                                  int32_t *__restrict__ indptr, int64_t nrows) {
+    for (int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x; r <= nrows;
+         r += (int64_t)gridDim.x * TB)
+        indptr[r] = (int32_t)eidx[rowstart[r]];
+}
+
+__global__ void set_tail(int32_t *cptr, int64_t nent, int64_t C) { cptr[nent] = (int32_t)C; }
+
+__global__ __launch_bounds__(TB) void fill_i32(int32_t *p, int32_t v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        p[i] = v;
+}
+
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Group one family of stamps (matrix or rhs) into entries.  On return:
+//   *nent entries, *ncon contributions; rowidx / cptr / contrib filled;
+//   indices, indptr, diag_pos filled when non-null.
+template <class E>
+int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int64_t *ncon_out,
+                DevBuf &indices, DevBuf &rowidx, DevBuf &cptr, DevBuf &contrib, DevBuf *indptr,
+                DevBuf *diag_pos) {
+    hipStream_t st = h->stream;
+    if (en.nitems >= (1ll << 29) || nrows >= (1ll << 31) - 2)
+        return nodal_fail(h, NODAL_E_UNSUPPORTED, "too many items for 32-bit grouping keys");
+
+    // work layout: rowcount/rowstart [nrows+1] | fill [nrows] | counts[4] | scan tmp
+    const size_t off_start = 0;
+    const size_t off_fill = align_up((size_t)(nrows + 1) * 4);
+    const size_t off_counts = off_fill + align_up((size_t)nrows * 4);
+    const size_t off_scan = off_counts + 256;
+    const size_t scan_bytes = scan_tmp_bytes(nrows + 1);
+    NODAL_HIP_TRY(h, h->work.reserve(off_scan + scan_bytes));
+    char *w = h->work.as<char>();
+    uint32_t *rowstart = reinterpret_cast<uint32_t *>(w + off_start);
+    uint32_t *fill = reinterpret_cast<uint32_t *>(w + off_fill);
+    uint32_t *counts = reinterpret_cast<uint32_t *>(w + off_counts);  // [0] medium [1] long [2] C [3] nent
+    NODAL_HIP_TRY(h, hipMemsetAsync(w, 0, off_scan, st));
+
+    count_rows<E><<<grid_for(en.nitems), TB, 0, st>>>(en, rowstart);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    NODAL_TRY(scan_exclusive_u32(h, rowstart, rowstart, nrows + 1, &counts[2], w + off_scan));
+    uint32_t C32 = 0;
+    NODAL_HIP_TRY(h, hipMemcpyAsync(&C32, &counts[2], 4, hipMemcpyDeviceToHost, st));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    const int64_t C = C32;
+    if (C > 0x7fffffffll)
+        return nodal_fail(h, NODAL_E_UNSUPPORTED, "more than 2^31 stamps");
+    *ncon_out = C;
+    if (C == 0) {
+        *nent_out = 0;
+        NODAL_HIP_TRY(h, cptr.reserve(4));
+        NODAL_HIP_TRY(h, hipMemsetAsync(cptr.p, 0, 4, st));
+        if (indptr) {
+            NODAL_HIP_TRY(h, indptr->reserve((size_t)(nrows + 1) * 4));
+            NODAL_HIP_TRY(h, hipMemsetAsync(indptr->p, 0, (size_t)(nrows + 1) * 4, st));
+        }
+        if (diag_pos) {
+            NODAL_HIP_TRY(h, diag_pos->reserve((size_t)nrows * 4 + 4));
+            fill_i32<<<grid_for(nrows), TB, 0, st>>>(diag_pos->as<int32_t>(), -1, nrows);
+        }
+        return NODAL_OK;
+    }
+
+    // work2 layout: skey [C] u64 | srow [C] i32 | head/eidx [C+1] u32 | lists 2 x [nrows] | scan tmp
+    const size_t o_key = 0;
+    const size_t o_row = o_key + align_up((size_t)C * 8);
+    const size_t o_head = o_row + align_up((size_t)C * 4);
+    const size_t o_eidx = o_head + align_up((size_t)(C + 1) * 4);
+    const size_t o_med = o_eidx + align_up((size_t)(C + 1) * 4);
+    const size_t o_long = o_med + align_up((size_t)nrows * 4);
+    const size_t o_scan2 = o_long + align_up((size_t)nrows * 4);
+    NODAL_HIP_TRY(h, h->work2.reserve(o_scan2 + scan_tmp_bytes(C + 1)));
+    char *w2 = h->work2.as<char>();
+    uint64_t *skey = reinterpret_cast<uint64_t *>(w2 + o_key);
+    int32_t *srow = reinterpret_cast<int32_t *>(w2 + o_row);
+    uint32_t *head = reinterpret_cast<uint32_t *>(w2 + o_head);
+    uint32_t *eidx = reinterpret_cast<uint32_t *>(w2 + o_eidx);
+    int32_t *medium_list = reinterpret_cast<int32_t *>(w2 + o_med);
+    int32_t *long_list = reinterpret_cast<int32_t *>(w2 + o_long);
+
+    emit_tuples<E><<<grid_for(en.nitems), TB, 0, st>>>(en, rowstart, fill, skey, srow);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    sort_rows_short<<<grid_for(nrows), TB, 0, st>>>(rowstart, skey, nrows, medium_list, long_list,
+                                                   counts);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    uint32_t lc[2] = {0, 0};
+    NODAL_HIP_TRY(h, hipMemcpyAsync(lc, counts, 8, hipMemcpyDeviceToHost, st));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    if (lc[0] > 0) {
+        sort_rows_medium<<<lc[0] > 2048 ? 2048 : lc[0], TB, 0, st>>>(rowstart, skey, medium_list,
+                                                                    counts);
+        NODAL_HIP_TRY(h, hipGetLastError());
+    }
+    if (lc[1] > 0) {
+        NODAL_HIP_TRY(h, h->work3.reserve((size_t)C * 16));  // padded scratch
+        sort_rows_long<<<lc[1] > 256 ? 256 : lc[1], 1024, 0, st>>>(
+            rowstart, skey, h->work3.as<uint64_t>(), long_list, counts);
+        NODAL_HIP_TRY(h, hipGetLastError());
+    }
+
+    mark_heads<<<grid_for(C), TB, 0, st>>>(skey, srow, rowstart, head, C);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    // scanned over C+1 slots: slot C (zero) receives the number of entries
+    NODAL_HIP_TRY(h, hipMemsetAsync(head + C, 0, 4, st));
+    NODAL_TRY(scan_exclusive_u32(h, head, eidx, C + 1, nullptr, w2 + o_scan2));
+    uint32_t nent32 = 0;
+    NODAL_HIP_TRY(h, hipMemcpyAsync(&nent32, eidx + C, 4, hipMemcpyDeviceToHost, st));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    const int64_t nent = nent32;
+    *nent_out = nent;
+
+    NODAL_HIP_TRY(h, indices.reserve((size_t)nent * 4 + 4));
+    NODAL_HIP_TRY(h, rowidx.reserve((size_t)nent * 4 + 4));
+    NODAL_HIP_TRY(h, cptr.reserve((size_t)(nent + 1) * 4));
+    NODAL_HIP_TRY(h, contrib.reserve((size_t)C * 4));
+    if (diag_pos) {
+        NODAL_HIP_TRY(h, diag_pos->reserve((size_t)nrows * 4 + 4));
+        fill_i32<<<grid_for(nrows), TB, 0, st>>>(diag_pos->as<int32_t>(), -1, nrows);
+        NODAL_HIP_TRY(h, hipGetLastError());
+    }
+    fill_entries<<<grid_for(C), TB, 0, st>>>(skey, srow, head, eidx, C, indices.as<int32_t>(),
+                                            rowidx.as<int32_t>(), cptr.as<int32_t>(),
+                                            contrib.as<uint32_t>(),
+                                            diag_pos ? diag_pos->as<int32_t>() : nullptr);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    set_tail<<<1, 1, 0, st>>>(cptr.as<int32_t>(), nent, C);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    if (indptr) {
+        NODAL_HIP_TRY(h, indptr->reserve((size_t)(nrows + 1) * 4));
+        fill_indptr<<<grid_for(nrows + 1), TB, 0, st>>>(rowstart, eidx, indptr->as<int32_t>(), nrows);
+        NODAL_HIP_TRY(h, hipGetLastError());
+    }
+    return NODAL_OK;
+}
+
+
+}  // namespace grp
+}  // namespace

@@ -348,6 +348,165 @@ int pcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
     return NODAL_OK;
 }
 
+// ---- flexible CG with the multigrid preconditioner (amg.hip) ----------------------
+// The K-cycle is a (mildly) non-linear operator, so beta uses the flexible
+// (Polak-Ribiere) form  beta = z_new.(r_new - r_old) / (z_old.r_old)
+//                             = -alpha (z_new . A p) / (z_old . r_old).
+
+enum { F_RZ0 = 0, F_RZ1 = 1, F_RR = 2, F_BB = 3, F_ALPHA = 4, F_FLAG = 5, F_COUNT = 8 };
+
+__global__ __launch_bounds__(TB) void fcg_init(const double *__restrict__ b, double *__restrict__ x,
+                                               double *__restrict__ r,
+                                               double *__restrict__ part_rr, int64_t n) {
+    double srr = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        const double ri = b[i];
+        x[i] = 0.0;
+        r[i] = ri;
+        srr = fma(ri, ri, srr);
+    }
+    srr = block_sum(srr);
+    if (threadIdx.x == 0) part_rr[blockIdx.x] = srr;
+}
+
+// partials of z.r and z.Ap
+__global__ __launch_bounds__(TB) void fcg_dots(const double *__restrict__ z,
+                                               const double *__restrict__ r,
+                                               const double *__restrict__ Ap,
+                                               double *__restrict__ part_rz,
+                                               double *__restrict__ part_zap, int64_t n) {
+    double a = 0.0, c = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        const double zi = z[i];
+        a = fma(zi, r[i], a);
+        c = fma(zi, Ap[i], c);
+    }
+    a = block_sum(a);
+    c = block_sum(c);
+    if (threadIdx.x == 0) {
+        part_rz[blockIdx.x] = a;
+        part_zap[blockIdx.x] = c;
+    }
+}
+
+__global__ __launch_bounds__(TB) void fcg_direction(const double *__restrict__ z,
+                                                    double *__restrict__ p,
+                                                    const double *__restrict__ part_rz,
+                                                    const double *__restrict__ part_zap,
+                                                    const double *__restrict__ part_rr, int nparts,
+                                                    double *__restrict__ sc, int iter, int64_t n) {
+    const double rz_new = reduce_partials(part_rz, nparts);
+    const double zap = reduce_partials(part_zap, nparts);
+    const double rr = reduce_partials(part_rr, nparts);
+    const double rz_old = iter > 0 ? sc[(iter - 1) & 1] : 1.0;
+    const double beta = (iter > 0 && rz_old != 0.0) ? -sc[F_ALPHA] * zap / rz_old : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc[iter & 1] = rz_new;
+        sc[F_RR] = rr;
+        if (iter == 0) sc[F_BB] = rr;
+        if (!(rz_new >= 0.0)) sc[F_FLAG] = 1.0;  // preconditioner not positive: not SPD
+    }
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        p[i] = iter > 0 ? fma(beta, p[i], z[i]) : z[i];
+}
+
+__global__ __launch_bounds__(TB) void fcg_update(double *__restrict__ x, double *__restrict__ r,
+                                                 const double *__restrict__ p,
+                                                 const double *__restrict__ Ap,
+                                                 const double *__restrict__ part_pap, int nparts_s,
+                                                 double *__restrict__ part_rr,
+                                                 double *__restrict__ sc, int iter, int64_t n) {
+    const double pap = reduce_partials(part_pap, nparts_s);
+    const double rz = sc[iter & 1];
+    const bool bad = !(pap > 0.0) && rz != 0.0;
+    const double alpha = (pap > 0.0) ? rz / pap : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc[F_ALPHA] = alpha;
+        if (bad) sc[F_FLAG] = 1.0;
+    }
+    double srr = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        x[i] = fma(alpha, p[i], x[i]);
+        const double ri = fma(-alpha, Ap[i], r[i]);
+        r[i] = ri;
+        srr = fma(ri, ri, srr);
+    }
+    srr = block_sum(srr);
+    if (threadIdx.x == 0) part_rr[blockIdx.x] = srr;
+}
+
+int amg_fcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
+    const int64_t n = h->n;
+    hipStream_t st = h->stream;
+    const size_t vec = align_up((size_t)n * 8);
+    NODAL_HIP_TRY(h, h->solver.reserve(4 * vec + 4 * MAX_PARTIALS * 8 + 256));
+    char *base = h->solver.as<char>();
+    double *r = reinterpret_cast<double *>(base);
+    double *z = reinterpret_cast<double *>(base + vec);
+    double *p = reinterpret_cast<double *>(base + 2 * vec);
+    double *Ap = reinterpret_cast<double *>(base + 3 * vec);
+    double *part_rz = reinterpret_cast<double *>(base + 4 * vec);
+    double *part_rr = part_rz + MAX_PARTIALS;
+    double *part_pap = part_rr + MAX_PARTIALS;
+    double *part_zap = part_pap + MAX_PARTIALS;
+    double *sc = part_zap + MAX_PARTIALS;
+    double *x = h->x.as<double>();
+    const int32_t *indptr = h->indptr.as<int32_t>();
+    const int32_t *indices = h->indices.as<int32_t>();
+    const double *data = h->data.as<double>();
+    const double *b = h->rhs.as<double>();
+
+    const int lpr = lanes_per_row(h);
+    const unsigned gv = grid_rows(n, 1), gs = grid_rows(n, lpr);
+    NODAL_HIP_TRY(h, hipMemsetAsync(sc, 0, F_COUNT * 8, st));
+    NODAL_HIP_TRY(h, hipMemsetAsync(part_zap, 0, MAX_PARTIALS * 8, st));
+    NODAL_TRY(amg_setup(h, sc + F_FLAG));
+    h->amg_levels = amg_num_levels(h);
+    fcg_init<<<gv, TB, 0, st>>>(b, x, r, part_rr, n);
+    NODAL_HIP_TRY(h, hipGetLastError());
+
+    const double tol = 1e-13;
+    const int64_t maxit = 500;
+    const int check = 4;
+    double hs[F_COUNT];
+    int64_t it = 0;
+    int status = 0;  // 0 running, 1 converged, 2 breakdown, 3 maxit
+    hipEvent_t e0 = h->ev[2], e1 = h->ev[3];
+    h->kern_ms = 0;
+    h->kern_launches = 0;
+    while (status == 0) {
+        for (int c = 0; c < check; ++c, ++it) {
+            NODAL_TRY(amg_apply(h, r, z));
+            fcg_dots<<<gv, TB, 0, st>>>(z, r, Ap, part_rz, part_zap, n);
+            fcg_direction<<<gv, TB, 0, st>>>(z, p, part_rz, part_zap, part_rr, (int)gv, sc, (int)it, n);
+            const bool timed = (c == check - 1);
+            if (timed) NODAL_HIP_TRY(h, hipEventRecord(e0, st));
+            DISPATCH_LPR(lpr, (pcg_spmv<L><<<gs, TB, 0, st>>>(indptr, indices, data, p, Ap, part_pap, n)));
+            if (timed) NODAL_HIP_TRY(h, hipEventRecord(e1, st));
+            fcg_update<<<gv, TB, 0, st>>>(x, r, p, Ap, part_pap, (int)gs, part_rr, sc, (int)it, n);
+        }
+        NODAL_HIP_TRY(h, hipGetLastError());
+        NODAL_HIP_TRY(h, hipMemcpyAsync(hs, sc, F_COUNT * 8, hipMemcpyDeviceToHost, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+            h->kern_ms += ms;
+            h->kern_launches += 1;
+        }
+        // sc[F_RR] is |r|^2 as of the direction kernel of the last iteration
+        if (hs[F_FLAG] != 0.0 || !(hs[F_RR] == hs[F_RR])) status = 2;
+        else if (hs[F_BB] == 0.0 || hs[F_RR] <= tol * tol * hs[F_BB]) status = 1;
+        else if (it >= maxit) status = 3;
+    }
+    *iters = (int32_t)it;
+    *resid = hs[F_BB] > 0 ? sqrt(hs[F_RR] / hs[F_BB]) : 0.0;
+    h->kern_alg = 12.0 * (double)h->nnz + 4.0 * (double)(n + 1) + 16.0 * (double)n;
+    if (status == 2) return -1;  // not SPD / singular: caller falls back
+    if (status == 3) return -1;  // stagnation: let the plain path decide
+    *info = 0;
+    return NODAL_OK;
+}
+
 __global__ __launch_bounds__(TB) void copy_rhs_column(const double *__restrict__ rhs,
                                                       double *__restrict__ col, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
@@ -387,7 +546,11 @@ int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, do
         else method = n <= densify_max ? NODAL_SPARSE_DENSIFY : NODAL_SPARSE_LU;
     }
     if (method == NODAL_SPARSE_PCG) {
-        int s = pcg_solve(h, info, iters, resid);
+        // multigrid-preconditioned flexible CG for large networks; Jacobi-CG below
+        // that (the hierarchy would not pay for itself) or if the cycle breaks down
+        int s = -1;
+        if (n >= h->amg_min_n) s = amg_fcg_solve(h, info, iters, resid);
+        if (s < 0) s = pcg_solve(h, info, iters, resid);
         if (s == NODAL_OK) {
             h->have_x = true;
             return NODAL_OK;
