@@ -53,10 +53,35 @@ struct Level {
 };
 enum { V_X = 0, V_R = 1, V_RC = 2, V_C1 = 3, V_C2 = 4, V_V1 = 5, V_V2 = 6, V_R2 = 7, V_COUNT = 8 };
 
+// ---- LDS-resident tail --------------------------------------------------------
+// All levels from `tail` down fit in one CU's LDS (160 KB): their matrices are packed
+// once into an image (f64 values, u16 indices) that a single 1024-thread workgroup
+// copies into LDS and then runs the whole coarse solve on -- the two flexible-CG
+// steps at level `tail` with V-cycles below -- with workgroup barriers instead of
+// ~130 kernel launches of 3-6 us each.
+constexpr int TAIL_THREADS = 1024;
+constexpr int TAIL_MAX_LEVELS = 8;
+constexpr int TAIL_LDS_BUDGET = 150 * 1024;
+
+struct TailLevel {
+    int n, nnz, nc;
+    int o_data, o_dinv, o_indptr, o_memptr, o_indices, o_agg, o_mem;  // image offsets (bytes)
+    int o_B, o_X, o_E, o_R;                                            // vectors (bytes)
+};
+struct TailDesc {
+    int nlev;  // levels in the tail, the last one is the dense coarsest level
+    TailLevel lv[TAIL_MAX_LEVELS];
+    int o_inv, o_C1, o_V1;
+    int image_bytes, total_bytes;
+};
+
 struct Hierarchy {
     std::vector<Level *> levels;
     DevBuf coarse_inv;  // dense inverse of the last level
     bool coarse_direct = false;
+    int tail = -1;      // first level handled by the LDS tail kernel (-1: none)
+    TailDesc tdesc;
+    DevBuf tail_image;
     ~Hierarchy() { clear(); }
     void clear() {
         for (Level *l : levels) {
@@ -67,6 +92,8 @@ struct Hierarchy {
         }
         levels.clear();
         coarse_inv.release();
+        tail_image.release();
+        tail = -1;
     }
 };
 
@@ -392,6 +419,185 @@ __global__ __launch_bounds__(TB) void jacobi_apply(int64_t n, const double *__re
         out[i] = dinv[i] * b[i];
 }
 
+
+// ---- tail kernels ----------------------------------------------------------------
+
+__global__ __launch_bounds__(TB) void pack_f64(char *img, int off, const double *src, int64_t n) {
+    double *dst = reinterpret_cast<double *>(img + off);
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        dst[i] = src[i];
+}
+__global__ __launch_bounds__(TB) void pack_i32(char *img, int off, const int32_t *src, int64_t n) {
+    int32_t *dst = reinterpret_cast<int32_t *>(img + off);
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        dst[i] = src[i];
+}
+__global__ __launch_bounds__(TB) void pack_u16(char *img, int off, const int32_t *src, int64_t n) {
+    uint16_t *dst = reinterpret_cast<uint16_t *>(img + off);
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        dst[i] = (uint16_t)src[i];
+}
+
+struct TailView {  // one level, pointers into LDS
+    int n, nnz, nc;
+    const double *data, *dinv;
+    const int32_t *indptr, *memptr;
+    const uint16_t *indices, *agg, *mem;
+    double *B, *X, *E, *R;
+};
+
+__device__ __forceinline__ TailView tail_view(char *smem, const TailLevel &t) {
+    TailView v;
+    v.n = t.n; v.nnz = t.nnz; v.nc = t.nc;
+    v.data = reinterpret_cast<const double *>(smem + t.o_data);
+    v.dinv = reinterpret_cast<const double *>(smem + t.o_dinv);
+    v.indptr = reinterpret_cast<const int32_t *>(smem + t.o_indptr);
+    v.memptr = reinterpret_cast<const int32_t *>(smem + t.o_memptr);
+    v.indices = reinterpret_cast<const uint16_t *>(smem + t.o_indices);
+    v.agg = reinterpret_cast<const uint16_t *>(smem + t.o_agg);
+    v.mem = reinterpret_cast<const uint16_t *>(smem + t.o_mem);
+    v.B = reinterpret_cast<double *>(smem + t.o_B);
+    v.X = reinterpret_cast<double *>(smem + t.o_X);
+    v.E = reinterpret_cast<double *>(smem + t.o_E);
+    v.R = reinterpret_cast<double *>(smem + t.o_R);
+    return v;
+}
+
+// sums of three per-thread values over the 1024-thread workgroup, valid everywhere
+__device__ __forceinline__ void tail_reduce3(double &a, double &b, double &c, double *scratch) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    c = wave_sum(c);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        scratch[wave] = a;
+        scratch[16 + wave] = b;
+        scratch[32 + wave] = c;
+    }
+    __syncthreads();
+    double sa = 0.0, sb = 0.0, sc = 0.0;
+#pragma unroll
+    for (int w = 0; w < TAIL_THREADS / 64; ++w) {
+        sa += scratch[w];
+        sb += scratch[16 + w];
+        sc += scratch[32 + w];
+    }
+    a = sa; b = sb; c = sc;
+}
+
+// V-cycle over the tail levels [0, nlev): rhs in lv[0].B, result in lv[0].E
+__device__ void tail_vcycle(char *smem, const TailDesc &d) {
+    const int last = d.nlev - 1;
+    for (int l = 0; l < last; ++l) {
+        const TailView v = tail_view(smem, d.lv[l]);
+        for (int i = threadIdx.x; i < v.n; i += TAIL_THREADS) {
+            double s = v.B[i];
+            for (int e = v.indptr[i]; e < v.indptr[i + 1]; ++e) {
+                const int j = v.indices[e];
+                s = fma(-v.data[e], OMEGA * v.dinv[j] * v.B[j], s);
+            }
+            v.X[i] = OMEGA * v.dinv[i] * v.B[i];
+            v.R[i] = s;
+        }
+        __syncthreads();
+        double *Bc = reinterpret_cast<double *>(smem + d.lv[l + 1].o_B);
+        for (int I = threadIdx.x; I < v.nc; I += TAIL_THREADS) {
+            double s = 0.0;
+            for (int p = v.memptr[I]; p < v.memptr[I + 1]; ++p) s += v.R[v.mem[p]];
+            Bc[I] = s;
+        }
+        __syncthreads();
+    }
+    {   // dense coarsest solve
+        const TailLevel &t = d.lv[last];
+        const double *inv = reinterpret_cast<const double *>(smem + d.o_inv);
+        const double *B = reinterpret_cast<const double *>(smem + t.o_B);
+        double *E = reinterpret_cast<double *>(smem + t.o_E);
+        for (int i = threadIdx.x; i < t.n; i += TAIL_THREADS) {
+            double s = 0.0;
+            for (int j = 0; j < t.n; ++j) s = fma(inv[i * t.n + j], B[j], s);
+            E[i] = s;
+        }
+        __syncthreads();
+    }
+    for (int l = last - 1; l >= 0; --l) {
+        const TailView v = tail_view(smem, d.lv[l]);
+        const double *Ec = reinterpret_cast<const double *>(smem + d.lv[l + 1].o_E);
+        for (int i = threadIdx.x; i < v.n; i += TAIL_THREADS) {
+            double s = v.B[i];
+            for (int e = v.indptr[i]; e < v.indptr[i + 1]; ++e) {
+                const int j = v.indices[e];
+                s = fma(-v.data[e], v.X[j] + Ec[v.agg[j]], s);
+            }
+            v.E[i] = fma(OMEGA * v.dinv[i], s, v.X[i] + Ec[v.agg[i]]);
+        }
+        __syncthreads();
+    }
+}
+
+// Coarse solve at level `tail` for the K-cycle of the level above: two flexible-CG
+// steps preconditioned by the tail V-cycle.  Outputs c1, c2 (global) and the five
+// dot products (one partial each) that prolong_smooth turns into s1, s2.
+__global__ __launch_bounds__(TAIL_THREADS) void amg_tail_kernel(TailDesc d, const char *image,
+                                                                const double *__restrict__ rc,
+                                                                double *__restrict__ c1_out,
+                                                                double *__restrict__ c2_out,
+                                                                double *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[48];
+    // image -> LDS (16-byte pieces)
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(image);
+        int4 *dst = reinterpret_cast<int4 *>(smem);
+        for (int i = threadIdx.x; i < d.image_bytes / 16; i += TAIL_THREADS) dst[i] = src[i];
+    }
+    const TailView top = tail_view(smem, d.lv[0]);
+    double *C1 = reinterpret_cast<double *>(smem + d.o_C1);
+    double *V1 = reinterpret_cast<double *>(smem + d.o_V1);
+    for (int i = threadIdx.x; i < top.n; i += TAIL_THREADS) top.B[i] = rc[i];
+    __syncthreads();
+
+    tail_vcycle(smem, d);  // c1 in top.E
+    double rho1 = 0.0, alpha1 = 0.0, zero = 0.0;
+    for (int i = threadIdx.x; i < top.n; i += TAIL_THREADS) {
+        double s = 0.0;
+        for (int e = top.indptr[i]; e < top.indptr[i + 1]; ++e)
+            s = fma(top.data[e], top.E[top.indices[e]], s);
+        const double ci = top.E[i];
+        V1[i] = s;
+        C1[i] = ci;
+        rho1 = fma(ci, s, rho1);
+        alpha1 = fma(ci, top.B[i], alpha1);
+    }
+    tail_reduce3(rho1, alpha1, zero, red);
+    const double t1 = rho1 > 0.0 ? alpha1 / rho1 : 0.0;
+    for (int i = threadIdx.x; i < top.n; i += TAIL_THREADS) top.B[i] = fma(-t1, V1[i], top.B[i]);
+    __syncthreads();
+
+    tail_vcycle(smem, d);  // c2 in top.E, r2 in top.B
+    double gamma = 0.0, beta = 0.0, alpha2 = 0.0;
+    for (int i = threadIdx.x; i < top.n; i += TAIL_THREADS) {
+        double s = 0.0;
+        for (int e = top.indptr[i]; e < top.indptr[i + 1]; ++e)
+            s = fma(top.data[e], top.E[top.indices[e]], s);
+        const double ci = top.E[i];
+        gamma = fma(ci, V1[i], gamma);
+        beta = fma(ci, s, beta);
+        alpha2 = fma(ci, top.B[i], alpha2);
+        c1_out[i] = C1[i];
+        c2_out[i] = ci;
+    }
+    tail_reduce3(gamma, beta, alpha2, red);
+    if (threadIdx.x == 0) {
+        part[0 * DOT_BLOCKS] = rho1;
+        part[1 * DOT_BLOCKS] = alpha1;
+        part[2 * DOT_BLOCKS] = gamma;
+        part[3 * DOT_BLOCKS] = beta;
+        part[4 * DOT_BLOCKS] = alpha2;
+    }
+}
+
 unsigned dot_grid(int64_t n) {
     const unsigned g = grid_for(n);
     return g > DOT_BLOCKS ? DOT_BLOCKS : g;
@@ -460,6 +666,76 @@ int finish_level(nodal_ctx *h, Level *l, const int32_t *diag_pos, double *flag) 
     NODAL_HIP_TRY(h, hipGetLastError());
     NODAL_HIP_TRY(h, l->vec.reserve((size_t)V_COUNT * (((size_t)n + 31) & ~(size_t)31) * 8 + 256));
     NODAL_HIP_TRY(h, l->part.reserve(5 * DOT_BLOCKS * 8));
+    return NODAL_OK;
+}
+
+
+// Choose the first level from which everything fits in LDS and pack its image.
+int build_tail(nodal_ctx *h, Hierarchy *H) {
+    const int L = (int)H->levels.size() - 1;
+    H->tail = -1;
+    auto up16 = [](int x) { return (x + 15) & ~15; };
+    for (int t = 1; t < L; ++t) {  // level 0 and the coarsest alone never form a tail
+        if (L - t + 1 > TAIL_MAX_LEVELS) continue;
+        if (H->levels[t]->A.n > 65535 || H->levels[t]->A.nnz > (1 << 22)) continue;
+        TailDesc d;
+        memset(&d, 0, sizeof d);
+        d.nlev = L - t + 1;
+        int off = 0;
+        for (int k = 0; k < d.nlev; ++k) {
+            const Level *lv = H->levels[t + k];
+            TailLevel &tl = d.lv[k];
+            tl.n = (int)lv->A.n;
+            tl.nnz = (int)lv->A.nnz;
+            tl.nc = (int)lv->nc;
+            if (k == d.nlev - 1) continue;  // the coarsest level only needs vectors + inverse
+            tl.o_data = off; off = up16(off + tl.nnz * 8);
+            tl.o_dinv = off; off = up16(off + tl.n * 8);
+            tl.o_indptr = off; off = up16(off + (tl.n + 1) * 4);
+            tl.o_memptr = off; off = up16(off + (tl.nc + 1) * 4);
+            tl.o_indices = off; off = up16(off + tl.nnz * 2);
+            tl.o_agg = off; off = up16(off + tl.n * 2);
+            tl.o_mem = off; off = up16(off + tl.n * 2);
+        }
+        const int nco = d.lv[d.nlev - 1].n;
+        d.o_inv = off; off = up16(off + nco * nco * 8);
+        d.image_bytes = off;
+        for (int k = 0; k < d.nlev; ++k) {
+            TailLevel &tl = d.lv[k];
+            tl.o_B = off; off = up16(off + tl.n * 8);
+            tl.o_X = off; off = up16(off + tl.n * 8);
+            tl.o_E = off; off = up16(off + tl.n * 8);
+            tl.o_R = off; off = up16(off + tl.n * 8);
+        }
+        d.o_C1 = off; off = up16(off + d.lv[0].n * 8);
+        d.o_V1 = off; off = up16(off + d.lv[0].n * 8);
+        d.total_bytes = off;
+        if (off > TAIL_LDS_BUDGET) continue;
+        // pack
+        NODAL_HIP_TRY(h, H->tail_image.reserve((size_t)d.image_bytes + 64));
+        char *img = H->tail_image.as<char>();
+        hipStream_t st = h->stream;
+        for (int k = 0; k + 1 < d.nlev; ++k) {
+            const Level *lv = H->levels[t + k];
+            const TailLevel &tl = d.lv[k];
+            pack_f64<<<grid_for(tl.nnz), TB, 0, st>>>(img, tl.o_data, lv->A.data, tl.nnz);
+            pack_f64<<<grid_for(tl.n), TB, 0, st>>>(img, tl.o_dinv, lv->dinv.as<double>(), tl.n);
+            pack_i32<<<grid_for(tl.n + 1), TB, 0, st>>>(img, tl.o_indptr, lv->A.indptr, tl.n + 1);
+            pack_i32<<<grid_for(tl.nc + 1), TB, 0, st>>>(img, tl.o_memptr, lv->memptr.as<int32_t>(), tl.nc + 1);
+            pack_u16<<<grid_for(tl.nnz), TB, 0, st>>>(img, tl.o_indices, lv->A.indices, tl.nnz);
+            pack_u16<<<grid_for(tl.n), TB, 0, st>>>(img, tl.o_agg, lv->agg.as<int32_t>(), tl.n);
+            pack_u16<<<grid_for(tl.n), TB, 0, st>>>(img, tl.o_mem, lv->mem.as<int32_t>(), tl.n);
+        }
+        pack_f64<<<grid_for(nco * nco), TB, 0, st>>>(img, d.o_inv, H->coarse_inv.as<double>(),
+                                                   (int64_t)nco * nco);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        NODAL_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(amg_tail_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             d.total_bytes));
+        H->tdesc = d;
+        H->tail = t;
+        break;
+    }
     return NODAL_OK;
 }
 
@@ -558,6 +834,7 @@ int amg_setup(nodal_ctx *h, double *flag) {
         NODAL_HIP_TRY(h, H->coarse_inv.reserve((size_t)last->A.n * last->A.n * 8 + 8));
         coarsest_inverse<<<1, 256, 0, st>>>(last->A, H->coarse_inv.as<double>(), flag);
         NODAL_HIP_TRY(h, hipGetLastError());
+        NODAL_TRY(build_tail(h, H));
     }
     return NODAL_OK;
 }
@@ -595,7 +872,13 @@ int cycle(nodal_ctx *h, Hierarchy *H, int l, const double *b, double *out) {
     NODAL_HIP_TRY(h, hipGetLastError());
     int nparts = 0;
     const bool coarse_is_last = (l + 1 == (int)H->levels.size() - 1);
-    if (coarse_is_last) {
+    if (l + 1 == H->tail) {
+        // the whole coarse solve (two FCG steps + everything below) in one LDS-resident launch
+        nparts = 1;
+        amg_tail_kernel<<<1, TAIL_THREADS, H->tdesc.total_bytes, st>>>(
+            H->tdesc, H->tail_image.as<char>(), rc, c1, c2, C->part.as<double>());
+        NODAL_HIP_TRY(h, hipGetLastError());
+    } else if (coarse_is_last) {
         NODAL_TRY(cycle(h, H, l + 1, rc, c1));  // direct coarse solve: one call is exact
     } else {
         // two flexible-CG steps on the coarse problem, preconditioned by its own cycle
