@@ -22,6 +22,42 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def replicate_table(table, values):
+    """One block-diagonal system holding every member of a value sweep.
+
+    Independent circuits that share the ground node do not couple (the ground row is
+    eliminated), so M members of a K-node, B-branch topology are one netlist with
+    M*K nodes and M*B branch unknowns.  Solving them together keeps the GPU full
+    (a single 1e4-node circuit occupies a few CUs) and costs one symbolic phase and
+    one multigrid setup.  Unknown layout: member m owns x[m*K:(m+1)*K] and
+    x[M*K + m*B : M*K + (m+1)*B]."""
+    from .lowering import ComponentTable
+    M = values.shape[0]
+    nc, K, B = table.ncomp, table.K, table.B
+    big = ComponentTable(M * nc, M * K, M * B)
+    big.type[:] = np.tile(table.type, M)
+    big.value[:] = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+    member = np.repeat(np.arange(M, dtype=np.int64), nc)
+
+    def shift(col, stride):
+        col = np.tile(col.astype(np.int64), M)
+        return np.where(col >= 0, col + member * stride, -1).astype(np.int32)
+
+    big.a[:], big.b[:] = shift(table.a, K), shift(table.b, K)
+    big.c[:], big.d[:] = shift(table.c, K), shift(table.d, K)
+    big.drv[:] = shift(table.drv, nc)
+    big.k[:] = shift(table.k, B)
+    return big
+
+
+def split_solution(x, M, K, B):
+    """[members, K+B] view of the block-diagonal solution vector."""
+    out = np.empty((M, K + B))
+    out[:, :K] = x[: M * K].reshape(M, K)
+    out[:, K:] = x[M * K:].reshape(M, B)
+    return out
+
+
 def solve_members(table, values, sparse=True, device=0, solver=None):
     """Solve every row of `values` ([members, ncomp]) on one GPU with a shared
     symbolic phase.  Returns [members, n] float64.  `solver` lets tests inject
@@ -29,6 +65,16 @@ def solve_members(table, values, sparse=True, device=0, solver=None):
     if solver is not None:
         return solver(table, values, sparse)
     from . import _ffi
+    if sparse and values.shape[0] > 1:
+        # all members at once, as one block-diagonal system
+        h = _ffi.Handle(device)
+        try:
+            h.upload(replicate_table(table, values))
+            info = h.run(False)
+            x = h.download_x()
+            return split_solution(x, values.shape[0], table.K, table.B)
+        finally:
+            h.close()
     h = _ffi.Handle(device)
     try:
         h.upload(table)

@@ -301,6 +301,23 @@ def test_value_sweep_batch_reuses_symbolic():
     h.close()
 
 
+def test_block_diagonal_batch_matches_per_member_oracle():
+    """BASELINE.json config 4: a shard's members are solved as one block-diagonal
+    system (nodal_amd.batch); every member must match its own oracle solve."""
+    from nodal_amd import batch
+    N, members = 24, 12  # 12 x 575 nodes: above the multigrid threshold
+    table = gen.grid_table(N)
+    vals = np.ones((members, table.ncomp))
+    for b in range(members):
+        vals[b, :-1] = gen.cfg4_values(b, N)
+    out = batch.solve_members(table, vals, sparse=True, device=0)
+    assert out.shape == (members, table.n)
+    for b in range(members):
+        Go, Ao = oracle.assemble_fast(gen.grid_table(N, vals[b, :-1]))
+        xo, _ = oracle.solve(Go.tocsr(), Ao, True)
+        assert normwise(out[b], xo) <= TOL
+
+
 def test_cli_scripts(tmp_path, capsys):
     from nodal_amd import solver
     case = next(c for c in CASES if c["name"] == "doc/1.6.1")
