@@ -46,8 +46,10 @@ enum { NODAL_T_R = 0, NODAL_T_A = 1, NODAL_T_E = 2, NODAL_T_VCVS = 3,
        NODAL_T_CCVS = 4, NODAL_T_CCCS = 5 };
 
 /* sparse solver selection for nodal_solve_sparse */
-enum { NODAL_SPARSE_AUTO = 0, NODAL_SPARSE_PCG = 1, NODAL_SPARSE_DENSIFY = 2,
-       NODAL_SPARSE_LU = 3 };
+enum { NODAL_SPARSE_AUTO = 0,
+       NODAL_SPARSE_PCG = 1,      /* SPD: multigrid-preconditioned flexible CG (Jacobi-CG when small) */
+       NODAL_SPARSE_DENSIFY = 2,  /* scatter to a dense panel, LU with pivoting                      */
+       NODAL_SPARSE_LU = 3 };     /* general: block-preconditioned flexible GMRES (historic name)   */
 
 /* ---- lifetime ---------------------------------------------------------- */
 int nodal_create(int device_id, nodal_handle *out);

@@ -751,6 +751,17 @@ void amg_destroy(nodal_ctx *h) {
 // Build the hierarchy for the CSR matrix of the context.  `flag` (device double) is
 // set non-zero if a diagonal or coarse pivot is not positive (not SPD).
 int amg_setup(nodal_ctx *h, double *flag) {
+    return amg_setup_csr(h, h->n, h->nnz, h->indptr.as<int32_t>(), h->indices.as<int32_t>(),
+                         h->rowidx.as<int32_t>(), h->data.as<double>(),
+                         h->diag_pos.as<int32_t>(), flag);
+}
+
+// The same for any device CSR matrix (sorted columns, rowidx = row of each entry,
+// diag_pos = position of the diagonal entry of each row).  The arrays must stay
+// alive as long as the hierarchy is used: level 0 aliases them.
+int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
+                  const int32_t *indices, const int32_t *rowidx, const double *data,
+                  const int32_t *diag_pos, double *flag) {
     amg_destroy(h);
     Hierarchy *H = new Hierarchy();
     h->amg = H;
@@ -758,13 +769,13 @@ int amg_setup(nodal_ctx *h, double *flag) {
 
     Level *l0 = new Level();
     H->levels.push_back(l0);
-    l0->A.n = h->n;
-    l0->A.nnz = h->nnz;
-    l0->A.indptr = h->indptr.as<int32_t>();
-    l0->A.indices = h->indices.as<int32_t>();
-    l0->A.rowidx = h->rowidx.as<int32_t>();
-    l0->A.data = h->data.as<double>();
-    NODAL_TRY(finish_level(h, l0, h->diag_pos.as<int32_t>(), flag));
+    l0->A.n = n0;
+    l0->A.nnz = nnz0;
+    l0->A.indptr = indptr;
+    l0->A.indices = indices;
+    l0->A.rowidx = rowidx;
+    l0->A.data = data;
+    NODAL_TRY(finish_level(h, l0, diag_pos, flag));
 
     while ((int)H->levels.size() < MAX_LEVELS) {
         Level *fine = H->levels.back();
@@ -909,7 +920,8 @@ int amg_apply(nodal_ctx *h, const double *r, double *z) {
     Hierarchy *H = static_cast<Hierarchy *>(h->amg);
     if (!H || H->levels.empty()) return nodal_fail(h, NODAL_E_INVALID, "amg_setup not called");
     if (H->levels.size() == 1) {
-        jacobi_apply<<<grid_for(h->n), TB, 0, h->stream>>>(h->n, H->levels[0]->dinv.as<double>(), r, z);
+        const int64_t n0 = H->levels[0]->A.n;
+        jacobi_apply<<<grid_for(n0), TB, 0, h->stream>>>(n0, H->levels[0]->dinv.as<double>(), r, z);
         NODAL_HIP_TRY(h, hipGetLastError());
         return NODAL_OK;
     }

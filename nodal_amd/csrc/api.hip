@@ -61,7 +61,8 @@ int nodal_destroy(nodal_handle h) {
                       &h->values_batch, &h->indptr, &h->indices, &h->rowidx, &h->cptr,
                       &h->contrib, &h->rhs_row, &h->rhs_cptr, &h->rhs_contrib, &h->diag_pos,
                       &h->data, &h->rhs, &h->status, &h->x, &h->dense, &h->piv, &h->work,
-                      &h->work2, &h->work3, &h->solver};
+                      &h->work2, &h->work3, &h->solver, &h->krylov, &h->gn_indptr, &h->gn_indices,
+                      &h->gn_rowidx, &h->gn_data, &h->gn_diag, &h->schur};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);

@@ -80,6 +80,9 @@ struct nodal_ctx {
     DevBuf work2;
     DevBuf work3;           // grouping: padded scratch for hub-row sorts
     DevBuf solver;          // persistent solver vectors
+    DevBuf krylov;          // FGMRES bases (sparse_general.hip)
+    DevBuf gn_indptr, gn_indices, gn_rowidx, gn_data, gn_diag;  // node block of G
+    DevBuf schur;           // diagonal Schur-complement approximation of the branch block
 
     // ---- timing ----
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -147,6 +150,9 @@ int dense_factor_solve(nodal_ctx *h, int32_t *info);
 
 // ---- aggregation multigrid preconditioner (amg.hip) ----
 int amg_setup(nodal_ctx *h, double *flag_dev);
+int amg_setup_csr(nodal_ctx *h, int64_t n, int64_t nnz, const int32_t *indptr,
+                  const int32_t *indices, const int32_t *rowidx, const double *data,
+                  const int32_t *diag_pos, double *flag_dev);
 int amg_apply(nodal_ctx *h, const double *r, double *z);
 int amg_num_levels(nodal_ctx *h);
 int64_t amg_level_size(nodal_ctx *h, int level);

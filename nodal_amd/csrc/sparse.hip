@@ -10,7 +10,8 @@
 //     LPR lanes and reduces with wavefront shuffles.
 //   * otherwise (branch equations present: zero diagonals, non-symmetric): small
 //     systems are scattered into a dense column-major panel and factorised by
-//     the dense LU (dense_lu.hip); large ones need the sparse LU (sparse_lu.hip).
+//     the dense LU (dense_lu.hip); large ones go to the block-preconditioned flexible
+//     GMRES of sparse_general.hip.
 //
 // Singular systems: x is filled with NaN and info > 0, without an error status,
 // because the reference's sparse path warns and returns NaNs (SURVEY.md section 0
@@ -527,7 +528,7 @@ int dense_prepare(nodal_ctx *h) {
     return NODAL_OK;
 }
 
-int sparse_lu_solve(nodal_ctx *h, int32_t *info);  // sparse_lu.hip
+int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid);  // sparse_general.hip
 
 int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, double *resid) {
     if (!h->have_numeric) return nodal_fail(h, NODAL_E_INVALID, "assemble_numeric not called");
@@ -540,7 +541,7 @@ int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, do
         h->have_x = true;
         return NODAL_OK;
     }
-    const int64_t densify_max = 16384;
+    const int64_t densify_max = 4096;
     if (method == NODAL_SPARSE_AUTO) {
         if (h->B == 0 && n > 64) method = NODAL_SPARSE_PCG;
         else method = n <= densify_max ? NODAL_SPARSE_DENSIFY : NODAL_SPARSE_LU;
@@ -563,12 +564,23 @@ int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, do
         NODAL_TRY(dense_prepare(h));
         NODAL_TRY(dense_factor_solve(h, info));
     } else if (method == NODAL_SPARSE_LU) {
-        NODAL_TRY(sparse_lu_solve(h, info));
+        NODAL_TRY(sparse_general_solve(h, info, iters, resid));
     } else {
         return nodal_fail(h, NODAL_E_INVALID, "unknown sparse method");
     }
     if (*info > 0) NODAL_TRY(dense_fill_nan(h, h->x.as<double>(), n));
     h->have_x = true;
+    return NODAL_OK;
+}
+
+// y = G x with the context's CSR matrix (used by the general Krylov path)
+int csr_spmv(nodal_ctx *h, const double *x, double *y) {
+    const int64_t n = h->n;
+    const int lpr = lanes_per_row(h);
+    DISPATCH_LPR(lpr, (spmv_kernel<L><<<grid_rows(n, lpr), TB, 0, h->stream>>>(
+                          h->indptr.as<int32_t>(), h->indices.as<int32_t>(), h->data.as<double>(), x,
+                          y, n)));
+    NODAL_HIP_TRY(h, hipGetLastError());
     return NODAL_OK;
 }
 

@@ -170,6 +170,28 @@ def test_cfg3_large_grid_sparse(name):
     h.close()
 
 
+def test_cfg5_full_size_general_sparse():
+    """BASELINE.json config 5 at full size (1e6-node grid + 1% E + CCCS/VCVS,
+    non-symmetric, zero diagonals): samples of the reference's own SuperLU solution."""
+    case = next(c for c in LARGE if c["name"] == "cfg5(1000)")
+    table = gen.cfg5_table(1000)
+    assert (table.K, table.B, table.ncomp) == (case["nums"]["kcl"], case["nums"]["be"], case["ncomp"])
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.nnz == case["nnz"]
+    assert h.assemble_numeric()[0] == _ffi.OK
+    indptr, indices, data, rhs = h.export_csr()
+    assert float(np.abs(data).sum()) == case["G_abs_sum"]
+    assert float(rhs.sum()) == case["A_sum"] and np.count_nonzero(rhs) == case["A_nnz"]
+    x, info, iters, relres = h.solve_sparse()
+    assert info == 0
+    assert normwise(x[case["x_idx"]], case["x_sparse_samples"]) <= TOL
+    assert abs(np.abs(x).max() - case["x_sparse_absmax"]) <= TOL * case["x_sparse_absmax"]
+    assert h.residual() <= 1e-12
+    h.close()
+
+
 def test_equivalent_resistance_golden():
     for case in EQUIV:
         if "gen" in case:
