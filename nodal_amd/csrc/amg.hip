@@ -21,6 +21,7 @@
 // level's cycle.  One damped-Jacobi pre- and post-smoothing step, fused with the
 // residual / prolongation so a level visit costs three kernels.
 #include "group.h"
+#include "spmv_stream.h"
 
 namespace {
 
@@ -33,6 +34,7 @@ constexpr int COARSEST_MAX = 64;
 constexpr int MAX_LEVELS = 16;
 constexpr double OMEGA = 0.67;
 constexpr int DOT_BLOCKS = 128;  // partial sums per dot product
+constexpr int64_t SPLIT_PROLONG_MIN = 200000;  // levels this large prolong in a separate pass
 
 struct Csr {
     int64_t n = 0, nnz = 0;
@@ -292,21 +294,20 @@ __device__ __forceinline__ double reduce_partials(const double *__restrict__ par
     return block_sum(s);
 }
 
-// pre-smoothing from a zero guess, fused with the residual:
+// pre-smoothing from a zero guess, fused with the residual (CSR-stream):
 //   x = w D^-1 b ;  r = b - A x          (x_j is recomputed from b_j on the fly)
 __global__ __launch_bounds__(TB) void smooth_residual(Csr A, const double *__restrict__ dinv,
                                                       const double *__restrict__ b,
                                                       double *__restrict__ x,
                                                       double *__restrict__ r) {
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
-        double s = b[i];
-        for (int32_t e = A.indptr[i]; e < A.indptr[i + 1]; ++e) {
-            const int j = A.indices[e];
-            s = fma(-A.data[e], OMEGA * dinv[j] * b[j], s);
-        }
-        x[i] = OMEGA * dinv[i] * b[i];
-        r[i] = s;
-    }
+    stream::for_rows(
+        A.indptr, A.indices, A.data, A.n,
+        [&](int32_t, int32_t col, double val) { return val * (OMEGA * dinv[col] * b[col]); },
+        [&](int64_t i, double sum) {
+            const double bi = b[i];
+            x[i] = OMEGA * dinv[i] * bi;
+            r[i] = bi - sum;
+        });
 }
 
 // rc[I] = sum of r over the members of aggregate I (fixed order)
@@ -336,7 +337,7 @@ __device__ __forceinline__ KCoef kcycle_coefficients(const double *__restrict__ 
     return KCoef{alpha1 / rho1 - gamma * alpha2 / (rho1 * rho2), alpha2 / rho2};
 }
 
-// coarse correction + post-smoothing, fused:
+// coarse correction + post-smoothing, fused (CSR-stream; small and medium levels):
 //   x' = x + P (s1 c1 + s2 c2) ;  out = x' + w D^-1 (b - A x')
 __global__ __launch_bounds__(TB) void prolong_smooth(Csr A, const double *__restrict__ dinv,
                                                      const double *__restrict__ b,
@@ -347,21 +348,44 @@ __global__ __launch_bounds__(TB) void prolong_smooth(Csr A, const double *__rest
                                                      const double *__restrict__ part, int nparts,
                                                      double *__restrict__ out) {
     const KCoef k = kcycle_coefficients(part, nparts);
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
-        double s = b[i];
-        for (int32_t e = A.indptr[i]; e < A.indptr[i + 1]; ++e) {
-            const int j = A.indices[e];
-            const int J = agg[j];
-            const double xj = x[j] + k.s1 * c1[J] + (nparts ? k.s2 * c2[J] : 0.0);
-            s = fma(-A.data[e], xj, s);
-        }
-        const int I = agg[i];
-        const double xi = x[i] + k.s1 * c1[I] + (nparts ? k.s2 * c2[I] : 0.0);
-        out[i] = fma(OMEGA * dinv[i], s, xi);
-    }
+    const bool two = nparts != 0;
+    auto corrected = [&](int64_t j) {
+        const int J = agg[j];
+        return x[j] + k.s1 * c1[J] + (two ? k.s2 * c2[J] : 0.0);
+    };
+    stream::for_rows(
+        A.indptr, A.indices, A.data, A.n,
+        [&](int32_t, int32_t col, double val) { return val * corrected(col); },
+        [&](int64_t i, double sum) { out[i] = fma(OMEGA * dinv[i], b[i] - sum, corrected(i)); });
 }
 
-// v = A c and the partial dot products c.v, c.u1 (and c.u2 when given)
+// The same in two launches for large levels, where gathering agg / c1 / c2 once per
+// ENTRY costs more HBM traffic than one extra pass over the vectors:
+//   (1) xp = x + P (s1 c1 + s2 c2)        (2) out = xp + w D^-1 (b - A xp)
+__global__ __launch_bounds__(TB) void prolong_add(int64_t n, const double *__restrict__ x,
+                                                  const int32_t *__restrict__ agg,
+                                                  const double *__restrict__ c1,
+                                                  const double *__restrict__ c2,
+                                                  const double *__restrict__ part, int nparts,
+                                                  double *__restrict__ xp) {
+    const KCoef k = kcycle_coefficients(part, nparts);
+    const bool two = nparts != 0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        const int I = agg[i];
+        xp[i] = x[i] + k.s1 * c1[I] + (two ? k.s2 * c2[I] : 0.0);
+    }
+}
+__global__ __launch_bounds__(TB) void post_smooth(Csr A, const double *__restrict__ dinv,
+                                                  const double *__restrict__ b,
+                                                  const double *__restrict__ xp,
+                                                  double *__restrict__ out) {
+    stream::for_rows(
+        A.indptr, A.indices, A.data, A.n,
+        [&](int32_t, int32_t col, double val) { return val * xp[col]; },
+        [&](int64_t i, double sum) { out[i] = fma(OMEGA * dinv[i], b[i] - sum, xp[i]); });
+}
+
+// v = A c and the partial dot products c.v, c.u1 (and c.u2 when given)  (CSR-stream)
 __global__ __launch_bounds__(TB) void spmv_dots(Csr A, const double *__restrict__ c,
                                                 double *__restrict__ v,
                                                 const double *__restrict__ u1,
@@ -370,16 +394,16 @@ __global__ __launch_bounds__(TB) void spmv_dots(Csr A, const double *__restrict_
                                                 double *__restrict__ p_cu1,
                                                 double *__restrict__ p_cu2) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
-        double s = 0.0;
-        for (int32_t e = A.indptr[i]; e < A.indptr[i + 1]; ++e)
-            s = fma(A.data[e], c[A.indices[e]], s);
-        v[i] = s;
-        const double ci = c[i];
-        a0 = fma(ci, s, a0);
-        a1 = fma(ci, u1[i], a1);
-        if (u2) a2 = fma(ci, u2[i], a2);
-    }
+    stream::for_rows(
+        A.indptr, A.indices, A.data, A.n,
+        [&](int32_t, int32_t col, double val) { return val * c[col]; },
+        [&](int64_t i, double sum) {
+            v[i] = sum;
+            const double ci = c[i];
+            a0 = fma(ci, sum, a0);
+            a1 = fma(ci, u1[i], a1);
+            if (u2) a2 = fma(ci, u2[i], a2);
+        });
     a0 = block_sum(a0);
     a1 = block_sum(a1);
     a2 = block_sum(a2);
@@ -598,10 +622,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void amg_tail_kernel(TailDesc d, cons
     }
 }
 
-unsigned dot_grid(int64_t n) {
-    const unsigned g = grid_for(n);
-    return g > DOT_BLOCKS ? DOT_BLOCKS : g;
-}
+unsigned dot_grid(int64_t n) { return stream::grid_for_rows(n, DOT_BLOCKS); }
 
 // ---------------------------------------------------------------------------------
 // host side
@@ -878,7 +899,7 @@ int cycle(nodal_ctx *h, Hierarchy *H, int l, const double *b, double *out) {
     const double *dinv = L->dinv.as<double>();
     double *x = L->v(V_X), *r = L->v(V_R);
     double *rc = C->v(V_RC), *c1 = C->v(V_C1), *c2 = C->v(V_C2);
-    smooth_residual<<<grid_for(n), TB, 0, st>>>(L->A, dinv, b, x, r);
+    smooth_residual<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, dinv, b, x, r);
     restrict_sum<<<grid_for(nc), TB, 0, st>>>(nc, L->memptr.as<int32_t>(), L->mem.as<int32_t>(), r, rc);
     NODAL_HIP_TRY(h, hipGetLastError());
     int nparts = 0;
@@ -907,8 +928,16 @@ int cycle(nodal_ctx *h, Hierarchy *H, int l, const double *b, double *out) {
                                     part + 2 * DOT_BLOCKS, part + 4 * DOT_BLOCKS);
         NODAL_HIP_TRY(h, hipGetLastError());
     }
-    prolong_smooth<<<grid_for(n), TB, 0, st>>>(L->A, dinv, b, x, L->agg.as<int32_t>(), c1, c2,
-                                              C->part.as<double>(), nparts, out);
+    if (n >= SPLIT_PROLONG_MIN) {
+        double *xp = r;  // the residual vector is dead after the restriction
+        prolong_add<<<grid_for(n), TB, 0, st>>>(n, x, L->agg.as<int32_t>(), c1, c2,
+                                               C->part.as<double>(), nparts, xp);
+        post_smooth<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, dinv, b, xp, out);
+    } else {
+        prolong_smooth<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, dinv, b, x, L->agg.as<int32_t>(),
+                                                               c1, c2, C->part.as<double>(), nparts,
+                                                               out);
+    }
     NODAL_HIP_TRY(h, hipGetLastError());
     return NODAL_OK;
 }

@@ -17,6 +17,7 @@
 // because the reference's sparse path warns and returns NaNs (SURVEY.md section 0
 // quirk 3).
 #include "ctx.h"
+#include "spmv_stream.h"
 
 int dense_fill_nan(nodal_ctx *h, double *x, int64_t n);
 
@@ -64,22 +65,15 @@ __device__ __forceinline__ double row_dot(const int32_t *__restrict__ indptr,
     return s;  // valid in sub == 0
 }
 
-// y = A x
-template <int LPR>
+// y = A x  (CSR-stream)
 __global__ __launch_bounds__(TB) void spmv_kernel(const int32_t *__restrict__ indptr,
                                                   const int32_t *__restrict__ indices,
                                                   const double *__restrict__ data,
                                                   const double *__restrict__ x,
                                                   double *__restrict__ y, int64_t n) {
-    const int sub = threadIdx.x % LPR;
-    const int64_t rows_per_pass = (int64_t)gridDim.x * (TB / LPR);
-    const int64_t passes = (n + rows_per_pass - 1) / rows_per_pass;
-    for (int64_t it = 0; it < passes; ++it) {
-        const int64_t row = it * rows_per_pass + (int64_t)blockIdx.x * (TB / LPR) + threadIdx.x / LPR;
-        const bool live = row < n;
-        const double s = live ? row_dot<LPR>(indptr, indices, data, x, row, sub) : 0.0;
-        if (live && sub == 0) y[row] = s;
-    }
+    stream::for_rows(
+        indptr, indices, data, n, [&](int32_t, int32_t col, double val) { return val * x[col]; },
+        [&](int64_t r, double sum) { y[r] = sum; });
 }
 
 // scalars kept on the device (doubles)
@@ -129,27 +123,21 @@ __global__ __launch_bounds__(TB) void pcg_direction(const double *__restrict__ z
         p[i] = iter > 0 ? fma(beta, p[i], z[i]) : z[i];
 }
 
-// K2: Ap = A p, partials of p.Ap
-template <int LPR>
+// K2: Ap = A p, partials of p.Ap  (CSR-stream: spmv_stream.h)
 __global__ __launch_bounds__(TB) void pcg_spmv(const int32_t *__restrict__ indptr,
                                                const int32_t *__restrict__ indices,
                                                const double *__restrict__ data,
                                                const double *__restrict__ p,
                                                double *__restrict__ Ap,
                                                double *__restrict__ part_pap, int64_t n) {
-    const int sub = threadIdx.x % LPR;
-    const int64_t rows_per_pass = (int64_t)gridDim.x * (TB / LPR);
-    const int64_t passes = (n + rows_per_pass - 1) / rows_per_pass;
     double acc = 0.0;
-    for (int64_t it = 0; it < passes; ++it) {
-        const int64_t row = it * rows_per_pass + (int64_t)blockIdx.x * (TB / LPR) + threadIdx.x / LPR;
-        const bool live = row < n;
-        const double s = live ? row_dot<LPR>(indptr, indices, data, p, row, sub) : 0.0;
-        if (live && sub == 0) {
-            Ap[row] = s;
-            acc = fma(p[row], s, acc);
-        }
-    }
+    stream::for_rows(
+        indptr, indices, data, n,
+        [&](int32_t, int32_t col, double val) { return val * p[col]; },
+        [&](int64_t r, double sum) {
+            Ap[r] = sum;
+            acc = fma(p[r], sum, acc);
+        });
     acc = block_sum(acc);
     if (threadIdx.x == 0) part_pap[blockIdx.x] = acc;
 }
@@ -299,7 +287,7 @@ int pcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
 
     const int lpr = lanes_per_row(h);
     const unsigned gv = grid_rows(n, 1);     // vector kernels
-    const unsigned gs = grid_rows(n, lpr);   // spmv kernels
+    const unsigned gs = stream::grid_for_rows(n, MAX_PARTIALS);   // spmv kernels
     const int nparts_v = (int)gv, nparts_s = (int)gs;
 
     NODAL_HIP_TRY(h, hipMemsetAsync(sc, 0, S_COUNT * 8, st));
@@ -321,7 +309,7 @@ int pcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
             pcg_direction<<<gv, TB, 0, st>>>(z, p, part_rz, part_rr, nparts_v, sc, (int)it, n);
             const bool timed = (c == check - 1);
             if (timed) NODAL_HIP_TRY(h, hipEventRecord(e0, st));
-            DISPATCH_LPR(lpr, (pcg_spmv<L><<<gs, TB, 0, st>>>(indptr, indices, data, p, Ap, part_pap, n)));
+            pcg_spmv<<<gs, TB, 0, st>>>(indptr, indices, data, p, Ap, part_pap, n);
             if (timed) NODAL_HIP_TRY(h, hipEventRecord(e1, st));
             pcg_update<<<gv, TB, 0, st>>>(x, r, z, p, Ap, dinv, part_pap, part_rz, part_rr,
                                           nparts_s, sc, (int)it, n);
@@ -458,7 +446,7 @@ int amg_fcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
     const double *b = h->rhs.as<double>();
 
     const int lpr = lanes_per_row(h);
-    const unsigned gv = grid_rows(n, 1), gs = grid_rows(n, lpr);
+    const unsigned gv = grid_rows(n, 1), gs = stream::grid_for_rows(n, MAX_PARTIALS);
     NODAL_HIP_TRY(h, hipMemsetAsync(sc, 0, F_COUNT * 8, st));
     NODAL_HIP_TRY(h, hipMemsetAsync(part_zap, 0, MAX_PARTIALS * 8, st));
     NODAL_TRY(amg_setup(h, sc + F_FLAG));
@@ -482,7 +470,7 @@ int amg_fcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
             fcg_direction<<<gv, TB, 0, st>>>(z, p, part_rz, part_zap, part_rr, (int)gv, sc, (int)it, n);
             const bool timed = (c == check - 1);
             if (timed) NODAL_HIP_TRY(h, hipEventRecord(e0, st));
-            DISPATCH_LPR(lpr, (pcg_spmv<L><<<gs, TB, 0, st>>>(indptr, indices, data, p, Ap, part_pap, n)));
+            pcg_spmv<<<gs, TB, 0, st>>>(indptr, indices, data, p, Ap, part_pap, n);
             if (timed) NODAL_HIP_TRY(h, hipEventRecord(e1, st));
             fcg_update<<<gv, TB, 0, st>>>(x, r, p, Ap, part_pap, (int)gs, part_rr, sc, (int)it, n);
         }
@@ -576,10 +564,8 @@ int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, do
 // y = G x with the context's CSR matrix (used by the general Krylov path)
 int csr_spmv(nodal_ctx *h, const double *x, double *y) {
     const int64_t n = h->n;
-    const int lpr = lanes_per_row(h);
-    DISPATCH_LPR(lpr, (spmv_kernel<L><<<grid_rows(n, lpr), TB, 0, h->stream>>>(
-                          h->indptr.as<int32_t>(), h->indices.as<int32_t>(), h->data.as<double>(), x,
-                          y, n)));
+    spmv_kernel<<<stream::grid_for_rows(n), TB, 0, h->stream>>>(
+        h->indptr.as<int32_t>(), h->indices.as<int32_t>(), h->data.as<double>(), x, y, n);
     NODAL_HIP_TRY(h, hipGetLastError());
     return NODAL_OK;
 }
