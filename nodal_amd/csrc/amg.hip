@@ -32,7 +32,7 @@ constexpr int PASSES = 3;
 constexpr int MATCH_ROUNDS = 5;
 constexpr int COARSEST_MAX = 64;
 constexpr int MAX_LEVELS = 16;
-constexpr double OMEGA = 0.67;
+constexpr double OMEGA = 0.85;
 constexpr int DOT_BLOCKS = 128;  // partial sums per dot product
 constexpr int64_t SPLIT_PROLONG_MIN = 200000;  // levels this large prolong in a separate pass
 

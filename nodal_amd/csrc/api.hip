@@ -1,4 +1,6 @@
 // extern "C" entry points of libnodal_hip.so (see include/nodal_hip.h).
+#include <stdlib.h>
+
 #include "ctx.h"
 
 int dense_prepare(nodal_ctx *h);  // sparse.hip
@@ -38,8 +40,12 @@ int nodal_create(int device_id, nodal_handle *out) {
         return NODAL_E_HIP;
     nodal_ctx *h = new nodal_ctx();
     h->device = device_id;
+    // main stream: highest priority -- it carries the latency-critical chains (LU panel
+    // factorisation, multigrid cycles)
+    int lo = 0, hi = 0;  // least / greatest priority
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (hipSetDevice(device_id) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, hi) != hipSuccess) {
         delete h;
         return NODAL_E_HIP;
     }
@@ -48,6 +54,31 @@ int nodal_create(int device_id, nodal_handle *out) {
             delete h;
             return NODAL_E_HIP;
         }
+    // second stream for the dense LU's trailing updates (lookahead).  It is confined to
+    // 224 of the 256 CUs: the panel chain on the main stream is a sequence of small
+    // latency-bound kernels and must always find idle CUs, otherwise every one of its
+    // ~1300 launches queues behind 58-us GEMM workgroups.  (If the CU mask is refused,
+    // fall back to a low-priority stream.)
+    {
+        uint32_t mask[8];
+        int reserve = 32;  // CUs kept free for the main stream (NODAL_PANEL_CUS to tune)
+        if (const char *e = getenv("NODAL_PANEL_CUS")) reserve = atoi(e);
+        if (reserve < 0) reserve = 0;
+        if (reserve > 224) reserve = 224;
+        for (int i = 0; i < 8; ++i) mask[i] = 0xFFFFFFFFu;
+        for (int cu = 0; cu < reserve; ++cu) mask[cu / 32] &= ~(1u << (cu % 32));
+        if (hipExtStreamCreateWithCUMask(&h->stream2, 8, mask) != hipSuccess) {
+            h->stream2 = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    if ((!h->stream2 &&
+         hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, lo) != hipSuccess) ||
+        hipEventCreateWithFlags(&h->ev_la[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_la[1], hipEventDisableTiming) != hipSuccess) {
+        delete h;
+        return NODAL_E_HIP;
+    }
     *out = h;
     return NODAL_OK;
 }
@@ -67,6 +98,9 @@ int nodal_destroy(nodal_handle h) {
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
+    for (auto &e : h->ev_la)
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return NODAL_OK;
@@ -294,7 +328,7 @@ int nodal_debug_gemm(nodal_handle h, int32_t M, int32_t N, int32_t K, const doub
     NODAL_HIP_TRY(h, hipMemcpyAsync(dA, A, sa, hipMemcpyHostToDevice, h->stream));
     NODAL_HIP_TRY(h, hipMemcpyAsync(dB, B, sb, hipMemcpyHostToDevice, h->stream));
     NODAL_HIP_TRY(h, hipMemcpyAsync(dC, C, sc, hipMemcpyHostToDevice, h->stream));
-    NODAL_TRY(gemm_sub_f64(h, dC, M, dA, M, dB, K, M, N, K));
+    NODAL_TRY(gemm_sub_f64(h, h->stream, dC, M, dA, M, dB, K, M, N, K));
     NODAL_HIP_TRY(h, hipMemcpyAsync(C, dC, sc, hipMemcpyDeviceToHost, h->stream));
     NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
     return NODAL_OK;

@@ -36,6 +36,8 @@ struct DevBuf {
 struct nodal_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // trailing updates of the dense LU (lookahead)
+    hipEvent_t ev_la[2] = {nullptr, nullptr};
     std::string err;
 
     // ---- component table (HBM, structure of arrays) ----
@@ -134,8 +136,8 @@ int stamp_numeric(nodal_ctx *h, int32_t member, int64_t *bad_component);
 int stamp_to_dense(nodal_ctx *h, double *G_dev, int64_t ld, bool col_major);
 
 // ---- fp64 MFMA GEMM (gemm_f64.hip): C -= A * B, column-major ----
-int gemm_sub_f64(nodal_ctx *h, double *C, int64_t ldc, const double *A, int64_t lda,
-                 const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K);
+int gemm_sub_f64(nodal_ctx *h, hipStream_t stream, double *C, int64_t ldc, const double *A,
+                 int64_t lda, const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K);
 
 // ---- dense LU (dense_lu.hip) ----
 // leading dimension of the column-major dense panel: padded so that 32-row tiles

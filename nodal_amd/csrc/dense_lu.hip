@@ -330,35 +330,45 @@ __global__ __launch_bounds__(SLAB) void tslu_select(
     }
 }
 
-// Unpivoted LU of the nbc x nbc diagonal block at (c0, c0), in LDS; the factors go to
-// lu11 (and tslu_apply writes them back).  piv = identity.
-__global__ __launch_bounds__(256) void diag_lu_nopivot(const double *__restrict__ A, int64_t lda,
-                                                       int c0, int nbc, double *__restrict__ lu11,
-                                                       int32_t *__restrict__ piv,
-                                                       int32_t *__restrict__ info) {
-    __shared__ double D[NB][NB + 1];  // D[r][c]
-    for (int t = threadIdx.x; t < NB * NB; t += 256) {
-        const int r = t % NB, c = t / NB;
-        D[r][c] = (r < nbc && c < nbc) ? A[(int64_t)(c0 + c) * lda + c0 + r] : (r == c ? 1.0 : 0.0);
-    }
-    if (threadIdx.x < nbc) piv[c0 + threadIdx.x] = c0 + threadIdx.x;
-    __syncthreads();
-    const int r = threadIdx.x % NB, cg = threadIdx.x / NB;  // 8 column groups
-    for (int k = 0; k < NB - 1; ++k) {
-        const double pv = D[k][k];
-        if (pv == 0.0 && threadIdx.x == 0 && k < nbc) atomicCAS(info, 0, c0 + k + 1);
-        const double l = (r > k && pv != 0.0) ? D[r][k] * (1.0 / pv) : 0.0;
-        __syncthreads();
-        if (r > k) {
-            if (cg == 0) D[r][k] = l;
-            for (int c = k + 1 + cg; c < NB; c += 8) D[r][c] = fma(-l, D[k][c], D[r][c]);
+// Unpivoted LU of the nbc x nbc diagonal block at (c0, c0) by ONE wave: lane r holds
+// row r in registers, the pivot row is broadcast through a double-buffered LDS line,
+// and there is no workgroup barrier (a wave executes in lock step).  The factors go
+// to lu11 (tslu_apply writes them back into the matrix).  piv = identity.
+__global__ __launch_bounds__(64) void diag_lu_nopivot(const double *__restrict__ A, int64_t lda,
+                                                      int c0, int nbc, double *__restrict__ lu11,
+                                                      int32_t *__restrict__ piv,
+                                                      int32_t *__restrict__ info) {
+    __shared__ double prow[2][NB];
+    const int r = threadIdx.x;
+    double a[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+        a[q] = (r < nbc && q < nbc) ? A[(int64_t)(c0 + q) * lda + c0 + r] : (r == q ? 1.0 : 0.0);
+    if (r < nbc) piv[c0 + r] = c0 + r;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int buf = k & 1;
+        if (r == k) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+                if (q >= k) prow[buf][q] = a[q];
+            if (a[k] == 0.0 && k < nbc) atomicCAS(info, 0, c0 + k + 1);  // exact zero pivot
         }
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the LDS line is written
+        __builtin_amdgcn_wave_barrier();
+        if (r > k && r < NB) {
+            const double pv = prow[buf][k];
+            if (pv != 0.0) {
+                const double l = a[k] * (1.0 / pv);
+                a[k] = l;
+#pragma unroll
+                for (int q = k + 1; q < NB; ++q) a[q] = fma(-l, prow[buf][q], a[q]);
+            }
+        }
     }
-    if (threadIdx.x == 0 && nbc == NB && D[NB - 1][NB - 1] == 0.0) atomicCAS(info, 0, c0 + NB);
-    for (int t = threadIdx.x; t < NB * NB; t += 256) {
-        const int rr = t % NB, c = t / NB;
-        lu11[c * NB + rr] = D[rr][c];
+    if (r < NB) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) lu11[q * NB + r] = a[q];
     }
 }
 
@@ -382,30 +392,32 @@ __global__ __launch_bounds__(256) void tslu_apply(double *__restrict__ A, int64_
     }
     __syncthreads();
     lds_cptr Up = opaque_lds(&U[0][0]);
-    for (int64_t r = c0 + (int64_t)blockIdx.x * 256 + threadIdx.x; r < n;
-         r += (int64_t)gridDim.x * 256) {
-        double *ar = A + (int64_t)c0 * lda + r;
-        if (r < c0 + nbc) {
-            const int rr = (int)(r - c0);
-            for (int q = 0; q < nbc; ++q) ar[(int64_t)q * lda] = lu11[q * NB + rr];
-            continue;
-        }
-        double x[NB];
-#pragma unroll
-        for (int q = 0; q < NB; ++q) x[q] = (FULL || q < nbc) ? ar[(int64_t)q * lda] : 0.0;
-#pragma unroll
-        for (int c = 0; c < NB; ++c) {
-            const double xc = x[c] * rcp[c];
-            x[c] = xc;
-#pragma unroll
-            for (int q = c + 1; q < NB; ++q) x[q] = fma(-xc, Up[c * (NB + 1) + q], x[q]);
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int q = 0; q < NB; ++q)
-            if (FULL || q < nbc) ar[(int64_t)q * lda] = x[q];
+    // one row per lane, no grid-stride loop: with a loop the compiler hoists every
+    // (loop-invariant) LDS read of U out of it -- 256 VGPRs, and then the kernel cannot
+    // co-reside with the trailing update's waves on the second stream
+    const int64_t r = c0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    double *ar = A + (int64_t)c0 * lda + r;
+    if (r < c0 + nbc) {
+        const int rr = (int)(r - c0);
+        for (int q = 0; q < nbc; ++q) ar[(int64_t)q * lda] = lu11[q * NB + rr];
+        return;
     }
+    double x[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) x[q] = (FULL || q < nbc) ? ar[(int64_t)q * lda] : 0.0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        const double xc = x[c] * rcp[c];
+        x[c] = xc;
+#pragma unroll
+        for (int q = c + 1; q < NB; ++q) x[q] = fma(-xc, Up[c * (NB + 1) + q], x[q]);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+        if (FULL || q < nbc) ar[(int64_t)q * lda] = x[q];
 }
 
 // U12 = L11^-1 A12 with a W x W unit lower triangular L11 at (j0, j0): one workgroup
@@ -471,38 +483,41 @@ __global__ __launch_bounds__(256) void trsm_outer(double *__restrict__ A, int64_
 // back substitution
 // ---------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(64) void bs_diag(const double *__restrict__ A, int64_t lda,
-                                              double *__restrict__ y, int j0, int j1) {
+// One back-substitution step, fused: every workgroup solves the nb x nb diagonal
+// block U[j0:j1, j0:j1] x = y redundantly in LDS (32 cheap steps), then updates its
+// share of y[0:j0] -= U[0:j0, j0:j1] x.  Workgroup 0 also stores x.  One launch per
+// block instead of two.  The solved x_J goes to xout, y[0:j0] is updated in place.
+__global__ __launch_bounds__(256) void bs_step(const double *__restrict__ A, int64_t lda,
+                                               double *__restrict__ y, double *__restrict__ xout,
+                                               int j0, int j1) {
     __shared__ double U[NB][NB + 1];
     __shared__ double x[NB];
     const int nb = j1 - j0;
-    for (int t = threadIdx.x; t < NB * NB; t += 64) {
+    for (int t = threadIdx.x; t < NB * NB; t += 256) {
         const int r = t % NB, s = t / NB;
-        U[r][s] = (r < nb && s < nb) ? A[(int64_t)(j0 + s) * lda + j0 + r] : 0.0;
+        U[r][s] = (r < nb && s < nb) ? A[(int64_t)(j0 + s) * lda + j0 + r] : (r == s ? 1.0 : 0.0);
     }
     if (threadIdx.x < NB) x[threadIdx.x] = (int)threadIdx.x < nb ? y[j0 + threadIdx.x] : 0.0;
     __syncthreads();
-    for (int r = nb - 1; r >= 0; --r) {
-        if (threadIdx.x == 0) x[r] = x[r] / U[r][r];
-        __syncthreads();
-        if ((int)threadIdx.x < r) x[threadIdx.x] = fma(-U[threadIdx.x][r], x[r], x[threadIdx.x]);
-        __syncthreads();
+    if (threadIdx.x < 64) {  // one wave: no workgroup barrier inside the 32 steps
+        for (int r = nb - 1; r >= 0; --r) {
+            if (threadIdx.x == 0) x[r] = x[r] / U[r][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if ((int)threadIdx.x < r) x[threadIdx.x] = fma(-U[threadIdx.x][r], x[r], x[threadIdx.x]);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
     }
-    if ((int)threadIdx.x < nb) y[j0 + threadIdx.x] = x[threadIdx.x];
-}
-
-__global__ __launch_bounds__(256) void bs_update(const double *__restrict__ A, int64_t lda,
-                                                 double *__restrict__ y, int j0, int j1) {
-    __shared__ double x[NB];
-    if (threadIdx.x < NB) x[threadIdx.x] = (j0 + (int)threadIdx.x < j1) ? y[j0 + threadIdx.x] : 0.0;
     __syncthreads();
-    const int nb = j1 - j0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < j0;
-         i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < j0; i += (int64_t)gridDim.x * 256) {
         double acc = y[i];
         for (int s = 0; s < nb; ++s) acc = fma(-A[(int64_t)(j0 + s) * lda + i], x[s], acc);
         y[i] = acc;
     }
+    // x goes to a separate vector: y[j0:j1] must stay intact, workgroups that start
+    // late still read it
+    if (blockIdx.x == 0 && (int)threadIdx.x < nb) xout[j0 + threadIdx.x] = x[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void fill_nan(double *x, int64_t n) {
@@ -521,17 +536,17 @@ struct GemmTimer {
     nodal_ctx *h;
     size_t used = 0;
     double flops = 0;
-    int begin() {
+    int begin(hipStream_t st) {
         while (h->evpool.size() < 2 * (used + 1)) {
             hipEvent_t e;
             NODAL_HIP_TRY(h, hipEventCreate(&e));
             h->evpool.push_back(e);
         }
-        NODAL_HIP_TRY(h, hipEventRecord(h->evpool[2 * used], h->stream));
+        NODAL_HIP_TRY(h, hipEventRecord(h->evpool[2 * used], st));
         return NODAL_OK;
     }
-    int end(double f) {
-        NODAL_HIP_TRY(h, hipEventRecord(h->evpool[2 * used + 1], h->stream));
+    int end(hipStream_t st, double f) {
+        NODAL_HIP_TRY(h, hipEventRecord(h->evpool[2 * used + 1], st));
         ++used;
         flops += f;
         return NODAL_OK;
@@ -547,6 +562,45 @@ struct GemmTimer {
         h->kern_alg = used ? flops / (double)used : 0.0;  // average flops per launch
     }
 };
+
+// After the outer panel [J0, J1) is factored on the panel stream: apply it to the rest
+// of the matrix with one panel of LOOKAHEAD.  The next panel's columns [J1, LA1) are
+// updated on the panel stream right away, so its factorisation (a chain of small,
+// latency-bound kernels) can start while the big trailing update of everything to
+// the right, [LA1, ncols), runs on the second stream.  ev_la[0]: panel done;
+// ev_la[1]: trailing update done.  `piv` != nullptr: apply the panel's interchanges.
+int trailing_update(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncols, int64_t J0,
+                    int64_t J1, const int32_t *piv, GemmTimer &tm, bool &trail_pending) {
+    hipStream_t sa = h->stream, sb = h->stream2;
+    const int w = (int)(J1 - J0);
+    const int64_t LA1 = J1 + W < n ? J1 + W : n;  // end of the lookahead columns
+    NODAL_HIP_TRY(h, hipEventRecord(h->ev_la[0], sa));
+    // the previous trailing update also touched [J1, LA1): wait for it
+    if (trail_pending) NODAL_HIP_TRY(h, hipStreamWaitEvent(sa, h->ev_la[1], 0));
+    if (piv)  // columns left of the panel and the lookahead columns
+        lu_swap_cols<<<blocks_for(LA1, 256), 256, 0, sa>>>(A, lda, 0, LA1, J0, J1, (int)J0, (int)J1, piv);
+    if (LA1 > J1) {
+        trsm_outer<<<(unsigned)((LA1 - J1 + 31) / 32), 256, 0, sa>>>(A, lda, J1, LA1, (int)J0, w);
+        NODAL_TRY(gemm_sub_f64(h, sa, A + J1 * lda + J1, lda, A + J0 * lda + J1, lda,
+                               A + J1 * lda + J0, lda, n - J1, LA1 - J1, w));
+    }
+    // everything to the right (including the rhs column) on the second stream
+    NODAL_HIP_TRY(h, hipStreamWaitEvent(sb, h->ev_la[0], 0));
+    if (piv)
+        lu_swap_cols<<<blocks_for(ncols - LA1, 256), 256, 0, sb>>>(A, lda, LA1, ncols, 0, 0, (int)J0,
+                                                                  (int)J1, piv);
+    trsm_outer<<<(unsigned)((ncols - LA1 + 31) / 32), 256, 0, sb>>>(A, lda, LA1, ncols, (int)J0, w);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    if (J1 < n) {
+        NODAL_TRY(tm.begin(sb));
+        NODAL_TRY(gemm_sub_f64(h, sb, A + LA1 * lda + J1, lda, A + J0 * lda + J1, lda,
+                               A + LA1 * lda + J0, lda, n - J1, ncols - LA1, w));
+        NODAL_TRY(tm.end(sb, 2.0 * (double)w * (double)(n - J1) * (double)(ncols - LA1)));
+    }
+    NODAL_HIP_TRY(h, hipEventRecord(h->ev_la[1], sb));
+    trail_pending = true;
+    return NODAL_OK;
+}
 
 int factor_gepp(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncols, int32_t *piv,
                 int32_t *dinfo, GemmTimer &tm) {
@@ -568,10 +622,10 @@ int factor_gepp(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncols, 
                                                                          (int)j0, (int)(j1 - j0));
         NODAL_HIP_TRY(h, hipGetLastError());
         if (j1 < n) {
-            NODAL_TRY(tm.begin());
-            NODAL_TRY(gemm_sub_f64(h, A + j1 * lda + j1, lda, A + j0 * lda + j1, lda,
+            NODAL_TRY(tm.begin(st));
+            NODAL_TRY(gemm_sub_f64(h, st, A + j1 * lda + j1, lda, A + j0 * lda + j1, lda,
                                    A + j1 * lda + j0, lda, n - j1, ncols - j1, j1 - j0));
-            NODAL_TRY(tm.end(2.0 * (double)(j1 - j0) * (double)(n - j1) * (double)(ncols - j1)));
+            NODAL_TRY(tm.end(st, 2.0 * (double)(j1 - j0) * (double)(n - j1) * (double)(ncols - j1)));
         }
     }
     return NODAL_OK;
@@ -593,6 +647,7 @@ int factor_tournament(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t n
     double *cval[2] = {reinterpret_cast<double *>(wbase + 2 * idx_bytes),
                        reinterpret_cast<double *>(wbase + 2 * idx_bytes + val_bytes)};
     double *lu11 = reinterpret_cast<double *>(wbase + 2 * (idx_bytes + val_bytes));
+    bool trail_pending = false;
 
     for (int64_t J0 = 0; J0 < n; J0 += W) {
         const int64_t J1 = J0 + W < n ? J0 + W : n;
@@ -636,24 +691,15 @@ int factor_tournament(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t n
                     lu_trsm32<true><<<blocks_for(J1 - c1, 256), 256, 0, st>>>(A, lda, c1, J1, (int)c0, NB);
                 else
                     lu_trsm32<false><<<blocks_for(J1 - c1, 256), 256, 0, st>>>(A, lda, c1, J1, (int)c0, nbc);
-                NODAL_TRY(gemm_sub_f64(h, A + c1 * lda + c1, lda, A + c0 * lda + c1, lda,
+                NODAL_TRY(gemm_sub_f64(h, st, A + c1 * lda + c1, lda, A + c0 * lda + c1, lda,
                                        A + c1 * lda + c0, lda, n - c1, J1 - c1, nbc));
             }
             NODAL_HIP_TRY(h, hipGetLastError());
         }
-        // outside the panel: interchanges, U12, trailing update
-        lu_swap_cols<<<blocks_for(ncols, 256), 256, 0, st>>>(A, lda, 0, ncols, J0, J1, (int)J0,
-                                                            (int)J1, piv);
-        trsm_outer<<<(unsigned)((ncols - J1 + 31) / 32), 256, 0, st>>>(A, lda, J1, ncols, (int)J0,
-                                                                      (int)(J1 - J0));
-        NODAL_HIP_TRY(h, hipGetLastError());
-        if (J1 < n) {
-            NODAL_TRY(tm.begin());
-            NODAL_TRY(gemm_sub_f64(h, A + J1 * lda + J1, lda, A + J0 * lda + J1, lda,
-                                   A + J1 * lda + J0, lda, n - J1, ncols - J1, J1 - J0));
-            NODAL_TRY(tm.end(2.0 * (double)(J1 - J0) * (double)(n - J1) * (double)(ncols - J1)));
-        }
+        // outside the panel: interchanges, U12, trailing update (with lookahead)
+        NODAL_TRY(trailing_update(h, A, n, lda, ncols, J0, J1, piv, tm, trail_pending));
     }
+    if (trail_pending) NODAL_HIP_TRY(h, hipStreamWaitEvent(st, h->ev_la[1], 0));
     return NODAL_OK;
 }
 
@@ -663,11 +709,12 @@ int factor_nopivot(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncol
     hipStream_t st = h->stream;
     NODAL_HIP_TRY(h, h->work.reserve(NB * NB * 8 + 256));
     double *lu11 = h->work.as<double>();
+    bool trail_pending = false;
     for (int64_t J0 = 0; J0 < n; J0 += W) {
         const int64_t J1 = J0 + W < n ? J0 + W : n;
         for (int64_t c0 = J0; c0 < J1; c0 += NB) {
             const int nbc = (int)(c0 + NB < J1 ? NB : J1 - c0);
-            diag_lu_nopivot<<<1, 256, 0, st>>>(A, lda, (int)c0, nbc, lu11, piv, dinfo);
+            diag_lu_nopivot<<<1, 64, 0, st>>>(A, lda, (int)c0, nbc, lu11, piv, dinfo);
             if (nbc == NB)
                 tslu_apply<true><<<blocks_for(n - c0, 256), 256, 0, st>>>(A, lda, (int)n, (int)c0, NB, lu11);
             else
@@ -678,21 +725,14 @@ int factor_nopivot(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncol
                     lu_trsm32<true><<<blocks_for(J1 - c1, 256), 256, 0, st>>>(A, lda, c1, J1, (int)c0, NB);
                 else
                     lu_trsm32<false><<<blocks_for(J1 - c1, 256), 256, 0, st>>>(A, lda, c1, J1, (int)c0, nbc);
-                NODAL_TRY(gemm_sub_f64(h, A + c1 * lda + c1, lda, A + c0 * lda + c1, lda,
+                NODAL_TRY(gemm_sub_f64(h, st, A + c1 * lda + c1, lda, A + c0 * lda + c1, lda,
                                        A + c1 * lda + c0, lda, n - c1, J1 - c1, nbc));
             }
             NODAL_HIP_TRY(h, hipGetLastError());
         }
-        trsm_outer<<<(unsigned)((ncols - J1 + 31) / 32), 256, 0, st>>>(A, lda, J1, ncols, (int)J0,
-                                                                      (int)(J1 - J0));
-        NODAL_HIP_TRY(h, hipGetLastError());
-        if (J1 < n) {
-            NODAL_TRY(tm.begin());
-            NODAL_TRY(gemm_sub_f64(h, A + J1 * lda + J1, lda, A + J0 * lda + J1, lda,
-                                   A + J1 * lda + J0, lda, n - J1, ncols - J1, J1 - J0));
-            NODAL_TRY(tm.end(2.0 * (double)(J1 - J0) * (double)(n - J1) * (double)(ncols - J1)));
-        }
+        NODAL_TRY(trailing_update(h, A, n, lda, ncols, J0, J1, nullptr, tm, trail_pending));
     }
+    if (trail_pending) NODAL_HIP_TRY(h, hipStreamWaitEvent(st, h->ev_la[1], 0));
     return NODAL_OK;
 }
 
@@ -725,12 +765,11 @@ int dense_factor_solve(nodal_ctx *h, int32_t *info) {
     double *y = A + n * lda;
     for (int64_t j1 = n; j1 > 0;) {
         int64_t j0 = ((j1 - 1) / NB) * NB;
-        bs_diag<<<1, 64, 0, st>>>(A, lda, y, (int)j0, (int)j1);
-        if (j0 > 0) bs_update<<<blocks_for(j0, 256), 256, 0, st>>>(A, lda, y, (int)j0, (int)j1);
+        bs_step<<<blocks_for(j0 > 0 ? j0 : 1, 256), 256, 0, st>>>(A, lda, y, h->x.as<double>(), (int)j0,
+                                                                 (int)j1);
         j1 = j0;
     }
     NODAL_HIP_TRY(h, hipGetLastError());
-    NODAL_HIP_TRY(h, hipMemcpyAsync(h->x.p, y, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
     int32_t hinfo = 0;
     NODAL_HIP_TRY(h, hipMemcpyAsync(&hinfo, dinfo, 4, hipMemcpyDeviceToHost, st));
     NODAL_HIP_TRY(h, hipStreamSynchronize(st));

@@ -114,11 +114,11 @@ __global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C
 }  // namespace
 
 // C -= A * B on the handle's stream.  All matrices column-major, device pointers.
-int gemm_sub_f64(nodal_ctx *h, double *C, int64_t ldc, const double *A, int64_t lda,
-                 const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
+int gemm_sub_f64(nodal_ctx *h, hipStream_t stream, double *C, int64_t ldc, const double *A,
+                 int64_t lda, const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return NODAL_OK;
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
-    gemm_sub_kernel<<<grid, 256, 0, h->stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
+    gemm_sub_kernel<<<grid, 256, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
     NODAL_HIP_TRY(h, hipGetLastError());
     return NODAL_OK;
 }
