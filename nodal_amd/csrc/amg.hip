@@ -622,6 +622,64 @@ __global__ __launch_bounds__(TAIL_THREADS) void amg_tail_kernel(TailDesc d, cons
     }
 }
 
+
+// ---- structural singularity check -----------------------------------------------------
+// A passive network is singular iff some connected component has no resistor to
+// ground.  Aggregation never merges across components and the Galerkin product keeps
+// an edge between two aggregates iff a fine edge joins them, so the LAST level has the
+// same components as the netlist; "touches ground" flags are OR-ed up the hierarchy.
+
+__global__ __launch_bounds__(TB) void flags_restrict(int64_t nc, const int32_t *__restrict__ memptr,
+                                                     const int32_t *__restrict__ mem,
+                                                     const uint8_t *__restrict__ fine,
+                                                     uint8_t *__restrict__ coarse) {
+    for (int64_t I = (int64_t)blockIdx.x * TB + threadIdx.x; I < nc; I += (int64_t)gridDim.x * TB) {
+        uint8_t f = 0;
+        for (int32_t p = memptr[I]; p < memptr[I + 1]; ++p) f |= fine[mem[p]];
+        coarse[I] = f;
+    }
+}
+
+__global__ __launch_bounds__(TB) void cc_init(int64_t n, int32_t *__restrict__ label) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        label[i] = (int32_t)i;
+}
+// hook: the root of the larger label is attached to the smaller label
+__global__ __launch_bounds__(TB) void cc_hook(Csr A, int32_t *__restrict__ label,
+                                              int32_t *__restrict__ changed) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        const int li = label[i];
+        for (int32_t e = A.indptr[i]; e < A.indptr[i + 1]; ++e) {
+            if (A.data[e] == 0.0) continue;
+            const int lj = label[A.indices[e]];
+            if (lj < li) {
+                atomicMin(&label[li], lj);
+                *changed = 1;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(TB) void cc_jump(int64_t n, int32_t *__restrict__ label) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        int l = label[i];
+        while (label[l] != l) l = label[l];
+        label[i] = l;
+    }
+}
+// per component root: does it hold a grounded node?
+__global__ __launch_bounds__(TB) void cc_mark(int64_t n, const int32_t *__restrict__ label,
+                                              const uint8_t *__restrict__ grounded,
+                                              int32_t *__restrict__ root_ok) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        if (grounded[i]) root_ok[label[i]] = 1;
+}
+__global__ __launch_bounds__(TB) void cc_verdict(int64_t n, const int32_t *__restrict__ label,
+                                                 const int32_t *__restrict__ root_ok,
+                                                 int32_t *__restrict__ floating) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        if (label[i] == (int32_t)i && !root_ok[i]) *floating = 1;
+}
+
 unsigned dot_grid(int64_t n) { return stream::grid_for_rows(n, DOT_BLOCKS); }
 
 // ---------------------------------------------------------------------------------
@@ -955,4 +1013,51 @@ int amg_apply(nodal_ctx *h, const double *r, double *z) {
         return NODAL_OK;
     }
     return cycle(h, H, 0, r, z);
+}
+
+// grounded0: u8[n] at level 0, 1 where a resistor joins the node to ground.
+// *floating = 1 if some connected component of the network has no such node.
+int amg_has_floating_component(nodal_ctx *h, const uint8_t *grounded0, int32_t *floating) {
+    Hierarchy *H = static_cast<Hierarchy *>(h->amg);
+    if (!H || H->levels.empty()) return nodal_fail(h, NODAL_E_INVALID, "amg_setup not called");
+    hipStream_t st = h->stream;
+    // OR the flags up the hierarchy (two ping-pong byte vectors in work2)
+    const int64_t n0 = H->levels[0]->A.n;
+    const size_t half = ((size_t)n0 + 255) & ~(size_t)255;
+    const Level *last = H->levels.back();
+    const int64_t nl = last->A.n;
+    const size_t a4 = ((size_t)nl * 4 + 255) & ~(size_t)255;
+    NODAL_HIP_TRY(h, h->work2.reserve(2 * half + 2 * a4 + 512));
+    uint8_t *f[2] = {h->work2.as<uint8_t>(), h->work2.as<uint8_t>() + half};
+    const uint8_t *cur = grounded0;
+    for (size_t l = 0; l + 1 < H->levels.size(); ++l) {
+        const Level *L = H->levels[l];
+        uint8_t *dst = f[l & 1];
+        flags_restrict<<<grid_for(L->nc), TB, 0, st>>>(L->nc, L->memptr.as<int32_t>(),
+                                                      L->mem.as<int32_t>(), cur, dst);
+        cur = dst;
+    }
+    NODAL_HIP_TRY(h, hipGetLastError());
+    // connected components of the last level
+    int32_t *label = reinterpret_cast<int32_t *>(h->work2.as<char>() + 2 * half);
+    int32_t *root_ok = reinterpret_cast<int32_t *>(h->work2.as<char>() + 2 * half + a4);
+    int32_t *flags = reinterpret_cast<int32_t *>(h->work2.as<char>() + 2 * half + 2 * a4);  // changed, floating
+    cc_init<<<grid_for(nl), TB, 0, st>>>(nl, label);
+    for (int it = 0; it < 4096; ++it) {
+        NODAL_HIP_TRY(h, hipMemsetAsync(flags, 0, 4, st));
+        cc_hook<<<grid_for(nl), TB, 0, st>>>(last->A, label, flags);
+        cc_jump<<<grid_for(nl), TB, 0, st>>>(nl, label);
+        int32_t changed = 0;
+        NODAL_HIP_TRY(h, hipMemcpyAsync(&changed, flags, 4, hipMemcpyDeviceToHost, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        if (!changed) break;
+    }
+    NODAL_HIP_TRY(h, hipMemsetAsync(root_ok, 0, (size_t)nl * 4, st));
+    NODAL_HIP_TRY(h, hipMemsetAsync(flags + 1, 0, 4, st));
+    cc_mark<<<grid_for(nl), TB, 0, st>>>(nl, label, cur, root_ok);
+    cc_verdict<<<grid_for(nl), TB, 0, st>>>(nl, label, root_ok, flags + 1);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    NODAL_HIP_TRY(h, hipMemcpyAsync(floating, flags + 1, 4, hipMemcpyDeviceToHost, st));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    return NODAL_OK;
 }

@@ -97,7 +97,7 @@ struct nodal_ctx {
     void *amg = nullptr;  // multigrid hierarchy (amg.hip)
     int32_t last_iterations = 0;
     int32_t amg_levels = 0;
-    int64_t amg_min_n = 4096;  // below this the sparse SPD path uses Jacobi-CG
+    int64_t amg_min_n = 65;    // below this the sparse SPD path goes dense
 };
 
 #define NODAL_HIP_TRY(h, expr)                                                   \
@@ -159,6 +159,10 @@ int amg_apply(nodal_ctx *h, const double *r, double *z);
 int amg_num_levels(nodal_ctx *h);
 int64_t amg_level_size(nodal_ctx *h, int level);
 void amg_destroy(nodal_ctx *h);
+int amg_has_floating_component(nodal_ctx *h, const uint8_t *grounded0, int32_t *floating);
+
+// u8[n] flags: 1 where a resistor connects the node to ground (stamp.hip)
+int stamp_grounded_flags(nodal_ctx *h, uint8_t *flags_dev);
 
 // ---- sparse solvers (sparse_*.hip) ----
 int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, double *resid);

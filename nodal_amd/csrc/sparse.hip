@@ -451,6 +451,20 @@ int amg_fcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
     NODAL_HIP_TRY(h, hipMemsetAsync(part_zap, 0, MAX_PARTIALS * 8, st));
     NODAL_TRY(amg_setup(h, sc + F_FLAG));
     h->amg_levels = amg_num_levels(h);
+    {
+        // structurally singular (a floating island): the reference's spsolve returns
+        // NaNs; CG would happily return one of the infinitely many solutions
+        NODAL_HIP_TRY(h, h->work3.reserve((size_t)n + 256));
+        NODAL_TRY(stamp_grounded_flags(h, h->work3.as<uint8_t>()));
+        int32_t floating = 0;
+        NODAL_TRY(amg_has_floating_component(h, h->work3.as<uint8_t>(), &floating));
+        if (floating) {
+            *info = 1;
+            *iters = 0;
+            *resid = 0.0;
+            return -2;  // singular: caller fills NaNs
+        }
+    }
     fcg_init<<<gv, TB, 0, st>>>(b, x, r, part_rr, n);
     NODAL_HIP_TRY(h, hipGetLastError());
 
@@ -539,6 +553,11 @@ int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, do
         // that (the hierarchy would not pay for itself) or if the cycle breaks down
         int s = -1;
         if (n >= h->amg_min_n) s = amg_fcg_solve(h, info, iters, resid);
+        if (s == -2) {  // structurally singular network
+            NODAL_TRY(dense_fill_nan(h, h->x.as<double>(), n));
+            h->have_x = true;
+            return NODAL_OK;
+        }
         if (s < 0) s = pcg_solve(h, info, iters, resid);
         if (s == NODAL_OK) {
             h->have_x = true;

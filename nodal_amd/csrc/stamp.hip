@@ -220,6 +220,16 @@ __global__ __launch_bounds__(TB) void scatter_dense(const int32_t *__restrict__ 
     }
 }
 
+__global__ __launch_bounds__(TB) void grounded_flags(Table tb, uint8_t *__restrict__ flags) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < tb.ncomp;
+         i += (int64_t)gridDim.x * TB) {
+        if (tb.type[i] != NODAL_T_R) continue;
+        const int ia = tb.a[i], ib = tb.b[i];
+        if (ia >= 0 && ib < 0) flags[ia] = 1;  // benign race: every writer stores 1
+        if (ib >= 0 && ia < 0) flags[ib] = 1;
+    }
+}
+
 Table table_of(nodal_ctx *h) {
     Table tb;
     tb.type = h->type.as<uint8_t>();
@@ -311,6 +321,15 @@ int stamp_to_dense(nodal_ctx *h, double *G_dev, int64_t ld, bool col_major) {
                                                              h->indices.as<int32_t>(),
                                                              h->data.as<double>(), G_dev, ld, h->nnz,
                                                              col_major);
+        NODAL_HIP_TRY(h, hipGetLastError());
+    }
+    return NODAL_OK;
+}
+
+int stamp_grounded_flags(nodal_ctx *h, uint8_t *flags_dev) {
+    NODAL_HIP_TRY(h, hipMemsetAsync(flags_dev, 0, (size_t)h->n, h->stream));
+    if (h->ncomp > 0) {
+        grounded_flags<<<grid_for(h->ncomp), TB, 0, h->stream>>>(table_of(h), flags_dev);
         NODAL_HIP_TRY(h, hipGetLastError());
     }
     return NODAL_OK;

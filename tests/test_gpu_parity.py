@@ -192,6 +192,32 @@ def test_cfg5_full_size_general_sparse():
     h.close()
 
 
+def test_floating_island_sparse_returns_nan_like_reference():
+    """A resistor island with no path to ground makes G singular.  The reference's
+    sparse path (SuperLU) warns and returns NaNs; an
+    iterative solver would silently return one of infinitely many solutions, so the
+    sparse SPD path checks connectivity structurally."""
+    rows = [r for r in gen.grid_rows(12)]
+    rows += [[f"f{i}", "R", "1", f"x{i}", f"x{i + 1}"] for i in range(150)]
+    rows += [["fa", "A", "1", "x3", "x77"]]
+    nl = n.Netlist.from_rows(rows)
+    Go, Ao, _ = oracle.build_model(nl, True)
+    xo, warns = oracle.solve(Go, Ao, True)
+    assert np.isnan(xo).all() and warns == ["MatrixRankWarning"]  # what the reference does
+    circ = n.Circuit(nl, sparse=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        x = circ.solve().result
+    assert np.isnan(x).all()
+    assert any(issubclass(i.category, MatrixRankWarning) for i in w)
+    # the same network with the island tied to ground is regular
+    nl2 = n.Netlist.from_rows(rows + [["tie", "R", "5", "x0", "g"]])
+    c2 = n.Circuit(nl2, sparse=True)
+    x2 = c2.solve().result
+    G2, A2, _ = oracle.build_model(nl2, True)
+    assert normwise(x2, oracle.solve(G2, A2, True)[0]) <= TOL
+
+
 def test_equivalent_resistance_golden():
     for case in EQUIV:
         if "gen" in case:
