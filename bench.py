@@ -36,6 +36,20 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP64_MFMA_PEAK_TF = 78.6    # vendor dense fp64 matrix peak
+# measured on this hardware with tools/mfma_f64_peak.hip (profiles/r01_mfma_f64_peak.txt):
+FP64_MFMA_INSTR_TF = 36.2   # v_mfma_f64_16x16x4_f64, 138 cycles/instruction/wave
+FP64_VALU_FMA_TF = 59.3     # v_fma_f64
+
+
+def pmc_traffic(workload):
+    """HBM bytes per launch of the workload's dominant kernel from the committed
+    rocprofv3 PMC summary (FETCH_SIZE x2 + WRITE_SIZE, separate passes; see
+    profiles/r01_pmc_traffic.json).  None if that workload was not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)["dominant"][workload]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def build_workload(name, rank, per_gpu):
@@ -104,11 +118,13 @@ def time_workload(name, rank, world, steps, warmup, per_gpu, dist):
         elapsed = float(t.item())
     resid = h.residual()
     x = h.download_x()
+    iterations, amg_levels, _ = h.solve_info()
     if name == "cfg4":
         members = per_gpu  # circuits per step (one block-diagonal solve)
     stats = dict(elapsed=elapsed, members=members, dense=dense, desc=desc, table=table,
                  kern_ms=kern_ms, kern_n=kern_n, kern_alg=alg, resid=resid, x0=float(x[0]),
-                 phase_ms=(phase / steps).tolist(), n=h.n, nnz=h.nnz)
+                 phase_ms=(phase / steps).tolist(), n=h.n, nnz=h.nnz, name=name,
+                 iterations=iterations, amg_levels=amg_levels)
     h.close()
     return stats
 
@@ -119,13 +135,18 @@ def roofline_of(stats):
     avg_s = stats["kern_ms"] / stats["kern_n"] * 1e-3
     if stats["dense"]:
         achieved = stats["kern_alg"] / avg_s / 1e12
-        return {"bound": "mfma", "kernel": "lu_gemm (trailing update)", "achieved": achieved,
-                "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TF,
-                "traffic": None, "avg_launch_us": avg_s * 1e6, "launches_timed": stats["kern_n"]}
+        return {"bound": "mfma", "kernel": "gemm_sub_kernel (K=256 trailing update of the LU)",
+                "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": achieved / FP64_MFMA_PEAK_TF, "traffic": pmc_traffic(stats["name"]),
+                "avg_launch_us": avg_s * 1e6, "launches_timed": stats["kern_n"],
+                "alg_flops_per_launch": stats["kern_alg"],
+                "measured_instruction_ceiling": {"v_mfma_f64_16x16x4": FP64_MFMA_INSTR_TF,
+                                                 "v_fma_f64": FP64_VALU_FMA_TF, "unit": "TFLOP/s"}}
     achieved = stats["kern_alg"] / avg_s / 1e9
-    return {"bound": "hbm", "kernel": "pcg_spmv (CSR SpMV + p.Ap)", "achieved": achieved,
+    return {"bound": "hbm", "kernel": "CSR-stream SpMV (pcg_spmv / spmv_kernel)", "achieved": achieved,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "avg_launch_us": avg_s * 1e6, "launches_timed": stats["kern_n"]}
+            "traffic": pmc_traffic(stats["name"]), "avg_launch_us": avg_s * 1e6,
+            "launches_timed": stats["kern_n"], "alg_bytes_per_launch": stats["kern_alg"]}
 
 
 def cpu_baseline(name, table, members=1):
@@ -204,6 +225,7 @@ def main():
         "phase_ms": {"symbolic": st["phase_ms"][0], "numeric": st["phase_ms"][1],
                      "solve": st["phase_ms"][2]},
         "scaled_residual": st["resid"],
+        "solver": {"iterations": st["iterations"], "amg_levels": st["amg_levels"]},
         "roofline": roofline_of(st),
     }
     if rank == 0 and world == 1:
@@ -212,7 +234,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         if not args.no_also:
             also = {}
-            for other in ("cfg3", "cfg4"):
+            for other in ("cfg3", "cfg4", "cfg5"):
                 if other == args.workload:
                     continue
                 s2 = time_workload(other, 0, 1, 2, 1, {"cfg4": 128}.get(other, 1), None)
@@ -220,6 +242,7 @@ def main():
                                "circuits_per_sec": s2["members"] * 2 / s2["elapsed"],
                                "ms_per_solve": s2["elapsed"] / (s2["members"] * 2) * 1e3,
                                "phase_ms": s2["phase_ms"], "scaled_residual": s2["resid"],
+                               "solver": {"iterations": s2["iterations"], "amg_levels": s2["amg_levels"]},
                                "roofline": roofline_of(s2)}
             out["also"] = also
     if rank == 0:

@@ -127,6 +127,11 @@ int nodal_last_timings(nodal_handle h, double *ms3);
 int nodal_last_kernel_stats(nodal_handle h, double *ms_total, int64_t *launches,
                             double *alg_bytes_or_flops);
 
+/* iterations of the last sparse solve (0 for direct paths), multigrid levels used
+ * and the solver's own relative residual estimate */
+int nodal_last_solve_info(nodal_handle h, int32_t *iterations, int32_t *amg_levels,
+                          double *relative_residual);
+
 int nodal_synchronize(nodal_handle h);
 
 /* ---- options -------------------------------------------------------------

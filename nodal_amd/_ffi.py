@@ -44,6 +44,7 @@ SIGNATURES = {
     "nodal_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _i32p]),
     "nodal_last_timings": (C.c_int, [C.c_void_p, _f64p]),
     "nodal_last_kernel_stats": (C.c_int, [C.c_void_p, _f64p, _i64p, _f64p]),
+    "nodal_last_solve_info": (C.c_int, [C.c_void_p, _i32p, _i32p, _f64p]),
     "nodal_synchronize": (C.c_int, [C.c_void_p]),
     "nodal_set_option": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "nodal_debug_gemm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p, _f64p]),
@@ -222,6 +223,12 @@ class Handle:
                                               _ptr(A, C.c_double), _ptr(B, C.c_double),
                                               _ptr(out, C.c_double)))
         return out
+
+    def solve_info(self):
+        """(iterations, multigrid levels, relative residual) of the last sparse solve."""
+        it, lv, rr = C.c_int32(0), C.c_int32(0), C.c_double(0)
+        self._check(self.lib.nodal_last_solve_info(self._h, C.byref(it), C.byref(lv), C.byref(rr)))
+        return it.value, lv.value, rr.value
 
     def synchronize(self):
         self._check(self.lib.nodal_synchronize(self._h))

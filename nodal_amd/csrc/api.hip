@@ -241,6 +241,8 @@ int nodal_solve_dense(nodal_handle h, double *x, int32_t *info) {
     DeviceGuard g(h);
     *info = 0;
     h->have_x = false;
+    h->last_iterations = 0;
+    h->amg_levels = 0;
     NODAL_HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
     if (h->n > 0) {
         NODAL_TRY(dense_prepare(h));
@@ -262,7 +264,10 @@ int nodal_solve_sparse(nodal_handle h, int32_t method, double *x, int32_t *info,
     int32_t it = 0;
     double rs = 0;
     NODAL_HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
+    h->amg_levels = 0;
     int s = sparse_solve(h, method, info, &it, &rs);
+    h->last_iterations = it;
+    h->last_relres = rs;
     NODAL_HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
     NODAL_HIP_TRY(h, hipEventSynchronize(h->ev[1]));
     h->ms[2] = elapsed(h, 0, 1);
@@ -331,6 +336,15 @@ int nodal_debug_gemm(nodal_handle h, int32_t M, int32_t N, int32_t K, const doub
     NODAL_TRY(gemm_sub_f64(h, h->stream, dC, M, dA, M, dB, K, M, N, K));
     NODAL_HIP_TRY(h, hipMemcpyAsync(C, dC, sc, hipMemcpyDeviceToHost, h->stream));
     NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NODAL_OK;
+}
+
+int nodal_last_solve_info(nodal_handle h, int32_t *iterations, int32_t *amg_levels,
+                          double *relative_residual) {
+    if (!h) return NODAL_E_INVALID;
+    if (iterations) *iterations = h->last_iterations;
+    if (amg_levels) *amg_levels = h->amg_levels;
+    if (relative_residual) *relative_residual = h->last_relres;
     return NODAL_OK;
 }
 

@@ -96,6 +96,7 @@ struct nodal_ctx {
 
     void *amg = nullptr;  // multigrid hierarchy (amg.hip)
     int32_t last_iterations = 0;
+    double last_relres = 0;
     int32_t amg_levels = 0;
     int64_t amg_min_n = 65;    // below this the sparse SPD path goes dense
 };
