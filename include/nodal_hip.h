@@ -43,7 +43,11 @@ typedef enum {
  * VCCS rows carry NODAL_T_VCVS: the reference dispatches them to write_VCVS
  * (reference nodal/nodal.py:377-378). */
 enum { NODAL_T_R = 0, NODAL_T_A = 1, NODAL_T_E = 2, NODAL_T_VCVS = 3,
-       NODAL_T_CCVS = 4, NODAL_T_CCCS = 5 };
+       NODAL_T_CCVS = 4, NODAL_T_CCCS = 5,
+       /* internal (never produced by the netlist front end): transconductance stamp
+        * without a branch unknown -- a current value*(e_c - e_d) flows from lead a to
+        * lead b.  Used by the presolve that eliminates branch equations (presolve.hip). */
+       NODAL_T_GM = 6 };
 
 /* sparse solver selection for nodal_solve_sparse */
 enum { NODAL_SPARSE_AUTO = 0,

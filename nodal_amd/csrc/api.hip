@@ -4,6 +4,9 @@
 #include "ctx.h"
 
 int dense_prepare(nodal_ctx *h);  // sparse.hip
+int nodal_upload_internal(nodal_ctx *h, int64_t ncomp, const uint8_t *type, const double *value,
+                          const int32_t *a, const int32_t *b, const int32_t *c, const int32_t *d,
+                          const int32_t *drv, const int32_t *k, int32_t K, int32_t B);
 
 namespace {
 
@@ -83,21 +86,36 @@ int nodal_create(int device_id, nodal_handle *out) {
     return NODAL_OK;
 }
 
-int nodal_destroy(nodal_handle h) {
-    if (!h) return NODAL_OK;
-    DeviceGuard g(h);
-    (void)hipStreamSynchronize(h->stream);
+}  // extern "C"
+
+void nodal_free_buffers(nodal_ctx *h) {
     amg_destroy(h);
+    if (h->reduced) {
+        nodal_free_buffers(h->reduced);
+        delete h->reduced;
+        h->reduced = nullptr;
+    }
     DevBuf *bufs[] = {&h->type, &h->value, &h->a, &h->b, &h->c, &h->d, &h->drv, &h->k,
                       &h->values_batch, &h->indptr, &h->indices, &h->rowidx, &h->cptr,
                       &h->contrib, &h->rhs_row, &h->rhs_cptr, &h->rhs_contrib, &h->diag_pos,
                       &h->data, &h->rhs, &h->status, &h->x, &h->dense, &h->piv, &h->work,
                       &h->work2, &h->work3, &h->solver, &h->krylov, &h->gn_indptr, &h->gn_indices,
-                      &h->gn_rowidx, &h->gn_data, &h->gn_diag, &h->schur};
+                      &h->gn_rowidx, &h->gn_data, &h->gn_diag, &h->schur, &h->ps_buf};
     for (DevBuf *b : bufs) b->release();
+    for (auto &e : h->evpool) (void)hipEventDestroy(e);
+    h->evpool.clear();
+}
+
+extern "C" {
+
+int nodal_destroy(nodal_handle h) {
+    if (!h) return NODAL_OK;
+    DeviceGuard g(h);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    nodal_free_buffers(h);
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
-    for (auto &e : h->evpool) (void)hipEventDestroy(e);
     for (auto &e : h->ev_la)
         if (e) (void)hipEventDestroy(e);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
@@ -112,6 +130,14 @@ int nodal_upload_components(nodal_handle h, int64_t ncomp, const uint8_t *type,
                             const double *value, const int32_t *a, const int32_t *b,
                             const int32_t *c, const int32_t *d, const int32_t *drv,
                             const int32_t *k, int32_t K, int32_t B) {
+    return nodal_upload_internal(h, ncomp, type, value, a, b, c, d, drv, k, K, B);
+}
+
+}  // extern "C"
+
+int nodal_upload_internal(nodal_ctx *h, int64_t ncomp, const uint8_t *type, const double *value,
+                          const int32_t *a, const int32_t *b, const int32_t *c, const int32_t *d,
+                          const int32_t *drv, const int32_t *k, int32_t K, int32_t B) {
     if (!h || ncomp < 0 || K < 0 || B < 0) return NODAL_E_INVALID;
     if (ncomp > 0 && (!type || !value || !a || !b || !c || !d || !drv || !k))
         return nodal_fail(h, NODAL_E_INVALID, "null component column");
@@ -119,10 +145,11 @@ int nodal_upload_components(nodal_handle h, int64_t ncomp, const uint8_t *type,
     // validate indices on the host: a kernel must never see an out-of-range node
     const int64_t n = (int64_t)K + B;
     for (int64_t i = 0; i < ncomp; ++i) {
-        const bool ok = type[i] <= NODAL_T_CCCS && a[i] >= -1 && a[i] < K && b[i] >= -1 &&
+        const bool branch = type[i] >= NODAL_T_E && type[i] <= NODAL_T_CCCS;
+        const bool ok = type[i] <= NODAL_T_GM && a[i] >= -1 && a[i] < K && b[i] >= -1 &&
                         b[i] < K && c[i] >= -1 && c[i] < K && d[i] >= -1 && d[i] < K &&
                         drv[i] >= -1 && drv[i] < ncomp && k[i] >= -1 && k[i] < B &&
-                        ((type[i] >= NODAL_T_E) == (k[i] >= 0));
+                        (branch == (k[i] >= 0));
         if (!ok) return nodal_fail(h, NODAL_E_INVALID, "component table row out of range");
     }
     h->have_table = h->have_symbolic = h->have_numeric = h->have_x = false;
@@ -140,15 +167,33 @@ int nodal_upload_components(nodal_handle h, int64_t ncomp, const uint8_t *type,
     NODAL_TRY(upload(h, h->drv, drv, ncomp));
     NODAL_TRY(upload(h, h->k, k, ncomp));
     NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->keep_host_table && B > 0) {  // only systems with branch equations are presolved
+        HostTable &t = h->host;
+        t.type.assign(type, type + ncomp);
+        t.value.assign(value, value + ncomp);
+        t.a.assign(a, a + ncomp);
+        t.b.assign(b, b + ncomp);
+        t.c.assign(c, c + ncomp);
+        t.d.assign(d, d + ncomp);
+        t.drv.assign(drv, drv + ncomp);
+        t.k.assign(k, k + ncomp);
+        t.values_batch.clear();
+    } else {
+        h->host = HostTable();
+    }
     h->have_table = true;
     return NODAL_OK;
 }
+
+extern "C" {
 
 int nodal_upload_values(nodal_handle h, int32_t batch, const double *values) {
     if (!h || !h->have_table || batch < 1 || !values) return NODAL_E_INVALID;
     DeviceGuard g(h);
     NODAL_TRY(upload(h, h->values_batch, values, (int64_t)batch * h->ncomp));
     NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->keep_host_table && h->B > 0)
+        h->host.values_batch.assign(values, values + (size_t)batch * h->ncomp);
     h->batch = batch;
     h->have_numeric = h->have_x = false;
     return NODAL_OK;

@@ -33,6 +33,14 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// host copy of the component table (the presolve of presolve.hip works on it)
+struct HostTable {
+    std::vector<uint8_t> type;
+    std::vector<double> value;
+    std::vector<int32_t> a, b, c, d, drv, k;
+    std::vector<double> values_batch;
+};
+
 struct nodal_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -48,6 +56,13 @@ struct nodal_ctx {
     DevBuf values_batch;  // [batch][ncomp] doubles
     int32_t batch = 0;
     bool have_table = false;
+    HostTable host;
+    bool keep_host_table = true;
+    int32_t member = 0;            // batch member of the last numeric assembly
+    nodal_ctx *reduced = nullptr;  // presolved (branch-free) system, see presolve.hip
+    bool owns_streams = true;
+    bool use_presolve = true;
+    DevBuf ps_buf;
 
     // ---- symbolic assembly results ----
     bool have_symbolic = false;
@@ -168,3 +183,5 @@ int stamp_grounded_flags(nodal_ctx *h, uint8_t *flags_dev);
 // ---- sparse solvers (sparse_*.hip) ----
 int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, double *resid);
 int sparse_residual(nodal_ctx *h, double *scaled);
+int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, double *resid);
+void nodal_free_buffers(nodal_ctx *h);  // api.hip

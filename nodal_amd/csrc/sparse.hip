@@ -545,7 +545,8 @@ int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, do
     }
     const int64_t densify_max = 4096;
     if (method == NODAL_SPARSE_AUTO) {
-        if (h->B == 0 && n > 64) method = NODAL_SPARSE_PCG;
+        // passive network (B == 0, every R > 0, no transconductance): symmetric M-matrix
+        if (h->B == 0 && h->passive_network && n > 64) method = NODAL_SPARSE_PCG;
         else method = n <= densify_max ? NODAL_SPARSE_DENSIFY : NODAL_SPARSE_LU;
     }
     if (method == NODAL_SPARSE_PCG) {

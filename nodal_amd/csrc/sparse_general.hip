@@ -262,6 +262,13 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
     double *x = h->x.as<double>();
     *info = 0;
 
+    // branch equations present: first try to eliminate them exactly (presolve.hip)
+    if (h->B > 0 && h->use_presolve) {
+        bool done = false;
+        NODAL_TRY(presolve_solve(h, &done, info, iters, resid));
+        if (done) return NODAL_OK;
+    }
+
     // ---- preconditioner setup: node block + multigrid + Schur diagonal ----
     NODAL_HIP_TRY(h, h->work.reserve(align_up((size_t)(K + 1) * 4) + scan_tmp_bytes(K + 1) + 512));
     uint32_t *cnt = h->work.as<uint32_t>();

@@ -25,6 +25,7 @@
 //   CCVS as E without asserts, then s4 (m,ic)=v/Rd  s5 (m,id)=(-v)/Rd  SET
 //   CCCS s0 (ia,m)=-1* s1 (ib,m)=1* s2 (m,m)=1* s3 (m,ic)=v/Rd* s4 (m,id)=(-v)/Rd*
 //   A    rhs s0 (ia)+v  s1 (ib)-v
+//   GM   s0 (ia,ic)+v  s1 (ia,id)-v  s2 (ib,ic)-v  s3 (ib,id)+v  ADD  (internal, presolve.hip)
 //   (* = the reference asserts the entry is zero before writing it)
 #include "ctx.h"
 
@@ -67,6 +68,12 @@ struct MatrixStampRule {
             if (t == NODAL_T_E) return false;
             if (s == 4) { row = m; col = ic; return ic >= 0; }
             if (s == 5) { row = m; col = id; return id >= 0; }
+            return false;
+        case NODAL_T_GM:  // current v (e_c - e_d) leaves a, enters b
+            if (s == 0) { row = ia; col = ic; return ia >= 0 && ic >= 0; }
+            if (s == 1) { row = ia; col = id; return ia >= 0 && id >= 0; }
+            if (s == 2) { row = ib; col = ic; return ib >= 0 && ic >= 0; }
+            if (s == 3) { row = ib; col = id; return ib >= 0 && id >= 0; }
             return false;
         case NODAL_T_CCCS:
             if (s == 0) { row = ia; col = m; return ia >= 0; }
@@ -140,6 +147,9 @@ __device__ __forceinline__ double matrix_value(int t, int s, double v, double Rd
         flags = F_SET;
         if (s < 4) return (s == 0 || s == 3) ? 1.0 : -1.0;
         return s == 4 ? v / Rd : (-v) / Rd;
+    case NODAL_T_GM:
+        flags = 0;
+        return (s == 0 || s == 3) ? v : -v;
     default:  // CCCS
         flags = F_SET | F_ASSERT0;
         if (s == 0) return -1.0;
@@ -175,12 +185,13 @@ __global__ __launch_bounds__(TB) void fold_matrix(Table tb, const double *__rest
             const int t = tb.type[comp];
             const double v = value[comp];
             double Rd = 1.0;
-            if (t >= NODAL_T_CCVS && s >= 3) {
+            if ((t == NODAL_T_CCVS || t == NODAL_T_CCCS) && s >= 3) {
                 const int32_t dr = tb.drv[comp];
                 if (dr >= 0) Rd = value[dr];
             }
             if (t == NODAL_T_R && v == 0.0) note_min(&status[0], comp);
-            if (t == NODAL_T_R && !(v > 0.0)) status[2] = 1;  // not a passive network (benign race)
+            if ((t == NODAL_T_R && !(v > 0.0)) || t == NODAL_T_GM)
+                status[2] = 1;  // not a passive network (benign race)
             unsigned flags;
             const double val = matrix_value(t, s, v, Rd, flags);
             if ((flags & F_ASSERT0) && x != 0.0) note_min(&status[1], comp);
@@ -296,6 +307,7 @@ int stamp_numeric(nodal_ctx *h, int32_t member, int64_t *bad_component) {
     NODAL_HIP_TRY(h, hipStreamSynchronize(st));
     h->have_numeric = true;
     h->have_x = false;
+    h->member = member;
     // resistors and current sources only, every resistance positive: G is a column
     // diagonally dominant M-matrix (used by the dense LU to skip the pivot search)
     h->passive_network = (h->B == 0) && st_host[2] == 0;

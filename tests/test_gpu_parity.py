@@ -192,6 +192,64 @@ def test_cfg5_full_size_general_sparse():
     h.close()
 
 
+def _grid_with_sources(N, seed):
+    """grid(N) plus sources in the patterns the presolve eliminates exactly: grounded
+    and floating E, VCVS / CCVS driving a fresh node, CCCS between grid nodes."""
+    rng = random.Random(seed)
+    rows = list(gen.grid_rows(N))[:-1]
+    lab = lambda k: "g" if k == N * N - 1 else str(k + 1)  # noqa: E731
+    free = list(range(N * N - 1))
+    rng.shuffle(free)
+    take = iter(free)
+    for i in range(6):
+        k = next(take)
+        rows.append([f"eg{i}", "E", repr(rng.uniform(-3, 3)), lab(k), "g"])  # pins a grid node
+    for i in range(6):
+        k = next(take)
+        rows.append([f"es{i}", "E", repr(rng.uniform(-3, 3)), f"s{i}", "g"])
+        rows.append([f"rs{i}", "R", "2", f"s{i}", lab(k)])
+    for i in range(4):
+        k, k2 = next(take), next(take)
+        rows.append([f"ef{i}", "E", repr(rng.uniform(-1, 1)), lab(k), lab(k2)])  # floating source
+    for i in range(5):
+        k = next(take)
+        c_, d_ = rng.sample(range(N * N - 1), 2)
+        rows.append([f"vv{i}", "VCVS", repr(rng.uniform(0.1, 0.5)), f"v{i}", "g", lab(c_), lab(d_)])
+        rows.append([f"rv{i}", "R", "1.5", f"v{i}", lab(k)])
+    grid_res = [r for r in rows if r[0].startswith("rh") or r[0].startswith("rv") and r[1] == "R"]
+    for i in range(5):
+        drv = rng.choice([r for r in rows if r[0].startswith("rh")])
+        k = next(take)
+        rows.append([f"hh{i}", "CCVS", repr(rng.uniform(0.1, 0.5)), f"h{i}", "g", drv[3], drv[4], drv[0]])
+        rows.append([f"rq{i}", "R", "1.2", f"h{i}", lab(k)])
+        drv = rng.choice([r for r in rows if r[0].startswith("rh")])
+        k, k2 = next(take), next(take)
+        rows.append([f"ff{i}", "CCCS", repr(rng.uniform(0.1, 0.5)), lab(k), lab(k2), drv[4], drv[3], drv[0]])
+    rows.append(["a1", "A", "1", "1", "g"])
+    return rows
+
+
+@pytest.mark.parametrize("N,seed", [(12, 0), (30, 1), (70, 2)])
+def test_general_sparse_path_with_presolve(N, seed):
+    """The large-system general path (branch equations eliminated by the presolve, then
+    multigrid-preconditioned Krylov on the reduced netlist) against the oracle, forced
+    through NODAL_SPARSE_LU also for sizes the automatic choice would densify."""
+    nl = n.Netlist.from_rows(_grid_with_sources(N, seed))
+    table = lower(nl)
+    assert table.first_error is None
+    Go, Ao, _ = oracle.build_model(nl, True) if N <= 30 else (*oracle.assemble_fast(table), None)
+    xo, _ = oracle.solve(Go.tocsr(), Ao, True)
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    x, info, iters, relres = h.solve_sparse(method=_ffi.SPARSE_LU)
+    assert info == 0
+    assert normwise(x, xo) <= TOL
+    assert h.residual() <= 1e-12
+    h.close()
+
+
 def test_floating_island_sparse_returns_nan_like_reference():
     """A resistor island with no path to ground makes G singular.  The reference's
     sparse path (SuperLU) warns and returns NaNs; an
