@@ -62,6 +62,7 @@ struct nodal_ctx {
     nodal_ctx *reduced = nullptr;  // presolved (branch-free) system, see presolve.hip
     bool owns_streams = true;
     bool use_presolve = true;
+    bool use_graphs = false;       // hipGraph replay of the FCG iteration: measured no gain (kernels are not host-bound)
     DevBuf ps_buf;
 
     // ---- symbolic assembly results ----

@@ -342,7 +342,11 @@ int pcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
 // (Polak-Ribiere) form  beta = z_new.(r_new - r_old) / (z_old.r_old)
 //                             = -alpha (z_new . A p) / (z_old . r_old).
 
-enum { F_RZ0 = 0, F_RZ1 = 1, F_RR = 2, F_BB = 3, F_ALPHA = 4, F_FLAG = 5, F_COUNT = 8 };
+enum { F_RZ0 = 0, F_RZ1 = 1, F_RR = 2, F_BB = 3, F_ALPHA = 4, F_FLAG = 5, F_ITER = 6, F_COUNT = 8 };
+
+// The iteration number lives on the device (sc[F_ITER]) so that one iteration can be
+// captured into a hipGraph and replayed: kernel arguments are frozen in a graph.
+__global__ void fcg_advance(double *sc) { sc[F_ITER] += 1.0; }
 
 __global__ __launch_bounds__(TB) void fcg_init(const double *__restrict__ b, double *__restrict__ x,
                                                double *__restrict__ r,
@@ -383,7 +387,8 @@ __global__ __launch_bounds__(TB) void fcg_direction(const double *__restrict__ z
                                                     const double *__restrict__ part_rz,
                                                     const double *__restrict__ part_zap,
                                                     const double *__restrict__ part_rr, int nparts,
-                                                    double *__restrict__ sc, int iter, int64_t n) {
+                                                    double *__restrict__ sc, int64_t n) {
+    const int iter = (int)sc[F_ITER];
     const double rz_new = reduce_partials(part_rz, nparts);
     const double zap = reduce_partials(part_zap, nparts);
     const double rr = reduce_partials(part_rr, nparts);
@@ -404,7 +409,8 @@ __global__ __launch_bounds__(TB) void fcg_update(double *__restrict__ x, double 
                                                  const double *__restrict__ Ap,
                                                  const double *__restrict__ part_pap, int nparts_s,
                                                  double *__restrict__ part_rr,
-                                                 double *__restrict__ sc, int iter, int64_t n) {
+                                                 double *__restrict__ sc, int64_t n) {
+    const int iter = (int)sc[F_ITER];
     const double pap = reduce_partials(part_pap, nparts_s);
     const double rz = sc[iter & 1];
     const bool bad = !(pap > 0.0) && rz != 0.0;
@@ -477,18 +483,42 @@ int amg_fcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
     hipEvent_t e0 = h->ev[2], e1 = h->ev[3];
     h->kern_ms = 0;
     h->kern_launches = 0;
+    // one iteration = the multigrid cycle + four CG kernels: ~45 small dependent
+    // launches.  Capture it once into a hipGraph and replay it; the last iteration of
+    // every check interval runs eagerly with HIP events around the SpMV (roofline).
+    auto iteration = [&](bool timed) -> int {
+        NODAL_TRY(amg_apply(h, r, z));
+        fcg_dots<<<gv, TB, 0, st>>>(z, r, Ap, part_rz, part_zap, n);
+        fcg_direction<<<gv, TB, 0, st>>>(z, p, part_rz, part_zap, part_rr, (int)gv, sc, n);
+        if (timed) NODAL_HIP_TRY(h, hipEventRecord(e0, st));
+        pcg_spmv<<<gs, TB, 0, st>>>(indptr, indices, data, p, Ap, part_pap, n);
+        if (timed) NODAL_HIP_TRY(h, hipEventRecord(e1, st));
+        fcg_update<<<gv, TB, 0, st>>>(x, r, p, Ap, part_pap, (int)gs, part_rr, sc, n);
+        fcg_advance<<<1, 1, 0, st>>>(sc);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        return NODAL_OK;
+    };
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (h->use_graphs) {
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int cs = iteration(false);
+            const hipError_t ce = hipStreamEndCapture(st, &graph);
+            if (cs != NODAL_OK || ce != hipSuccess || !graph ||
+                hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+                exec = nullptr;
+                (void)hipGetLastError();
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     while (status == 0) {
         for (int c = 0; c < check; ++c, ++it) {
-            NODAL_TRY(amg_apply(h, r, z));
-            fcg_dots<<<gv, TB, 0, st>>>(z, r, Ap, part_rz, part_zap, n);
-            fcg_direction<<<gv, TB, 0, st>>>(z, p, part_rz, part_zap, part_rr, (int)gv, sc, (int)it, n);
             const bool timed = (c == check - 1);
-            if (timed) NODAL_HIP_TRY(h, hipEventRecord(e0, st));
-            pcg_spmv<<<gs, TB, 0, st>>>(indptr, indices, data, p, Ap, part_pap, n);
-            if (timed) NODAL_HIP_TRY(h, hipEventRecord(e1, st));
-            fcg_update<<<gv, TB, 0, st>>>(x, r, p, Ap, part_pap, (int)gs, part_rr, sc, (int)it, n);
+            if (exec && !timed) NODAL_HIP_TRY(h, hipGraphLaunch(exec, st));
+            else NODAL_TRY(iteration(timed));
         }
-        NODAL_HIP_TRY(h, hipGetLastError());
         NODAL_HIP_TRY(h, hipMemcpyAsync(hs, sc, F_COUNT * 8, hipMemcpyDeviceToHost, st));
         NODAL_HIP_TRY(h, hipStreamSynchronize(st));
         float ms = 0;
@@ -501,6 +531,8 @@ int amg_fcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
         else if (hs[F_BB] == 0.0 || hs[F_RR] <= tol * tol * hs[F_BB]) status = 1;
         else if (it >= maxit) status = 3;
     }
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
     *iters = (int32_t)it;
     *resid = hs[F_BB] > 0 ? sqrt(hs[F_RR] / hs[F_BB]) : 0.0;
     h->kern_alg = 12.0 * (double)h->nnz + 4.0 * (double)(n + 1) + 16.0 * (double)n;

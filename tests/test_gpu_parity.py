@@ -250,6 +250,38 @@ def test_general_sparse_path_with_presolve(N, seed):
     h.close()
 
 
+@pytest.mark.parametrize("rows", [
+    [["r1", "R", "1", "g", "g"]],                                                   # no unknown at all
+    [["r1", "R", "2", "1", "g"], ["a1", "A", "3", "1", "g"]],                       # one unknown
+    [["a1", "A", "1", "1", "g"], ["r1", "R", "1", "1", "g"], ["e1", "E", "2", "2", "g"]],
+    [["r1", "R", "-2", "1", "g"], ["r2", "R", "1", "1", "2"], ["r3", "R", "3", "2", "g"],
+     ["a1", "A", "1", "1", "g"]],                                                   # negative resistance
+], ids=["n0", "n1", "source_only_node", "negative_r"])
+def test_degenerate_sizes_and_non_passive(rows):
+    for sparse in (False, True):
+        nl = n.Netlist.from_rows(rows)
+        x = n.Circuit(nl, sparse=sparse).solve().result
+        G, A, _ = oracle.build_model(nl, sparse)
+        xo, _ = oracle.solve(G, A, sparse)
+        assert len(x) == len(xo)
+        if len(x):
+            assert normwise(x, xo) <= TOL
+
+
+def test_large_non_passive_network_takes_general_path():
+    """B == 0 but 2 % negative resistances: not an M-matrix, so the sparse path must not
+    use CG; the general Krylov path has to agree with SuperLU."""
+    rng = random.Random(3)
+    vals = [rng.choice([2.0, -7.0]) if rng.random() < 0.02 else 1.0
+            for _ in range(gen.grid_resistor_count(80))]
+    nl = n.Netlist.from_rows(gen.grid_rows(80, vals))
+    circ = n.Circuit(nl, sparse=True)
+    x = circ.solve().result
+    Go, Ao = oracle.assemble_fast(lower(nl))
+    xo, _ = oracle.solve(Go.tocsr(), Ao, True)
+    assert normwise(x, xo) <= TOL and circ.scaled_residual() <= 1e-13
+
+
 def test_floating_island_sparse_returns_nan_like_reference():
     """A resistor island with no path to ground makes G singular.  The reference's
     sparse path (SuperLU) warns and returns NaNs; an
