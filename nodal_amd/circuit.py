@@ -59,7 +59,7 @@ class Circuit:
         """Lower the netlist, upload the component table and assemble G, A on
         the device (reference nodal/nodal.py:338-398).  Returns `currents`."""
         nl = self.netlist
-        table = lower(nl)
+        table = self._lower(nl)
         self.table = table
         if table.first_error is not None:
             row, exc, probe = table.first_error
@@ -69,8 +69,20 @@ class Circuit:
                 self._assemble(prefix)
             raise exc
         self._assemble(table)
+        if getattr(nl, "_fast", False):
+            return nl._name[nl._is_anom].tolist()
         comps = nl.components
         return [key for key in nl.component_keys if comps[key].type in c.NODE_TYPES_ANOM]
+
+    @staticmethod
+    def _lower(nl):
+        if getattr(nl, "_fast", False):
+            from . import fastparse
+            try:
+                return fastparse.lower_fast(nl)
+            except fastparse.Irregular:
+                nl._demote()
+        return lower(nl)
 
     def _assemble(self, table):
         if self._handle is None:

@@ -18,6 +18,8 @@ parser.add_argument("-s", "--sparse", action="store_true", help="use a sparse ma
 
 def check_resistive(netlist):
     """True iff every component of the netlist is a resistor."""
+    if getattr(netlist, "_fast", False):
+        return bool((netlist._type.astype(str) == "R").all())
     return all(comp.type == "R" for comp in netlist.components.values())
 
 

@@ -1,0 +1,276 @@
+"""Vectorised netlist front-end for large, regular CSV files.
+
+The reference parses row by row into Python objects and dicts (reference
+nodal/nodal.py:222-296): 19.7 s for the 2e6-row grid(1000) netlist, two orders of
+magnitude more than the GPU path needs for the same circuit.  `read_fast` produces
+the SAME observable state -- `component_keys`, `degrees`, `ground`, `nodenum`,
+`anomnum`, `nums`, `components` -- from whole-column operations:
+
+  * pandas' C reader splits the file (skipinitialspace, quoted fields, ragged rows);
+  * `factorize` on the interleaved (anode, bnode) labels yields the nodes in order of
+    first appearance, anode before bnode -- exactly the dict insertion order the
+    reference's node numbering depends on;
+  * `components` is a lazy mapping that builds `Component` objects on demand.
+
+Anything irregular -- malformed rows, OPMODEL macros, duplicated names, fields that
+need the reference's exact exception -- raises `Irregular`, and `Netlist` falls back
+to the exact row-by-row parser, which then reports the problem with the reference's
+own message.  `lower_fast` is the matching vectorised lowering (the component table
+of lowering.py) for such a netlist.
+"""
+
+from collections.abc import Mapping
+
+import numpy as np
+
+from . import constants as c
+
+try:
+    import pandas as pd
+except Exception:  # pragma: no cover - pandas is optional
+    pd = None
+
+
+class Irregular(Exception):
+    """The file needs the exact row-by-row parser."""
+
+
+_NARGS = c.NODE_ARGS_NUMBER
+
+
+class LazyComponents(Mapping):
+    """name -> Component, materialised on demand from the parsed columns."""
+
+    def __init__(self, netlist):
+        self._nl = netlist
+        self._cache = {}
+
+    def __deepcopy__(self, memo):  # equivalent_resistance deep-copies the netlist
+        import copy
+        clone = LazyComponents(memo.get(id(self._nl), self._nl))
+        clone._cache = copy.copy(self._cache)
+        return clone
+
+    def __getitem__(self, key):
+        comp = self._cache.get(key)
+        if comp is None:
+            row = self._nl._row_of.get(key)
+            if row is None:
+                raise KeyError(key)
+            from .netlist import Component
+            comp = Component(self._nl._row_fields(row))
+            self._cache[key] = comp
+        return comp
+
+    def __iter__(self):
+        return iter(self._nl._row_of)
+
+    def __len__(self):
+        return len(self._nl._row_of)
+
+
+def read_fast(netlist, path):
+    """Fill `netlist` (a Netlist whose `_reset()` has run) from the CSV at `path`."""
+    if pd is None:
+        raise Irregular("pandas not available")
+    # fields per line, counted on the raw bytes: pandas pads short rows silently, the
+    # reference rejects them, so the count has to come from the text itself
+    with open(path, "rb") as f:
+        raw = f.read()
+    if b'"' in raw:
+        raise Irregular("quoted fields")  # commas inside quotes: let csv.reader decide
+    buf = np.frombuffer(raw, dtype=np.uint8)
+    ends = np.flatnonzero(buf == 10)
+    if len(buf) and (len(ends) == 0 or ends[-1] != len(buf) - 1):
+        ends = np.append(ends, len(buf))  # last line without a newline
+    starts = np.concatenate(([0], ends[:-1] + 1))
+    length = ends - starts
+    # segment reductions over the byte buffer (reduceat on an empty segment returns the
+    # element at its start, so empty lines are masked out explicitly)
+    seg = np.minimum(starts, len(buf) - 1)
+    line_commas = np.add.reduceat((buf == 44).view(np.uint8), seg, dtype=np.int32)
+    nonblank = ((buf != 32) & (buf != 9) & (buf != 13) & (buf != 10)).view(np.uint8)
+    content = np.maximum.reduceat(nonblank, seg)
+    content[length == 0] = 0
+    line_commas[length == 0] = 0
+    only_cr = (length == 1) & (buf[np.minimum(starts, len(buf) - 1)] == 13)
+    if ((content == 0) & (length > 0) & ~only_cr).any():
+        raise Irregular("whitespace-only line")  # the reference raises IndexError there
+    line_fields = line_commas[content > 0] + 1
+    if len(line_fields) == 0 or line_fields.max() > 8:
+        raise Irregular("row with more than 8 fields")  # (or a comment line full of commas)
+    try:
+        df = pd.read_csv(path, header=None, names=list(range(8)), dtype=str, engine="c",
+                         skipinitialspace=True, keep_default_na=False, na_values=[],
+                         skip_blank_lines=True, quotechar='"')
+    except Exception as exc:  # tokenising error: let the exact parser explain it
+        raise Irregular(str(exc))
+    if len(df) == 0 or len(df) != len(line_fields):
+        raise Irregular("line structure")
+    if (df[0].str.len() == 0).any():
+        raise Irregular("empty first field")
+    # comment rows: first field starts with '#'
+    keep = (df[0].str.slice(0, 1) != "#").to_numpy()
+    if not keep.all():
+        df = df[keep].reset_index(drop=True)
+        line_fields = line_fields[keep]
+    if len(df) == 0:
+        raise Irregular("no components")
+    name = df[0].to_numpy(dtype=object)
+    nfields = line_fields
+    ctype = df[1].to_numpy(dtype=object)
+    kinds, kind_code = np.unique(ctype.astype(str), return_inverse=True)
+    for kd in kinds:
+        if kd not in _NARGS or kd in ("OPMODEL", "OPAMP"):
+            raise Irregular(f"type {kd}")
+    expected = np.array([_NARGS[kd] for kd in kinds])[kind_code]
+    if not (nfields == expected).all():
+        raise Irregular("wrong number of arguments")
+    try:
+        value = df[2].astype(np.float64).to_numpy()
+    except Exception:
+        raise Irregular("bad component value")
+    if not pd.Index(name).is_unique:
+        raise Irregular("duplicated component names")
+
+    an = df[3].to_numpy(dtype=object)
+    bn = df[4].to_numpy(dtype=object)
+    leads = np.empty(2 * len(df), dtype=object)
+    leads[0::2], leads[1::2] = an, bn
+    codes, labels = pd.factorize(leads, sort=False)  # first-appearance order
+    deg = np.bincount(codes, minlength=len(labels))
+    labels = labels.tolist()
+
+    nl = netlist
+    nl._fast = True
+    nl._df = df
+    nl._name, nl._type, nl._value = name, ctype, value
+    nl._nfields = nfields
+    nl._acode, nl._bcode = codes[0::2], codes[1::2]
+    nl.component_keys = name.tolist()
+    nl._row_of = dict(zip(nl.component_keys, range(len(name))))
+    nl.components = LazyComponents(nl)
+    nl.degrees = dict(zip(labels, deg.tolist()))
+    is_anom = np.isin(ctype.astype(str), c.NODE_TYPES_ANOM)
+    nl._is_anom = is_anom
+    anom_rows = np.flatnonzero(is_anom)
+    nl.anomnum = dict(zip(name[anom_rows].tolist(), range(len(anom_rows))))
+    nl.nums["components"] = int(len(name))
+    nl.nums["anomalies"] = int(len(anom_rows))
+    # ground: "g" if present, else the first node of maximal degree
+    if "g" in nl.degrees:
+        nl.ground = "g"
+        gcode = labels.index("g")
+    else:
+        gcode = int(np.argmax(deg))
+        nl.ground = labels[gcode]
+    order = [lab for i, lab in enumerate(labels) if i != gcode]
+    nl.nodenum = dict(zip(order, range(len(order))))
+    node_index = np.arange(len(labels), dtype=np.int64)
+    node_index[gcode + 1:] -= 1
+    node_index[gcode] = -1
+    nl._node_index = node_index  # label code -> nodenum index (-1 = ground)
+    nl.nums["kcl"] = len(order)
+    nl.nums["be"] = nl.nums["anomalies"]
+    return nl
+
+
+def row_fields(netlist, row):
+    """The CSV fields of one row as the list the row-by-row parser would have seen."""
+    if row >= len(netlist._df):
+        return list(netlist._extra_rows[row - len(netlist._df)])
+    return netlist._df.iloc[row].tolist()[: int(netlist._nfields[row])]
+
+
+def append_row(netlist, data):
+    """process_component() on a fast netlist (equivalent_resistance adds its probe
+    source this way).  Same bookkeeping as the reference's method, on the columns."""
+    from .netlist import Component
+    nl = netlist
+    comp = Component(data)  # validates, raises the reference's ValueErrors
+    key = data[c.NCOL]
+    if key in nl._row_of or data[c.TCOL] in ("OPMODEL", "OPAMP"):
+        raise Irregular("needs the row-by-row bookkeeping")
+    if not hasattr(nl, "_extra_rows"):
+        nl._extra_rows = []
+        nl._label_code = {lab: i for i, lab in enumerate(nl.degrees)}
+    row = len(nl._name)
+    nl._extra_rows.append(list(data))
+    nl.component_keys.append(key)
+    nl._row_of[key] = row
+    nl.components._cache[key] = comp
+    nl.nums["components"] += 1
+    codes = []
+    for lab in (data[c.ACOL], data[c.BCOL]):
+        if lab not in nl.degrees:
+            nl.degrees[lab] = 0
+            nl._label_code[lab] = len(nl._label_code)
+            nl._node_index = np.append(nl._node_index, -2)  # not in nodenum: KeyError later
+        codes.append(nl._label_code[lab])
+    for lab in (data[c.ACOL], data[c.BCOL]):
+        nl.degrees[lab] += 1
+    anom = data[c.TCOL] in c.NODE_TYPES_ANOM
+    if anom:
+        nl.anomnum[key] = nl.nums["anomalies"]
+        nl.nums["anomalies"] += 1
+    nl._name = np.append(nl._name, key)
+    nl._type = np.append(nl._type, data[c.TCOL])
+    nl._value = np.append(nl._value, comp.value)
+    nl._acode = np.append(nl._acode, codes[0])
+    nl._bcode = np.append(nl._bcode, codes[1])
+    nl._is_anom = np.append(nl._is_anom, anom)
+
+
+def lower_fast(netlist):
+    """Vectorised equivalent of lowering.lower for a netlist read by `read_fast`."""
+    from .lowering import ComponentTable, lower
+    nl = netlist
+    kinds = nl._type.astype(str)
+    codes = np.array([c.TYPE_CODE[k] for k in np.unique(kinds)])
+    _, inv = np.unique(kinds, return_inverse=True)
+    tcode = codes[inv].astype(np.uint8)
+    table = ComponentTable(len(tcode), nl.nums["kcl"], nl.nums["be"])
+    if int(nl._is_anom.sum()) != nl.nums["be"]:
+        raise Irregular("branch added after numbering")
+    table.type[:] = tcode
+    table.value[:] = nl._value
+    table.a[:] = nl._node_index[nl._acode]
+    table.b[:] = nl._node_index[nl._bcode]
+    unknown = np.flatnonzero((table.a == -2) | (table.b == -2))
+    if len(unknown):  # a lead that is not in nodenum (added after numbering): KeyError
+        row = int(unknown[0])
+        fields = row_fields(nl, row)
+        lab = fields[c.ACOL] if table.a[row] == -2 else fields[c.BCOL]
+        table.first_error = (row, KeyError(lab), False)
+        return table
+    # nums["be"] may lag behind anomalies added after numbering, exactly as in the reference
+    table.k[nl._is_anom] = np.arange(int(nl._is_anom.sum()))
+    # first string-level stamping error in file order, as lower() records it
+    bad_r = np.flatnonzero((tcode == c.T_R) & (nl._value == 0))
+    dep = np.flatnonzero(tcode >= c.T_VCVS)
+    if len(dep):
+        # dependent sources are few: reuse the exact per-row logic on them
+        from .lowering import _lower_current_controlled, _node_index
+        first_row = nl._row_of
+        for row in dep.tolist():
+            if len(bad_r) and bad_r[0] < row:
+                break
+            comp = nl.components[nl._name[row]]
+            try:
+                comp.cnode, comp.dnode = comp.pos_control, comp.neg_control
+                if comp.type in c.NODE_TYPES_CC:
+                    _lower_current_controlled(table, row, comp, nl.components, first_row,
+                                              nl.ground, nl.nodenum)
+                else:
+                    table.c[row] = _node_index(comp.pos_control, nl.ground, nl.nodenum)
+                    table.d[row] = _node_index(comp.neg_control, nl.ground, nl.nodenum)
+            except (KeyError, ValueError, AssertionError, AttributeError, NotImplementedError,
+                    ZeroDivisionError) as exc:
+                probe = comp.type in ("VCVS", "VCCS", "CCCS")
+                table.c[row] = table.d[row] = table.drv[row] = -1
+                table.first_error = (row, exc, probe)
+                return table
+    if len(bad_r):
+        table.first_error = (int(bad_r[0]),
+                             ValueError("Model error: resistors can't have null resistance"), False)
+    return table

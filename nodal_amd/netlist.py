@@ -16,11 +16,15 @@ Behaviour mirrored from the reference (file:line into /root/reference):
 
 import csv
 import logging
+import os
 from collections import deque
 
 from . import constants as c
 
 logging.basicConfig(level=logging.ERROR)
+
+
+FAST_PARSE_MIN_BYTES = 1 << 18  # files this large use the vectorised reader
 
 
 class UnconnectedCircuitError(Exception):
@@ -151,6 +155,12 @@ class Netlist:
         (reference nodal/nodal.py:222-257)."""
         if data == [] or data[0][0] == "#":
             return
+        if getattr(self, "_fast", False):
+            from . import fastparse
+            try:
+                return fastparse.append_row(self, data)
+            except fastparse.Irregular:
+                self._demote()
         if data[c.TCOL] == "OPMODEL":
             # macro rows are queued and only registered after every file row
             self.opmodel_equivalents.extend(build_opmodel(data))
@@ -171,14 +181,42 @@ class Netlist:
             self.degrees[node] += 1
 
     def read_netlist(self, path):
-        """Parse the file at `path` (reference nodal/nodal.py:259-296)."""
+        """Parse the file at `path` (reference nodal/nodal.py:259-296).
+
+        Large regular files go through the vectorised reader of fastparse.py, which
+        produces the same attributes; anything it does not recognise is re-read by the
+        exact row-by-row parser below."""
         try:
             infile = open(path, "r")
         except FileNotFoundError:
             logging.error(f"File '{path}' not found.")
             raise
         with infile:
+            if os.path.getsize(path) >= FAST_PARSE_MIN_BYTES:
+                from . import fastparse
+                try:
+                    fastparse.read_fast(self, path)
+                    return
+                except fastparse.Irregular:
+                    self._reset()
             self._ingest(csv.reader(infile, skipinitialspace=True))
+
+    def _row_fields(self, row):
+        from . import fastparse
+        return fastparse.row_fields(self, row)
+
+    def _demote(self):
+        """Turn a vectorised netlist back into a row-by-row one (rare: a row was added
+        that needs the reference's duplicate / macro bookkeeping)."""
+        rows = [self._row_fields(i) for i in range(len(self._name))]
+        ground, nodenum, nums = self.ground, self.nodenum, dict(self.nums)
+        self._fast = False
+        self._reset()
+        for data in rows:
+            self.process_component(data)
+        # numbering is NOT recomputed by process_component in the reference either
+        self.ground, self.nodenum = ground, nodenum
+        self.nums["kcl"], self.nums["be"] = nums["kcl"], nums["be"]
 
     def _ingest(self, rows):
         for data in rows:

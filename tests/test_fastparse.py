@@ -1,0 +1,123 @@
+"""The vectorised front-end (fastparse.py) must leave a Netlist in exactly the state
+the row-by-row parser produces, and its lowering must give the same component table."""
+import random
+
+import numpy as np
+import pytest
+
+import nodal_amd as n
+from nodal_amd import equiv, fastparse, generators as gen, netlist as netlist_mod
+from nodal_amd.circuit import Circuit
+from nodal_amd.lowering import lower
+
+FIELDS = ("type", "value", "a", "b", "c", "d", "drv", "k")
+
+
+def both(tmp_path, rows, monkeypatch):
+    path = tmp_path / "c.csv"
+    gen.write_csv(rows, str(path))
+    monkeypatch.setattr(netlist_mod, "FAST_PARSE_MIN_BYTES", 1 << 60)
+    slow = n.Netlist(str(path))
+    monkeypatch.setattr(netlist_mod, "FAST_PARSE_MIN_BYTES", 0)
+    fast = n.Netlist(str(path))
+    return slow, fast
+
+
+def same_state(slow, fast):
+    assert getattr(fast, "_fast", False) and not getattr(slow, "_fast", False)
+    assert fast.component_keys == slow.component_keys
+    assert list(fast.degrees.items()) == list(slow.degrees.items())
+    assert fast.ground == slow.ground
+    assert list(fast.nodenum.items()) == list(slow.nodenum.items())
+    assert list(fast.anomnum.items()) == list(slow.anomnum.items())
+    assert fast.nums == slow.nums
+    t1, t2 = lower(slow), Circuit._lower(fast)
+    assert (t1.K, t1.B, t1.ncomp) == (t2.K, t2.B, t2.ncomp)
+    for f in FIELDS:
+        assert np.array_equal(getattr(t1, f), getattr(t2, f)), f
+    assert (t1.first_error is None) == (t2.first_error is None)
+    if t1.first_error:
+        assert t1.first_error[0] == t2.first_error[0]
+        assert type(t1.first_error[1]) is type(t2.first_error[1])
+        assert t1.first_error[1].args == t2.first_error[1].args
+
+
+@pytest.mark.parametrize("rows", [
+    list(gen.grid_rows(7)), gen.cfg5_rows(16), list(gen.grid_rows(5, gen.cfg4_values(2, 5))),
+    [["1", "A", "1", "1", "3"], ["r2", "R", "1", "2", "3"], ["r3", "R", "1", "1", "2"]],  # no "g"
+], ids=["grid", "cfg5", "values", "no_g"])
+def test_fast_reader_equals_row_by_row(tmp_path, monkeypatch, rows):
+    slow, fast = both(tmp_path, rows, monkeypatch)
+    same_state(slow, fast)
+    comp = fast.components[rows[0][0]]
+    ref = slow.components[rows[0][0]]
+    assert (comp.name, comp.type, comp.value, comp.anode, comp.bnode) == (
+        ref.name, ref.type, ref.value, ref.anode, ref.bnode)
+
+
+def test_value_parsing_is_bit_exact(tmp_path, monkeypatch):
+    rng = random.Random(1)
+    rows = [[f"r{i}", "R", repr(rng.uniform(1e-9, 1e9) * 10 ** rng.randint(-20, 20)), str(i), "g"]
+            for i in range(300)]
+    rows += [["ra", "R", "1e7", "1", "2"], ["rb", "R", ".5", "2", "3"], ["rc", "R", "-0.0", "3", "4"]]
+    slow, fast = both(tmp_path, rows, monkeypatch)
+    same_state(slow, fast)
+
+
+def test_comments_blank_lines_and_spaces(tmp_path, monkeypatch):
+    path = tmp_path / "c.csv"
+    path.write_text("# header, with, commas\n\nr1, R, 1, 1, 2\n# mid\nr2, R, 1, 2 , g\n\na1, A, 1, 1, g\n")
+    monkeypatch.setattr(netlist_mod, "FAST_PARSE_MIN_BYTES", 1 << 60)
+    slow = n.Netlist(str(path))
+    monkeypatch.setattr(netlist_mod, "FAST_PARSE_MIN_BYTES", 0)
+    fast = n.Netlist(str(path))
+    same_state(slow, fast)
+    assert "2 " in fast.degrees  # trailing blanks are significant, as in the reference
+
+
+@pytest.mark.parametrize("text,exc", [
+    ("r1,R,1,1,g\nq1,OPMODEL,1,2,g,3,1\nv1,E,1,3,g\nr2,R,1,g,1\n", None),   # macro -> fallback, fine
+    ("r1,R,1,1,g\nr1,R,4,1,2\nr2,R,1,2,g\n", None),                          # duplicate name
+    ("r1,R,one,1,g\n", ValueError), ("r1,R,1,1\n", ValueError), ("r1,X,1,1,g\n", ValueError),
+    ("r1,R,1,1,g,extra\n", ValueError), ("r1,R,1,1,g\n   \n", IndexError),
+])
+def test_irregular_files_fall_back_to_exact_parser(tmp_path, monkeypatch, text, exc):
+    path = tmp_path / "c.csv"
+    path.write_text(text)
+    monkeypatch.setattr(netlist_mod, "FAST_PARSE_MIN_BYTES", 0)
+    if exc:
+        with pytest.raises(exc):
+            n.Netlist(str(path))
+    else:
+        nl = n.Netlist(str(path))
+        assert not getattr(nl, "_fast", False)
+        monkeypatch.setattr(netlist_mod, "FAST_PARSE_MIN_BYTES", 1 << 60)
+        ref = n.Netlist(str(path))
+        assert nl.component_keys == ref.component_keys and nl.nodenum == ref.nodenum
+
+
+def test_probe_source_can_be_added_like_equivalent_resistance_does(tmp_path, monkeypatch):
+    from copy import deepcopy
+    rows = list(gen.grid_rows(6))[:-1]
+    slow, fast = both(tmp_path, rows, monkeypatch)
+    for nl in (slow, fast):
+        nl2 = deepcopy(nl)
+        nl2.process_component(["a1", "A", "1", "1", "g"])
+        assert nl2.component_keys[-1] == "a1" and nl2.nums["components"] == len(rows) + 1
+        assert len(nl.component_keys) == len(rows)  # the original is untouched
+    s2, f2 = deepcopy(slow), deepcopy(fast)
+    s2.process_component(["a1", "A", "1", "1", "g"])
+    f2.process_component(["a1", "A", "1", "1", "g"])
+    same_state(s2, f2)
+    assert equiv.check_resistive(fast) and not equiv.check_resistive(f2)
+
+
+def test_large_file_is_read_fast(tmp_path):
+    path = tmp_path / "big.csv"
+    gen.write_csv(gen.grid_rows(120), str(path))  # > 256 KB
+    nl = n.Netlist(str(path))
+    assert getattr(nl, "_fast", False)
+    t = Circuit._lower(nl)
+    ref = gen.grid_table(120)
+    for f in FIELDS:
+        assert np.array_equal(getattr(t, f), getattr(ref, f)), f
