@@ -113,6 +113,16 @@ int nodal_solve_sparse(nodal_handle h, int32_t method, double *x, int32_t *info,
                        int32_t *iters, double *resid);
 int nodal_download_x(nodal_handle h, double *x);
 
+/* ---- equivalent-resistance sweep (replaces one equivalent_resistance() call per
+ *      pair, reference nodal/equiv.py:31-61: deepcopy + rebuild + re-solve) ---------
+ * For every pair (ia[q], ib[q]) of node indices (-1 = ground) a 1 A probe enters ia and
+ * leaves ib; resistance[q] = e(ia) - e(ib).  G is factorised (dense) or its multigrid
+ * hierarchy built (sparse) once for all pairs.  The circuit's own rhs is ignored, as
+ * it is zero for the resistive networks the reference accepts here.  *info > 0:
+ * singular network (dense: status NODAL_E_SINGULAR; sparse: NaNs, status OK). */
+int nodal_solve_pairs(nodal_handle h, int32_t dense, int32_t npairs, const int32_t *ia,
+                      const int32_t *ib, double *resistance, int32_t *info);
+
 /* scaled residual ||G x - A||_inf / (||G||_inf ||x||_inf + ||A||_inf) of the
  * solution currently on the device, computed on the device from the CSR form */
 int nodal_residual(nodal_handle h, double *scaled_residual);

@@ -40,6 +40,7 @@ SIGNATURES = {
     "nodal_solve_dense": (C.c_int, [C.c_void_p, _f64p, _i32p]),
     "nodal_solve_sparse": (C.c_int, [C.c_void_p, C.c_int32, _f64p, _i32p, _i32p, _f64p]),
     "nodal_download_x": (C.c_int, [C.c_void_p, _f64p]),
+    "nodal_solve_pairs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _i32p, _i32p, _f64p, _i32p]),
     "nodal_residual": (C.c_int, [C.c_void_p, _f64p]),
     "nodal_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _i32p]),
     "nodal_last_timings": (C.c_int, [C.c_void_p, _f64p]),
@@ -183,6 +184,17 @@ class Handle:
             self._h, method, _ptr(x, C.c_double) if download else None,
             C.byref(info), C.byref(iters), C.byref(resid)))
         return x, info.value, iters.value, resid.value
+
+    def solve_pairs(self, ia, ib, dense):
+        """Equivalent resistance for every node-index pair; returns (R array, info)."""
+        ia = np.ascontiguousarray(ia, dtype=np.int32)
+        ib = np.ascontiguousarray(ib, dtype=np.int32)
+        out = np.empty(len(ia), dtype=np.float64)
+        info = C.c_int32(0)
+        self._check(self.lib.nodal_solve_pairs(self._h, int(dense), len(ia), _ptr(ia, C.c_int32),
+                                               _ptr(ib, C.c_int32), _ptr(out, C.c_double),
+                                               C.byref(info)), allow=(E_SINGULAR,))
+        return out, info.value
 
     def download_x(self):
         x = np.empty(self.n, dtype=np.float64)

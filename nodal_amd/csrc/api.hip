@@ -4,6 +4,7 @@
 #include "ctx.h"
 
 int dense_prepare(nodal_ctx *h);  // sparse.hip
+int pair_read_host(nodal_ctx *h, const double *x, int32_t ia, int32_t ib, double *out);  // sparse.hip
 int nodal_upload_internal(nodal_ctx *h, int64_t ncomp, const uint8_t *type, const double *value,
                           const int32_t *a, const int32_t *b, const int32_t *c, const int32_t *d,
                           const int32_t *drv, const int32_t *k, int32_t K, int32_t B);
@@ -320,6 +321,55 @@ int nodal_solve_sparse(nodal_handle h, int32_t method, double *x, int32_t *info,
     if (resid) *resid = rs;
     if (s != NODAL_OK) return s;
     if (x) return nodal_download_x(h, x);
+    return NODAL_OK;
+}
+
+int nodal_solve_pairs(nodal_handle h, int32_t dense, int32_t npairs, const int32_t *ia,
+                      const int32_t *ib, double *resistance, int32_t *info) {
+    if (!h || !info || npairs < 0 || (npairs > 0 && (!ia || !ib || !resistance)))
+        return NODAL_E_INVALID;
+    if (!h->have_numeric) return nodal_fail(h, NODAL_E_INVALID, "assemble_numeric not called");
+    DeviceGuard g(h);
+    *info = 0;
+    const int64_t n = h->n;
+    for (int32_t q = 0; q < npairs; ++q)
+        if (ia[q] < -1 || ia[q] >= h->K || ib[q] < -1 || ib[q] >= h->K)
+            return nodal_fail(h, NODAL_E_INVALID, "pair index out of range");
+    if (npairs == 0) return NODAL_OK;
+    h->have_x = false;
+    NODAL_HIP_TRY(h, h->schur.reserve((size_t)npairs * 8 + 64));
+    double *res = h->schur.as<double>();
+    if (n == 0) {
+        for (int32_t q = 0; q < npairs; ++q) resistance[q] = 0.0;
+        return NODAL_OK;
+    }
+    if (dense || n <= 64 || !(h->B == 0 && h->passive_network)) {
+        // one LU for up to CHUNK pairs: they are extra right-hand-side columns
+        const int32_t CHUNK = 512;
+        for (int32_t q0 = 0; q0 < npairs; q0 += CHUNK) {
+            const int32_t m = npairs - q0 < CHUNK ? npairs - q0 : CHUNK;
+            NODAL_TRY(dense_prepare_pairs(h, m, ia + q0, ib + q0));
+            NODAL_HIP_TRY(h, h->solver.reserve((size_t)n * m * 8 + 64));
+            NODAL_TRY(dense_factor_solve_multi(h, m, h->solver.as<double>(), n, info));
+            if (*info > 0) {
+                if (dense) return nodal_fail(h, NODAL_E_SINGULAR, "singular matrix: exact zero pivot");
+                for (int32_t q = 0; q < npairs; ++q) resistance[q] = __builtin_nan("");
+                return NODAL_OK;
+            }
+            for (int32_t q = 0; q < m; ++q)
+                NODAL_TRY(pair_read_host(h, h->solver.as<double>() + (int64_t)q * n, ia[q0 + q],
+                                         ib[q0 + q], res + q0 + q));
+        }
+    } else {
+        NODAL_TRY(sparse_solve_pairs(h, npairs, ia, ib, res, info));
+        if (*info > 0) {
+            for (int32_t q = 0; q < npairs; ++q) resistance[q] = __builtin_nan("");
+            return NODAL_OK;
+        }
+    }
+    NODAL_HIP_TRY(h, hipMemcpyAsync(resistance, res, (size_t)npairs * 8, hipMemcpyDeviceToHost,
+                                    h->stream));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
     return NODAL_OK;
 }
 

@@ -166,6 +166,10 @@ static inline int64_t dense_lda(int64_t n) {
     return l;
 }
 int dense_factor_solve(nodal_ctx *h, int32_t *info);
+int dense_factor_solve_multi(nodal_ctx *h, int32_t nrhs, double *xout, int64_t ldx, int32_t *info);
+int dense_prepare_pairs(nodal_ctx *h, int32_t nrhs, const int32_t *ia, const int32_t *ib);
+int sparse_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const int32_t *ib,
+                       double *res_dev, int32_t *info);
 
 // ---- aggregation multigrid preconditioner (amg.hip) ----
 int amg_setup(nodal_ctx *h, double *flag_dev);

@@ -489,10 +489,12 @@ __global__ __launch_bounds__(256) void trsm_outer(double *__restrict__ A, int64_
 // block instead of two.  The solved x_J goes to xout, y[0:j0] is updated in place.
 __global__ __launch_bounds__(256) void bs_step(const double *__restrict__ A, int64_t lda,
                                                double *__restrict__ y, double *__restrict__ xout,
-                                               int j0, int j1) {
+                                               int64_t ldx, int j0, int j1) {
     __shared__ double U[NB][NB + 1];
     __shared__ double x[NB];
     const int nb = j1 - j0;
+    y += (int64_t)blockIdx.y * lda;      // right-hand side column blockIdx.y
+    xout += (int64_t)blockIdx.y * ldx;
     for (int t = threadIdx.x; t < NB * NB; t += 256) {
         const int r = t % NB, s = t / NB;
         U[r][s] = (r < nb && s < nb) ? A[(int64_t)(j0 + s) * lda + j0 + r] : (r == s ? 1.0 : 0.0);
@@ -744,10 +746,15 @@ int dense_fill_nan(nodal_ctx *h, double *x, int64_t n) {
     return NODAL_OK;
 }
 
-// Factor the column-major augmented matrix in h->dense (lda = dense_lda(n), n + 1
-// columns) and leave the solution in h->x.  *info as LAPACK dgesv.
 int dense_factor_solve(nodal_ctx *h, int32_t *info) {
-    const int64_t n = h->n, lda = dense_lda(n), ncols = n + 1;
+    return dense_factor_solve_multi(h, 1, h->x.as<double>(), h->n, info);
+}
+
+// Factor the column-major augmented matrix in h->dense (lda = dense_lda(n), n + nrhs
+// columns) and leave the solutions in xout (column c at xout + c * ldx).  *info as
+// LAPACK dgesv.
+int dense_factor_solve_multi(nodal_ctx *h, int32_t nrhs, double *xout, int64_t ldx, int32_t *info) {
+    const int64_t n = h->n, lda = dense_lda(n), ncols = n + nrhs;
     hipStream_t st = h->stream;
     double *A = h->dense.as<double>();
     NODAL_HIP_TRY(h, h->piv.reserve((size_t)n * 4 + 64));
@@ -765,8 +772,9 @@ int dense_factor_solve(nodal_ctx *h, int32_t *info) {
     double *y = A + n * lda;
     for (int64_t j1 = n; j1 > 0;) {
         int64_t j0 = ((j1 - 1) / NB) * NB;
-        bs_step<<<blocks_for(j0 > 0 ? j0 : 1, 256), 256, 0, st>>>(A, lda, y, h->x.as<double>(), (int)j0,
-                                                                 (int)j1);
+        dim3 grid(blocks_for(j0 > 0 ? j0 : 1, 256), (unsigned)nrhs);
+        if (grid.x > 64 && nrhs > 1) grid.x = 64;  // many columns: fewer workgroups per column
+        bs_step<<<grid, 256, 0, st>>>(A, lda, y, xout, ldx, (int)j0, (int)j1);
         j1 = j0;
     }
     NODAL_HIP_TRY(h, hipGetLastError());

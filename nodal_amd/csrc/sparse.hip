@@ -430,7 +430,11 @@ __global__ __launch_bounds__(TB) void fcg_update(double *__restrict__ x, double 
     if (threadIdx.x == 0) part_rr[blockIdx.x] = srr;
 }
 
-int amg_fcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
+// b: right-hand side (device).  do_setup: build the hierarchy and run the structural
+// singularity check first; false re-uses the hierarchy of the previous call (sweeps
+// over right-hand sides, nodal_solve_pairs).
+int amg_fcg_solve_ex(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, int32_t *iters,
+                     double *resid) {
     const int64_t n = h->n;
     hipStream_t st = h->stream;
     const size_t vec = align_up((size_t)n * 8);
@@ -449,15 +453,13 @@ int amg_fcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
     const int32_t *indptr = h->indptr.as<int32_t>();
     const int32_t *indices = h->indices.as<int32_t>();
     const double *data = h->data.as<double>();
-    const double *b = h->rhs.as<double>();
 
-    const int lpr = lanes_per_row(h);
     const unsigned gv = grid_rows(n, 1), gs = stream::grid_for_rows(n, MAX_PARTIALS);
     NODAL_HIP_TRY(h, hipMemsetAsync(sc, 0, F_COUNT * 8, st));
     NODAL_HIP_TRY(h, hipMemsetAsync(part_zap, 0, MAX_PARTIALS * 8, st));
-    NODAL_TRY(amg_setup(h, sc + F_FLAG));
-    h->amg_levels = amg_num_levels(h);
-    {
+    if (do_setup) {
+        NODAL_TRY(amg_setup(h, sc + F_FLAG));
+        h->amg_levels = amg_num_levels(h);
         // structurally singular (a floating island): the reference's spsolve returns
         // NaNs; CG would happily return one of the infinitely many solutions
         NODAL_HIP_TRY(h, h->work3.reserve((size_t)n + 256));
@@ -542,6 +544,15 @@ int amg_fcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
     return NODAL_OK;
 }
 
+__global__ void pair_rhs(double *__restrict__ b, int32_t ia, int32_t ib) {
+    if (ia >= 0) b[ia] += 1.0;   // 1 A enters the first node ...
+    if (ib >= 0) b[ib] -= 1.0;   // ... and leaves the second (reference nodal/models.py:27-32)
+}
+__global__ void pair_read(const double *__restrict__ x, int32_t ia, int32_t ib,
+                          double *__restrict__ out) {
+    *out = (ia >= 0 ? x[ia] : 0.0) - (ib >= 0 ? x[ib] : 0.0);
+}
+
 __global__ __launch_bounds__(TB) void copy_rhs_column(const double *__restrict__ rhs,
                                                       double *__restrict__ col, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
@@ -562,7 +573,63 @@ int dense_prepare(nodal_ctx *h) {
     return NODAL_OK;
 }
 
+// dense panel with `nrhs` probe-pair columns (e_ia - e_ib) instead of the circuit's rhs
+int dense_prepare_pairs(nodal_ctx *h, int32_t nrhs, const int32_t *ia, const int32_t *ib) {
+    const int64_t n = h->n, lda = dense_lda(n);
+    NODAL_HIP_TRY(h, h->dense.reserve((size_t)lda * (size_t)(n + nrhs) * 8 + 64));
+    NODAL_TRY(stamp_to_dense(h, h->dense.as<double>(), lda, true));
+    double *cols = h->dense.as<double>() + n * lda;
+    NODAL_HIP_TRY(h, hipMemsetAsync(cols, 0, (size_t)lda * nrhs * 8, h->stream));
+    for (int32_t q = 0; q < nrhs; ++q) pair_rhs<<<1, 1, 0, h->stream>>>(cols + (int64_t)q * lda, ia[q], ib[q]);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
+}
+
 int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid);  // sparse_general.hip
+
+int amg_fcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
+    return amg_fcg_solve_ex(h, h->rhs.as<double>(), true, info, iters, resid);
+}
+
+// ---- equivalent-resistance sweeps --------------------------
+// The reference rebuilds and re-solves the whole circuit per node pair
+// (reference nodal/equiv.py:31-61: deepcopy + Circuit + solve).  G does not depend on the
+// pair -- only the probe current source does -- so one multigrid setup (sparse) or one
+// LU factorisation (dense, the pairs ride along as extra right-hand-side columns) serves
+// every pair.
+
+
+int pair_read_host(nodal_ctx *h, const double *x, int32_t ia, int32_t ib, double *out) {
+    pair_read<<<1, 1, 0, h->stream>>>(x, ia, ib, out);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
+}
+
+int sparse_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const int32_t *ib,
+                       double *res_dev, int32_t *info) {
+    const int64_t n = h->n;
+    hipStream_t st = h->stream;
+    NODAL_HIP_TRY(h, h->ps_buf.reserve((size_t)n * 8 + 64));
+    double *b = h->ps_buf.as<double>();
+    *info = 0;
+    for (int32_t q = 0; q < npairs; ++q) {
+        NODAL_HIP_TRY(h, hipMemsetAsync(b, 0, (size_t)n * 8, st));
+        pair_rhs<<<1, 1, 0, st>>>(b, ia[q], ib[q]);
+        int32_t it = 0, inf = 0;
+        double rs = 0;
+        int s = amg_fcg_solve_ex(h, b, q == 0, &inf, &it, &rs);
+        if (s == -2) {  // floating island: every pair is singular, as in the reference
+            *info = 1;
+            return NODAL_OK;
+        }
+        if (s < 0) return nodal_fail(h, NODAL_E_UNSUPPORTED, "pair sweep: multigrid CG broke down");
+        if (s != NODAL_OK) return s;
+        h->last_iterations = it;
+        pair_read<<<1, 1, 0, st>>>(h->x.as<double>(), ia[q], ib[q], res_dev + q);
+    }
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
+}
 
 int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, double *resid) {
     if (!h->have_numeric) return nodal_fail(h, NODAL_E_INVALID, "assemble_numeric not called");

@@ -46,6 +46,35 @@ def equivalent_resistance(netlist, a, b, sparse=False):
     return potential[0] - potential[1]
 
 
+def equivalent_resistance_sweep(netlist, pairs, sparse=False):
+    """Equivalent resistance for many node pairs of one resistive network.
+
+    Same results as `[equivalent_resistance(netlist, a, b, sparse) for a, b in pairs]`
+    (and the same exceptions for a non-resistive network or an unknown node), but G is
+    assembled once and factorised once (dense) / its multigrid hierarchy built once
+    (sparse): only the 1 A probe source depends on the pair (SURVEY.md section 8f N1;
+    the reference deep-copies the netlist and rebuilds everything per pair,
+    nodal/equiv.py:50-53).  Returns a list of floats."""
+    import numpy as np
+    if not check_resistive(netlist):
+        raise ValueError("Network is not resistive")
+    ia, ib = [], []
+    for a, b in pairs:
+        for node in (a, b):
+            if node not in netlist.nodenum and node != netlist.ground:
+                raise KeyError(f"Node `{node}` not found in netlist")
+        # the reference treats a node as grounded only if it is literally "g"
+        ia.append(-1 if a == "g" else netlist.nodenum[a])
+        ib.append(-1 if b == "g" else netlist.nodenum[b])
+    circuit = n.Circuit(netlist, sparse=sparse)
+    res, info = circuit._handle.solve_pairs(ia, ib, dense=not sparse)
+    if info > 0 and not sparse:
+        if not n.is_connected(netlist):
+            raise n.UnconnectedCircuitError
+        raise np.linalg.LinAlgError("Singular matrix")
+    return [np.float64(r) for r in res]
+
+
 def main(argv=None):
     args = parser.parse_args(argv)
     try:

@@ -324,6 +324,21 @@ def test_equivalent_resistance_golden():
             assert abs(r - want) <= TOL * abs(want), (case["name"], sparse, r, want)
 
 
+@pytest.mark.parametrize("N,sparse", [(4, False), (12, True), (40, True), (60, False)])
+def test_equivalent_resistance_sweep_matches_per_pair_calls(N, sparse):
+    """one factorisation / multigrid setup for all pairs."""
+    rng = random.Random(N)
+    nl = n.Netlist.from_rows(list(gen.grid_rows(N))[:-1])
+    labels = list(nl.nodenum) + ["g"]
+    pairs = [("1", "g")] + [tuple(rng.sample(labels, 2)) for _ in range(7)]
+    got = equiv.equivalent_resistance_sweep(nl, pairs, sparse=sparse)
+    for (a, b), r in zip(pairs, got):
+        want = equiv.equivalent_resistance(nl, a, b, sparse=sparse)
+        assert abs(r - want) <= 1e-9 * max(abs(want), 1e-300), (a, b, r, want)
+    with pytest.raises(KeyError):
+        equiv.equivalent_resistance_sweep(nl, [("1", "nope")], sparse=sparse)
+
+
 def test_reference_resistance_tests_exact():
     """reference tests.py:24-29 asserts exact equality for resistive_{1,2,3}."""
     want = {"doc/resistive_1": 2.0, "doc/resistive_2": 1.0, "doc/resistive_3": 1.0}
