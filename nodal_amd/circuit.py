@@ -159,10 +159,14 @@ class Solution:
         self.anomnum = netlist.anomnum
 
     def __str__(self):
+        # values as str(np.float64) prints them (shortest round-trip repr), names in
+        # lexicographic string order: reference nodal/nodal.py:422-434.  tolist() +
+        # repr() gives the same digits as formatting np.float64 one by one, without a
+        # numpy scalar object per line.
+        values = np.asarray(self.result, dtype=np.float64).tolist()
         lines = [f"Ground node: {self.ground}"]
-        for name in sorted(self.nodenum):
-            lines.append(f"e({name}) \t= {self.result[self.nodenum[name]]}")
-        offset = self.nums["kcl"]
-        for name in sorted(self.anomnum):
-            lines.append(f"i({name}) \t= {self.result[offset + self.anomnum[name]]}")
+        nodenum = self.nodenum
+        lines += [f"e({name}) \t= {values[nodenum[name]]!r}" for name in sorted(nodenum)]
+        offset, anomnum = self.nums["kcl"], self.anomnum
+        lines += [f"i({name}) \t= {values[offset + anomnum[name]]!r}" for name in sorted(anomnum)]
         return "\n".join(lines)

@@ -240,6 +240,8 @@ def is_connected(netlist):
     Same answer as the reference's BFS, but with an O(V+E) visited set
     instead of its O(V^2) list membership test.
     """
+    if getattr(netlist, "_fast", False):
+        return _is_connected_fast(netlist)
     neighbours = {node: set() for node in netlist.degrees}
     for comp in netlist.components.values():
         neighbours[comp.anode].add(comp.bnode)
@@ -253,3 +255,28 @@ def is_connected(netlist):
                 seen.add(nxt)
                 frontier.append(nxt)
     return len(seen) == len(netlist.degrees)
+
+
+def _is_connected_fast(netlist):
+    """is_connected for a vectorised netlist: union-find by repeated min-label
+    propagation over the lead pairs (numpy), no per-component Python objects."""
+    import numpy as np
+    a, b = netlist._acode.astype(np.int64), netlist._bcode.astype(np.int64)
+    n = len(netlist.degrees)
+    label = np.arange(n, dtype=np.int64)
+    while True:
+        la, lb = label[a], label[b]
+        lo = np.minimum(la, lb)
+        new = label.copy()
+        np.minimum.at(new, la, lo)
+        np.minimum.at(new, lb, lo)
+        new = new[new]  # pointer jumping
+        if np.array_equal(new, label):
+            break
+        label = new
+    while True:  # full compression
+        nxt = label[label]
+        if np.array_equal(nxt, label):
+            break
+        label = nxt
+    return bool((label == label[0]).all()) if n else True

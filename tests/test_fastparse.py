@@ -121,3 +121,12 @@ def test_large_file_is_read_fast(tmp_path):
     ref = gen.grid_table(120)
     for f in FIELDS:
         assert np.array_equal(getattr(t, f), getattr(ref, f)), f
+
+
+def test_is_connected_on_vectorised_netlists(tmp_path, monkeypatch):
+    rows = list(gen.grid_rows(9))
+    slow, fast = both(tmp_path, rows, monkeypatch)
+    assert n.is_connected(slow) and n.is_connected(fast)
+    rows2 = rows + [["x1", "R", "1", "p", "q"], ["x2", "R", "1", "q", "r"]]  # floating island
+    slow, fast = both(tmp_path, rows2, monkeypatch)
+    assert not n.is_connected(slow) and not n.is_connected(fast)
