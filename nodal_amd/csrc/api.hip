@@ -101,7 +101,8 @@ void nodal_free_buffers(nodal_ctx *h) {
                       &h->contrib, &h->rhs_row, &h->rhs_cptr, &h->rhs_contrib, &h->diag_pos,
                       &h->data, &h->rhs, &h->status, &h->x, &h->dense, &h->piv, &h->work,
                       &h->work2, &h->work3, &h->solver, &h->krylov, &h->gn_indptr, &h->gn_indices,
-                      &h->gn_rowidx, &h->gn_data, &h->gn_diag, &h->schur, &h->ps_buf};
+                      &h->gn_rowidx, &h->gn_data, &h->gn_diag, &h->schur, &h->ps_buf, &h->ps_newidx,
+                      &h->ps_hits};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
     h->evpool.clear();

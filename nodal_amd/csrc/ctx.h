@@ -63,7 +63,7 @@ struct nodal_ctx {
     bool owns_streams = true;
     bool use_presolve = true;
     bool use_graphs = false;       // hipGraph replay of the FCG iteration: measured no gain (kernels are not host-bound)
-    DevBuf ps_buf;
+    DevBuf ps_buf, ps_newidx, ps_hits;
 
     // ---- symbolic assembly results ----
     bool have_symbolic = false;

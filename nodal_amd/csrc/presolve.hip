@@ -99,28 +99,117 @@ __global__ __launch_bounds__(TB) void recover_currents(int pass, int K, int B,
 struct PresolvePlan {
     bool ok = false;
     std::vector<Expr> exprs;
-    std::vector<int32_t> newidx;   // K
+    std::vector<int32_t> pivots;   // sorted pivot nodes
     std::vector<int32_t> row_of;   // B: row that determines each branch current
-    // reduced component table
-    std::vector<uint8_t> type;
-    std::vector<double> value;
-    std::vector<int32_t> a, b, c, d, drv, k;
     int32_t Kr = 0;
+    int32_t newidx(int node) const {  // surviving node -> reduced index (pivots are sorted)
+        if (node < 0) return -1;
+        return node - (int32_t)(std::lower_bound(pivots.begin(), pivots.end(), node) - pivots.begin());
+    }
 };
 
-// Host analysis + rewrite.  `value` = the member's component values (host).
+// ---- device side of the rewrite ---------------------------------------------------------
+
+__global__ __launch_bounds__(TB) void mark_pivots(int np, const int32_t *__restrict__ pivots,
+                                                  uint32_t *__restrict__ survive) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < np; i += (int64_t)gridDim.x * TB)
+        survive[pivots[i]] = 0u;
+}
+__global__ __launch_bounds__(TB) void fill_u32(uint32_t *p, uint32_t v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        p[i] = v;
+}
+// newidx[j] = reduced index of node j, -1 for pivots (scan = exclusive scan of survive)
+__global__ __launch_bounds__(TB) void make_newidx(int K, const uint32_t *__restrict__ survive,
+                                                  const uint32_t *__restrict__ scan,
+                                                  int32_t *__restrict__ newidx) {
+    for (int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x; j < K; j += (int64_t)gridDim.x * TB)
+        newidx[j] = survive[j] ? (int32_t)scan[j] : -1;
+}
+
+struct DevTable {
+    const uint8_t *type;
+    const double *value;
+    const int32_t *a, *b, *c, *d, *drv;
+};
+struct DevTableOut {
+    uint8_t *type;
+    double *value;
+    int32_t *a, *b, *c, *d, *drv, *k;
+};
+
+// keep[i] = 1: component survives unchanged (up to node renumbering);
+// hit[i]  = 1: it touches an eliminated node and is rewritten by the host;
+// branch components are dropped.  A dependent source controlled by a pivot node makes
+// the pattern unsupported (*invalid = 1).
+__global__ __launch_bounds__(TB) void classify(DevTable t, int64_t nc,
+                                               const int32_t *__restrict__ newidx,
+                                               uint32_t *__restrict__ keep,
+                                               uint32_t *__restrict__ hit,
+                                               int32_t *__restrict__ invalid) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < nc; i += (int64_t)gridDim.x * TB) {
+        const int ty = t.type[i];
+        uint32_t kp = 0, ht = 0;
+        if (ty == NODAL_T_R || ty == NODAL_T_A || ty == NODAL_T_CCCS || ty == NODAL_T_GM) {
+            const int a = t.a[i], b = t.b[i];
+            const bool touched = (a >= 0 && newidx[a] < 0) || (b >= 0 && newidx[b] < 0);
+            if (ty == NODAL_T_CCCS || ty == NODAL_T_GM) {
+                const int c = t.c[i], d = t.d[i];
+                if ((c >= 0 && newidx[c] < 0) || (d >= 0 && newidx[d] < 0)) *invalid = 1;
+            }
+            if (touched) ht = 1; else kp = 1;
+        }
+        keep[i] = kp;
+        hit[i] = ht;
+    }
+}
+
+__global__ __launch_bounds__(TB) void compact(DevTable t, int64_t nc,
+                                              const int32_t *__restrict__ newidx,
+                                              const uint32_t *__restrict__ keep,
+                                              const uint32_t *__restrict__ keep_pos,
+                                              const uint32_t *__restrict__ hit,
+                                              const uint32_t *__restrict__ hit_pos,
+                                              DevTableOut o, int32_t *__restrict__ hit_list) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < nc; i += (int64_t)gridDim.x * TB) {
+        if (hit[i]) hit_list[hit_pos[i]] = (int32_t)i;
+        if (!keep[i]) continue;
+        const uint32_t p = keep_pos[i];
+        int ty = t.type[i];
+        double v = t.value[i];
+        auto nid = [&](int node) { return node < 0 ? -1 : newidx[node]; };
+        if (ty == NODAL_T_CCCS) {  // a transconductance outright
+            v = v / t.value[t.drv[i]];
+            ty = NODAL_T_GM;
+        }
+        o.type[p] = (uint8_t)ty;
+        o.value[p] = v;
+        o.a[p] = nid(t.a[i]);
+        o.b[p] = nid(t.b[i]);
+        const bool ctl = ty == NODAL_T_GM;
+        o.c[p] = ctl ? nid(t.c[i]) : -1;
+        o.d[p] = ctl ? nid(t.d[i]) : -1;
+        o.drv[p] = -1;
+        o.k[p] = -1;
+    }
+}
+
+// Host analysis: pivots and expressions from the (few) branch components.
 static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan &plan) {
     const HostTable &t = h->host;
     const int64_t nc = h->ncomp;
     const int K = h->K, B = h->B;
     plan.ok = false;
-    std::vector<int32_t> expr_of(K, -1);
-    std::vector<char> seen_k(B, 0);
     plan.exprs.clear();
     plan.row_of.assign(B, -1);
-    // 1. pivots
+    std::vector<char> seen_k(B, 0);
+    std::vector<int32_t> taken;  // pivot nodes so far (few): kept sorted for lookups
+    auto is_pivot = [&](int node) {
+        return node >= 0 && std::binary_search(taken.begin(), taken.end(), node);
+    };
+    const uint8_t *ty_arr = t.type.data();
     for (int64_t i = 0; i < nc; ++i) {
-        const int ty = t.type[i];
+        const int ty = ty_arr[i];
         if (ty < NODAL_T_E || ty > NODAL_T_CCCS) continue;
         const int kk = t.k[i];
         if (kk < 0 || kk >= B || seen_k[kk]) return;  // duplicated names: not handled
@@ -147,71 +236,64 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
         }
         int p = -1, q = -1;
         double sign = 1.0;
-        if (a >= 0 && expr_of[a] < 0 && a != c && a != d) { p = a; q = b; }
-        else if (b >= 0 && expr_of[b] < 0 && b != c && b != d) { p = b; q = a; sign = -1.0; }
+        if (a >= 0 && !is_pivot(a) && a != c && a != d) { p = a; q = b; }
+        else if (b >= 0 && !is_pivot(b) && b != c && b != d) { p = b; q = a; sign = -1.0; }
         else return;
-        expr_of[p] = (int32_t)plan.exprs.size();
+        taken.insert(std::upper_bound(taken.begin(), taken.end(), p), p);
         plan.exprs.push_back(Expr{p, q, sign * cst, c, d, (c < 0 && d < 0) ? 0.0 : sign * gain});
         plan.row_of[kk] = p;
     }
     for (int kk = 0; kk < B; ++kk)
         if (plan.row_of[kk] < 0) return;
-    // 2. no pivot may serve as a base or a control node
-    for (const Expr &e : plan.exprs) {
-        if (e.q >= 0 && expr_of[e.q] >= 0) return;
-        if (e.c >= 0 && expr_of[e.c] >= 0) return;
-        if (e.d >= 0 && expr_of[e.d] >= 0) return;
-    }
-    for (int64_t i = 0; i < nc; ++i) {
-        const int ty = t.type[i];
-        if (ty == NODAL_T_CCCS || ty == NODAL_T_GM) {
-            if (t.c[i] >= 0 && expr_of[t.c[i]] >= 0) return;
-            if (t.d[i] >= 0 && expr_of[t.d[i]] >= 0) return;
-        }
-    }
-    // 3. renumber the surviving nodes
-    plan.newidx.assign(K, -1);
-    int32_t Kr = 0;
-    for (int j = 0; j < K; ++j)
-        if (expr_of[j] < 0) plan.newidx[j] = Kr++;
-    plan.Kr = Kr;
-    auto nid = [&](int node) { return node < 0 ? -1 : plan.newidx[node]; };
-    // 4. rewrite
-    auto &T = plan;
-    T.type.clear(); T.value.clear(); T.a.clear(); T.b.clear(); T.c.clear(); T.d.clear();
-    T.drv.clear(); T.k.clear();
-    const size_t guess = (size_t)nc + 8 * plan.exprs.size() + 16;
-    T.type.reserve(guess); T.value.reserve(guess); T.a.reserve(guess); T.b.reserve(guess);
-    T.c.reserve(guess); T.d.reserve(guess); T.drv.reserve(guess); T.k.reserve(guess);
+    // no pivot may serve as a base or a control node of an expression
+    for (const Expr &e : plan.exprs)
+        if (is_pivot(e.q) || is_pivot(e.c) || is_pivot(e.d)) return;
+    plan.pivots = taken;
+    plan.Kr = K - (int32_t)taken.size();
+    plan.ok = true;
+}
+
+// Rewrite of the components that touch an eliminated node (host; they are few).
+struct Extras {
+    std::vector<uint8_t> type;
+    std::vector<double> value;
+    std::vector<int32_t> a, b, c, d;
+};
+static void rewrite_hits(const nodal_ctx *h, const double *value, const PresolvePlan &plan,
+                         const std::vector<int32_t> &hits, Extras &x) {
+    const HostTable &t = h->host;
+    std::vector<std::pair<int32_t, int32_t>> by_pivot(plan.exprs.size());
+    for (size_t i = 0; i < plan.exprs.size(); ++i) by_pivot[i] = {plan.exprs[i].p, (int32_t)i};
+    std::sort(by_pivot.begin(), by_pivot.end());
+    auto expr_of = [&](int node) -> const Expr * {
+        if (node < 0) return nullptr;
+        auto it = std::lower_bound(by_pivot.begin(), by_pivot.end(), std::make_pair((int32_t)node, (int32_t)-1));
+        return (it != by_pivot.end() && it->first == node) ? &plan.exprs[it->second] : nullptr;
+    };
     auto emit = [&](int ty, double v, int a, int b, int c, int d) {
-        T.type.push_back((uint8_t)ty); T.value.push_back(v);
-        T.a.push_back(nid(a)); T.b.push_back(nid(b)); T.c.push_back(nid(c)); T.d.push_back(nid(d));
-        T.drv.push_back(-1); T.k.push_back(-1);
+        x.type.push_back((uint8_t)ty); x.value.push_back(v);
+        x.a.push_back(plan.newidx(a)); x.b.push_back(plan.newidx(b));
+        x.c.push_back(plan.newidx(c)); x.d.push_back(plan.newidx(d));
     };
     struct Side { int base; double cst; int c, d; double g; };
     auto side = [&](int node) {
-        if (node >= 0 && expr_of[node] >= 0) {
-            const Expr &e = plan.exprs[expr_of[node]];
-            return Side{e.q, e.cst, e.c, e.d, e.g};
-        }
+        if (const Expr *e = expr_of(node)) return Side{e->q, e->cst, e->c, e->d, e->g};
         return Side{node, 0.0, -1, -1, 0.0};
     };
-    for (int64_t i = 0; i < nc; ++i) {
+    for (int32_t i : hits) {
         const int ty = t.type[i];
         const double v = value[i];
         if (ty == NODAL_T_R) {
-            const int x = t.a[i], y = t.b[i];
-            const bool ex = x >= 0 && expr_of[x] >= 0, ey = y >= 0 && expr_of[y] >= 0;
-            if (!ex && !ey) { emit(NODAL_T_R, v, x, y, -1, -1); continue; }
-            const Side sx = side(x), sy = side(y);
+            const Side sx = side(t.a[i]), sy = side(t.b[i]);
+            if (sx.base == sy.base) continue;  // both leads collapse onto one node
             const double g = 1.0 / v;
-            if (sx.base != sy.base) emit(NODAL_T_R, v, sx.base, sy.base, -1, -1);
+            emit(NODAL_T_R, v, sx.base, sy.base, -1, -1);
             // current g (e_x - e_y) flows from x's super-node to y's: constant part ...
             const double cstd = sx.cst - sy.cst;
-            if (cstd != 0.0 && sx.base != sy.base) emit(NODAL_T_A, g * cstd, sy.base, sx.base, -1, -1);
+            if (cstd != 0.0) emit(NODAL_T_A, g * cstd, sy.base, sx.base, -1, -1);
             // ... and the controlled parts
-            if (sx.g != 0.0 && sx.base != sy.base) emit(NODAL_T_GM, g * sx.g, sx.base, sy.base, sx.c, sx.d);
-            if (sy.g != 0.0 && sx.base != sy.base) emit(NODAL_T_GM, -g * sy.g, sx.base, sy.base, sy.c, sy.d);
+            if (sx.g != 0.0) emit(NODAL_T_GM, g * sx.g, sx.base, sy.base, sx.c, sx.d);
+            if (sy.g != 0.0) emit(NODAL_T_GM, -g * sy.g, sx.base, sy.base, sy.c, sy.d);
         } else if (ty == NODAL_T_A) {
             const Side sa = side(t.a[i]), sb = side(t.b[i]);
             if (sa.base != sb.base) emit(NODAL_T_A, v, sa.base, sb.base, -1, -1);
@@ -220,9 +302,97 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
             const Side sa = side(t.a[i]), sb = side(t.b[i]);
             if (sa.base != sb.base) emit(NODAL_T_GM, gm, sa.base, sb.base, t.c[i], t.d[i]);
         }
-        // E / VCVS / CCVS: encoded in the expressions
     }
-    plan.ok = true;
+}
+
+// Build the reduced component table directly in the child context's device arrays.
+static int presolve_build_reduced(nodal_ctx *h, nodal_ctx *r, const double *value_host,
+                                  const double *value_dev, const PresolvePlan &plan, bool *ok) {
+    *ok = false;
+    hipStream_t st = h->stream;
+    const int64_t nc = h->ncomp;
+    const int K = h->K;
+    const int np = (int)plan.pivots.size();
+    // scratch layout in work3: survive/scan [K+1] | keep [nc+1] | hit [nc+1] | pivots | flags | scan tmp
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_surv = 0, o_scan = o_surv + al((size_t)(K + 1) * 4);
+    const size_t o_keep = o_scan + al((size_t)(K + 1) * 4), o_kpos = o_keep + al((size_t)(nc + 1) * 4);
+    const size_t o_hit = o_kpos + al((size_t)(nc + 1) * 4), o_hpos = o_hit + al((size_t)(nc + 1) * 4);
+    const size_t o_piv = o_hpos + al((size_t)(nc + 1) * 4), o_flag = o_piv + al((size_t)np * 4 + 4);
+    const size_t o_tmp = o_flag + 256;
+    NODAL_HIP_TRY(h, h->work3.reserve(o_tmp + scan_tmp_bytes(std::max<int64_t>(nc, K) + 1)));
+    char *w = h->work3.as<char>();
+    uint32_t *survive = reinterpret_cast<uint32_t *>(w + o_surv), *sscan = reinterpret_cast<uint32_t *>(w + o_scan);
+    uint32_t *keep = reinterpret_cast<uint32_t *>(w + o_keep), *kpos = reinterpret_cast<uint32_t *>(w + o_kpos);
+    uint32_t *hit = reinterpret_cast<uint32_t *>(w + o_hit), *hpos = reinterpret_cast<uint32_t *>(w + o_hpos);
+    int32_t *d_piv = reinterpret_cast<int32_t *>(w + o_piv);
+    int32_t *flags = reinterpret_cast<int32_t *>(w + o_flag);  // [0] invalid
+    void *tmp = w + o_tmp;
+    NODAL_HIP_TRY(h, h->ps_newidx.reserve((size_t)K * 4 + 64));
+    int32_t *newidx = h->ps_newidx.as<int32_t>();
+
+    NODAL_HIP_TRY(h, hipMemcpyAsync(d_piv, plan.pivots.data(), (size_t)np * 4, hipMemcpyHostToDevice, st));
+    NODAL_HIP_TRY(h, hipMemsetAsync(flags, 0, 16, st));
+    fill_u32<<<grid_for(K + 1), TB, 0, st>>>(survive, 1u, K);
+    NODAL_HIP_TRY(h, hipMemsetAsync(survive + K, 0, 4, st));
+    mark_pivots<<<grid_for(np), TB, 0, st>>>(np, d_piv, survive);
+    NODAL_TRY(scan_exclusive_u32(h, survive, sscan, (int64_t)K + 1, nullptr, tmp));
+    make_newidx<<<grid_for(K), TB, 0, st>>>(K, survive, sscan, newidx);
+    DevTable t{h->type.as<uint8_t>(), value_dev, h->a.as<int32_t>(), h->b.as<int32_t>(),
+               h->c.as<int32_t>(), h->d.as<int32_t>(), h->drv.as<int32_t>()};
+    classify<<<grid_for(nc), TB, 0, st>>>(t, nc, newidx, keep, hit, flags);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    NODAL_HIP_TRY(h, hipMemsetAsync(keep + nc, 0, 4, st));
+    NODAL_HIP_TRY(h, hipMemsetAsync(hit + nc, 0, 4, st));
+    NODAL_TRY(scan_exclusive_u32(h, keep, kpos, nc + 1, nullptr, tmp));
+    NODAL_TRY(scan_exclusive_u32(h, hit, hpos, nc + 1, nullptr, tmp));
+    uint32_t counts[2] = {0, 0};
+    int32_t invalid = 0;
+    NODAL_HIP_TRY(h, hipMemcpyAsync(&counts[0], kpos + nc, 4, hipMemcpyDeviceToHost, st));
+    NODAL_HIP_TRY(h, hipMemcpyAsync(&counts[1], hpos + nc, 4, hipMemcpyDeviceToHost, st));
+    NODAL_HIP_TRY(h, hipMemcpyAsync(&invalid, flags, 4, hipMemcpyDeviceToHost, st));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    if (invalid) return NODAL_OK;  // a dependent source is controlled by a pivot node
+    const int64_t nkeep = counts[0], nhit = counts[1];
+    // worst case 4 rewritten components per hit
+    const int64_t cap = nkeep + 4 * nhit + 16;
+    NODAL_HIP_TRY(h, r->type.reserve((size_t)cap + 16));
+    NODAL_HIP_TRY(h, r->value.reserve((size_t)cap * 8 + 16));
+    DevBuf *icols[] = {&r->a, &r->b, &r->c, &r->d, &r->drv, &r->k};
+    for (DevBuf *b : icols) NODAL_HIP_TRY(h, b->reserve((size_t)cap * 4 + 16));
+    NODAL_HIP_TRY(h, h->ps_hits.reserve((size_t)nhit * 4 + 64));
+    DevTableOut o{r->type.as<uint8_t>(), r->value.as<double>(), r->a.as<int32_t>(), r->b.as<int32_t>(),
+                  r->c.as<int32_t>(), r->d.as<int32_t>(), r->drv.as<int32_t>(), r->k.as<int32_t>()};
+    compact<<<grid_for(nc), TB, 0, st>>>(t, nc, newidx, keep, kpos, hit, hpos, o, h->ps_hits.as<int32_t>());
+    NODAL_HIP_TRY(h, hipGetLastError());
+    std::vector<int32_t> hits((size_t)nhit);
+    if (nhit)
+        NODAL_HIP_TRY(h, hipMemcpyAsync(hits.data(), h->ps_hits.p, (size_t)nhit * 4, hipMemcpyDeviceToHost, st));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    Extras x;
+    rewrite_hits(h, value_host, plan, hits, x);
+    const int64_t nx = (int64_t)x.type.size();
+    if (nx) {
+        std::vector<int32_t> minus((size_t)nx, -1);
+        NODAL_HIP_TRY(h, hipMemcpyAsync(o.type + nkeep, x.type.data(), (size_t)nx, hipMemcpyHostToDevice, st));
+        NODAL_HIP_TRY(h, hipMemcpyAsync(o.value + nkeep, x.value.data(), (size_t)nx * 8, hipMemcpyHostToDevice, st));
+        NODAL_HIP_TRY(h, hipMemcpyAsync(o.a + nkeep, x.a.data(), (size_t)nx * 4, hipMemcpyHostToDevice, st));
+        NODAL_HIP_TRY(h, hipMemcpyAsync(o.b + nkeep, x.b.data(), (size_t)nx * 4, hipMemcpyHostToDevice, st));
+        NODAL_HIP_TRY(h, hipMemcpyAsync(o.c + nkeep, x.c.data(), (size_t)nx * 4, hipMemcpyHostToDevice, st));
+        NODAL_HIP_TRY(h, hipMemcpyAsync(o.d + nkeep, x.d.data(), (size_t)nx * 4, hipMemcpyHostToDevice, st));
+        NODAL_HIP_TRY(h, hipMemcpyAsync(o.drv + nkeep, minus.data(), (size_t)nx * 4, hipMemcpyHostToDevice, st));
+        NODAL_HIP_TRY(h, hipMemcpyAsync(o.k + nkeep, minus.data(), (size_t)nx * 4, hipMemcpyHostToDevice, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    }
+    r->ncomp = nkeep + nx;
+    r->K = plan.Kr;
+    r->B = 0;
+    r->n = plan.Kr;
+    r->batch = 0;
+    r->have_table = true;
+    r->have_symbolic = r->have_numeric = r->have_x = false;
+    *ok = true;
+    return NODAL_OK;
 }
 
 // y (reduced potentials, device) -> x (full unknown vector of h, device)
@@ -241,7 +411,7 @@ static int presolve_recover(nodal_ctx *h, const PresolvePlan &plan, const double
     const size_t a8e = ((size_t)ne * 8 + 255) & ~(size_t)255, a4b = ((size_t)B * 4 + 255) & ~(size_t)255;
     NODAL_HIP_TRY(h, h->ps_buf.reserve(a4k + 4 * a4e + 2 * a8e + a4b + 256));
     char *w = h->ps_buf.as<char>();
-    int32_t *d_new = reinterpret_cast<int32_t *>(w);
+    const int32_t *d_new = h->ps_newidx.as<int32_t>();  // built by presolve_build_reduced
     int32_t *d_p = reinterpret_cast<int32_t *>(w + a4k);
     int32_t *d_q = reinterpret_cast<int32_t *>(w + a4k + a4e);
     int32_t *d_c = reinterpret_cast<int32_t *>(w + a4k + 2 * a4e);
@@ -252,7 +422,6 @@ static int presolve_recover(nodal_ctx *h, const PresolvePlan &plan, const double
     auto up = [&](void *dst, const void *src, size_t bytes) {
         return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess;
     };
-    NODAL_HIP_TRY(h, up(d_new, plan.newidx.data(), (size_t)K * 4));
     NODAL_HIP_TRY(h, up(d_p, p.data(), (size_t)ne * 4));
     NODAL_HIP_TRY(h, up(d_q, q.data(), (size_t)ne * 4));
     NODAL_HIP_TRY(h, up(d_c, c.data(), (size_t)ne * 4));
@@ -271,10 +440,6 @@ static int presolve_recover(nodal_ctx *h, const PresolvePlan &plan, const double
     NODAL_HIP_TRY(h, hipStreamSynchronize(st));  // host vectors above go out of scope
     return NODAL_OK;
 }
-
-int nodal_upload_internal(nodal_ctx *h, int64_t ncomp, const uint8_t *type, const double *value,
-                          const int32_t *a, const int32_t *b, const int32_t *c, const int32_t *d,
-                          const int32_t *drv, const int32_t *k, int32_t K, int32_t B);  // api.hip
 
 // Try the presolve route for the system of `h` (B > 0).  Returns NODAL_OK with
 // *done = true when x was produced and verified; *done = false means "not applicable"
@@ -308,9 +473,11 @@ int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, doub
         h->reduced->keep_host_table = false;
     }
     nodal_ctx *r = h->reduced;
-    NODAL_TRY(nodal_upload_internal(r, (int64_t)plan.type.size(), plan.type.data(), plan.value.data(),
-                                    plan.a.data(), plan.b.data(), plan.c.data(), plan.d.data(),
-                                    plan.drv.data(), plan.k.data(), plan.Kr, 0));
+    const double *value_dev =
+        h->batch > 0 ? h->values_batch.as<double>() + (int64_t)h->member * h->ncomp : h->value.as<double>();
+    bool built = false;
+    NODAL_TRY(presolve_build_reduced(h, r, value, value_dev, plan, &built));
+    if (!built) return NODAL_OK;
     const auto t2 = now();
     int s = stamp_symbolic(r);
     if (s == NODAL_OK) s = stamp_numeric(r, 0, nullptr);
