@@ -82,6 +82,7 @@ struct Hierarchy {
     DevBuf coarse_inv;  // dense inverse of the last level
     bool coarse_direct = false;
     int tail = -1;      // first level handled by the LDS tail kernel (-1: none)
+    int kmax = 1 << 20; // coarse levels above this index get a plain V hand-over (NODAL_AMG_KMAX)
     TailDesc tdesc;
     DevBuf tail_image;
     ~Hierarchy() { clear(); }
@@ -844,6 +845,7 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
     amg_destroy(h);
     Hierarchy *H = new Hierarchy();
     h->amg = H;
+    if (const char *e = getenv("NODAL_AMG_KMAX")) H->kmax = atoi(e);
     hipStream_t st = h->stream;
 
     Level *l0 = new Level();
@@ -968,8 +970,8 @@ int cycle(nodal_ctx *h, Hierarchy *H, int l, const double *b, double *out) {
         amg_tail_kernel<<<1, TAIL_THREADS, H->tdesc.total_bytes, st>>>(
             H->tdesc, H->tail_image.as<char>(), rc, c1, c2, C->part.as<double>());
         NODAL_HIP_TRY(h, hipGetLastError());
-    } else if (coarse_is_last) {
-        NODAL_TRY(cycle(h, H, l + 1, rc, c1));  // direct coarse solve: one call is exact
+    } else if (coarse_is_last || l + 1 > H->kmax) {
+        NODAL_TRY(cycle(h, H, l + 1, rc, c1));  // direct coarse solve (exact) or plain V hand-over
     } else {
         // two flexible-CG steps on the coarse problem, preconditioned by its own cycle
         double *v1 = C->v(V_V1), *v2 = C->v(V_V2), *r2 = C->v(V_R2);

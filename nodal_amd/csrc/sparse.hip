@@ -209,6 +209,10 @@ __global__ __launch_bounds__(TB) void residual_kernel(const int32_t *__restrict_
     const int sub = threadIdx.x % LPR;
     const int64_t rows_per_pass = (int64_t)gridDim.x * (TB / LPR);
     const int64_t passes = (n + rows_per_pass - 1) / rows_per_pass;
+    // per-thread maxima, reduced per block: one atomic per block and quantity (a million
+    // same-address atomics serialise in L2 and cost milliseconds)
+    double m_res = 0.0, m_an = 0.0, m_x = 0.0, m_b = 0.0;
+    bool poisoned = false;
     for (int64_t it = 0; it < passes; ++it) {
         const int64_t row = it * rows_per_pass + (int64_t)blockIdx.x * (TB / LPR) + threadIdx.x / LPR;
         const bool live = row < n;
@@ -227,15 +231,39 @@ __global__ __launch_bounds__(TB) void residual_kernel(const int32_t *__restrict_
         }
         if (live && sub == 0) {
             const double res = fabs(s - b[row]);
-            if (res != res || x[row] != x[row]) out[4] = 1.0;
+            if (res != res || x[row] != x[row]) poisoned = true;
             else {
-                atomic_max_nonneg(&out[0], res);
-                atomic_max_nonneg(&out[2], fabs(x[row]));
+                m_res = fmax(m_res, res);
+                m_x = fmax(m_x, fabs(x[row]));
             }
-            atomic_max_nonneg(&out[1], an);
-            atomic_max_nonneg(&out[3], fabs(b[row]));
+            m_an = fmax(m_an, an);
+            m_b = fmax(m_b, fabs(b[row]));
         }
     }
+    __shared__ double red[4][TB / 64];
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    if (poisoned) bad = 1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m_res = fmax(m_res, __shfl_down(m_res, off));
+        m_an = fmax(m_an, __shfl_down(m_an, off));
+        m_x = fmax(m_x, __shfl_down(m_x, off));
+        m_b = fmax(m_b, __shfl_down(m_b, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        red[0][w] = m_res; red[1][w] = m_an; red[2][w] = m_x; red[3][w] = m_b;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double m = 0.0;
+        for (int w = 0; w < TB / 64; ++w) m = fmax(m, red[threadIdx.x][w]);
+        // out[0] res, out[1] |A| row sum, out[2] |x|, out[3] |b|
+        if (m > 0.0) atomic_max_nonneg(&out[threadIdx.x], m);
+    }
+    if (threadIdx.x == 0 && bad) out[4] = 1.0;
 }
 
 int lanes_per_row(nodal_ctx *h) {

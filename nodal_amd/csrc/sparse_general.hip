@@ -25,7 +25,7 @@ namespace {
 constexpr int TB = 256;
 constexpr int RESTART = 40;
 constexpr int MAXV = RESTART + 1;
-constexpr int DOT_GRID = 240;
+constexpr int DOT_GRID = 1024;
 
 inline unsigned grid_for(int64_t n, unsigned cap = 4096) {
     int64_t g = (n + TB - 1) / TB;
@@ -150,64 +150,137 @@ __global__ __launch_bounds__(TB) void branch_solve(const int32_t *__restrict__ i
 
 // ---- Gram-Schmidt kernels -----------------------------------------------------------
 
+// All three kernels are instantiated for NV = nv rounded up to a multiple of 4, so the
+// loop over the basis is fully unrolled with unconditional loads (a run-time bound turns
+// every load into its own branch + wait).  The padding lanes re-read vector nv-1 (L2
+// hits) with a zero coefficient.
+
 // partial[block][i] = sum over the block's rows of V_i . w, i < nv
+template <int NV>
 __global__ __launch_bounds__(TB) void gs_dots(const double *__restrict__ V, int64_t ld, int nv,
                                               const double *__restrict__ w, int64_t n,
                                               double *__restrict__ partial) {
-    double acc[MAXV];
+    double acc[NV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) acc[i] = 0.0;
+    for (int i = 0; i < NV; ++i) acc[i] = 0.0;
     for (int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x; r < n; r += (int64_t)gridDim.x * TB) {
         const double wr = w[r];
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i)
-            if (i < nv) acc[i] = fma(V[(int64_t)i * ld + r], wr, acc[i]);
+        for (int i = 0; i < NV; ++i)
+            acc[i] = fma(V[(int64_t)(i < nv ? i : nv - 1) * ld + r], wr, acc[i]);
     }
+    __shared__ double ws[TB / 64][NV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        if (i < nv) {  // uniform
-            const double s = block_sum(acc[i]);
-            if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * MAXV + i] = s;
-        }
+    for (int i = 0; i < NV; ++i) {
+        const double v = wave_sum(acc[i]);
+        if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nv) {
+        double s = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < TB / 64; ++wv) s += ws[wv][threadIdx.x];
+        partial[(int64_t)blockIdx.x * MAXV + threadIdx.x] = s;
     }
 }
 
-// out[i] = sum over blocks (fixed order); out[MAXV] = sum of partial2 (squared norm)
-__global__ __launch_bounds__(64) void gs_reduce(const double *__restrict__ partial, int nblocks,
-                                                int nv, double *__restrict__ out,
-                                                const double *__restrict__ partial2,
-                                                int nblocks2) {
-    const int i = threadIdx.x;
-    if (i < nv) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * MAXV + i];
-        out[i] = s;
+// w -= sum_i h_i V_i, and in the same pass over V the inner products of the UPDATED w with
+// the basis (the second Gram-Schmidt sweep): partial[block][i] = sum V_i . w'
+template <int NV>
+__global__ __launch_bounds__(TB) void gs_update_dots(const double *__restrict__ V, int64_t ld, int nv,
+                                                     const double *__restrict__ hh,
+                                                     double *__restrict__ w, int64_t n,
+                                                     double *__restrict__ partial) {
+    double hv[NV], acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        hv[i] = i < nv ? hh[i] : 0.0;
+        acc[i] = 0.0;
     }
-    if (i == 63 && partial2) {
+    for (int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x; r < n; r += (int64_t)gridDim.x * TB) {
+        double v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = V[(int64_t)(i < nv ? i : nv - 1) * ld + r];
+        double wr = w[r];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) wr = fma(-hv[i], v[i], wr);
+        w[r] = wr;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc[i] = fma(v[i], wr, acc[i]);
+    }
+    __shared__ double ws[TB / 64][NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double s = wave_sum(acc[i]);
+        if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6][i] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nv) {
         double s = 0.0;
-        for (int b = 0; b < nblocks2; ++b) s += partial2[b];
-        out[MAXV] = s;
+#pragma unroll
+        for (int wv = 0; wv < TB / 64; ++wv) s += ws[wv][threadIdx.x];
+        partial[(int64_t)blockIdx.x * MAXV + threadIdx.x] = s;
     }
 }
 
 // w -= sum_i h_i V_i ; partial2[block] = |w|^2 of the block's rows afterwards
+template <int NV>
 __global__ __launch_bounds__(TB) void gs_update(const double *__restrict__ V, int64_t ld, int nv,
                                                 const double *__restrict__ hh,
                                                 double *__restrict__ w, int64_t n,
                                                 double *__restrict__ partial2) {
-    __shared__ double hs[MAXV];
-    if (threadIdx.x < MAXV) hs[threadIdx.x] = (int)threadIdx.x < nv ? hh[threadIdx.x] : 0.0;
-    __syncthreads();
+    double hv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) hv[i] = i < nv ? hh[i] : 0.0;
     double nrm = 0.0;
     for (int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x; r < n; r += (int64_t)gridDim.x * TB) {
+        double v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = V[(int64_t)(i < nv ? i : nv - 1) * ld + r];
         double wr = w[r];
-        for (int i = 0; i < nv; ++i) wr = fma(-hs[i], V[(int64_t)i * ld + r], wr);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) wr = fma(-hv[i], v[i], wr);
         w[r] = wr;
         nrm = fma(wr, wr, nrm);
     }
     nrm = block_sum(nrm);
     if (threadIdx.x == 0) partial2[blockIdx.x] = nrm;
 }
+
+// Block i < nv: out[i] = sum over blocks of partial[.][i]; block nv (when partial2 is
+// given): out[MAXV] = sum of partial2.  Fixed order, so the result is reproducible.
+__global__ __launch_bounds__(TB) void gs_reduce(const double *__restrict__ partial, int nblocks,
+                                                int nv, double *__restrict__ out,
+                                                const double *__restrict__ partial2,
+                                                int nblocks2) {
+    const int i = blockIdx.x;
+    double s = 0.0;
+    if (i < nv) {
+        for (int b = threadIdx.x; b < nblocks; b += TB) s += partial[(int64_t)b * MAXV + i];
+    } else if (partial2) {
+        for (int b = threadIdx.x; b < nblocks2; b += TB) s += partial2[b];
+    }
+    s = block_sum(s);
+    if (threadIdx.x == 0) {
+        if (i < nv) out[i] = s;
+        else if (partial2) out[MAXV] = s;
+    }
+}
+
+#define DISPATCH_NV(nv, CALL)                          \
+    switch (((nv) + 3) / 4) {                          \
+    case 1: { constexpr int NV = 4; CALL; } break;     \
+    case 2: { constexpr int NV = 8; CALL; } break;     \
+    case 3: { constexpr int NV = 12; CALL; } break;    \
+    case 4: { constexpr int NV = 16; CALL; } break;    \
+    case 5: { constexpr int NV = 20; CALL; } break;    \
+    case 6: { constexpr int NV = 24; CALL; } break;    \
+    case 7: { constexpr int NV = 28; CALL; } break;    \
+    case 8: { constexpr int NV = 32; CALL; } break;    \
+    case 9: { constexpr int NV = 36; CALL; } break;    \
+    case 10: { constexpr int NV = 40; CALL; } break;   \
+    default: { constexpr int NV = 44; CALL; } break;   \
+    }
 
 // dst = src * scale
 __global__ __launch_bounds__(TB) void scale_to(const double *__restrict__ src, double scale,
@@ -322,7 +395,7 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
     NODAL_HIP_TRY(h, hipMemsetAsync(x, 0, (size_t)n * 8, st));
 
     auto device_norm = [&](double *out) -> int {  // sqrt(sum partial2) -> host
-        gs_reduce<<<1, 64, 0, st>>>(partial, 0, 0, hdev, partial2, (int)gd);
+        gs_reduce<<<1, TB, 0, st>>>(partial, 0, 0, hdev, partial2, (int)gd);
         double v = 0.0;
         NODAL_HIP_TRY(h, hipMemcpyAsync(&v, hdev + MAXV, 8, hipMemcpyDeviceToHost, st));
         NODAL_HIP_TRY(h, hipStreamSynchronize(st));
@@ -367,13 +440,12 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
             NODAL_HIP_TRY(h, hipEventRecord(e1, st));
             // classical Gram-Schmidt, twice
             const int nv = j + 1;
-            gs_dots<<<gd, TB, 0, st>>>(V, ld, nv, w, n, partial);
-            gs_reduce<<<1, 64, 0, st>>>(partial, (int)gd, nv, hdev, nullptr, 0);
-            gs_update<<<gd, TB, 0, st>>>(V, ld, nv, hdev, w, n, partial2);
-            gs_dots<<<gd, TB, 0, st>>>(V, ld, nv, w, n, partial);
-            gs_reduce<<<1, 64, 0, st>>>(partial, (int)gd, nv, hdev2, nullptr, 0);
-            gs_update<<<gd, TB, 0, st>>>(V, ld, nv, hdev2, w, n, partial2);
-            gs_reduce<<<1, 64, 0, st>>>(partial, 0, 0, hdev2, partial2, (int)gd);  // |w|^2 -> hdev2[MAXV]
+            DISPATCH_NV(nv, (gs_dots<NV><<<gd, TB, 0, st>>>(V, ld, nv, w, n, partial)));
+            gs_reduce<<<nv, TB, 0, st>>>(partial, (int)gd, nv, hdev, nullptr, 0);
+            DISPATCH_NV(nv, (gs_update_dots<NV><<<gd, TB, 0, st>>>(V, ld, nv, hdev, w, n, partial)));
+            gs_reduce<<<nv, TB, 0, st>>>(partial, (int)gd, nv, hdev2, nullptr, 0);
+            DISPATCH_NV(nv, (gs_update<NV><<<gd, TB, 0, st>>>(V, ld, nv, hdev2, w, n, partial2)));
+            gs_reduce<<<1, TB, 0, st>>>(partial, 0, 0, hdev2, partial2, (int)gd);  // |w|^2 -> hdev2[MAXV]
             NODAL_HIP_TRY(h, hipGetLastError());
             NODAL_HIP_TRY(h, hipMemcpyAsync(hcol, hdev, 2 * (MAXV + 1) * 8, hipMemcpyDeviceToHost, st));
             NODAL_HIP_TRY(h, hipStreamSynchronize(st));
