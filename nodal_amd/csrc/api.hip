@@ -83,6 +83,16 @@ int nodal_create(int device_id, nodal_handle *out) {
         delete h;
         return NODAL_E_HIP;
     }
+    if (hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, lo) != hipSuccess) {
+        delete h;
+        return NODAL_E_HIP;
+    }
+    for (auto &e : h->ev_bi)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            delete h;
+            return NODAL_E_HIP;
+        }
+    if (const char *e = getenv("NODAL_DENSE_BLOCKINV")) h->dense_blockinv = atoi(e) != 0;
     *out = h;
     return NODAL_OK;
 }
@@ -115,11 +125,15 @@ int nodal_destroy(nodal_handle h) {
     DeviceGuard g(h);
     (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    if (h->stream3) (void)hipStreamSynchronize(h->stream3);
     nodal_free_buffers(h);
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : h->ev_la)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : h->ev_bi)
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream3) (void)hipStreamDestroy(h->stream3);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;

@@ -46,6 +46,9 @@ struct nodal_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // trailing updates of the dense LU (lookahead)
     hipEvent_t ev_la[2] = {nullptr, nullptr};
+    hipStream_t stream3 = nullptr;   // bulk stream of the block-inverse elimination (all CUs)
+    hipEvent_t ev_bi[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool dense_blockinv = true;      // passive dense systems: block elimination (NODAL_DENSE_BLOCKINV=0: LU)
     std::string err;
 
     // ---- component table (HBM, structure of arrays) ----
@@ -152,7 +155,10 @@ int stamp_symbolic(nodal_ctx *h);
 int stamp_numeric(nodal_ctx *h, int32_t member, int64_t *bad_component);
 int stamp_to_dense(nodal_ctx *h, double *G_dev, int64_t ld, bool col_major);
 
-// ---- fp64 MFMA GEMM (gemm_f64.hip): C -= A * B, column-major ----
+// ---- fp64 MFMA GEMM (gemm_f64.hip), column-major ----
+enum { GEMM_SUB = 0, GEMM_SET = 1, GEMM_SETNEG = 2 };  // C -= A B | C = A B | C = -A B
+int gemm_f64(nodal_ctx *h, hipStream_t stream, int mode, double *C, int64_t ldc, const double *A,
+             int64_t lda, const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K);
 int gemm_sub_f64(nodal_ctx *h, hipStream_t stream, double *C, int64_t ldc, const double *A,
                  int64_t lda, const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K);
 

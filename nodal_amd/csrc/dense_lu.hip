@@ -29,6 +29,8 @@
 //                  pivot search is skipped: same pivot sequence as dgetrf, none of its
 //                  latency.  (BASELINE.json configs 2 and 4.)
 // An exactly zero pivot sets info = column + 1 (LAPACK convention).
+#include <cstdlib>
+
 #include "ctx.h"
 
 namespace {
@@ -738,6 +740,270 @@ int factor_nopivot(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncol
     return NODAL_OK;
 }
 
+// ---------------------------------------------------------------------------------
+// Passive networks (B == 0, every R > 0): G is symmetric positive definite, so block
+// Gaussian elimination with EXPLICITLY INVERTED diagonal blocks needs no pivoting and
+// is stable (the diagonal blocks of an SPD matrix are at least as well conditioned as
+// the matrix).  Per 256-column block k:
+//     Q    = A11^-1                      (small chain on the high-priority stream)
+//     A12 <- Q A12                       (GEMM; includes the right-hand sides)
+//     A22 <- A22 - A21 A12               (GEMM, the bulk of the flops)
+// A21 is never touched: there is no tall-skinny panel factorisation, the critical
+// path per block is one 256 x 256 inverse, and that runs while the previous block's
+// big GEMM is still busy (its diagonal block is updated first).  Back substitution is
+// x1 = A12[:, rhs] - A12[:, rest] x2, block by block: no triangular solves.
+//
+// Q for w = 256 comes from the 2 x 2 Schur-complement formula on 128 x 128 quadrants:
+//     [A B]^-1   [A^-1 + T1 S^-1 T2   -T1 S^-1]     T1 = A^-1 B, T2 = C A^-1,
+//     [C D]    = [-S^-1 T2             S^-1   ]     S  = D - C T1
+// with the two 128 x 128 inverses by in-register Gauss-Jordan (one workgroup, the
+// block distributed 4 x 4 per thread, pivot row / column broadcast through LDS).
+
+constexpr int GJ = 128;
+
+// dst (m x m, ldd) = inverse of src (m x m, lds_), m <= 128.  No pivoting.  A zero or
+// NaN pivot records its 1-based global index in *dinfo (first one wins).
+__global__ __launch_bounds__(1024) void gj128(const double *__restrict__ src, int64_t lds_, int m,
+                                               double *__restrict__ dst, int64_t ldd,
+                                               int32_t *__restrict__ dinfo, int base) {
+    __shared__ double rowb[2][GJ], colb[2][GJ];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    double a[4][4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int r = ty + 32 * ii, c = tx + 32 * jj;
+            a[ii][jj] = (r < m && c < m) ? src[(int64_t)c * lds_ + r] : (r == c ? 1.0 : 0.0);
+        }
+    // Step k: the owners of column k publish it (with a zero in row k) and clear their
+    // copy; the owners of row k publish the scaled row (1/p in column k) and keep it as
+    // the new row k.  After the barrier every element takes the SAME update
+    // a -= col[i] * row[j]: rows other than k get a_ij - a_ik a_kj / p, column k gets
+    // 0 - a_ik / p, and row k is left alone by its zero multiplier.
+    for (int k = 0; k < m; ++k) {
+        const int kb = k >> 5, kr = k & 31, buf = k & 1;
+        const bool rowowner = ty == kr, colowner = tx == kr;
+        double rv[4];
+        if (rowowner) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                rv[jj] = kb == 0 ? a[0][jj] : kb == 1 ? a[1][jj] : kb == 2 ? a[2][jj] : a[3][jj];
+        }
+        if (colowner) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const double v = kb == 0 ? a[ii][0] : kb == 1 ? a[ii][1] : kb == 2 ? a[ii][2] : a[ii][3];
+                colb[buf][ty + 32 * ii] = (ty + 32 * ii) == k ? 0.0 : v;
+            }
+            switch (kb) {
+            case 0: a[0][0] = a[1][0] = a[2][0] = a[3][0] = 0.0; break;
+            case 1: a[0][1] = a[1][1] = a[2][1] = a[3][1] = 0.0; break;
+            case 2: a[0][2] = a[1][2] = a[2][2] = a[3][2] = 0.0; break;
+            default: a[0][3] = a[1][3] = a[2][3] = a[3][3] = 0.0; break;
+            }
+        }
+        if (rowowner) {
+            // the pivot sits in lane tx == kr of this half-wave, register rv[kb]
+            const double dk = kb == 0 ? rv[0] : kb == 1 ? rv[1] : kb == 2 ? rv[2] : rv[3];
+            const double p = __shfl(dk, (int)(threadIdx.x & 32u) + kr, 64);
+            if (tx == 0 && !(p != 0.0 && p == p) && *dinfo == 0) *dinfo = base + k + 1;
+            const double ip = 1.0 / p;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                rv[jj] = (tx + 32 * jj) == k ? ip : rv[jj] * ip;
+                rowb[buf][tx + 32 * jj] = rv[jj];
+            }
+            switch (kb) {
+            case 0: a[0][0] = rv[0]; a[0][1] = rv[1]; a[0][2] = rv[2]; a[0][3] = rv[3]; break;
+            case 1: a[1][0] = rv[0]; a[1][1] = rv[1]; a[1][2] = rv[2]; a[1][3] = rv[3]; break;
+            case 2: a[2][0] = rv[0]; a[2][1] = rv[1]; a[2][2] = rv[2]; a[2][3] = rv[3]; break;
+            default: a[3][0] = rv[0]; a[3][1] = rv[1]; a[3][2] = rv[2]; a[3][3] = rv[3]; break;
+            }
+        }
+        __syncthreads();
+        double rr[4], ff[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) rr[jj] = rowb[buf][tx + 32 * jj];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) ff[ii] = colb[buf][ty + 32 * ii];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) a[ii][jj] = fma(-ff[ii], rr[jj], a[ii][jj]);
+    }
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int r = ty + 32 * ii, c = tx + 32 * jj;
+            if (r < m && c < m) dst[(int64_t)c * ldd + r] = a[ii][jj];
+        }
+}
+
+// dst (rows x cols, ldd) = src (rows x cols, lds_), rows <= 256: one column per
+// 256-thread row of the grid-stride loop, whole lines moved
+__global__ __launch_bounds__(256) void copy_block(const double *__restrict__ src, int64_t lds_,
+                                                  double *__restrict__ dst, int64_t ldd, int rows,
+                                                  int64_t cols) {
+    for (int64_t c = (int64_t)blockIdx.x * 4; c < cols; c += (int64_t)gridDim.x * 4) {
+        double v[4];
+        const int r = threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (c + u < cols && r < rows) ? src[(c + u) * lds_ + r] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c + u < cols && r < rows) dst[(c + u) * ldd + r] = v[u];
+    }
+}
+
+// Back substitution for the block-inverse form: x[j0:j1] = y[j0:j1] is final; the rows
+// above lose A[0:j0, j0:j1] x[j0:j1].  A workgroup owns 64 rows (one per lane); its four
+// waves split the block's columns, 16 independent loads in flight each, and meet in
+// LDS.  blockIdx.y = right-hand side.
+__global__ __launch_bounds__(256) void bs_block(const double *__restrict__ A, int64_t lda,
+                                                double *__restrict__ y, double *__restrict__ xout,
+                                                int64_t ldx, int j0, int j1) {
+    __shared__ double xs[W];
+    __shared__ double part[3][64];
+    y += (int64_t)blockIdx.y * lda;
+    xout += (int64_t)blockIdx.y * ldx;
+    const int w = j1 - j0, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)threadIdx.x < w) xs[threadIdx.x] = y[j0 + threadIdx.x];
+    __syncthreads();
+    if (blockIdx.x == 0 && (int)threadIdx.x < w) xout[j0 + threadIdx.x] = xs[threadIdx.x];
+    const int per = (w + 3) / 4, s0 = wave * per, s1 = s0 + per < w ? s0 + per : w;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < j0; base += (int64_t)gridDim.x * 64) {
+        const int64_t i = base + lane;
+        double acc = 0.0;
+        if (i < j0) {
+            const double *col = A + (int64_t)j0 * lda + i;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int s = s0;
+            for (; s + 16 <= s1; s += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = col[(int64_t)(s + u) * lda];
+#pragma unroll
+                for (int u = 0; u < 16; u += 4) {
+                    a0 = fma(v[u + 0], xs[s + u + 0], a0);
+                    a1 = fma(v[u + 1], xs[s + u + 1], a1);
+                    a2 = fma(v[u + 2], xs[s + u + 2], a2);
+                    a3 = fma(v[u + 3], xs[s + u + 3], a3);
+                }
+            }
+            for (; s < s1; ++s) a0 = fma(col[(int64_t)s * lda], xs[s], a0);
+            acc = (a0 + a1) + (a2 + a3);
+        }
+        if (wave > 0) part[wave - 1][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && i < j0) y[i] -= (acc + part[0][lane]) + (part[1][lane] + part[2][lane]);
+        __syncthreads();
+    }
+}
+
+// Q (ld W) = inverse of the w x w block at D (ld lda); D itself is overwritten.
+int invert_diag(nodal_ctx *h, hipStream_t sp, double *D, int64_t lda, int w, double *Q, double *T1,
+                double *T2, int32_t *dinfo, int base) {
+    if (w <= GJ) {
+        gj128<<<1, 1024, 0, sp>>>(D, lda, w, Q, W, dinfo, base);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        return NODAL_OK;
+    }
+    const int m2 = w - GJ;
+    double *Bq = D + (int64_t)GJ * lda, *Cq = D + GJ, *Dq = D + (int64_t)GJ * lda + GJ;
+    double *Q11 = Q, *Q12 = Q + (int64_t)GJ * W, *Q21 = Q + GJ, *Q22 = Q + (int64_t)GJ * W + GJ;
+    gj128<<<1, 1024, 0, sp>>>(D, lda, GJ, Q11, W, dinfo, base);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    NODAL_TRY(gemm_f64(h, sp, GEMM_SET, T1, GJ, Q11, W, Bq, lda, GJ, m2, GJ));     // T1 = A^-1 B
+    NODAL_TRY(gemm_f64(h, sp, GEMM_SET, T2, GJ, Cq, lda, Q11, W, m2, GJ, GJ));     // T2 = C A^-1
+    NODAL_TRY(gemm_f64(h, sp, GEMM_SUB, Dq, lda, Cq, lda, T1, GJ, m2, m2, GJ));    // S = D - C T1
+    gj128<<<1, 1024, 0, sp>>>(Dq, lda, m2, Q22, W, dinfo, base + GJ);              // S^-1
+    NODAL_HIP_TRY(h, hipGetLastError());
+    NODAL_TRY(gemm_f64(h, sp, GEMM_SETNEG, Q12, W, T1, GJ, Q22, W, GJ, m2, m2));   // -T1 S^-1
+    NODAL_TRY(gemm_f64(h, sp, GEMM_SETNEG, Q21, W, Q22, W, T2, GJ, m2, GJ, m2));   // -S^-1 T2
+    NODAL_TRY(gemm_f64(h, sp, GEMM_SUB, Q11, W, Q12, W, T2, GJ, GJ, GJ, m2));      // + T1 S^-1 T2
+    return NODAL_OK;
+}
+
+int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncols, int32_t *dinfo,
+                    GemmTimer &tm) {
+    // Three streams.  Per block k = [J0, J1), next block [J1, J2), once A12(k) <- Q A12(k)
+    // is done and the previous bulk update has retired:
+    //   sp (high priority): diag   A[J1:J2, J1:J2] -= A[J1:J2, J0:J1] A12   (small)
+    //                       Q = inv(A[J1:J2, J1:J2])                        (chain)
+    //   s3:                 strip  A[J1:J2, J2:]   -= A[J1:J2, J0:J1] A12   (block row k+1)
+    //   sg:                 rest   A[J2:,   J1:]   -= A[J2:,   J0:J1] A12   (the bulk)
+    //   sp: after the strip: A[J1:J2, J2:] <- Q A[J1:J2, J2:]
+    // strip, rest and the chain run concurrently; sg sees one bulk GEMM after the other.
+    static const bool full_mask = getenv("NODAL_BI_FULL") != nullptr;
+    hipStream_t sp = h->stream, sg = full_mask ? h->stream3 : h->stream2;
+    hipStream_t s3 = full_mask ? h->stream2 : h->stream3;
+    hipEvent_t ev_w = h->ev_bi[0], ev_strip = h->ev_bi[1], ev_rest = h->ev_bi[2], ev_start = h->ev_bi[3],
+               ev_done = h->ev_bi[4];
+    // scratch: Q (W x W), T1, T2 (128 x 128), S (W x ncols)
+    const size_t qb = (size_t)W * W * 8, tb = (size_t)GJ * GJ * 8;
+    NODAL_HIP_TRY(h, h->work.reserve(qb + 2 * tb + (size_t)W * (size_t)ncols * 8 + 256));
+    double *Q = h->work.as<double>();
+    double *T1 = Q + (size_t)W * W, *T2 = T1 + (size_t)GJ * GJ, *S = T2 + (size_t)GJ * GJ;
+
+    // A12 <- Q A12 for the block [J0, J1) (columns right of it, right-hand sides included)
+    auto scale_row_block = [&](int64_t J0, int64_t J1) -> int {
+        const int w = (int)(J1 - J0);
+        const int64_t nr = ncols - J1;
+        copy_block<<<blocks_for(nr, 4), 256, 0, sp>>>(A + J1 * lda + J0, lda, S, W, w, nr);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        NODAL_TRY(gemm_f64(h, sp, GEMM_SET, A + J1 * lda + J0, lda, Q, W, S, W, w, nr, w));
+        NODAL_HIP_TRY(h, hipEventRecord(ev_w, sp));
+        return NODAL_OK;
+    };
+
+    NODAL_HIP_TRY(h, hipEventRecord(ev_start, sp));  // the matrix was prepared on the main stream
+    NODAL_HIP_TRY(h, hipStreamWaitEvent(sg, ev_start, 0));
+    NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_start, 0));
+    {
+        const int64_t J1 = n < W ? n : W;
+        NODAL_TRY(invert_diag(h, sp, A, lda, (int)J1, Q, T1, T2, dinfo, 0));
+        NODAL_TRY(scale_row_block(0, J1));
+    }
+    bool rest_pending = false;
+    for (int64_t J0 = 0; J0 < n; J0 += W) {
+        const int64_t J1 = J0 + W < n ? J0 + W : n;
+        const int w = (int)(J1 - J0);
+        if (J1 >= n) break;
+        const int64_t J2 = J1 + W < n ? J1 + W : n;
+        const double *L = A + J0 * lda, *U = A + J1 * lda + J0;  // A[:, J0:J1] and A12
+        if (rest_pending) {  // block row k+1 was last written by the previous bulk update
+            NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_rest, 0));
+            NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_rest, 0));
+        }
+        NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_w, 0));
+        NODAL_HIP_TRY(h, hipStreamWaitEvent(sg, ev_w, 0));
+        // diag + inverse chain
+        NODAL_TRY(gemm_sub_f64(h, sp, A + J1 * lda + J1, lda, L + J1, lda, U, lda, J2 - J1, J2 - J1, w));
+        NODAL_TRY(invert_diag(h, sp, A + J1 * lda + J1, lda, (int)(J2 - J1), Q, T1, T2, dinfo, (int)J1));
+        // strip
+        NODAL_TRY(gemm_sub_f64(h, s3, A + J2 * lda + J1, lda, L + J1, lda, U + (J2 - J1) * lda, lda,
+                               J2 - J1, ncols - J2, w));
+        NODAL_HIP_TRY(h, hipEventRecord(ev_strip, s3));
+        // rest
+        if (J2 < n) {
+            NODAL_TRY(tm.begin(sg));
+            NODAL_TRY(gemm_sub_f64(h, sg, A + J1 * lda + J2, lda, L + J2, lda, U, lda, n - J2, ncols - J1, w));
+            NODAL_TRY(tm.end(sg, 2.0 * (double)w * (double)(n - J2) * (double)(ncols - J1)));
+            NODAL_HIP_TRY(h, hipEventRecord(ev_rest, sg));
+            rest_pending = true;
+        } else rest_pending = false;
+        NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_strip, 0));
+        NODAL_TRY(scale_row_block(J1, J2));
+    }
+    NODAL_HIP_TRY(h, hipEventRecord(ev_done, sg));
+    NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_done, 0));
+    NODAL_HIP_TRY(h, hipEventRecord(ev_done, s3));
+    NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_done, 0));
+    return NODAL_OK;
+}
+
 }  // namespace
 
 int dense_fill_nan(nodal_ctx *h, double *x, int64_t n) {
@@ -763,13 +1029,26 @@ int dense_factor_solve_multi(nodal_ctx *h, int32_t nrhs, double *xout, int64_t l
     NODAL_HIP_TRY(h, hipMemsetAsync(dinfo, 0, 4, st));
 
     GemmTimer tm{h};
+    bool block_form = false;
     if (n <= GEPP_MAX) NODAL_TRY(factor_gepp(h, A, n, lda, ncols, piv, dinfo, tm));
+    else if (h->passive_network && !h->force_pivoting && h->dense_blockinv)
+        block_form = true;
     else if (h->passive_network && !h->force_pivoting)
         NODAL_TRY(factor_nopivot(h, A, n, lda, ncols, piv, dinfo, tm));
     else NODAL_TRY(factor_tournament(h, A, n, lda, ncols, piv, dinfo, tm));
 
     // back substitution on the transformed rhs (column n)
     double *y = A + n * lda;
+    if (block_form) {
+        NODAL_TRY(factor_blockinv(h, A, n, lda, ncols, dinfo, tm));
+        for (int64_t j1 = n; j1 > 0;) {
+            const int64_t j0 = ((j1 - 1) / W) * W;
+            dim3 grid(blocks_for(j0 > 0 ? j0 : 1, 64), (unsigned)nrhs);
+            if (grid.x > 256 && nrhs > 1) grid.x = 256;  // many columns: fewer workgroups per column
+            bs_block<<<grid, 256, 0, st>>>(A, lda, y, xout, ldx, (int)j0, (int)j1);
+            j1 = j0;
+        }
+    } else
     for (int64_t j1 = n; j1 > 0;) {
         int64_t j0 = ((j1 - 1) / NB) * NB;
         dim3 grid(blocks_for(j0 > 0 ? j0 : 1, 256), (unsigned)nrhs);

@@ -1,5 +1,7 @@
 // C[M x N] -= A[M x K] * B[K x N], fp64, column-major, on the CDNA4 matrix cores
 // (v_mfma_f64_16x16x4_f64).  The trailing update of the dense LU (dense_lu.hip).
+// MODE selects the epilogue: GEMM_SUB  C -= A B,  GEMM_SET  C = A B,  GEMM_SETNEG  C = -A B
+// (the two overwrite forms serve the block-inverse elimination of dense_lu.hip).
 //
 // Tiling for 64-wide wavefronts: a 256-thread workgroup (4 waves in a 2 x 2 grid)
 // owns a 128 x 128 tile of C; each wave a 64 x 64 sub-tile = 4 x 4 MFMA tiles,
@@ -29,6 +31,7 @@ constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int LDA_S = 144;  // A image row stride (doubles)
 constexpr int LDB_S = 145;  // B image row stride: odd/2 -> conflict-free transposing writes
 
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C, int64_t ldc,
                                                           const double *__restrict__ A,
                                                           int64_t lda,
@@ -105,20 +108,114 @@ __global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int gr = row0 + wm + mi * 16 + li;
-                if (gr < M) cc[gr] -= acc[mi][ni][r];
+                if (gr < M) {
+                    if (MODE == GEMM_SUB) cc[gr] -= acc[mi][ni][r];
+                    else if (MODE == GEMM_SET) cc[gr] = acc[mi][ni][r];
+                    else cc[gr] = -acc[mi][ni][r];
+                }
             }
         }
     }
 }
 
+// Small products (the 128 / 256-wide blocks of the block-inverse chain): the big kernel
+// would run them on one to four workgroups, a chain of K / 16 dependent global loads
+// each.  Here a workgroup owns a 32 x 32 tile of C, its four waves split K, every wave
+// loads its MFMA fragments straight from global memory (L2-resident operands) with all
+// loads of 16 k-steps in flight, and the four partial tiles meet in LDS.
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_small_kernel(double *__restrict__ C, int64_t ldc,
+                                                         const double *__restrict__ A, int64_t lda,
+                                                         const double *__restrict__ B, int64_t ldb,
+                                                         int M, int N, int K) {
+    __shared__ double part[3][4][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
+    // k-steps (of 4) split evenly over the four waves
+    const int ksteps = (K + 3) / 4, per = (ksteps + 3) / 4;
+    const int s0 = wave * per, s1 = s0 + per < ksteps ? s0 + per : ksteps;
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = v4f64{0.0, 0.0, 0.0, 0.0};
+    const int r0 = row0 + li, r1 = row0 + 16 + li, c0 = col0 + li, c1 = col0 + 16 + li;
+    const bool r0ok = r0 < M, r1ok = r1 < M, c0ok = c0 < N, c1ok = c1 < N;
+    const double *a0 = A + r0, *a1 = A + r1;
+    const double *b0 = B + (int64_t)c0 * ldb, *b1 = B + (int64_t)c1 * ldb;
+#pragma unroll 16
+    for (int s = s0; s < s1; ++s) {
+        const int k = 4 * s + lk;
+        const bool kok = k < K;
+        const double af0 = (kok && r0ok) ? a0[(int64_t)k * lda] : 0.0;
+        const double af1 = (kok && r1ok) ? a1[(int64_t)k * lda] : 0.0;
+        const double bf0 = (kok && c0ok) ? b0[k] : 0.0;
+        const double bf1 = (kok && c1ok) ? b1[k] : 0.0;
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf0, af0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf1, af0, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf0, af1, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf1, af1, acc[1][1], 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[wave - 1][mi * 2 + ni][lane][r] = acc[mi][ni][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gc = col0 + ni * 16 + lk + 4 * r;
+            if (gc >= N) continue;
+            double *cc = C + (int64_t)gc * ldc;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int gr = row0 + mi * 16 + li;
+                if (gr >= M) continue;
+                const double v = ((acc[mi][ni][r] + part[0][mi * 2 + ni][lane][r]) +
+                                  (part[1][mi * 2 + ni][lane][r] + part[2][mi * 2 + ni][lane][r]));
+                if (MODE == GEMM_SUB) cc[gr] -= v;
+                else if (MODE == GEMM_SET) cc[gr] = v;
+                else cc[gr] = -v;
+            }
+        }
+}
+
 }  // namespace
 
-// C -= A * B on the handle's stream.  All matrices column-major, device pointers.
-int gemm_sub_f64(nodal_ctx *h, hipStream_t stream, double *C, int64_t ldc, const double *A,
-                 int64_t lda, const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
+// C (op)= A * B on `stream`.  All matrices column-major, device pointers.
+int gemm_f64(nodal_ctx *h, hipStream_t stream, int mode, double *C, int64_t ldc, const double *A,
+             int64_t lda, const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return NODAL_OK;
+    if (M <= 256 && N <= 256) {
+        dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32));
+        if (mode == GEMM_SUB)
+            gemm_small_kernel<GEMM_SUB><<<grid, 256, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
+        else if (mode == GEMM_SET)
+            gemm_small_kernel<GEMM_SET><<<grid, 256, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
+        else
+            gemm_small_kernel<GEMM_SETNEG><<<grid, 256, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        return NODAL_OK;
+    }
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
-    gemm_sub_kernel<<<grid, 256, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
+    if (mode == GEMM_SUB)
+        gemm_sub_kernel<GEMM_SUB><<<grid, 256, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
+    else if (mode == GEMM_SET)
+        gemm_sub_kernel<GEMM_SET><<<grid, 256, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
+    else
+        gemm_sub_kernel<GEMM_SETNEG><<<grid, 256, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
     NODAL_HIP_TRY(h, hipGetLastError());
     return NODAL_OK;
+}
+
+int gemm_sub_f64(nodal_ctx *h, hipStream_t stream, double *C, int64_t ldc, const double *A,
+                 int64_t lda, const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
+    return gemm_f64(h, stream, GEMM_SUB, C, ldc, A, lda, B, ldb, M, N, K);
 }

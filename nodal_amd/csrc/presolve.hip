@@ -469,6 +469,9 @@ int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, doub
         for (int i = 0; i < 4; ++i) h->reduced->ev[i] = h->ev[i];
         h->reduced->ev_la[0] = h->ev_la[0];
         h->reduced->ev_la[1] = h->ev_la[1];
+        h->reduced->stream3 = h->stream3;
+        for (int i = 0; i < 6; ++i) h->reduced->ev_bi[i] = h->ev_bi[i];
+        h->reduced->dense_blockinv = h->dense_blockinv;
         h->reduced->owns_streams = false;
         h->reduced->keep_host_table = false;
     }

@@ -61,3 +61,49 @@ def test_dense_lu_tournament_on_general_matrix():
     xo, _ = oracle.solve(G.tocsr(), A, True)
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
     h.close()
+
+
+@pytest.mark.parametrize("side", [46, 47, 50])  # last block of 67, 160 and 195 columns
+def test_dense_block_inverse_elimination_on_passive_network(side, monkeypatch):
+    """Passive networks above GEPP_MAX: block elimination with inverted diagonal blocks
+    (default) against the plain no-pivot LU (NODAL_DENSE_BLOCKINV=0) and the oracle."""
+    from nodal_amd import generators as gen
+    from oracle import nodal_oracle as oracle
+    table = gen.grid_table(side)
+    out = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("NODAL_DENSE_BLOCKINV", flag)
+        h = _ffi.Handle(0)
+        h.upload(table)
+        h.assemble_symbolic()
+        assert h.assemble_numeric()[0] == _ffi.OK
+        x, info = h.solve_dense()
+        assert info == 0 and h.residual() <= 1e-14
+        out.append(x)
+        h.close()
+    G, A = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(G.tocsr(), A, True)
+    scale = np.abs(xo).max()
+    assert np.abs(out[0] - xo).max() <= 1e-10 * scale
+    assert np.abs(out[0] - out[1]).max() <= 1e-11 * scale
+
+
+def test_dense_block_inverse_multiple_right_hand_sides():
+    """nodal_solve_pairs on the dense passive path: the extra right-hand sides ride
+    through the block elimination as extra columns."""
+    from nodal_amd import generators as gen
+    table = gen.grid_table(47)
+    rng = np.random.RandomState(5)
+    ia = rng.randint(0, table.K, size=7).astype(np.int32)
+    ib = rng.randint(-1, table.K, size=7).astype(np.int32)
+    ib[ib == ia] = -1
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    dense, info = h.solve_pairs(ia, ib, True)
+    assert info == 0
+    sparse, info = h.solve_pairs(ia, ib, False)
+    assert info == 0
+    assert np.abs(dense - sparse).max() <= 1e-9 * np.abs(sparse).max()
+    h.close()
