@@ -781,56 +781,49 @@ __global__ __launch_bounds__(1024) void gj128(const double *__restrict__ src, in
     // the new row k.  After the barrier every element takes the SAME update
     // a -= col[i] * row[j]: rows other than k get a_ij - a_ik a_kj / p, column k gets
     // 0 - a_ik / p, and row k is left alone by its zero multiplier.
-    for (int k = 0; k < m; ++k) {
-        const int kb = k >> 5, kr = k & 31, buf = k & 1;
-        const bool rowowner = ty == kr, colowner = tx == kr;
-        double rv[4];
-        if (rowowner) {
+    // (The loop over k is split as k = 32 kb + kr with kb unrolled, so that the register
+    // index of row / column k is a compile-time constant.)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                rv[jj] = kb == 0 ? a[0][jj] : kb == 1 ? a[1][jj] : kb == 2 ? a[2][jj] : a[3][jj];
+    for (int kb = 0; kb < 4; ++kb) {
+        for (int kr = 0; kr < 32; ++kr) {
+            const int k = 32 * kb + kr, buf = kr & 1;
+            if (k >= m) break;
+            const bool rowowner = ty == kr, colowner = tx == kr;
+            double rv[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) rv[jj] = a[kb][jj];
+            if (colowner) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    colb[buf][ty + 32 * ii] = (ii == kb && rowowner) ? 0.0 : a[ii][kb];
+                    a[ii][kb] = 0.0;
+                }
+            }
+            if (rowowner) {
+                // the pivot sits in lane tx == kr of this half-wave, register rv[kb]
+                const double p = __shfl(rv[kb], (int)(threadIdx.x & 32u) + kr, 64);
+                if (tx == 0 && !(p != 0.0 && p == p) && *dinfo == 0) *dinfo = base + k + 1;
+                double ip = __builtin_amdgcn_rcp(p);
+                ip = fma(fma(-p, ip, 1.0), ip, ip);  // one Newton step: full double accuracy
+                ip = fma(fma(-p, ip, 1.0), ip, ip);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    rv[jj] = (tx + 32 * jj) == k ? ip : rv[jj] * ip;
+                    rowb[buf][tx + 32 * jj] = rv[jj];
+                    a[kb][jj] = rv[jj];
+                }
+            }
+            __syncthreads();
+            double rr[4], ff[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) rr[jj] = rowb[buf][tx + 32 * jj];
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) ff[ii] = colb[buf][ty + 32 * ii];
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) a[ii][jj] = fma(-ff[ii], rr[jj], a[ii][jj]);
         }
-        if (colowner) {
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                const double v = kb == 0 ? a[ii][0] : kb == 1 ? a[ii][1] : kb == 2 ? a[ii][2] : a[ii][3];
-                colb[buf][ty + 32 * ii] = (ty + 32 * ii) == k ? 0.0 : v;
-            }
-            switch (kb) {
-            case 0: a[0][0] = a[1][0] = a[2][0] = a[3][0] = 0.0; break;
-            case 1: a[0][1] = a[1][1] = a[2][1] = a[3][1] = 0.0; break;
-            case 2: a[0][2] = a[1][2] = a[2][2] = a[3][2] = 0.0; break;
-            default: a[0][3] = a[1][3] = a[2][3] = a[3][3] = 0.0; break;
-            }
-        }
-        if (rowowner) {
-            // the pivot sits in lane tx == kr of this half-wave, register rv[kb]
-            const double dk = kb == 0 ? rv[0] : kb == 1 ? rv[1] : kb == 2 ? rv[2] : rv[3];
-            const double p = __shfl(dk, (int)(threadIdx.x & 32u) + kr, 64);
-            if (tx == 0 && !(p != 0.0 && p == p) && *dinfo == 0) *dinfo = base + k + 1;
-            const double ip = 1.0 / p;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                rv[jj] = (tx + 32 * jj) == k ? ip : rv[jj] * ip;
-                rowb[buf][tx + 32 * jj] = rv[jj];
-            }
-            switch (kb) {
-            case 0: a[0][0] = rv[0]; a[0][1] = rv[1]; a[0][2] = rv[2]; a[0][3] = rv[3]; break;
-            case 1: a[1][0] = rv[0]; a[1][1] = rv[1]; a[1][2] = rv[2]; a[1][3] = rv[3]; break;
-            case 2: a[2][0] = rv[0]; a[2][1] = rv[1]; a[2][2] = rv[2]; a[2][3] = rv[3]; break;
-            default: a[3][0] = rv[0]; a[3][1] = rv[1]; a[3][2] = rv[2]; a[3][3] = rv[3]; break;
-            }
-        }
-        __syncthreads();
-        double rr[4], ff[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) rr[jj] = rowb[buf][tx + 32 * jj];
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) ff[ii] = colb[buf][ty + 32 * ii];
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) a[ii][jj] = fma(-ff[ii], rr[jj], a[ii][jj]);
     }
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)

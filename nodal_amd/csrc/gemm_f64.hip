@@ -1,24 +1,29 @@
 // C[M x N] -= A[M x K] * B[K x N], fp64, column-major, on the CDNA4 matrix cores
-// (v_mfma_f64_16x16x4_f64).  The trailing update of the dense LU (dense_lu.hip).
+// (v_mfma_f64_4x4x4_4b_f64).  The trailing update of the dense LU (dense_lu.hip).
 // MODE selects the epilogue: GEMM_SUB  C -= A B,  GEMM_SET  C = A B,  GEMM_SETNEG  C = -A B
 // (the two overwrite forms serve the block-inverse elimination of dense_lu.hip).
 //
 // Tiling for 64-wide wavefronts: a 256-thread workgroup (4 waves in a 2 x 2 grid)
-// owns a 128 x 128 tile of C; each wave a 64 x 64 sub-tile = 4 x 4 MFMA tiles,
-// i.e. 16 accumulators of 4 f64 per lane (128 VGPRs).  K is walked in chunks of 16
+// owns a 128 x 128 tile of C; each wave a 64 x 64 sub-tile = 4 x 4 tiles of 16 x 16,
+// i.e. 64 accumulators of one f64 per lane (128 VGPRs; two workgroups per CU).  K is walked in chunks of 16
 // staged through LDS, double buffered: while the matrix cores work on chunk k the
 // global loads of chunk k+1 are in flight.
 //
-// MFMA f64 16x16x4 fragment layout (cdna_hip_programming.md section 3):
-//   A operand: lane l holds A[i = l & 15][k = l >> 4]
-//   B operand: lane l holds B[k = l >> 4][j = l & 15]
-//   C/D      : lane l, register r holds D[row = (l >> 4) + 4 r][col = l & 15]
-// The instruction is issued with the operands SWAPPED (a = B fragment, b = A
-// fragment), i.e. it accumulates the transposed tile D = (A B)^T.  Lane l,
-// register r then holds C[row = l & 15][col = (l >> 4) + 4 r]: the 16 lanes of a
-// quarter-wave cover 16 CONTIGUOUS rows of column-major C, so every epilogue load /
-// store moves whole 128-byte lines.  (Un-swapped, each access touched 16 columns x
-// 32 bytes and HBM over-fetched C about 2x: 36 TFLOP/s instead of the MFMA rate.)
+// Instruction: v_mfma_f64_4x4x4_4b_f64 (four independent 4 x 4 x 4 blocks per issue).
+// On gfx950 it sustains 72-74 TFLOP/s, twice the 36 TFLOP/s of v_mfma_f64_16x16x4_f64
+// (tools/fp64_mix.hip, profiles/r01_fp64_mix.txt).  Register layout, probed with one-hot
+// operands (tools/mfma444_probe.hip): with lane l = 16 k + 4 b + t,
+//   A operand holds A_b[i = t][k],  B operand holds B_b[k][j = t],
+//   D lane 16 i + 4 b + j holds D_b[i][j] = sum_k A_b[i][k] B_b[k][j].
+// It is issued here as  D = mfma(a := B fragment, b := A fragment):
+//   b operand: lane l holds A[row = R0 + (l & 15)][k = l >> 4]      (16 contiguous rows)
+//   a operand: lane l holds B[k = l >> 4][col = C0 + (l & 3)]       (4 columns, the same
+//              for all four blocks: a broadcast read of 16 values)
+//   D        : lane l holds C[row = R0 + (l & 15)][col = C0 + (l >> 4)]
+// i.e. one issue updates a 16 x 4 strip of C over 4 k; four issues (C0 = 0, 4, 8, 12) are
+// one 16 x 16 x 4 step with accumulator register r <-> column (l >> 4) + 4 r.  The 16
+// lanes of a quarter-wave cover 16 CONTIGUOUS rows of column-major C, so every
+// epilogue load / store moves whole 128-byte lines.
 // LDS images are k-major ([k][i] and [k][j]); the row stride 144 doubles puts the
 // two k values a 32-lane half reads on disjoint bank halves (ds_read_b64: 64 banks).
 #include "ctx.h"
@@ -28,76 +33,129 @@ namespace {
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int NT = 256;  // threads per workgroup of the big kernel
 constexpr int LDA_S = 144;  // A image row stride (doubles)
 constexpr int LDB_S = 145;  // B image row stride: odd/2 -> conflict-free transposing writes
 
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_sub_kernel(double *__restrict__ C, int64_t ldc,
-                                                          const double *__restrict__ A,
-                                                          int64_t lda,
-                                                          const double *__restrict__ B,
-                                                          int64_t ldb, int M, int N, int K) {
+__global__ __launch_bounds__(NT, 2) void gemm_sub_kernel(double *__restrict__ C, int64_t ldc,
+                                                         const double *__restrict__ A, int64_t lda,
+                                                         const double *__restrict__ B, int64_t ldb,
+                                                         int M, int N, int K) {
     __shared__ double As[2][BK][LDA_S];
     __shared__ double Bs[2][BK][LDB_S];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;  // 2 x 2 waves, 64 x 64 each
     const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
-    const int li = lane & 15, lk = lane >> 4;
+    const int li = lane & 15, lk = lane >> 4, lq = lane & 3;
 
-    v4f64 acc[4][4];
+    double acc[4][4][4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = v4f64{0.0, 0.0, 0.0, 0.0};
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.0;
 
-    // global -> register staging of one K chunk: 8 doubles of A and 8 of B per thread
+    // global -> register staging of one K chunk: 8 doubles of A and 8 of B per thread.
+    // Rows >= M and columns >= N are read from the clamped (last valid) row / column:
+    // they only feed C entries that are never stored.  k >= K is read from k = K - 1
+    // and multiplied by zero.  No divergent branches; uniform 64-bit bases (SGPRs) plus
+    // 32-bit per-thread byte offsets.
     double ra[8], rb[8];
+    const int ai = tid & 127, ak = tid >> 7;  // A image [k][i]: i contiguous in memory; k = ak + 2 r
+    const int bk = tid & 15, bj = tid >> 4;   // B: 16 contiguous k of one column; j = bj + 16 r
+    const char *Abase = reinterpret_cast<const char *>(A + row0);
+    const char *Bbase = reinterpret_cast<const char *>(B + (int64_t)col0 * ldb);
+    const int64_t lda8 = lda * 8, ldb8 = ldb * 8;
+    const uint32_t aoff = (uint32_t)((row0 + ai < M ? ai : M - 1 - row0) * 8);
+    const int jlast = N - 1 - col0;  // uniform
     auto load_chunk = [&](int k0) {
+        const int gkb = k0 + bk;
+        const uint32_t kb8 = (uint32_t)(gkb < K ? gkb : K - 1) * 8u;
+        const char *Ak = Abase + (int64_t)k0 * lda8;  // uniform
+        const int klast = K - 1 - k0;                 // uniform
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const int p = tid + 256 * r;           // 0 .. 2047
-            const int i = p & 127, k = p >> 7;     // A image [k][i]: i contiguous in memory
-            const int gi = row0 + i, gk = k0 + k;
-            ra[r] = (gi < M && gk < K) ? A[(int64_t)gk * lda + gi] : 0.0;
-            const int kb = p & 15, j = p >> 4;     // B: 16 contiguous k of one column
-            const int gj = col0 + j, gkb = k0 + kb;
-            rb[r] = (gj < N && gkb < K) ? B[(int64_t)gj * ldb + gkb] : 0.0;
+            const int kk = ak + 2 * r < klast ? ak + 2 * r : klast;
+            ra[r] = *reinterpret_cast<const double *>(Ak + ((uint32_t)kk * (uint32_t)lda8 + aoff));
+            const int jj = bj + 16 * r < jlast ? bj + 16 * r : jlast;
+            rb[r] = *reinterpret_cast<const double *>(Bbase + ((uint32_t)jj * (uint32_t)ldb8 + kb8));
         }
     };
-    auto store_chunk = [&](int buf) {
+    // (the zero mask is applied here, after the MFMA section, so that nothing waits on the
+    // global loads before the matrix cores have their work)
+    auto store_chunk = [&](int buf, int k0) {
+        const double mb = k0 + bk < K ? 1.0 : 0.0;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const int p = tid + 256 * r;
-            As[buf][p >> 7][p & 127] = ra[r];
-            Bs[buf][p & 15][p >> 4] = rb[r];
+            As[buf][ak + 2 * r][ai] = ra[r] * (k0 + ak + 2 * r < K ? 1.0 : 0.0);
+            Bs[buf][bk][bj + 16 * r] = rb[r] * mb;
         }
     };
 
     const int nchunks = (K + BK - 1) / BK;
     load_chunk(0);
-    store_chunk(0);
+    store_chunk(0, 0);
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         if (ch + 1 < nchunks) load_chunk((ch + 1) * BK);
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
-            double af[4], bf[4];
+            double af[4];
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) af[mi] = As[buf][ks * 4 + lk][wm + mi * 16 + li];
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) bf[ni] = Bs[buf][ks * 4 + lk][wn + ni * 16 + li];
+            for (int np = 0; np < 2; ++np) {  // two 16-column groups at a time
+                double bq[2][4];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+                for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[ni], af[mi], acc[mi][ni],
-                                                                      0, 0, 0);
+                    for (int r = 0; r < 4; ++r)
+                        bq[nh][r] = Bs[buf][ks * 4 + lk][wn + (2 * np + nh) * 16 + 4 * r + lq];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[mi][2 * np + nh][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
+                                bq[nh][r], af[mi], acc[mi][2 * np + nh][r], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // do not hoist the later k-steps' LDS reads above these MFMAs (register budget)
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (ch + 1 < nchunks) store_chunk(buf ^ 1);
+        if (ch + 1 < nchunks) store_chunk(buf ^ 1, (ch + 1) * BK);
         __syncthreads();
     }
 
+    if (row0 + BM <= M && col0 + BN <= N) {
+        // interior tile: no predicates, 16 independent loads in flight per step
+        double *cw = C + (int64_t)(col0 + wn + lk) * ldc + row0 + wm + li;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            double cv[4][4];
+            if (MODE == GEMM_SUB) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) cv[r][mi] = cw[(int64_t)(ni * 16 + 4 * r) * ldc + mi * 16];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    double v;
+                    if (MODE == GEMM_SUB) v = cv[r][mi] - acc[mi][ni][r];
+                    else if (MODE == GEMM_SET) v = acc[mi][ni][r];
+                    else v = -acc[mi][ni][r];
+                    cw[(int64_t)(ni * 16 + 4 * r) * ldc + mi * 16] = v;
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
 #pragma unroll
@@ -206,11 +264,11 @@ int gemm_f64(nodal_ctx *h, hipStream_t stream, int mode, double *C, int64_t ldc,
     }
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
     if (mode == GEMM_SUB)
-        gemm_sub_kernel<GEMM_SUB><<<grid, 256, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
+        gemm_sub_kernel<GEMM_SUB><<<grid, NT, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
     else if (mode == GEMM_SET)
-        gemm_sub_kernel<GEMM_SET><<<grid, 256, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
+        gemm_sub_kernel<GEMM_SET><<<grid, NT, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
     else
-        gemm_sub_kernel<GEMM_SETNEG><<<grid, 256, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
+        gemm_sub_kernel<GEMM_SETNEG><<<grid, NT, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
     NODAL_HIP_TRY(h, hipGetLastError());
     return NODAL_OK;
 }

@@ -1,0 +1,34 @@
+// Stand-alone timing of the fp64 trailing-update GEMM (nodal_amd/csrc/gemm_f64.hip).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Inodal_amd/csrc tools/gemm_bench.hip -o tools/gemm_bench
+#include "../nodal_amd/csrc/gemm_f64.hip"
+#include <cstdio>
+#include <vector>
+int main(int argc, char **argv) {
+    const int64_t M = argc > 1 ? atoll(argv[1]) : 8192, N = argc > 2 ? atoll(argv[2]) : 8192,
+                  K = argc > 3 ? atoll(argv[3]) : 256;
+    const int64_t ld = M + K + 32;
+    nodal_ctx *h = new nodal_ctx();
+    hipStream_t st;
+    (void)hipStreamCreate(&st);
+    double *buf;
+    (void)hipMalloc(&buf, (size_t)ld * (N + K) * 8);
+    std::vector<double> host((size_t)ld * (N + K));
+    for (size_t i = 0; i < host.size(); ++i) host[i] = (double)((i * 2654435761u) % 1000) * 1e-3 - 0.5;
+    (void)hipMemcpy(buf, host.data(), host.size() * 8, hipMemcpyHostToDevice);
+    // LU-like placement: C = trailing block, A = column panel left of it, B = row panel above
+    double *C = buf + K * ld + K, *A = buf + K, *B = buf + K * ld;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0, st);
+        const int iters = 10;
+        for (int i = 0; i < iters; ++i) gemm_sub_f64(h, st, C, ld, A, ld, B, ld, M, N, K);
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("M=%lld N=%lld K=%lld: %.1f us/launch  %.2f TFLOP/s\n", (long long)M, (long long)N, (long long)K,
+               ms * 1e3 / iters, 2.0 * M * N * K * iters / ms / 1e9);
+    }
+    return 0;
+}
