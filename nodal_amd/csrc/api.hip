@@ -78,8 +78,8 @@ int nodal_create(int device_id, nodal_handle *out) {
     }
     if ((!h->stream2 &&
          hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, lo) != hipSuccess) ||
-        hipEventCreateWithFlags(&h->ev_la[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_la[1], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_la[0], hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_la[1], hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) {
         delete h;
         return NODAL_E_HIP;
     }
@@ -88,7 +88,7 @@ int nodal_create(int device_id, nodal_handle *out) {
         return NODAL_E_HIP;
     }
     for (auto &e : h->ev_bi)
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) {
             delete h;
             return NODAL_E_HIP;
         }

@@ -159,6 +159,13 @@ int stamp_to_dense(nodal_ctx *h, double *G_dev, int64_t ld, bool col_major);
 enum { GEMM_SUB = 0, GEMM_SET = 1, GEMM_SETNEG = 2 };  // C -= A B | C = A B | C = -A B
 int gemm_f64(nodal_ctx *h, hipStream_t stream, int mode, double *C, int64_t ldc, const double *A,
              int64_t lda, const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K);
+struct GemmProblem {
+    double *C; int64_t ldc;
+    const double *A; int64_t lda;
+    const double *B; int64_t ldb;
+    int M, N, K;
+};
+int gemm_pair_f64(nodal_ctx *h, hipStream_t stream, int mode, const GemmProblem &p0, const GemmProblem &p1);
 int gemm_sub_f64(nodal_ctx *h, hipStream_t stream, double *C, int64_t ldc, const double *A,
                  int64_t lda, const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K);
 

@@ -94,13 +94,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_sub_kernel(double *__restrict__ C,
         }
     };
 
-    const int nchunks = (K + BK - 1) / BK;
-    load_chunk(0);
-    store_chunk(0, 0);
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int buf = ch & 1;
-        if (ch + 1 < nchunks) load_chunk((ch + 1) * BK);
+    auto mfma_chunk = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
             double af[4];
@@ -122,33 +116,48 @@ __global__ __launch_bounds__(NT, 2) void gemm_sub_kernel(double *__restrict__ C,
                         for (int r = 0; r < 4; ++r)
                             acc[mi][2 * np + nh][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(
                                 bq[nh][r], af[mi], acc[mi][2 * np + nh][r], 0, 0, 0);
+                // do not hoist the later LDS reads above these MFMAs (register budget)
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // do not hoist the later k-steps' LDS reads above these MFMAs (register budget)
-            __builtin_amdgcn_sched_barrier(0);
         }
-        if (ch + 1 < nchunks) store_chunk(buf ^ 1, (ch + 1) * BK);
+    };
+
+    const int nchunks = (K + BK - 1) / BK;
+    load_chunk(0);
+    store_chunk(0, 0);
+    __syncthreads();
+    for (int ch = 0; ch + 1 < nchunks; ++ch) {
+        load_chunk((ch + 1) * BK);
+        mfma_chunk(ch & 1);
+        store_chunk((ch & 1) ^ 1, (ch + 1) * BK);
         __syncthreads();
     }
 
-    if (row0 + BM <= M && col0 + BN <= N) {
-        // interior tile: no predicates, 16 independent loads in flight per step
+    const bool interior = row0 + BM <= M && col0 + BN <= N;
+    if (interior) {
+        // Interior tile, no predicates.  The C values of the first 16-column group are
+        // requested BEFORE the last chunk's MFMAs (the staging registers are free by
+        // then) and each later group while the previous one is subtracted and stored.
         double *cw = C + (int64_t)(col0 + wn + lk) * ldc + row0 + wm + li;
+        double cv[2][4][4];
+        auto request = [&](int ni, int slot) {
+            if (MODE != GEMM_SUB) return;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) cv[slot][r][mi] = cw[(int64_t)(ni * 16 + 4 * r) * ldc + mi * 16];
+        };
+        request(0, 0);
+        mfma_chunk((nchunks - 1) & 1);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            double cv[4][4];
-            if (MODE == GEMM_SUB) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) cv[r][mi] = cw[(int64_t)(ni * 16 + 4 * r) * ldc + mi * 16];
-            }
+            if (ni + 1 < 4) request(ni + 1, (ni + 1) & 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
                     double v;
-                    if (MODE == GEMM_SUB) v = cv[r][mi] - acc[mi][ni][r];
+                    if (MODE == GEMM_SUB) v = cv[ni & 1][r][mi] - acc[mi][ni][r];
                     else if (MODE == GEMM_SET) v = acc[mi][ni][r];
                     else v = -acc[mi][ni][r];
                     cw[(int64_t)(ni * 16 + 4 * r) * ldc + mi * 16] = v;
@@ -156,6 +165,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_sub_kernel(double *__restrict__ C,
         }
         return;
     }
+    mfma_chunk((nchunks - 1) & 1);
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
 #pragma unroll
@@ -182,10 +192,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_sub_kernel(double *__restrict__ C,
 // loads its MFMA fragments straight from global memory (L2-resident operands) with all
 // loads of 16 k-steps in flight, and the four partial tiles meet in LDS.
 template <int MODE>
-__global__ __launch_bounds__(256) void gemm_small_kernel(double *__restrict__ C, int64_t ldc,
-                                                         const double *__restrict__ A, int64_t lda,
-                                                         const double *__restrict__ B, int64_t ldb,
-                                                         int M, int N, int K) {
+__device__ __forceinline__ void gemm_small_body(double *__restrict__ C, int64_t ldc,
+                                                const double *__restrict__ A, int64_t lda,
+                                                const double *__restrict__ B, int64_t ldb, int M,
+                                                int N, int K) {
     __shared__ double part[3][4][64][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -245,13 +255,29 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(double *__restrict__ C,
         }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_small_kernel(double *__restrict__ C, int64_t ldc,
+                                                         const double *__restrict__ A, int64_t lda,
+                                                         const double *__restrict__ B, int64_t ldb,
+                                                         int M, int N, int K) {
+    gemm_small_body<MODE>(C, ldc, A, lda, B, ldb, M, N, K);
+}
+
+// two independent small products in one launch (blockIdx.z picks the problem)
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_small_pair_kernel(GemmProblem p0, GemmProblem p1) {
+    const GemmProblem &p = blockIdx.z == 0 ? p0 : p1;
+    if ((int)blockIdx.x * 32 >= p.M || (int)blockIdx.y * 32 >= p.N) return;
+    gemm_small_body<MODE>(p.C, p.ldc, p.A, p.lda, p.B, p.ldb, p.M, p.N, p.K);
+}
+
 }  // namespace
 
 // C (op)= A * B on `stream`.  All matrices column-major, device pointers.
 int gemm_f64(nodal_ctx *h, hipStream_t stream, int mode, double *C, int64_t ldc, const double *A,
              int64_t lda, const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return NODAL_OK;
-    if (M <= 256 && N <= 256) {
+    if ((M <= 256 && N <= 256) || (M <= 256 && N <= 8192 && K <= 256)) {
         dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32));
         if (mode == GEMM_SUB)
             gemm_small_kernel<GEMM_SUB><<<grid, 256, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
@@ -276,4 +302,17 @@ int gemm_f64(nodal_ctx *h, hipStream_t stream, int mode, double *C, int64_t ldc,
 int gemm_sub_f64(nodal_ctx *h, hipStream_t stream, double *C, int64_t ldc, const double *A,
                  int64_t lda, const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
     return gemm_f64(h, stream, GEMM_SUB, C, ldc, A, lda, B, ldb, M, N, K);
+}
+
+// Two independent small products (M, N <= 256 each) in ONE launch.
+int gemm_pair_f64(nodal_ctx *h, hipStream_t stream, int mode, const GemmProblem &p0,
+                  const GemmProblem &p1) {
+    const int mx = p0.M > p1.M ? p0.M : p1.M, nx = p0.N > p1.N ? p0.N : p1.N;
+    if (mx <= 0 || nx <= 0) return NODAL_OK;
+    dim3 grid((unsigned)((mx + 31) / 32), (unsigned)((nx + 31) / 32), 2);
+    if (mode == GEMM_SUB) gemm_small_pair_kernel<GEMM_SUB><<<grid, 256, 0, stream>>>(p0, p1);
+    else if (mode == GEMM_SET) gemm_small_pair_kernel<GEMM_SET><<<grid, 256, 0, stream>>>(p0, p1);
+    else gemm_small_pair_kernel<GEMM_SETNEG><<<grid, 256, 0, stream>>>(p0, p1);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
 }

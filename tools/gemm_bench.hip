@@ -6,6 +6,7 @@
 int main(int argc, char **argv) {
     const int64_t M = argc > 1 ? atoll(argv[1]) : 8192, N = argc > 2 ? atoll(argv[2]) : 8192,
                   K = argc > 3 ? atoll(argv[3]) : 256;
+    const int mode = argc > 4 ? atoi(argv[4]) : GEMM_SUB;
     const int64_t ld = M + K + 32;
     nodal_ctx *h = new nodal_ctx();
     hipStream_t st;
@@ -22,7 +23,7 @@ int main(int argc, char **argv) {
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipEventRecord(e0, st);
         const int iters = 10;
-        for (int i = 0; i < iters; ++i) gemm_sub_f64(h, st, C, ld, A, ld, B, ld, M, N, K);
+        for (int i = 0; i < iters; ++i) gemm_f64(h, st, mode, C, ld, A, ld, B, ld, M, N, K);
         (void)hipEventRecord(e1, st);
         (void)hipEventSynchronize(e1);
         float ms;
