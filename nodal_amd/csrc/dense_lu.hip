@@ -761,6 +761,7 @@ int factor_nopivot(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncol
 // block distributed 4 x 4 per thread, pivot row / column broadcast through LDS).
 
 constexpr int GJ = 128;
+constexpr int BLOCKINV_MIN = 256;  // passive systems larger than this: block elimination
 
 // dst (m x m, ldd) = inverse of src (m x m, lds_), m <= 128.  No pivoting.  A zero or
 // NaN pivot records its 1-based global index in *dinfo (first one wins).
@@ -1024,11 +1025,13 @@ int dense_factor_solve_multi(nodal_ctx *h, int32_t nrhs, double *xout, int64_t l
 
     GemmTimer tm{h};
     bool block_form = false;
-    if (n <= GEPP_MAX) NODAL_TRY(factor_gepp(h, A, n, lda, ncols, piv, dinfo, tm));
-    else if (h->passive_network && !h->force_pivoting && h->dense_blockinv)
-        block_form = true;
-    else if (h->passive_network && !h->force_pivoting)
-        NODAL_TRY(factor_nopivot(h, A, n, lda, ncols, piv, dinfo, tm));
+    // Small systems keep LAPACK's pivot order exactly (reference parity down to the
+    // exact-zero-pivot test of singular circuits); passive ones above BLOCKINV_MIN take
+    // the block elimination whatever their size.
+    const bool passive = h->passive_network && !h->force_pivoting;
+    if (passive && h->dense_blockinv && n > BLOCKINV_MIN) block_form = true;
+    else if (n <= GEPP_MAX) NODAL_TRY(factor_gepp(h, A, n, lda, ncols, piv, dinfo, tm));
+    else if (passive) NODAL_TRY(factor_nopivot(h, A, n, lda, ncols, piv, dinfo, tm));
     else NODAL_TRY(factor_tournament(h, A, n, lda, ncols, piv, dinfo, tm));
 
     // back substitution on the transformed rhs (column n)

@@ -63,7 +63,7 @@ def test_dense_lu_tournament_on_general_matrix():
     h.close()
 
 
-@pytest.mark.parametrize("side", [46, 47, 50])  # last block of 67, 160 and 195 columns
+@pytest.mark.parametrize("side", [17, 23, 32, 46, 47, 50])  # n = 288 .. 2499; last blocks of 32 .. 255 columns
 def test_dense_block_inverse_elimination_on_passive_network(side, monkeypatch):
     """Passive networks above GEPP_MAX: block elimination with inverted diagonal blocks
     (default) against the plain no-pivot LU (NODAL_DENSE_BLOCKINV=0) and the oracle."""
