@@ -83,6 +83,7 @@ struct Hierarchy {
     bool coarse_direct = false;
     int tail = -1;      // first level handled by the LDS tail kernel (-1: none)
     int kmax = 1 << 20; // coarse levels above this index get a plain V hand-over (NODAL_AMG_KMAX)
+    int passes0 = PASSES, passes1 = PASSES;  // pairwise matching passes at level 0 / below
     TailDesc tdesc;
     DevBuf tail_image;
     ~Hierarchy() { clear(); }
@@ -846,6 +847,8 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
     Hierarchy *H = new Hierarchy();
     h->amg = H;
     if (const char *e = getenv("NODAL_AMG_KMAX")) H->kmax = atoi(e);
+    if (const char *e = getenv("NODAL_AMG_PASSES0")) H->passes0 = atoi(e);
+    if (const char *e = getenv("NODAL_AMG_PASSES1")) H->passes1 = atoi(e);
     hipStream_t st = h->stream;
 
     Level *l0 = new Level();
@@ -871,7 +874,8 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
         DevBuf pass_map;
         bool stalled = false;
         Level *coarse = new Level();
-        for (int p = 0; p < PASSES; ++p) {
+        const int passes = (int)H->levels.size() == 1 ? H->passes0 : H->passes1;
+        for (int p = 0; p < passes; ++p) {
             NODAL_HIP_TRY(h, pass_map.reserve((size_t)cur.n * 4 + 8));
             int32_t *map = p == 0 ? agg : pass_map.as<int32_t>();
             int64_t na = 0;
@@ -882,7 +886,7 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
                 compose_map<<<grid_for(n), TB, 0, st>>>(n, agg, map);
                 NODAL_HIP_TRY(h, hipGetLastError());
             }
-            const bool last = (p == PASSES - 1) || na <= COARSEST_MAX || na > (int64_t)(0.9 * (double)cur.n);
+            const bool last = (p == passes - 1) || na <= COARSEST_MAX || na > (int64_t)(0.9 * (double)cur.n);
             Level *dst = last ? coarse : &tmp[p & 1];
             s = galerkin(h, cur, map, na, dst);
             if (s != NODAL_OK) { delete coarse; return s; }
