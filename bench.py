@@ -36,7 +36,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP64_MFMA_PEAK_TF = 78.6    # vendor dense fp64 matrix peak
-# measured on this hardware with tools/mfma_f64_peak.hip (profiles/r01_mfma_f64_peak.txt):
+# measured on this hardware with tools/mfma_f64_peak.hip / tools/fp64_mix.hip
+# (profiles/r01_mfma_f64_peak.txt, profiles/r01_fp64_mix.txt):
+FP64_MFMA_444_TF = 73.0     # v_mfma_f64_4x4x4_4b_f64 -- the instruction gemm_f64.hip issues
 FP64_MFMA_INSTR_TF = 36.2   # v_mfma_f64_16x16x4_f64, 138 cycles/instruction/wave
 FP64_VALU_FMA_TF = 59.3     # v_fma_f64
 
@@ -135,12 +137,13 @@ def roofline_of(stats):
     avg_s = stats["kern_ms"] / stats["kern_n"] * 1e-3
     if stats["dense"]:
         achieved = stats["kern_alg"] / avg_s / 1e12
-        return {"bound": "mfma", "kernel": "gemm_sub_kernel (K=256 trailing update of the LU)",
+        return {"bound": "mfma", "kernel": "gemm_sub_kernel (K=256 bulk update of the block elimination)",
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TF, "traffic": pmc_traffic(stats["name"]),
                 "avg_launch_us": avg_s * 1e6, "launches_timed": stats["kern_n"],
                 "alg_flops_per_launch": stats["kern_alg"],
-                "measured_instruction_ceiling": {"v_mfma_f64_16x16x4": FP64_MFMA_INSTR_TF,
+                "measured_instruction_ceiling": {"v_mfma_f64_4x4x4_4b": FP64_MFMA_444_TF,
+                                                 "v_mfma_f64_16x16x4": FP64_MFMA_INSTR_TF,
                                                  "v_fma_f64": FP64_VALU_FMA_TF, "unit": "TFLOP/s"}}
     achieved = stats["kern_alg"] / avg_s / 1e9
     return {"bound": "hbm", "kernel": "CSR-stream SpMV (pcg_spmv / spmv_kernel)", "achieved": achieved,
