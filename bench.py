@@ -88,16 +88,44 @@ def run_step(h, dense, members):
             raise RuntimeError(f"solver reported info={info}")
 
 
-def time_workload(name, rank, world, steps, warmup, per_gpu, dist):
+def time_workload(name, rank, world, steps, warmup, per_gpu, dist, concurrent=1):
+    """`concurrent` > 1 (independent-circuit workloads): the step's circuits are spread over that
+    many handles, each driven by its own host thread -- independent solves overlap on the GPU
+    (one circuit's latency-bound phases run beside another's bulk updates)."""
     import torch
+    from concurrent.futures import ThreadPoolExecutor
     from nodal_amd import _ffi
     table, vals, dense, members, desc = build_workload(name, rank, per_gpu)
-    h = _ffi.Handle(torch.cuda.current_device())
-    h.upload(table)
-    if vals is not None:
-        h.upload_values(vals)
-    for _ in range(warmup):
-        run_step(h, dense, members)
+    concurrent = max(1, min(concurrent, members)) if name == "cfg2" else 1
+    handles = []
+    for _ in range(concurrent):
+        hh = _ffi.Handle(torch.cuda.current_device())
+        hh.upload(table)
+        if vals is not None:
+            hh.upload_values(vals)
+        handles.append(hh)
+    h = handles[0]
+    pool = ThreadPoolExecutor(max_workers=concurrent) if concurrent > 1 else None
+
+    def run_share(idx, first):
+        # circuits idx, idx + concurrent, ... on handle idx; one symbolic assembly per step
+        hh = handles[idx]
+        for j, i in enumerate(range(idx, members, concurrent)):
+            info = hh.run(dense, member=i, reuse_symbolic=not (first or (idx == 0 and j == 0)))
+            if info != 0:
+                raise RuntimeError(f"solver reported info={info}")
+
+    def step(first=False):
+        if pool is None:
+            run_share(0, first)
+        else:
+            for f in [pool.submit(run_share, idx, first) for idx in range(concurrent)]:
+                f.result()
+
+    for w in range(warmup):
+        step(first=(w == 0))
+    if warmup == 0:
+        step(first=True)  # every handle needs its symbolic phase once (untimed)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -105,10 +133,11 @@ def time_workload(name, rank, world, steps, warmup, per_gpu, dist):
     kern_ms = kern_n = 0
     phase = np.zeros(3)
     for _ in range(steps):
-        run_step(h, dense, members)
-        ms, launches, alg = h.kernel_stats()
-        kern_ms += ms
-        kern_n += launches
+        step()
+        for hh in handles:
+            ms, launches, alg = hh.kernel_stats()
+            kern_ms += ms
+            kern_n += launches
         phase += np.array(h.timings())
     torch.cuda.synchronize()
     if dist is not None:
@@ -126,8 +155,11 @@ def time_workload(name, rank, world, steps, warmup, per_gpu, dist):
     stats = dict(elapsed=elapsed, members=members, dense=dense, desc=desc, table=table,
                  kern_ms=kern_ms, kern_n=kern_n, kern_alg=alg, resid=resid, x0=float(x[0]),
                  phase_ms=(phase / steps).tolist(), n=h.n, nnz=h.nnz, name=name,
-                 iterations=iterations, amg_levels=amg_levels)
-    h.close()
+                 iterations=iterations, amg_levels=amg_levels, concurrent=concurrent)
+    for hh in handles:
+        hh.close()
+    if pool is not None:
+        pool.shutdown()
     return stats
 
 
@@ -187,6 +219,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--per-gpu", type=int, default=0, help="circuits per GPU per step")
+    ap.add_argument("--concurrent", type=int, default=1,
+                    help="cfg2: independent solves in flight per GPU (one handle + host thread each)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
     args = ap.parse_args()
@@ -206,7 +240,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     per_gpu = args.per_gpu or {"cfg2": 2, "cfg4": 128}.get(args.workload, 1)
-    st = time_workload(args.workload, rank, world, args.steps, args.warmup, per_gpu, dist)
+    st = time_workload(args.workload, rank, world, args.steps, args.warmup, per_gpu, dist, args.concurrent)
     circuits = st["members"] * args.steps * world
     out = {
         "metric": "circuits_per_sec",
@@ -224,7 +258,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {st['desc']}", "circuits_per_gpu_per_step":
                    st["members"], "n": st["n"], "nnz": st["nnz"],
-                   "parallelism": f"independent circuits x{world}"},
+                   "parallelism": f"independent circuits x{world}",
+                   "concurrent_solves_per_gpu": st["concurrent"]},
         "phase_ms": {"symbolic": st["phase_ms"][0], "numeric": st["phase_ms"][1],
                      "solve": st["phase_ms"][2]},
         "scaled_residual": st["resid"],
