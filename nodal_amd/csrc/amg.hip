@@ -1067,3 +1067,41 @@ int amg_has_floating_component(nodal_ctx *h, const uint8_t *grounded0, int32_t *
     NODAL_HIP_TRY(h, hipStreamSynchronize(st));
     return NODAL_OK;
 }
+
+// The same verdict straight on the context's CSR matrix (no hierarchy): used by the dense
+// passive path when a solution does not satisfy the equations, to tell "singular: floating
+// sub-network" (reference: LinAlgError -> UnconnectedCircuitError) from anything else.
+int csr_has_floating_component(nodal_ctx *h, const uint8_t *grounded, int32_t *floating) {
+    hipStream_t st = h->stream;
+    const int64_t n = h->n;
+    Csr A;
+    A.n = n;
+    A.nnz = h->nnz;
+    A.indptr = h->indptr.as<int32_t>();
+    A.indices = h->indices.as<int32_t>();
+    A.rowidx = h->rowidx.as<int32_t>();
+    A.data = h->data.as<double>();
+    const size_t a4 = ((size_t)n * 4 + 255) & ~(size_t)255;
+    NODAL_HIP_TRY(h, h->work2.reserve(2 * a4 + 512));
+    int32_t *label = h->work2.as<int32_t>();
+    int32_t *root_ok = reinterpret_cast<int32_t *>(h->work2.as<char>() + a4);
+    int32_t *flags = reinterpret_cast<int32_t *>(h->work2.as<char>() + 2 * a4);  // changed, floating
+    cc_init<<<grid_for(n), TB, 0, st>>>(n, label);
+    for (int it = 0; it < 65536; ++it) {
+        NODAL_HIP_TRY(h, hipMemsetAsync(flags, 0, 4, st));
+        cc_hook<<<grid_for(n), TB, 0, st>>>(A, label, flags);
+        cc_jump<<<grid_for(n), TB, 0, st>>>(n, label);
+        int32_t changed = 0;
+        NODAL_HIP_TRY(h, hipMemcpyAsync(&changed, flags, 4, hipMemcpyDeviceToHost, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        if (!changed) break;
+    }
+    NODAL_HIP_TRY(h, hipMemsetAsync(root_ok, 0, (size_t)n * 4, st));
+    NODAL_HIP_TRY(h, hipMemsetAsync(flags + 1, 0, 4, st));
+    cc_mark<<<grid_for(n), TB, 0, st>>>(n, label, grounded, root_ok);
+    cc_verdict<<<grid_for(n), TB, 0, st>>>(n, label, root_ok, flags + 1);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    NODAL_HIP_TRY(h, hipMemcpyAsync(floating, flags + 1, 4, hipMemcpyDeviceToHost, st));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    return NODAL_OK;
+}

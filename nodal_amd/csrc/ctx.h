@@ -194,6 +194,7 @@ int amg_num_levels(nodal_ctx *h);
 int64_t amg_level_size(nodal_ctx *h, int level);
 void amg_destroy(nodal_ctx *h);
 int amg_has_floating_component(nodal_ctx *h, const uint8_t *grounded0, int32_t *floating);
+int csr_has_floating_component(nodal_ctx *h, const uint8_t *grounded, int32_t *floating);
 
 // u8[n] flags: 1 where a resistor connects the node to ground (stamp.hip)
 int stamp_grounded_flags(nodal_ctx *h, uint8_t *flags_dev);

@@ -1008,7 +1008,28 @@ int dense_fill_nan(nodal_ctx *h, double *x, int64_t n) {
 }
 
 int dense_factor_solve(nodal_ctx *h, int32_t *info) {
-    return dense_factor_solve_multi(h, 1, h->x.as<double>(), h->n, info);
+    NODAL_TRY(dense_factor_solve_multi(h, 1, h->x.as<double>(), h->n, info));
+    // Passive systems are eliminated without pivoting.  A floating sub-network makes G exactly
+    // singular, but rounding can hide the zero pivot; a solution that does not satisfy the
+    // equations triggers the structural test (a connected component without a path to ground),
+    // which then reports the matrix as singular like the reference's dgesv would.
+    const bool passive = h->passive_network && !h->force_pivoting;
+    if (*info == 0 && passive && h->n > BLOCKINV_MIN) {
+        const bool had_x = h->have_x;
+        h->have_x = true;
+        double scaled = 0.0;
+        int s = sparse_residual(h, &scaled);
+        h->have_x = had_x;
+        if (s != NODAL_OK) return s;
+        if (!(scaled <= 1e-9)) {
+            int32_t floating = 0;
+            NODAL_HIP_TRY(h, h->work3.reserve((size_t)h->n + 256));
+            NODAL_TRY(stamp_grounded_flags(h, h->work3.as<uint8_t>()));
+            NODAL_TRY(csr_has_floating_component(h, h->work3.as<uint8_t>(), &floating));
+            if (floating) *info = (int32_t)h->n;
+        }
+    }
+    return NODAL_OK;
 }
 
 // Factor the column-major augmented matrix in h->dense (lda = dense_lda(n), n + nrhs

@@ -107,3 +107,19 @@ def test_dense_block_inverse_multiple_right_hand_sides():
     assert info == 0
     assert np.abs(dense - sparse).max() <= 1e-9 * np.abs(sparse).max()
     h.close()
+
+
+@pytest.mark.parametrize("side", [20, 50])  # n = 402 (one block row of 146) and 2502
+def test_dense_passive_floating_island_is_reported_singular(side):
+    """A resistor island without a path to ground makes G exactly singular.  The passive
+    dense path eliminates without pivoting, where rounding can hide the zero pivot: the
+    structural test must still report the system singular (reference: dgesv info > 0 ->
+    LinAlgError -> UnconnectedCircuitError)."""
+    import nodal_amd as n
+    from nodal_amd import generators as gen
+    rows = [list(r) for r in gen.grid_rows(side)]
+    rows += [["Rx", "R", "5", "isl1", "isl2"], ["Ry", "R", "7", "isl2", "isl3"],
+             ["Rz", "R", "3", "isl3", "isl1"], ["Ax", "A", "1", "isl1", "isl3"]]
+    netlist = n.Netlist.from_rows(rows)
+    with pytest.raises(n.UnconnectedCircuitError):
+        n.Circuit(netlist, sparse=False).solve()
