@@ -836,6 +836,151 @@ __global__ __launch_bounds__(1024) void gj128(const double *__restrict__ src, in
         }
 }
 
+// The same inverse with RANK-4 steps on the matrix cores (v_mfma_f64_4x4x4_4b_f64), 32
+// block steps instead of 128 scalar ones.  The 128 x 128 block lives in accumulator
+// registers in the MFMA result layout: wave w owns the 32 x 32 tile (tr = w & 3, tc = w >> 2),
+// acc[mi][c8] lane l = element (32 tr + 16 mi + (l & 15), 32 tc + 4 c8 + (l >> 4)).
+// Block step p, pivots k0 = 4p .. 4p+3 (block Gauss-Jordan, no pivoting):
+//   1. the owners publish the four pivot rows and the four pivot columns (raw) through LDS
+//      and clear their copy of the pivot columns;
+//   2. one wave inverts the 4 x 4 pivot block P;
+//   3. row panel  Rp = P^-1 [pivot rows]  with P^-1 itself in the pivot columns,
+//      column panel Lp = -[pivot columns] with zeros in the pivot rows;
+//   4. every wave: acc += Lp Rp (16 MFMAs; the cleared pivot columns become -L P^-1, the
+//      pivot rows are untouched by their zero multipliers) and the row owners take Rp as
+//      their new pivot rows.
+constexpr int RP_S = 132;  // row panel stride (doubles): the 4 k of a fragment on disjoint banks
+constexpr int CP_S = 144;  // column panel stride
+
+__device__ __forceinline__ double rcp_f64(double p) {
+    double ip = __builtin_amdgcn_rcp(p);
+    ip = fma(fma(-p, ip, 1.0), ip, ip);
+    return fma(fma(-p, ip, 1.0), ip, ip);
+}
+
+__global__ __launch_bounds__(1024) void gj128_mfma(const double *__restrict__ src, int64_t lds_, int m,
+                                                    double *__restrict__ dst, int64_t ldd,
+                                                    int32_t *__restrict__ dinfo, int base) {
+    __shared__ double rowraw[4][128], colraw[4][128], pinv[16];
+    __shared__ double rowpan[4][RP_S], colpan[4][CP_S];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tr = wave & 3, tc = wave >> 2;
+    const int lr = lane & 15, lc = lane >> 4, lq = lane & 3;
+    double acc0[8], acc1[8];  // two separate arrays: a select between them cannot be turned
+                              // into a dynamically indexed (scratch-resident) array access
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+        const int r0 = 32 * tr + lr, r1 = r0 + 16, c = 32 * tc + 4 * c8 + lc;
+        acc0[c8] = (r0 < m && c < m) ? src[(int64_t)c * lds_ + r0] : (r0 == c ? 1.0 : 0.0);
+        acc1[c8] = (r1 < m && c < m) ? src[(int64_t)c * lds_ + r1] : (r1 == c ? 1.0 : 0.0);
+    }
+    const int nsteps = (m + 3) / 4;
+    for (int p = 0; p < nsteps; ++p) {
+        const int k0 = 4 * p, tp = p >> 3, mip = (p >> 2) & 1, ro = 4 * (p & 3), c8p = p & 7;
+        // ---- 1. publish ----
+        if (tr == tp && lr >= ro && lr < ro + 4) {
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8)
+                rowraw[lr - ro][32 * tc + 4 * c8 + lc] = mip == 0 ? acc0[c8] : acc1[c8];
+        }
+        if (tc == tp) {  // uniform per wave; static register indices, uniform selects
+            double v0 = acc0[0], v1 = acc1[0];
+#pragma unroll
+            for (int c8 = 1; c8 < 8; ++c8) {
+                v0 = c8 == c8p ? acc0[c8] : v0;
+                v1 = c8 == c8p ? acc1[c8] : v1;
+            }
+            colraw[lc][32 * tr + lr] = v0;
+            colraw[lc][32 * tr + 16 + lr] = v1;
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                acc0[c8] = c8 == c8p ? 0.0 : acc0[c8];
+                acc1[c8] = c8 == c8p ? 0.0 : acc1[c8];
+            }
+        }
+        __syncthreads();
+        // ---- 2. invert the pivot block (wave 0, every lane redundantly) ----
+        if (wave == 0) {
+            double a[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[i][j] = rowraw[i][k0 + j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double pv = a[k][k];
+                if (lane == 0 && !(pv != 0.0 && pv == pv) && *dinfo == 0) *dinfo = base + k0 + k + 1;
+                const double ip = rcp_f64(pv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[k][j] = j == k ? ip : a[k][j] * ip;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i == k) continue;
+                    const double f = a[i][k];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[i][j] = j == k ? -f * ip : fma(-f, a[k][j], a[i][j]);
+                }
+            }
+            if (lane < 16) {
+                double v = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (lane == 4 * i + j) v = a[i][j];
+                pinv[lane] = v;
+            }
+        }
+        __syncthreads();
+        // ---- 3. panels ----
+        {
+            const int t = threadIdx.x & 511, k = t >> 7, x = t & 127;
+            if (threadIdx.x < 512) {
+                double v;
+                if (x >= k0 && x < k0 + 4) v = pinv[4 * k + (x - k0)];
+                else {
+                    v = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v = fma(pinv[4 * k + j], rowraw[j][x], v);
+                }
+                rowpan[k][x] = v;
+            } else {
+                colpan[k][x] = (x >= k0 && x < k0 + 4) ? 0.0 : -colraw[k][x];
+            }
+        }
+        __syncthreads();
+        // ---- 4. rank-4 update ----
+        {
+            double bf[2], af[8];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) bf[mi] = colpan[lc][32 * tr + 16 * mi + lr];
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) af[c8] = rowpan[lc][32 * tc + 4 * c8 + lq];
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                acc0[c8] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[c8], bf[0], acc0[c8], 0, 0, 0);
+                acc1[c8] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[c8], bf[1], acc1[c8], 0, 0, 0);
+            }
+            if (tr == tp && lr >= ro && lr < ro + 4) {
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    const double v = rowpan[lr - ro][32 * tc + 4 * c8 + lc];
+                    acc0[c8] = mip == 0 ? v : acc0[c8];
+                    acc1[c8] = mip == 1 ? v : acc1[c8];
+                }
+            }
+        }
+        // (the next step's publish writes rowraw / colraw only; the panels are rewritten
+        // after two more barriers)
+    }
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+        const int r0 = 32 * tr + lr, r1 = r0 + 16, c = 32 * tc + 4 * c8 + lc;
+        if (r0 < m && c < m) dst[(int64_t)c * ldd + r0] = acc0[c8];
+        if (r1 < m && c < m) dst[(int64_t)c * ldd + r1] = acc1[c8];
+    }
+}
+
 // dst (rows x cols, ldd) = src (rows x cols, lds_), rows <= 256: one column per
 // 256-thread row of the grid-stride loop, whole lines moved
 __global__ __launch_bounds__(256) void copy_block(const double *__restrict__ src, int64_t lds_,
@@ -900,20 +1045,25 @@ __global__ __launch_bounds__(256) void bs_block(const double *__restrict__ A, in
 // Q (ld W) = inverse of the w x w block at D (ld lda); D itself is overwritten.
 int invert_diag(nodal_ctx *h, hipStream_t sp, double *D, int64_t lda, int w, double *Q, double *T1,
                 double *T2, int32_t *dinfo, int base) {
+    const bool scalar_gj = h->gj_scalar;
+    auto invert128 = [&](const double *src, int64_t ls, int mm, double *dst, int bs) {
+        if (scalar_gj) gj128<<<1, 1024, 0, sp>>>(src, ls, mm, dst, W, dinfo, bs);
+        else gj128_mfma<<<1, 1024, 0, sp>>>(src, ls, mm, dst, W, dinfo, bs);
+    };
     if (w <= GJ) {
-        gj128<<<1, 1024, 0, sp>>>(D, lda, w, Q, W, dinfo, base);
+        invert128(D, lda, w, Q, base);
         NODAL_HIP_TRY(h, hipGetLastError());
         return NODAL_OK;
     }
     const int m2 = w - GJ;
     double *Bq = D + (int64_t)GJ * lda, *Cq = D + GJ, *Dq = D + (int64_t)GJ * lda + GJ;
     double *Q11 = Q, *Q12 = Q + (int64_t)GJ * W, *Q21 = Q + GJ, *Q22 = Q + (int64_t)GJ * W + GJ;
-    gj128<<<1, 1024, 0, sp>>>(D, lda, GJ, Q11, W, dinfo, base);
+    invert128(D, lda, GJ, Q11, base);
     NODAL_HIP_TRY(h, hipGetLastError());
     NODAL_TRY(gemm_pair_f64(h, sp, GEMM_SET, GemmProblem{T1, GJ, Q11, W, Bq, lda, GJ, m2, GJ},    // T1 = A^-1 B
                             GemmProblem{T2, GJ, Cq, lda, Q11, W, m2, GJ, GJ}));                   // T2 = C A^-1
     NODAL_TRY(gemm_f64(h, sp, GEMM_SUB, Dq, lda, Cq, lda, T1, GJ, m2, m2, GJ));    // S = D - C T1
-    gj128<<<1, 1024, 0, sp>>>(Dq, lda, m2, Q22, W, dinfo, base + GJ);              // S^-1
+    invert128(Dq, lda, m2, Q22, base + GJ);                                        // S^-1
     NODAL_HIP_TRY(h, hipGetLastError());
     NODAL_TRY(gemm_pair_f64(h, sp, GEMM_SETNEG, GemmProblem{Q12, W, T1, GJ, Q22, W, GJ, m2, m2},  // -T1 S^-1
                             GemmProblem{Q21, W, Q22, W, T2, GJ, m2, GJ, m2}));                    // -S^-1 T2

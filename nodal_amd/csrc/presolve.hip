@@ -472,6 +472,7 @@ int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, doub
         h->reduced->stream3 = h->stream3;
         for (int i = 0; i < 6; ++i) h->reduced->ev_bi[i] = h->ev_bi[i];
         h->reduced->dense_blockinv = h->dense_blockinv;
+        h->reduced->gj_scalar = h->gj_scalar;
         h->reduced->owns_streams = false;
         h->reduced->keep_host_table = false;
     }

@@ -71,8 +71,9 @@ def test_dense_block_inverse_elimination_on_passive_network(side, monkeypatch):
     from oracle import nodal_oracle as oracle
     table = gen.grid_table(side)
     out = []
-    for flag in ("1", "0"):
+    for flag, scalar in (("1", "0"), ("0", "0"), ("1", "1")):  # rank-4 MFMA inverse, LU, scalar inverse
         monkeypatch.setenv("NODAL_DENSE_BLOCKINV", flag)
+        monkeypatch.setenv("NODAL_GJ_SCALAR", scalar)
         h = _ffi.Handle(0)
         h.upload(table)
         h.assemble_symbolic()
@@ -86,6 +87,7 @@ def test_dense_block_inverse_elimination_on_passive_network(side, monkeypatch):
     scale = np.abs(xo).max()
     assert np.abs(out[0] - xo).max() <= 1e-10 * scale
     assert np.abs(out[0] - out[1]).max() <= 1e-11 * scale
+    assert np.abs(out[0] - out[2]).max() <= 1e-11 * scale
 
 
 def test_dense_block_inverse_multiple_right_hand_sides():
