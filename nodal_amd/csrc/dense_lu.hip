@@ -1073,79 +1073,93 @@ int invert_diag(nodal_ctx *h, hipStream_t sp, double *D, int64_t lda, int w, dou
 
 int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncols, int32_t *dinfo,
                     GemmTimer &tm) {
-    // Three streams.  Per block k = [J0, J1), next block [J1, J2), once A12(k) <- Q A12(k)
-    // is done and the previous bulk update has retired:
-    //   sp (high priority): diag   A[J1:J2, J1:J2] -= A[J1:J2, J0:J1] A12   (small)
-    //                       Q = inv(A[J1:J2, J1:J2])                        (chain)
-    //   s3:                 strip  A[J1:J2, J2:]   -= A[J1:J2, J0:J1] A12   (block row k+1)
-    //   sg:                 rest   A[J2:,   J1:]   -= A[J2:,   J0:J1] A12   (the bulk)
-    //   sp: after the strip: A[J1:J2, J2:] <- Q A[J1:J2, J2:]
-    // strip, rest and the chain run concurrently; sg sees one bulk GEMM after the other.
+    // Three streams.  Per block k = [J0, J1), next block [J1, J2), once A12(k) <- Q(k) A12(k)
+    // (called W(k) below) is done and the previous bulk update has retired:
+    //   sp (high priority): diag   A[J1:J2, J1:J2] -= A[J1:J2, J0:J1] W(k)       (small)
+    //                       Q(k+1) = inv(A[J1:J2, J1:J2])                         (chain)
+    //                       W(k+1), first FIRST columns  (after the strip)
+    //   s3:                 strip  A[J1:J2, J2:]   -= A[J1:J2, J0:J1] W(k)       (block row k+1)
+    //                       W(k+1), remaining columns    (after Q(k+1))
+    //   sg:                 rest   A[J2:,   J1:]   -= A[J2:,   J0:J1] W(k)       (the bulk)
+    // The critical path per block is diag -> inverse -> first columns of W -> next diag; the
+    // strip, the wide part of W and the bulk update run beside it.
     static const bool full_mask = getenv("NODAL_BI_MASKED") == nullptr;  // bulk updates on all CUs
     hipStream_t sp = h->stream, sg = full_mask ? h->stream3 : h->stream2;
     hipStream_t s3 = full_mask ? h->stream2 : h->stream3;
-    hipEvent_t ev_w = h->ev_bi[0], ev_strip = h->ev_bi[1], ev_rest = nullptr, ev_start = h->ev_bi[3],
-               ev_done = h->ev_bi[4];
-    // scratch: Q (W x W), T1, T2 (128 x 128), S (W x ncols)
-    const size_t qb = (size_t)W * W * 8, tb = (size_t)GJ * GJ * 8;
-    NODAL_HIP_TRY(h, h->work.reserve(qb + 2 * tb + (size_t)W * (size_t)ncols * 8 + 256));
-    double *Q = h->work.as<double>();
-    double *T1 = Q + (size_t)W * W, *T2 = T1 + (size_t)GJ * GJ, *S = T2 + (size_t)GJ * GJ;
+    hipEvent_t ev_wfirst = h->ev_bi[0], ev_strip = h->ev_bi[1], ev_wrest = h->ev_bi[2],
+               ev_start = h->ev_bi[3], ev_done = h->ev_bi[4], ev_q = h->ev_bi[5], ev_rest = nullptr;
+    constexpr int64_t FIRST = 2 * W;  // columns of W(k) that the next two diagonal blocks need
+    // scratch: Q[2] (W x W), T1, T2 (128 x 128), S1 (W x FIRST), S (W x ncols)
+    const size_t qb = (size_t)W * W, tb = (size_t)GJ * GJ;
+    NODAL_HIP_TRY(h, h->work.reserve((2 * qb + 2 * tb + (size_t)W * FIRST + (size_t)W * (size_t)ncols) * 8 + 256));
+    double *Q[2] = {h->work.as<double>(), h->work.as<double>() + qb};
+    double *T1 = Q[1] + qb, *T2 = T1 + tb, *S1 = T2 + tb, *S = S1 + (size_t)W * FIRST;
 
-    // A12 <- Q A12 for the block [J0, J1) (columns right of it, right-hand sides included)
-    auto scale_row_block = [&](int64_t J0, int64_t J1) -> int {
+    // A12 <- Q A12 for the block [J0, J1): columns [c0, c1) on stream st through scratch buf
+    auto scale_cols = [&](hipStream_t st, const double *Qk, double *buf, int64_t J0, int64_t J1, int64_t c0,
+                          int64_t c1) -> int {
+        if (c1 <= c0) return NODAL_OK;
         const int w = (int)(J1 - J0);
-        const int64_t nr = ncols - J1;
-        copy_block<<<blocks_for(nr, 4), 256, 0, sp>>>(A + J1 * lda + J0, lda, S, W, w, nr);
+        copy_block<<<blocks_for(c1 - c0, 4), 256, 0, st>>>(A + c0 * lda + J0, lda, buf, W, w, c1 - c0);
         NODAL_HIP_TRY(h, hipGetLastError());
-        NODAL_TRY(gemm_f64(h, sp, GEMM_SET, A + J1 * lda + J0, lda, Q, W, S, W, w, nr, w));
-        NODAL_HIP_TRY(h, hipEventRecord(ev_w, sp));
-        return NODAL_OK;
+        return gemm_f64(h, st, GEMM_SET, A + c0 * lda + J0, lda, Qk, W, buf, W, w, c1 - c0, w);
     };
+    auto first_end = [&](int64_t J1) { return J1 + FIRST < ncols ? J1 + FIRST : ncols; };
 
     NODAL_HIP_TRY(h, hipEventRecord(ev_start, sp));  // the matrix was prepared on the main stream
     NODAL_HIP_TRY(h, hipStreamWaitEvent(sg, ev_start, 0));
     NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_start, 0));
     {
         const int64_t J1 = n < W ? n : W;
-        NODAL_TRY(invert_diag(h, sp, A, lda, (int)J1, Q, T1, T2, dinfo, 0));
-        NODAL_TRY(scale_row_block(0, J1));
+        NODAL_TRY(invert_diag(h, sp, A, lda, (int)J1, Q[0], T1, T2, dinfo, 0));
+        NODAL_HIP_TRY(h, hipEventRecord(ev_q, sp));
+        NODAL_TRY(scale_cols(sp, Q[0], S1, 0, J1, J1, first_end(J1)));
+        NODAL_HIP_TRY(h, hipEventRecord(ev_wfirst, sp));
+        NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_q, 0));
+        NODAL_TRY(scale_cols(s3, Q[0], S, 0, J1, first_end(J1), ncols));
+        NODAL_HIP_TRY(h, hipEventRecord(ev_wrest, s3));
     }
-    bool rest_pending = false;
-    for (int64_t J0 = 0; J0 < n; J0 += W) {
+    int blk = 0;
+    for (int64_t J0 = 0; J0 < n; J0 += W, ++blk) {
         const int64_t J1 = J0 + W < n ? J0 + W : n;
         const int w = (int)(J1 - J0);
         if (J1 >= n) break;
         const int64_t J2 = J1 + W < n ? J1 + W : n;
-        const double *L = A + J0 * lda, *U = A + J1 * lda + J0;  // A[:, J0:J1] and A12
-        if (rest_pending) {  // block row k+1 was last written by the previous bulk update
+        const double *L = A + J0 * lda, *U = A + J1 * lda + J0;  // A[:, J0:J1] and W(k)
+        double *Qn = Q[(blk + 1) & 1];
+        if (ev_rest) {  // block row k+1 was last written by the previous bulk update
             NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_rest, 0));
             NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_rest, 0));
         }
-        NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_w, 0));
-        NODAL_HIP_TRY(h, hipStreamWaitEvent(sg, ev_w, 0));
-        // diag + inverse chain
+        NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_wfirst, 0));
+        NODAL_HIP_TRY(h, hipStreamWaitEvent(sg, ev_wfirst, 0));
+        NODAL_HIP_TRY(h, hipStreamWaitEvent(sg, ev_wrest, 0));
+        // sp: diag + inverse chain
         NODAL_TRY(gemm_sub_f64(h, sp, A + J1 * lda + J1, lda, L + J1, lda, U, lda, J2 - J1, J2 - J1, w));
-        NODAL_TRY(invert_diag(h, sp, A + J1 * lda + J1, lda, (int)(J2 - J1), Q, T1, T2, dinfo, (int)J1));
-        // strip
+        NODAL_TRY(invert_diag(h, sp, A + J1 * lda + J1, lda, (int)(J2 - J1), Qn, T1, T2, dinfo, (int)J1));
+        NODAL_HIP_TRY(h, hipEventRecord(ev_q, sp));
+        // s3: strip
         NODAL_TRY(gemm_sub_f64(h, s3, A + J2 * lda + J1, lda, L + J1, lda, U + (J2 - J1) * lda, lda,
                                J2 - J1, ncols - J2, w));
         NODAL_HIP_TRY(h, hipEventRecord(ev_strip, s3));
-        // rest
+        // sg: rest
         if (J2 < n) {
             NODAL_TRY(tm.begin(sg));
             NODAL_TRY(gemm_sub_f64(h, sg, A + J1 * lda + J2, lda, L + J2, lda, U, lda, n - J2, ncols - J1, w));
             NODAL_TRY(tm.end(sg, 2.0 * (double)w * (double)(n - J2) * (double)(ncols - J1)));
             ev_rest = tm.last_end();  // the timing event doubles as the dependency (one packet less)
-            rest_pending = true;
-        } else rest_pending = false;
+        } else ev_rest = nullptr;
+        // W(k+1): the first columns on the critical stream, the wide remainder beside it
         NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_strip, 0));
-        NODAL_TRY(scale_row_block(J1, J2));
+        NODAL_TRY(scale_cols(sp, Qn, S1, J1, J2, J2, first_end(J2)));
+        NODAL_HIP_TRY(h, hipEventRecord(ev_wfirst, sp));
+        NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_q, 0));
+        NODAL_TRY(scale_cols(s3, Qn, S, J1, J2, first_end(J2), ncols));
+        NODAL_HIP_TRY(h, hipEventRecord(ev_wrest, s3));
     }
     NODAL_HIP_TRY(h, hipEventRecord(ev_done, sg));
     NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_done, 0));
-    NODAL_HIP_TRY(h, hipEventRecord(ev_done, s3));
-    NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_done, 0));
+    NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_wrest, 0));
     return NODAL_OK;
 }
 
