@@ -307,8 +307,20 @@ int nodal_solve_dense(nodal_handle h, double *x, int32_t *info) {
     h->amg_levels = 0;
     NODAL_HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
     if (h->n > 0) {
-        NODAL_TRY(dense_prepare(h));
-        NODAL_TRY(dense_factor_solve(h, info));
+        // Large systems with voltage-defined branches: eliminate those branches first
+        // (presolve.hip).  If what remains is a passive network, the dense block elimination
+        // solves it without pivoting; the answer is checked against the ORIGINAL equations.
+        bool done = false;
+        if (h->n > 2048 && h->B > 0 && h->use_presolve && !h->force_pivoting && !h->passive_network) {
+            int32_t it = 0;
+            double rs = 0.0;
+            NODAL_TRY(presolve_solve(h, &done, info, &it, &rs, true));
+        }
+        if (!done) {
+            *info = 0;
+            NODAL_TRY(dense_prepare(h));
+            NODAL_TRY(dense_factor_solve(h, info));
+        }
     }
     NODAL_HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
     NODAL_HIP_TRY(h, hipEventSynchronize(h->ev[1]));

@@ -181,6 +181,7 @@ static inline int64_t dense_lda(int64_t n) {
 }
 int dense_factor_solve(nodal_ctx *h, int32_t *info);
 int dense_factor_solve_multi(nodal_ctx *h, int32_t nrhs, double *xout, int64_t ldx, int32_t *info);
+int dense_prepare(nodal_ctx *h);
 int dense_prepare_pairs(nodal_ctx *h, int32_t nrhs, const int32_t *ia, const int32_t *ib);
 int sparse_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const int32_t *ib,
                        double *res_dev, int32_t *info);
@@ -203,5 +204,7 @@ int stamp_grounded_flags(nodal_ctx *h, uint8_t *flags_dev);
 // ---- sparse solvers (sparse_*.hip) ----
 int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, double *resid);
 int sparse_residual(nodal_ctx *h, double *scaled);
-int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, double *resid);
+// dense_child: solve the reduced system by the dense block elimination (only if it is passive)
+int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, double *resid,
+                   bool dense_child = false);
 void nodal_free_buffers(nodal_ctx *h);  // api.hip

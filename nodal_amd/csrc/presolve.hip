@@ -444,7 +444,8 @@ static int presolve_recover(nodal_ctx *h, const PresolvePlan &plan, const double
 // Try the presolve route for the system of `h` (B > 0).  Returns NODAL_OK with
 // *done = true when x was produced and verified; *done = false means "not applicable"
 // (the caller falls back to the full-system Krylov solve).
-int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, double *resid) {
+int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, double *resid,
+                   bool dense_child) {
     *done = false;
     if (h->B == 0 || h->host.type.empty()) return NODAL_OK;
     const double *value = h->host.value.data();
@@ -488,7 +489,17 @@ int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, doub
     if (s != NODAL_OK) { h->err = r->err; return s; }
     const auto t3 = now();
     int32_t rinfo = 0;
-    s = sparse_solve(r, NODAL_SPARSE_AUTO, &rinfo, iters, resid);
+    if (dense_child) {
+        // the dense path wants a direct solve: worth it only if the reduced network is
+        // passive (SPD -> block elimination); otherwise the caller factors the original
+        if (!r->passive_network || r->n == 0) return NODAL_OK;
+        *iters = 0;
+        *resid = 0.0;
+        s = dense_prepare(r);
+        if (s == NODAL_OK) s = dense_factor_solve(r, &rinfo);
+    } else {
+        s = sparse_solve(r, NODAL_SPARSE_AUTO, &rinfo, iters, resid);
+    }
     if (s != NODAL_OK) { h->err = r->err; return s; }
     const auto t4 = now();
     if (trace)

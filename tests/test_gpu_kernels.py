@@ -125,3 +125,40 @@ def test_dense_passive_floating_island_is_reported_singular(side):
     netlist = n.Netlist.from_rows(rows)
     with pytest.raises(n.UnconnectedCircuitError):
         n.Circuit(netlist, sparse=False).solve()
+
+
+def test_dense_voltage_sources_take_presolve_and_block_elimination():
+    """A large resistor network driven by voltage sources is not passive (branch rows with
+    zero diagonals), but eliminating the voltage-defined branches leaves a passive network:
+    the dense path then solves that one by block elimination and recovers node potentials and
+    branch currents.  Same answer as the tournament-pivoted LU of the original matrix and as
+    the oracle."""
+    import random
+    import nodal_amd as n
+    from nodal_amd import generators as gen, lowering
+    from oracle import nodal_oracle as oracle
+    rng = random.Random(7)
+    rows = [list(r) for r in gen.grid_rows(50)]
+    nodes = [str(k) for k in rng.sample(range(2, 2400), 40)]
+    for i, node in enumerate(nodes[:30]):
+        rows.append([f"e{i}", "E", repr(1.0 + 0.1 * i), node, "g"])
+    for i in range(5):  # floating sources between two grid nodes
+        rows.append([f"ef{i}", "E", repr(0.5 + i), nodes[30 + 2 * i], nodes[31 + 2 * i]])
+    table = lowering.lower(n.Netlist.from_rows(rows))
+    assert table.B == 35 and table.K + table.B > 2048
+    out = []
+    for force in (0, 1):
+        h = _ffi.Handle(0)
+        h.set_option(_ffi.OPT_FORCE_PIVOTING, force)
+        h.upload(table)
+        h.assemble_symbolic()
+        assert h.assemble_numeric()[0] == _ffi.OK
+        x, info = h.solve_dense()
+        assert info == 0 and h.residual() <= 1e-13
+        out.append(x)
+        h.close()
+    G, A = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(G.tocsr(), A, True)
+    scale = np.abs(xo).max()
+    assert np.abs(out[0] - xo).max() <= 1e-9 * scale
+    assert np.abs(out[0] - out[1]).max() <= 1e-10 * scale
