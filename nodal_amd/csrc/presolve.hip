@@ -15,9 +15,13 @@
 // sparse_general.hip cannot see (360 GMRES iterations on config 5).
 // Afterwards e_p follows from its expression and i_m from the ORIGINAL KCL row of p.
 //
-// Supported pattern (everything else falls back to the full-system GMRES): every
-// voltage-defined branch gets a distinct pivot among its non-ground leads, and no
-// pivot node is the other lead or a control node of any dependent source.
+// Supported pattern (everything else falls back to the full-system solve): the
+// voltage-defined branches form a forest on their lead nodes (no loops of sources); every
+// tree is rooted at ground if it touches ground and every other node of it is a pivot,
+// defined through the branch to its parent.  Chains resolve by substitution (stacked
+// sources add up, a control node that is itself a pivot is replaced by its expression) as
+// long as every pivot ends with at most one control term on surviving nodes.  Dependent
+// sources without a branch of their own (CCCS) must not be controlled by a pivot.
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -70,9 +74,11 @@ __global__ __launch_bounds__(TB) void eval_pivots(int ne, const int32_t *__restr
 }
 
 // branch currents from the ORIGINAL system.  pass 0: branches whose own row defines
-// them (CCCS: row K+k has a unit diagonal); pass 1: voltage-defined branches from the
-// KCL row of their pivot node (all other branch currents in that row are known then).
+// them (CCCS: row K+k has a unit diagonal); pass 1 + h: voltage-defined branches whose pivot
+// sits at height h of its source tree, from the KCL row of the pivot node (the currents of
+// the branches hanging below it and of the CCCS outputs in that row are known by then).
 __global__ __launch_bounds__(TB) void recover_currents(int pass, int K, int B,
+                                                       const int32_t *__restrict__ level_of,
                                                        const int32_t *__restrict__ row_of,
                                                        const int32_t *__restrict__ indptr,
                                                        const int32_t *__restrict__ indices,
@@ -80,9 +86,8 @@ __global__ __launch_bounds__(TB) void recover_currents(int pass, int K, int B,
                                                        const double *__restrict__ rhs,
                                                        double *__restrict__ x) {
     for (int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x; k < B; k += (int64_t)gridDim.x * TB) {
-        const int row = row_of[k];  // K + k for pass 0 branches, pivot node for pass 1 ones
-        const bool own = row >= K;
-        if (own != (pass == 0)) continue;
+        if (level_of[k] != pass) continue;
+        const int row = row_of[k];  // K + k for pass 0 branches, the pivot node otherwise
         const int col = K + (int)k;
         double s = rhs[row], coef = 0.0;
         for (int32_t e = indptr[row]; e < indptr[row + 1]; ++e) {
@@ -101,6 +106,8 @@ struct PresolvePlan {
     std::vector<Expr> exprs;
     std::vector<int32_t> pivots;   // sorted pivot nodes
     std::vector<int32_t> row_of;   // B: row that determines each branch current
+    std::vector<int32_t> level_of; // B: pass of the current recovery (0 = own row, 1 + height in the source tree)
+    int max_level = 0;
     int32_t Kr = 0;
     int32_t newidx(int node) const {  // surviving node -> reduced index (pivots are sorted)
         if (node < 0) return -1;
@@ -202,11 +209,13 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
     plan.ok = false;
     plan.exprs.clear();
     plan.row_of.assign(B, -1);
+    plan.level_of.assign(B, 0);
+    plan.max_level = 0;
     std::vector<char> seen_k(B, 0);
-    std::vector<int32_t> taken;  // pivot nodes so far (few): kept sorted for lookups
-    auto is_pivot = [&](int node) {
-        return node >= 0 && std::binary_search(taken.begin(), taken.end(), node);
-    };
+
+    // ---- the voltage-defined branches: e_a - e_b = cst + gain (e_c - e_d) ----
+    struct Raw { int kk, a, b, c, d; double cst, gain; };
+    std::vector<Raw> raws;
     const uint8_t *ty_arr = t.type.data();
     for (int64_t i = 0; i < nc; ++i) {
         const int ty = ty_arr[i];
@@ -216,38 +225,167 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
         seen_k[kk] = 1;
         if (ty == NODAL_T_CCCS) {
             if (t.drv[i] < 0) return;
-            plan.row_of[kk] = K + kk;
+            plan.row_of[kk] = K + kk;  // its own row defines the current (level 0)
             continue;
         }
-        const int a = t.a[i], b = t.b[i];
-        if (a == b) return;
-        double cst = 0.0, gain = 0.0;
-        int c = -1, d = -1;
-        if (ty == NODAL_T_E) cst = value[i];
+        Raw r{kk, t.a[i], t.b[i], -1, -1, 0.0, 0.0};
+        if (r.a == r.b) return;
+        if (ty == NODAL_T_E) r.cst = value[i];
         else {
-            c = t.c[i];
-            d = t.d[i];
-            if (c == d) { c = d = -1; }
-            else if (ty == NODAL_T_VCVS) gain = value[i];
+            r.c = t.c[i];
+            r.d = t.d[i];
+            if (r.c == r.d) r.c = r.d = -1;
+            else if (ty == NODAL_T_VCVS) r.gain = value[i];
             else {
                 if (t.drv[i] < 0) return;
-                gain = -value[i] / value[t.drv[i]];
+                r.gain = -value[i] / value[t.drv[i]];
             }
         }
-        int p = -1, q = -1;
-        double sign = 1.0;
-        if (a >= 0 && !is_pivot(a) && a != c && a != d) { p = a; q = b; }
-        else if (b >= 0 && !is_pivot(b) && b != c && b != d) { p = b; q = a; sign = -1.0; }
-        else return;
-        taken.insert(std::upper_bound(taken.begin(), taken.end(), p), p);
-        plan.exprs.push_back(Expr{p, q, sign * cst, c, d, (c < 0 && d < 0) ? 0.0 : sign * gain});
-        plan.row_of[kk] = p;
+        raws.push_back(r);
+    }
+    for (int kk = 0; kk < B; ++kk)
+        if (!seen_k[kk]) return;
+
+    // ---- orientation: the branches form a graph on their lead nodes; every connected
+    // component must be a tree, rooted at ground if it touches ground.  Each non-root node
+    // is a pivot, defined through the branch to its parent (chains of sources included).
+    std::vector<int32_t> ids;  // compact node ids; ground (-1) first
+    ids.push_back(-1);
+    for (const Raw &r : raws) {
+        if (r.a >= 0) ids.push_back(r.a);
+        if (r.b >= 0) ids.push_back(r.b);
+    }
+    std::sort(ids.begin() + 1, ids.end());
+    ids.erase(std::unique(ids.begin() + 1, ids.end()), ids.end());
+    const int nn = (int)ids.size();
+    auto id_of = [&](int node) {
+        return node < 0 ? 0 : (int)(std::lower_bound(ids.begin() + 1, ids.end(), node) - ids.begin());
+    };
+    std::vector<std::vector<std::pair<int, int>>> adj(nn);  // (neighbour id, raw index)
+    for (int m = 0; m < (int)raws.size(); ++m) {
+        const int ia = id_of(raws[m].a), ib = id_of(raws[m].b);
+        adj[ia].push_back({ib, m});
+        adj[ib].push_back({ia, m});
+    }
+    std::vector<int> parent(nn, -1), via(nn, -1), order;
+    std::vector<char> visited(nn, 0);
+    order.reserve(nn);
+    for (int root = 0; root < nn; ++root) {  // id 0 = ground goes first
+        if (visited[root] || adj[root].empty()) continue;
+        visited[root] = 1;
+        size_t head = order.size();
+        order.push_back(root);
+        while (head < order.size()) {
+            const int u = order[head++];
+            for (const auto &[v, m] : adj[u]) {
+                if (m == via[u]) continue;
+                if (visited[v]) return;  // a loop of voltage-defined branches
+                visited[v] = 1;
+                parent[v] = u;
+                via[v] = m;
+                order.push_back(v);
+            }
+        }
+    }
+
+    // ---- resolution: every pivot in terms of SURVIVING nodes, one control term at most ----
+    struct Res { int base; double cst; int c, d; double g; };  // base / c / d are node numbers
+    std::vector<Res> res(nn);
+    std::vector<char> state(nn, 0);  // 0 = open, 1 = in progress, 2 = done
+    bool failed = false;
+    auto is_pivot_id = [&](int id) { return via[id] >= 0; };
+    // id of a node that is a lead of some branch, -1 for ground and for plain surviving nodes
+    auto lead_id = [&](int node) {
+        if (node < 0) return -1;
+        const auto it = std::lower_bound(ids.begin() + 1, ids.end(), node);
+        return (it != ids.end() && *it == node) ? (int)(it - ids.begin()) : -1;
+    };
+    // explicit stack instead of recursion (chains can be long)
+    auto resolve = [&](int start) {
+        std::vector<int> stack{start};
+        while (!stack.empty() && !failed) {
+            const int v = stack.back();
+            if (state[v] == 2) { stack.pop_back(); continue; }
+            if (!is_pivot_id(v)) {
+                res[v] = Res{ids[v], 0.0, -1, -1, 0.0};
+                state[v] = 2;
+                stack.pop_back();
+                continue;
+            }
+            const Raw &r = raws[via[v]];
+            int deps[3] = {parent[v], -1, -1};
+            if (r.gain != 0.0) {
+                deps[1] = lead_id(r.c);
+                deps[2] = lead_id(r.d);
+            }
+            bool ready = true;
+            state[v] = 1;
+            for (int dpd : deps) {
+                if (dpd < 0 || state[dpd] == 2) continue;
+                if (state[dpd] == 1) { failed = true; break; }  // circular definition
+                stack.push_back(dpd);
+                ready = false;
+            }
+            if (failed) break;
+            if (!ready) continue;  // stays "in progress"; revisited when the dependencies are done
+            const double sign = ids[v] == r.a ? 1.0 : -1.0;
+            Res out = res[parent[v]];
+            out.cst += sign * r.cst;
+            if (r.gain != 0.0) {
+                auto ctl = [&](int node) -> Res {
+                    if (node < 0) return Res{-1, 0.0, -1, -1, 0.0};
+                    const int id = lead_id(node);
+                    return id >= 0 ? res[id] : Res{node, 0.0, -1, -1, 0.0};
+                };
+                const Res rc = ctl(r.c), rd = ctl(r.d);
+                if (rc.g != 0.0 || rd.g != 0.0) { failed = true; break; }  // nested control terms
+                const double g = sign * r.gain;
+                out.cst += g * (rc.cst - rd.cst);
+                if (rc.base != rd.base) {
+                    if (out.g != 0.0) { failed = true; break; }  // two control terms
+                    out.c = rc.base;
+                    out.d = rd.base;
+                    out.g = g;
+                }
+            }
+            res[v] = out;
+            state[v] = 2;
+            stack.pop_back();
+        }
+    };
+    for (int v : order) {
+        if (state[v] != 2) resolve(v);
+        if (failed) return;
+    }
+
+    // ---- the plan: expressions, rows and levels for the current recovery ----
+    std::vector<int> height(nn, 0);
+    for (size_t i = order.size(); i-- > 0;) {
+        const int v = order[i];
+        if (parent[v] >= 0) height[parent[v]] = std::max(height[parent[v]], height[v] + 1);
+    }
+    std::vector<int32_t> taken;
+    for (int v : order) {
+        if (!is_pivot_id(v)) continue;
+        const Res &r = res[v];
+        // a pivot that (after resolution) still controls itself cannot be substituted
+        if (r.g != 0.0 && (r.c == ids[v] || r.d == ids[v])) return;
+        plan.exprs.push_back(Expr{ids[v], r.base, r.cst, r.c, r.d, r.g});
+        taken.push_back(ids[v]);
+        const int kk = raws[via[v]].kk;
+        plan.row_of[kk] = ids[v];
+        plan.level_of[kk] = 1 + height[v];
+        plan.max_level = std::max(plan.max_level, 1 + height[v]);
     }
     for (int kk = 0; kk < B; ++kk)
         if (plan.row_of[kk] < 0) return;
-    // no pivot may serve as a base or a control node of an expression
+    std::sort(taken.begin(), taken.end());
+    // bases and controls must be surviving nodes by construction
     for (const Expr &e : plan.exprs)
-        if (is_pivot(e.q) || is_pivot(e.c) || is_pivot(e.d)) return;
+        if ((e.q >= 0 && std::binary_search(taken.begin(), taken.end(), e.q)) ||
+            (e.c >= 0 && std::binary_search(taken.begin(), taken.end(), e.c)) ||
+            (e.d >= 0 && std::binary_search(taken.begin(), taken.end(), e.d)))
+            return;
     plan.pivots = taken;
     plan.Kr = K - (int32_t)taken.size();
     plan.ok = true;
@@ -409,7 +547,7 @@ static int presolve_recover(nodal_ctx *h, const PresolvePlan &plan, const double
     }
     const size_t a4k = ((size_t)K * 4 + 255) & ~(size_t)255, a4e = ((size_t)ne * 4 + 255) & ~(size_t)255;
     const size_t a8e = ((size_t)ne * 8 + 255) & ~(size_t)255, a4b = ((size_t)B * 4 + 255) & ~(size_t)255;
-    NODAL_HIP_TRY(h, h->ps_buf.reserve(a4k + 4 * a4e + 2 * a8e + a4b + 256));
+    NODAL_HIP_TRY(h, h->ps_buf.reserve(a4k + 4 * a4e + 2 * a8e + 2 * a4b + 256));
     char *w = h->ps_buf.as<char>();
     const int32_t *d_new = h->ps_newidx.as<int32_t>();  // built by presolve_build_reduced
     int32_t *d_p = reinterpret_cast<int32_t *>(w + a4k);
@@ -419,6 +557,7 @@ static int presolve_recover(nodal_ctx *h, const PresolvePlan &plan, const double
     double *d_cst = reinterpret_cast<double *>(w + a4k + 4 * a4e);
     double *d_g = reinterpret_cast<double *>(w + a4k + 4 * a4e + a8e);
     int32_t *d_row = reinterpret_cast<int32_t *>(w + a4k + 4 * a4e + 2 * a8e);
+    int32_t *d_level = reinterpret_cast<int32_t *>(w + a4k + 4 * a4e + 2 * a8e + a4b);
     auto up = [&](void *dst, const void *src, size_t bytes) {
         return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess;
     };
@@ -429,11 +568,12 @@ static int presolve_recover(nodal_ctx *h, const PresolvePlan &plan, const double
     NODAL_HIP_TRY(h, up(d_cst, cst.data(), (size_t)ne * 8));
     NODAL_HIP_TRY(h, up(d_g, g.data(), (size_t)ne * 8));
     NODAL_HIP_TRY(h, up(d_row, plan.row_of.data(), (size_t)B * 4));
+    NODAL_HIP_TRY(h, up(d_level, plan.level_of.data(), (size_t)B * 4));
     double *x = h->x.as<double>();
     scatter_nodes<<<grid_for(K), TB, 0, st>>>(K, d_new, y, x);
     if (ne) eval_pivots<<<grid_for(ne), TB, 0, st>>>(ne, d_p, d_q, d_cst, d_c, d_d, d_g, x);
-    for (int pass = 0; pass < 2; ++pass)
-        recover_currents<<<grid_for(B), TB, 0, st>>>(pass, K, B, d_row, h->indptr.as<int32_t>(),
+    for (int pass = 0; pass <= plan.max_level; ++pass)
+        recover_currents<<<grid_for(B), TB, 0, st>>>(pass, K, B, d_level, d_row, h->indptr.as<int32_t>(),
                                                     h->indices.as<int32_t>(), h->data.as<double>(),
                                                     h->rhs.as<double>(), x);
     NODAL_HIP_TRY(h, hipGetLastError());
@@ -521,6 +661,9 @@ int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, doub
     double scaled = 0.0;
     NODAL_TRY(sparse_residual(h, &scaled));
     h->have_x = false;
+    if (trace)
+        fprintf(stderr, "[presolve] %s: scaled residual of the original system %.3e, %d pivots, %d recovery passes\n",
+                scaled <= 1e-11 ? "accepted" : "rejected", scaled, (int)plan.pivots.size(), plan.max_level + 1);
     if (!(scaled <= 1e-11)) return NODAL_OK;  // fall back to the full-system solve
     *info = 0;
     *done = true;
