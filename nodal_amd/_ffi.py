@@ -110,6 +110,10 @@ class Handle:
 
     __del__ = close
 
+    @property
+    def closed(self):
+        return not getattr(self, "_h", None)
+
     def _check(self, status, allow=()):
         if status != OK and status not in allow:
             raise NodalHipError(status, self.lib.nodal_last_error(self._h).decode())

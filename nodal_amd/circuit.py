@@ -38,6 +38,32 @@ def default_device():
     return int(os.environ.get("NODAL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
 
 
+# Device contexts are expensive to create (four HIP streams, one of them CU-masked, a dozen
+# events: ~30 ms) and cheap to reuse (their buffers grow on demand), so a Circuit borrows one
+# from this pool and hands it back when it is garbage collected.
+_IDLE_HANDLES = {}
+_MAX_IDLE = 4
+
+
+def _acquire_handle(device):
+    idle = _IDLE_HANDLES.get(device)
+    while idle:
+        h = idle.pop()
+        if not h.closed:
+            return h
+    return _ffi.Handle(device)
+
+
+def _release_handle(device, h):
+    if h is None or h.closed:
+        return
+    idle = _IDLE_HANDLES.setdefault(device, [])
+    if len(idle) < _MAX_IDLE:
+        idle.append(h)
+    else:
+        h.close()
+
+
 class Circuit:
     """Builds the linear system G e = A of a Netlist on the GPU.
 
@@ -53,6 +79,13 @@ class Circuit:
         self._handle = None
         self._G = self._A = None
         self.currents = self.build_model()
+
+    def __del__(self):
+        try:
+            handle, self._handle = self._handle, None
+            _release_handle(self._device, handle)
+        except Exception:  # interpreter shutdown
+            pass
 
     # -- assembly ----------------------------------------------------------
     def build_model(self):
@@ -86,7 +119,7 @@ class Circuit:
 
     def _assemble(self, table):
         if self._handle is None:
-            self._handle = _ffi.Handle(self._device)
+            self._handle = _acquire_handle(self._device)
         h = self._handle
         h.upload(table)
         h.assemble_symbolic()
