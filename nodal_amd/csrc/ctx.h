@@ -48,6 +48,7 @@ struct nodal_ctx {
     hipEvent_t ev_la[2] = {nullptr, nullptr};
     hipStream_t stream3 = nullptr;   // bulk stream of the block-inverse elimination (all CUs)
     hipEvent_t ev_bi[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool optimistic_nopivot = false; // dense: block elimination although not passive (caller verifies the answer)
     bool gj_scalar = false;          // NODAL_GJ_SCALAR=1: scalar Gauss-Jordan instead of the rank-4 MFMA one
     bool dense_blockinv = true;      // passive dense systems: block elimination (NODAL_DENSE_BLOCKINV=0: LU)
     std::string err;

@@ -1213,7 +1213,7 @@ int dense_factor_solve_multi(nodal_ctx *h, int32_t nrhs, double *xout, int64_t l
     // Small systems keep LAPACK's pivot order exactly (reference parity down to the
     // exact-zero-pivot test of singular circuits); passive ones above BLOCKINV_MIN take
     // the block elimination whatever their size.
-    const bool passive = h->passive_network && !h->force_pivoting;
+    const bool passive = (h->passive_network || h->optimistic_nopivot) && !h->force_pivoting;
     if (passive && h->dense_blockinv && n > BLOCKINV_MIN) block_form = true;
     else if (n <= GEPP_MAX) NODAL_TRY(factor_gepp(h, A, n, lda, ncols, piv, dinfo, tm));
     else if (passive) NODAL_TRY(factor_nopivot(h, A, n, lda, ncols, piv, dinfo, tm));

@@ -630,13 +630,21 @@ int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, doub
     const auto t3 = now();
     int32_t rinfo = 0;
     if (dense_child) {
-        // the dense path wants a direct solve: worth it only if the reduced network is
-        // passive (SPD -> block elimination); otherwise the caller factors the original
-        if (!r->passive_network || r->n == 0) return NODAL_OK;
+        // The dense path wants a direct solve.  A passive reduced network is SPD: block
+        // elimination.  With transconductance stamps left (dependent sources) the reduced
+        // matrix is still a conductance matrix plus a few off-diagonal terms, which the same
+        // pivot-free elimination almost always handles -- tried optimistically: a zero pivot
+        // or a residual above the acceptance bar hands the ORIGINAL system to the pivoted LU.
+        if (r->n == 0) return NODAL_OK;
         *iters = 0;
         *resid = 0.0;
+        r->optimistic_nopivot = !r->passive_network;
         s = dense_prepare(r);
         if (s == NODAL_OK) s = dense_factor_solve(r, &rinfo);
+        if (s == NODAL_OK && rinfo > 0 && r->optimistic_nopivot) {
+            if (trace) fprintf(stderr, "[presolve] pivot-free elimination of the reduced system hit a zero pivot\n");
+            return NODAL_OK;
+        }
     } else {
         s = sparse_solve(r, NODAL_SPARSE_AUTO, &rinfo, iters, resid);
     }

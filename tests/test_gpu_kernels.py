@@ -52,6 +52,7 @@ def test_dense_lu_tournament_on_general_matrix():
     from oracle import nodal_oracle as oracle
     table = gen.cfg5_table(56)  # n ~ 3200
     h = _ffi.Handle(0)
+    h.set_option(_ffi.OPT_FORCE_PIVOTING, 1)  # (the default route presolves: next test)
     h.upload(table)
     h.assemble_symbolic()
     assert h.assemble_numeric()[0] == _ffi.OK
@@ -208,6 +209,27 @@ def test_presolve_resolves_chains_of_sources(side, dense, monkeypatch, capfd):
     assert info == 0 and h.residual() <= 1e-12
     err = capfd.readouterr().err
     assert "[presolve] accepted" in err, err[-400:]
+    G, A = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(G.tocsr(), A, True)
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    h.close()
+
+
+def test_dense_dependent_sources_take_presolve_and_optimistic_elimination(monkeypatch, capfd):
+    """cfg5 (voltage sources + CCCS / VCVS) on the dense path: after the presolve the reduced
+    matrix is a conductance matrix plus transconductance terms; the pivot-free block elimination
+    is tried and accepted on the ORIGINAL system's residual."""
+    from nodal_amd import generators as gen
+    from oracle import nodal_oracle as oracle
+    monkeypatch.setenv("NODAL_TRACE", "1")
+    table = gen.cfg5_table(56)
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    x, info = h.solve_dense()
+    assert info == 0 and h.residual() <= 1e-13
+    assert "[presolve] accepted" in capfd.readouterr().err
     G, A = oracle.assemble_fast(table)
     xo, _ = oracle.solve(G.tocsr(), A, True)
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
