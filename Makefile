@@ -4,18 +4,23 @@ ARCH  ?= gfx950
 SRC   := $(wildcard nodal_amd/csrc/*.hip)
 HDR   := $(wildcard nodal_amd/csrc/*.h) include/nodal_hip.h
 LIB   := nodal_amd/libnodal_hip.so
+CSVLIB := nodal_amd/libnodal_csv.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -ffp-contract=on -mllvm -pragma-unroll-threshold=1000000 -Wall -Wno-unused-function
 
-all: $(LIB) oracle
+all: $(LIB) $(CSVLIB) oracle
 
 $(LIB): $(SRC) $(HDR)
 	$(HIPCC) $(HIPFLAGS) -o $@ $(SRC)
+
+# host-side netlist tokenizer (front-end, optional: fastparse.py falls back to pandas without it)
+$(CSVLIB): nodal_amd/csrc/fastcsv.cpp
+	g++ -O2 -std=c++17 -fPIC -shared -Wall -o $@ $<
 
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(LIB)
+	rm -f $(LIB) $(CSVLIB)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

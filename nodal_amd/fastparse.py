@@ -69,8 +69,125 @@ class LazyComponents(Mapping):
         return len(self._nl._row_of)
 
 
+# ---- native tokenizer (csrc/fastcsv.cpp -> libnodal_csv.so), optional -------------------------
+
+_TYPE_NAMES = np.array(["R", "A", "E", "VCVS", "VCCS", "CCVS", "CCCS"], dtype=object)
+_CSV_REASONS = {1: "quoted fields", 2: "whitespace-only line", 3: "empty first field",
+                4: "row with more than 8 fields", 5: "unknown or macro type", 6: "wrong number of arguments",
+                7: "component value spelling", 8: "duplicated component names", 9: "no components",
+                10: "carriage return inside a line", 11: "out of memory"}
+_csv_lib = None
+
+
+def _load_csv_lib():
+    global _csv_lib
+    if _csv_lib is None:
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnodal_csv.so")
+        if not os.path.exists(path):
+            _csv_lib = False
+            return False
+
+        class Result(C.Structure):
+            _fields_ = [("nrows", C.c_int64), ("nnodes", C.c_int64), ("status", C.c_int32),
+                        ("bad_line", C.c_int64), ("line_off", C.POINTER(C.c_int64)),
+                        ("line_len", C.POINTER(C.c_int32)), ("type_idx", C.POINTER(C.c_uint8)),
+                        ("nfields", C.POINTER(C.c_uint8)), ("value", C.POINTER(C.c_double)),
+                        ("acode", C.POINTER(C.c_int32)), ("bcode", C.POINTER(C.c_int32)),
+                        ("names_blob", C.POINTER(C.c_char)), ("names_bytes", C.c_int64),
+                        ("labels_blob", C.POINTER(C.c_char)), ("labels_bytes", C.c_int64)]
+
+        lib = C.CDLL(path)
+        lib.nodal_csv_parse.restype = C.c_int
+        lib.nodal_csv_parse.argtypes = [C.c_char_p, C.c_int64, C.POINTER(Result)]
+        lib.nodal_csv_free.restype = None
+        lib.nodal_csv_free.argtypes = [C.POINTER(Result)]
+        lib.Result = Result
+        _csv_lib = lib
+    return _csv_lib
+
+
+def _finish_fast(nl, name, type_names, value, nfields, acode, bcode, labels):
+    """Common tail of both readers: the Netlist attributes from the parsed columns."""
+    deg = np.bincount(np.concatenate((acode, bcode)), minlength=len(labels))
+    nl._fast = True
+    nl._name, nl._type, nl._value = name, type_names, value
+    nl._nfields = nfields
+    nl._acode, nl._bcode = acode, bcode
+    nl.component_keys = name.tolist()
+    nl._row_of = dict(zip(nl.component_keys, range(len(name))))
+    nl.components = LazyComponents(nl)
+    nl.degrees = dict(zip(labels, deg.tolist()))
+    is_anom = np.isin(type_names.astype(str), c.NODE_TYPES_ANOM) if not hasattr(nl, "_tidx") \
+        else (nl._tidx >= 2)  # everything after R, A owns a branch current
+    nl._is_anom = is_anom
+    anom_rows = np.flatnonzero(is_anom)
+    nl.anomnum = dict(zip(name[anom_rows].tolist(), range(len(anom_rows))))
+    nl.nums["components"] = int(len(name))
+    nl.nums["anomalies"] = int(len(anom_rows))
+    # ground: "g" if present, else the first node of maximal degree
+    if "g" in nl.degrees:
+        nl.ground = "g"
+        gcode = labels.index("g")
+    else:
+        gcode = int(np.argmax(deg))
+        nl.ground = labels[gcode]
+    order = labels[:gcode] + labels[gcode + 1:]
+    nl.nodenum = dict(zip(order, range(len(order))))
+    node_index = np.arange(len(labels), dtype=np.int64)
+    node_index[gcode + 1:] -= 1
+    node_index[gcode] = -1
+    nl._node_index = node_index  # label code -> nodenum index (-1 = ground)
+    nl.nums["kcl"] = len(order)
+    nl.nums["be"] = nl.nums["anomalies"]
+    return nl
+
+
+def _read_native(netlist, path, lib):
+    import ctypes as C
+    with open(path, "rb") as f:
+        raw = f.read()
+    res = lib.Result()
+    status = lib.nodal_csv_parse(raw, len(raw), C.byref(res))
+    try:
+        if status != 0:
+            raise Irregular(f"{_CSV_REASONS.get(status, status)} (line {res.bad_line + 1})")
+        n, m = res.nrows, res.nnodes
+
+        def arr(ptr, count, dtype):
+            return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dtype, copy=True)
+
+        line_off = arr(res.line_off, n, np.int64)
+        line_len = arr(res.line_len, n, np.int32)
+        tidx = arr(res.type_idx, n, np.uint8)
+        nfields = arr(res.nfields, n, np.int64)
+        value = arr(res.value, n, np.float64)
+        acode = arr(res.acode, n, np.int64)
+        bcode = arr(res.bcode, n, np.int64)
+        try:
+            names = C.string_at(res.names_blob, res.names_bytes).decode().split("\n")
+            labels = C.string_at(res.labels_blob, res.labels_bytes).decode().split("\n")
+        except UnicodeDecodeError:
+            raise Irregular("not UTF-8")
+    finally:
+        lib.nodal_csv_free(C.byref(res))
+    if len(names) != n or len(labels) != m:
+        raise Irregular("line structure")
+    nl = netlist
+    nl._df = None
+    nl._raw, nl._line_off, nl._line_len = raw, line_off, line_len
+    nl._tidx = tidx
+    name = np.empty(n, dtype=object)
+    name[:] = names
+    return _finish_fast(nl, name, _TYPE_NAMES[tidx], value, nfields, acode, bcode, labels)
+
+
 def read_fast(netlist, path):
     """Fill `netlist` (a Netlist whose `_reset()` has run) from the CSV at `path`."""
+    lib = _load_csv_lib()
+    if lib:
+        return _read_native(netlist, path, lib)
     if pd is None:
         raise Irregular("pandas not available")
     # fields per line, counted on the raw bytes: pandas pads short rows silently, the
@@ -177,6 +294,13 @@ def read_fast(netlist, path):
 
 def row_fields(netlist, row):
     """The CSV fields of one row as the list the row-by-row parser would have seen."""
+    if netlist._df is None:  # native tokenizer: split the stored line again
+        nfile = len(netlist._line_off)
+        if row >= nfile:
+            return list(netlist._extra_rows[row - nfile])
+        o = int(netlist._line_off[row])
+        line = netlist._raw[o:o + int(netlist._line_len[row])].decode()
+        return [f.lstrip(" ") for f in line.split(",")]
     if row >= len(netlist._df):
         return list(netlist._extra_rows[row - len(netlist._df)])
     return netlist._df.iloc[row].tolist()[: int(netlist._nfields[row])]

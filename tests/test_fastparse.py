@@ -13,6 +13,18 @@ from nodal_amd.lowering import lower
 FIELDS = ("type", "value", "a", "b", "c", "d", "drv", "k")
 
 
+@pytest.fixture(autouse=True, params=["native", "pandas"])
+def reader(request, monkeypatch):
+    """Every test runs with the native tokenizer (libnodal_csv.so) and with the pandas reader."""
+    if request.param == "pandas":
+        monkeypatch.setattr(fastparse, "_csv_lib", False)
+    else:
+        monkeypatch.setattr(fastparse, "_csv_lib", None)
+        if not fastparse._load_csv_lib():
+            pytest.skip("libnodal_csv.so not built")
+    return request.param
+
+
 def both(tmp_path, rows, monkeypatch):
     path = tmp_path / "c.csv"
     gen.write_csv(rows, str(path))
