@@ -311,7 +311,7 @@ int nodal_solve_dense(nodal_handle h, double *x, int32_t *info) {
         // (presolve.hip).  If what remains is a passive network, the dense block elimination
         // solves it without pivoting; the answer is checked against the ORIGINAL equations.
         bool done = false;
-        if (h->n > 2048 && h->B > 0 && h->use_presolve && !h->force_pivoting && !h->passive_network) {
+        if (h->n > 512 && h->B > 0 && h->use_presolve && !h->force_pivoting && !h->passive_network) {
             int32_t it = 0;
             double rs = 0.0;
             NODAL_TRY(presolve_solve(h, &done, info, &it, &rs, true));
