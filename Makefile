@@ -5,7 +5,7 @@ SRC   := $(wildcard nodal_amd/csrc/*.hip)
 HDR   := $(wildcard nodal_amd/csrc/*.h) include/nodal_hip.h
 LIB   := nodal_amd/libnodal_hip.so
 CSVLIB := nodal_amd/libnodal_csv.so
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -ffp-contract=on -mllvm -pragma-unroll-threshold=1000000 -Wall -Wno-unused-function
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -ffp-contract=on -mllvm -pragma-unroll-threshold=1000000 -Wall -Wno-unused-function -Wno-pass-failed
 
 all: $(LIB) $(CSVLIB) oracle
 

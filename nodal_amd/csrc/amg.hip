@@ -186,7 +186,7 @@ __global__ __launch_bounds__(TB) void compose_map(int64_t n, int32_t *__restrict
 
 // grouping enumerators (group.h)
 struct CoarseEntries {  // fine entry e -> (agg[row], agg[col])
-    static constexpr int SLOTS = 1;
+    [[maybe_unused]] static constexpr int SLOTS = 1;
     const int32_t *rowidx, *indices, *agg;
     int64_t nitems;
     template <class F>
@@ -195,7 +195,7 @@ struct CoarseEntries {  // fine entry e -> (agg[row], agg[col])
     }
 };
 struct Members {  // node i -> (agg[i], 0): one entry per aggregate, members ascending
-    static constexpr int SLOTS = 1;
+    [[maybe_unused]] static constexpr int SLOTS = 1;
     const int32_t *agg;
     int64_t nitems;
     template <class F>

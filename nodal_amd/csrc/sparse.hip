@@ -313,7 +313,6 @@ int pcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
     const double *data = h->data.as<double>();
     const double *b = h->rhs.as<double>();
 
-    const int lpr = lanes_per_row(h);
     const unsigned gv = grid_rows(n, 1);     // vector kernels
     const unsigned gs = stream::grid_for_rows(n, MAX_PARTIALS);   // spmv kernels
     const int nparts_v = (int)gv, nparts_s = (int)gs;
