@@ -82,7 +82,8 @@ struct Hierarchy {
     DevBuf coarse_inv;  // dense inverse of the last level
     bool coarse_direct = false;
     int tail = -1;      // first level handled by the LDS tail kernel (-1: none)
-    int kmax = 1 << 20; // coarse levels above this index get a plain V hand-over (NODAL_AMG_KMAX)
+    int kmax = 1;       // K-cycle (two inner FCG steps) down to this coarse level, plain V hand-over below;
+                        // measured: 1 beats 0 and >= 2 on configs 3, 4 and 5 (NODAL_AMG_KMAX to override)
     int passes0 = PASSES, passes1 = PASSES;  // pairwise matching passes at level 0 / below
     TailDesc tdesc;
     DevBuf tail_image;
