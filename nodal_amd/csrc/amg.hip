@@ -85,6 +85,7 @@ struct Hierarchy {
     int kmax = 1;       // K-cycle (two inner FCG steps) down to this coarse level, plain V hand-over below;
                         // measured: 1 beats 0 and >= 2 on configs 3, 4 and 5 (NODAL_AMG_KMAX to override)
     int passes0 = PASSES, passes1 = PASSES;  // pairwise matching passes at level 0 / below
+    int sweeps0 = 2;    // Jacobi sweeps before / after the coarse correction at level 0 (NODAL_AMG_SWEEPS0=1: one)
     TailDesc tdesc;
     DevBuf tail_image;
     ~Hierarchy() { clear(); }
@@ -310,6 +311,22 @@ __global__ __launch_bounds__(TB) void smooth_residual(Csr A, const double *__res
             const double bi = b[i];
             x[i] = OMEGA * dinv[i] * bi;
             r[i] = bi - sum;
+        });
+}
+
+// second pre-smoothing sweep (CSR-stream):  x2 = x + w D^-1 r ;  r2 = b - A x2
+// (x2_j is recomputed from x_j, r_j on the fly; outputs go to separate vectors)
+__global__ __launch_bounds__(TB) void smooth_again(Csr A, const double *__restrict__ dinv,
+                                                   const double *__restrict__ b,
+                                                   const double *__restrict__ x,
+                                                   const double *__restrict__ r,
+                                                   double *__restrict__ x2, double *__restrict__ r2) {
+    stream::for_rows(
+        A.indptr, A.indices, A.data, A.n,
+        [&](int32_t, int32_t col, double val) { return val * fma(OMEGA * dinv[col], r[col], x[col]); },
+        [&](int64_t i, double sum) {
+            x2[i] = fma(OMEGA * dinv[i], r[i], x[i]);
+            r2[i] = b[i] - sum;
         });
 }
 
@@ -849,6 +866,7 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
     h->amg = H;
     if (const char *e = getenv("NODAL_AMG_KMAX")) H->kmax = atoi(e);
     if (const char *e = getenv("NODAL_AMG_PASSES0")) H->passes0 = atoi(e);
+    if (const char *e = getenv("NODAL_AMG_SWEEPS0")) H->sweeps0 = atoi(e);
     if (const char *e = getenv("NODAL_AMG_PASSES1")) H->passes1 = atoi(e);
     hipStream_t st = h->stream;
 
@@ -965,6 +983,13 @@ int cycle(nodal_ctx *h, Hierarchy *H, int l, const double *b, double *out) {
     double *x = L->v(V_X), *r = L->v(V_R);
     double *rc = C->v(V_RC), *c1 = C->v(V_C1), *c2 = C->v(V_C2);
     smooth_residual<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, dinv, b, x, r);
+    const bool two_sweeps = l == 0 && H->sweeps0 == 2;  // level 0 only: bandwidth-bound there, latency-bound below
+    if (two_sweeps) {
+        double *x2 = L->v(V_V1), *r2 = L->v(V_V2);  // (the K-cycle vectors of level 0 are never used)
+        smooth_again<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, dinv, b, x, r, x2, r2);
+        x = x2;
+        r = r2;
+    }
     restrict_sum<<<grid_for(nc), TB, 0, st>>>(nc, L->memptr.as<int32_t>(), L->mem.as<int32_t>(), r, rc);
     NODAL_HIP_TRY(h, hipGetLastError());
     int nparts = 0;
@@ -997,7 +1022,13 @@ int cycle(nodal_ctx *h, Hierarchy *H, int l, const double *b, double *out) {
         double *xp = r;  // the residual vector is dead after the restriction
         prolong_add<<<grid_for(n), TB, 0, st>>>(n, x, L->agg.as<int32_t>(), c1, c2,
                                                C->part.as<double>(), nparts, xp);
-        post_smooth<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, dinv, b, xp, out);
+        if (two_sweeps) {
+            double *mid = L->v(V_R2);
+            post_smooth<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, dinv, b, xp, mid);
+            post_smooth<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, dinv, b, mid, out);
+        } else {
+            post_smooth<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, dinv, b, xp, out);
+        }
     } else {
         prolong_smooth<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, dinv, b, x, L->agg.as<int32_t>(),
                                                                c1, c2, C->part.as<double>(), nparts,
