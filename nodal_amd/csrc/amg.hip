@@ -32,7 +32,10 @@ constexpr int PASSES = 3;
 constexpr int MATCH_ROUNDS = 5;
 constexpr int COARSEST_MAX = 64;
 constexpr int MAX_LEVELS = 16;
-constexpr double OMEGA = 0.85;
+#ifndef NODAL_OMEGA
+#define NODAL_OMEGA 0.85
+#endif
+constexpr double OMEGA = NODAL_OMEGA;  // damped-Jacobi weight (0.7 / 0.85 / 1.0 measured: see DESIGN.md)
 constexpr int DOT_BLOCKS = 128;  // partial sums per dot product
 constexpr int64_t SPLIT_PROLONG_MIN = 200000;  // levels this large prolong in a separate pass
 
