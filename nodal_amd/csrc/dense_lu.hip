@@ -762,6 +762,7 @@ int factor_nopivot(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncol
 
 constexpr int GJ = 128;
 constexpr int BLOCKINV_MIN = 256;  // passive systems larger than this: block elimination
+constexpr int BI_MAX = 512;        // largest block width of the block elimination
 
 // dst (m x m, ldd) = inverse of src (m x m, lds_), m <= 128.  No pivoting.  A zero or
 // NaN pivot records its 1-based global index in *dinfo (first one wins).
@@ -981,20 +982,20 @@ __global__ __launch_bounds__(1024) void gj128_mfma(const double *__restrict__ sr
     }
 }
 
-// dst (rows x cols, ldd) = src (rows x cols, lds_), rows <= 256: one column per
-// 256-thread row of the grid-stride loop, whole lines moved
+// dst (rows x cols, ldd) = src (rows x cols, lds_): four columns per workgroup pass,
+// whole lines moved
 __global__ __launch_bounds__(256) void copy_block(const double *__restrict__ src, int64_t lds_,
                                                   double *__restrict__ dst, int64_t ldd, int rows,
                                                   int64_t cols) {
-    for (int64_t c = (int64_t)blockIdx.x * 4; c < cols; c += (int64_t)gridDim.x * 4) {
-        double v[4];
-        const int r = threadIdx.x;
+    for (int64_t c = (int64_t)blockIdx.x * 4; c < cols; c += (int64_t)gridDim.x * 4)
+        for (int r = threadIdx.x; r < rows; r += 256) {
+            double v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = (c + u < cols && r < rows) ? src[(c + u) * lds_ + r] : 0.0;
+            for (int u = 0; u < 4; ++u) v[u] = c + u < cols ? src[(c + u) * lds_ + r] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (c + u < cols && r < rows) dst[(c + u) * ldd + r] = v[u];
-    }
+            for (int u = 0; u < 4; ++u)
+                if (c + u < cols) dst[(c + u) * ldd + r] = v[u];
+        }
 }
 
 // Back substitution for the block-inverse form: x[j0:j1] = y[j0:j1] is final; the rows
@@ -1004,14 +1005,15 @@ __global__ __launch_bounds__(256) void copy_block(const double *__restrict__ src
 __global__ __launch_bounds__(256) void bs_block(const double *__restrict__ A, int64_t lda,
                                                 double *__restrict__ y, double *__restrict__ xout,
                                                 int64_t ldx, int j0, int j1) {
-    __shared__ double xs[W];
+    __shared__ double xs[BI_MAX];
     __shared__ double part[3][64];
     y += (int64_t)blockIdx.y * lda;
     xout += (int64_t)blockIdx.y * ldx;
     const int w = j1 - j0, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if ((int)threadIdx.x < w) xs[threadIdx.x] = y[j0 + threadIdx.x];
+    for (int t = threadIdx.x; t < w; t += 256) xs[t] = y[j0 + t];
     __syncthreads();
-    if (blockIdx.x == 0 && (int)threadIdx.x < w) xout[j0 + threadIdx.x] = xs[threadIdx.x];
+    if (blockIdx.x == 0)
+        for (int t = threadIdx.x; t < w; t += 256) xout[j0 + t] = xs[t];
     const int per = (w + 3) / 4, s0 = wave * per, s1 = s0 + per < w ? s0 + per : w;
     for (int64_t base = (int64_t)blockIdx.x * 64; base < j0; base += (int64_t)gridDim.x * 64) {
         const int64_t i = base + lane;
@@ -1042,37 +1044,35 @@ __global__ __launch_bounds__(256) void bs_block(const double *__restrict__ A, in
     }
 }
 
-// Q (ld W) = inverse of the w x w block at D (ld lda); D itself is overwritten.
-int invert_diag(nodal_ctx *h, hipStream_t sp, double *D, int64_t lda, int w, double *Q, double *T1,
-                double *T2, int32_t *dinfo, int base) {
-    const bool scalar_gj = h->gj_scalar;
-    auto invert128 = [&](const double *src, int64_t ls, int mm, double *dst, int bs) {
-        if (scalar_gj) gj128<<<1, 1024, 0, sp>>>(src, ls, mm, dst, W, dinfo, bs);
-        else gj128_mfma<<<1, 1024, 0, sp>>>(src, ls, mm, dst, W, dinfo, bs);
-    };
+// Q (ld ldq) = inverse of the w x w block at D (ld lda), w <= BI_MAX; D itself is overwritten.
+// w <= 128: one Gauss-Jordan workgroup; otherwise the 2 x 2 Schur-complement formula with the
+// leading m1 = 128 (w <= 256) or 256 columns, recursively.  `scratch` holds 2 * m1 * m2 doubles
+// per recursion level (T1, T2).
+int invert_diag(nodal_ctx *h, hipStream_t sp, double *D, int64_t lda, int w, double *Q, int64_t ldq,
+                double *scratch, int32_t *dinfo, int base) {
     if (w <= GJ) {
-        invert128(D, lda, w, Q, base);
+        if (h->gj_scalar) gj128<<<1, 1024, 0, sp>>>(D, lda, w, Q, ldq, dinfo, base);
+        else gj128_mfma<<<1, 1024, 0, sp>>>(D, lda, w, Q, ldq, dinfo, base);
         NODAL_HIP_TRY(h, hipGetLastError());
         return NODAL_OK;
     }
-    const int m2 = w - GJ;
-    double *Bq = D + (int64_t)GJ * lda, *Cq = D + GJ, *Dq = D + (int64_t)GJ * lda + GJ;
-    double *Q11 = Q, *Q12 = Q + (int64_t)GJ * W, *Q21 = Q + GJ, *Q22 = Q + (int64_t)GJ * W + GJ;
-    invert128(D, lda, GJ, Q11, base);
-    NODAL_HIP_TRY(h, hipGetLastError());
-    NODAL_TRY(gemm_pair_f64(h, sp, GEMM_SET, GemmProblem{T1, GJ, Q11, W, Bq, lda, GJ, m2, GJ},    // T1 = A^-1 B
-                            GemmProblem{T2, GJ, Cq, lda, Q11, W, m2, GJ, GJ}));                   // T2 = C A^-1
-    NODAL_TRY(gemm_f64(h, sp, GEMM_SUB, Dq, lda, Cq, lda, T1, GJ, m2, m2, GJ));    // S = D - C T1
-    invert128(Dq, lda, m2, Q22, base + GJ);                                        // S^-1
-    NODAL_HIP_TRY(h, hipGetLastError());
-    NODAL_TRY(gemm_pair_f64(h, sp, GEMM_SETNEG, GemmProblem{Q12, W, T1, GJ, Q22, W, GJ, m2, m2},  // -T1 S^-1
-                            GemmProblem{Q21, W, Q22, W, T2, GJ, m2, GJ, m2}));                    // -S^-1 T2
-    NODAL_TRY(gemm_f64(h, sp, GEMM_SUB, Q11, W, Q12, W, T2, GJ, GJ, GJ, m2));      // + T1 S^-1 T2
+    const int m1 = w <= 2 * GJ ? GJ : 2 * GJ, m2 = w - m1;
+    double *T1 = scratch, *T2 = scratch + (size_t)m1 * m2, *deeper = T2 + (size_t)m1 * m2;
+    double *Bq = D + (int64_t)m1 * lda, *Cq = D + m1, *Dq = D + (int64_t)m1 * lda + m1;
+    double *Q11 = Q, *Q12 = Q + (int64_t)m1 * ldq, *Q21 = Q + m1, *Q22 = Q + (int64_t)m1 * ldq + m1;
+    NODAL_TRY(invert_diag(h, sp, D, lda, m1, Q11, ldq, deeper, dinfo, base));
+    NODAL_TRY(gemm_pair_f64(h, sp, GEMM_SET, GemmProblem{T1, m1, Q11, ldq, Bq, lda, m1, m2, m1},    // T1 = A^-1 B
+                            GemmProblem{T2, m2, Cq, lda, Q11, ldq, m2, m1, m1}));                  // T2 = C A^-1
+    NODAL_TRY(gemm_f64(h, sp, GEMM_SUB, Dq, lda, Cq, lda, T1, m1, m2, m2, m1));                    // S = D - C T1
+    NODAL_TRY(invert_diag(h, sp, Dq, lda, m2, Q22, ldq, deeper, dinfo, base + m1));                // S^-1
+    NODAL_TRY(gemm_pair_f64(h, sp, GEMM_SETNEG, GemmProblem{Q12, ldq, T1, m1, Q22, ldq, m1, m2, m2},  // -T1 S^-1
+                            GemmProblem{Q21, ldq, Q22, ldq, T2, m2, m2, m1, m2}));                    // -S^-1 T2
+    NODAL_TRY(gemm_f64(h, sp, GEMM_SUB, Q11, ldq, Q12, ldq, T2, m2, m1, m1, m2));                  // + T1 S^-1 T2
     return NODAL_OK;
 }
 
 int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncols, int32_t *dinfo,
-                    GemmTimer &tm) {
+                    GemmTimer &tm, int64_t wb) {
     // Three streams.  Per block k = [J0, J1), next block [J1, J2), once A12(k) <- Q(k) A12(k)
     // (called W(k) below) is done and the previous bulk update has retired:
     //   sp (high priority): diag   A[J1:J2, J1:J2] -= A[J1:J2, J0:J1] W(k)       (small)
@@ -1088,21 +1088,21 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
     hipStream_t s3 = full_mask ? h->stream2 : h->stream3;
     hipEvent_t ev_wfirst = h->ev_bi[0], ev_strip = h->ev_bi[1], ev_wrest = h->ev_bi[2],
                ev_start = h->ev_bi[3], ev_done = h->ev_bi[4], ev_q = h->ev_bi[5], ev_rest = nullptr;
-    constexpr int64_t FIRST = 2 * W;  // columns of W(k) that the next two diagonal blocks need
-    // scratch: Q[2] (W x W), T1, T2 (128 x 128), S1 (W x FIRST), S (W x ncols)
-    const size_t qb = (size_t)W * W, tb = (size_t)GJ * GJ;
-    NODAL_HIP_TRY(h, h->work.reserve((2 * qb + 2 * tb + (size_t)W * FIRST + (size_t)W * (size_t)ncols) * 8 + 256));
+    const int64_t FIRST = 2 * wb;  // columns of W(k) that the next two diagonal blocks need
+    // scratch: Q[2] (wb x wb), the inverse's T1 / T2 per recursion level, S1 (wb x FIRST), S (wb x ncols)
+    const size_t qb = (size_t)wb * wb, tb = 2 * (size_t)(2 * GJ) * (2 * GJ) + 2 * (size_t)GJ * GJ;
+    NODAL_HIP_TRY(h, h->work.reserve((2 * qb + tb + (size_t)wb * FIRST + (size_t)wb * (size_t)ncols) * 8 + 256));
     double *Q[2] = {h->work.as<double>(), h->work.as<double>() + qb};
-    double *T1 = Q[1] + qb, *T2 = T1 + tb, *S1 = T2 + tb, *S = S1 + (size_t)W * FIRST;
+    double *T = Q[1] + qb, *S1 = T + tb, *S = S1 + (size_t)wb * FIRST;
 
     // A12 <- Q A12 for the block [J0, J1): columns [c0, c1) on stream st through scratch buf
     auto scale_cols = [&](hipStream_t st, const double *Qk, double *buf, int64_t J0, int64_t J1, int64_t c0,
                           int64_t c1) -> int {
         if (c1 <= c0) return NODAL_OK;
         const int w = (int)(J1 - J0);
-        copy_block<<<blocks_for(c1 - c0, 4), 256, 0, st>>>(A + c0 * lda + J0, lda, buf, W, w, c1 - c0);
+        copy_block<<<blocks_for(c1 - c0, 4), 256, 0, st>>>(A + c0 * lda + J0, lda, buf, wb, w, c1 - c0);
         NODAL_HIP_TRY(h, hipGetLastError());
-        return gemm_f64(h, st, GEMM_SET, A + c0 * lda + J0, lda, Qk, W, buf, W, w, c1 - c0, w);
+        return gemm_f64(h, st, GEMM_SET, A + c0 * lda + J0, lda, Qk, wb, buf, wb, w, c1 - c0, w);
     };
     auto first_end = [&](int64_t J1) { return J1 + FIRST < ncols ? J1 + FIRST : ncols; };
 
@@ -1110,8 +1110,8 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
     NODAL_HIP_TRY(h, hipStreamWaitEvent(sg, ev_start, 0));
     NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_start, 0));
     {
-        const int64_t J1 = n < W ? n : W;
-        NODAL_TRY(invert_diag(h, sp, A, lda, (int)J1, Q[0], T1, T2, dinfo, 0));
+        const int64_t J1 = n < wb ? n : wb;
+        NODAL_TRY(invert_diag(h, sp, A, lda, (int)J1, Q[0], wb, T, dinfo, 0));
         NODAL_HIP_TRY(h, hipEventRecord(ev_q, sp));
         NODAL_TRY(scale_cols(sp, Q[0], S1, 0, J1, J1, first_end(J1)));
         NODAL_HIP_TRY(h, hipEventRecord(ev_wfirst, sp));
@@ -1120,11 +1120,11 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
         NODAL_HIP_TRY(h, hipEventRecord(ev_wrest, s3));
     }
     int blk = 0;
-    for (int64_t J0 = 0; J0 < n; J0 += W, ++blk) {
-        const int64_t J1 = J0 + W < n ? J0 + W : n;
+    for (int64_t J0 = 0; J0 < n; J0 += wb, ++blk) {
+        const int64_t J1 = J0 + wb < n ? J0 + wb : n;
         const int w = (int)(J1 - J0);
         if (J1 >= n) break;
-        const int64_t J2 = J1 + W < n ? J1 + W : n;
+        const int64_t J2 = J1 + wb < n ? J1 + wb : n;
         const double *L = A + J0 * lda, *U = A + J1 * lda + J0;  // A[:, J0:J1] and W(k)
         double *Qn = Q[(blk + 1) & 1];
         if (ev_rest) {  // block row k+1 was last written by the previous bulk update
@@ -1136,7 +1136,7 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
         NODAL_HIP_TRY(h, hipStreamWaitEvent(sg, ev_wrest, 0));
         // sp: diag + inverse chain
         NODAL_TRY(gemm_sub_f64(h, sp, A + J1 * lda + J1, lda, L + J1, lda, U, lda, J2 - J1, J2 - J1, w));
-        NODAL_TRY(invert_diag(h, sp, A + J1 * lda + J1, lda, (int)(J2 - J1), Qn, T1, T2, dinfo, (int)J1));
+        NODAL_TRY(invert_diag(h, sp, A + J1 * lda + J1, lda, (int)(J2 - J1), Qn, wb, T, dinfo, (int)J1));
         NODAL_HIP_TRY(h, hipEventRecord(ev_q, sp));
         // s3: strip
         NODAL_TRY(gemm_sub_f64(h, s3, A + J2 * lda + J1, lda, L + J1, lda, U + (J2 - J1) * lda, lda,
@@ -1222,9 +1222,15 @@ int dense_factor_solve_multi(nodal_ctx *h, int32_t nrhs, double *xout, int64_t l
     // back substitution on the transformed rhs (column n)
     double *y = A + n * lda;
     if (block_form) {
-        NODAL_TRY(factor_blockinv(h, A, n, lda, ncols, dinfo, tm));
+        // Block width 256.  (512 is implemented -- NODAL_BI_WIDTH=512 -- and was measured on
+        // config 2: the K = 512 bulk updates run at 43 instead of 38 TFLOP/s, 13.1 instead of
+        // 15.9 ms in total, but their 150-us tiles make every launch of the inverse chain wait
+        // longer for a free CU: 20.4 ms per solve against 20.5.)
+        int64_t wb = 256;
+        if (const char *e = getenv("NODAL_BI_WIDTH")) wb = atoi(e) == 512 ? 512 : 256;
+        NODAL_TRY(factor_blockinv(h, A, n, lda, ncols, dinfo, tm, wb));
         for (int64_t j1 = n; j1 > 0;) {
-            const int64_t j0 = ((j1 - 1) / W) * W;
+            const int64_t j0 = ((j1 - 1) / wb) * wb;
             dim3 grid(blocks_for(j0 > 0 ? j0 : 1, 64), (unsigned)nrhs);
             if (grid.x > 256 && nrhs > 1) grid.x = 256;  // many columns: fewer workgroups per column
             bs_block<<<grid, 256, 0, st>>>(A, lda, y, xout, ldx, (int)j0, (int)j1);

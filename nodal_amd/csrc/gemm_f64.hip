@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void gemm_small_pair_kernel(GemmProblem p0, Ge
 int gemm_f64(nodal_ctx *h, hipStream_t stream, int mode, double *C, int64_t ldc, const double *A,
              int64_t lda, const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return NODAL_OK;
-    if ((M <= 256 && N <= 256) || (M <= 256 && K <= 256)) {
+    if (M * N <= 512 * 1024 || (M <= 256 && K <= 256)) {
         dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32));
         if (mode == GEMM_SUB)
             gemm_small_kernel<GEMM_SUB><<<grid, 256, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);

@@ -72,9 +72,11 @@ def test_dense_block_inverse_elimination_on_passive_network(side, monkeypatch):
     from oracle import nodal_oracle as oracle
     table = gen.grid_table(side)
     out = []
-    for flag, scalar in (("1", "0"), ("0", "0"), ("1", "1")):  # rank-4 MFMA inverse, LU, scalar inverse
+    # rank-4 MFMA inverse, LU, scalar inverse, 512-wide blocks (two levels of the Schur recursion)
+    for flag, scalar, width in (("1", "0", "256"), ("0", "0", "256"), ("1", "1", "256"), ("1", "0", "512")):
         monkeypatch.setenv("NODAL_DENSE_BLOCKINV", flag)
         monkeypatch.setenv("NODAL_GJ_SCALAR", scalar)
+        monkeypatch.setenv("NODAL_BI_WIDTH", width)
         h = _ffi.Handle(0)
         h.upload(table)
         h.assemble_symbolic()
@@ -89,6 +91,7 @@ def test_dense_block_inverse_elimination_on_passive_network(side, monkeypatch):
     assert np.abs(out[0] - xo).max() <= 1e-10 * scale
     assert np.abs(out[0] - out[1]).max() <= 1e-11 * scale
     assert np.abs(out[0] - out[2]).max() <= 1e-11 * scale
+    assert np.abs(out[0] - out[3]).max() <= 1e-11 * scale
 
 
 def test_dense_block_inverse_multiple_right_hand_sides():
