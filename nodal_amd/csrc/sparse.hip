@@ -371,13 +371,14 @@ int pcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
 
 enum { F_RZ0 = 0, F_RZ1 = 1, F_RR = 2, F_BB = 3, F_ALPHA = 4, F_FLAG = 5, F_ITER = 6, F_COUNT = 8 };
 
-// The iteration number lives on the device (sc[F_ITER]) so that one iteration can be
-// captured into a hipGraph and replayed: kernel arguments are frozen in a graph.
-__global__ void fcg_advance(double *sc) { sc[F_ITER] += 1.0; }
+// The iteration number lives on the device so that one iteration can be captured into a
+// hipGraph and replayed (kernel arguments are frozen in a graph): sc[F_ITER] holds the number
+// of the iteration minus one until fcg_dots -- the first CG kernel of an iteration and the
+// only one that does not read it -- bumps it.
 
 __global__ __launch_bounds__(TB) void fcg_init(const double *__restrict__ b, double *__restrict__ x,
-                                               double *__restrict__ r,
-                                               double *__restrict__ part_rr, int64_t n) {
+                                               double *__restrict__ r, double *__restrict__ part_rr,
+                                               double *__restrict__ sc, int64_t n) {
     double srr = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
         const double ri = b[i];
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(TB) void fcg_init(const double *__restrict__ b, dou
     }
     srr = block_sum(srr);
     if (threadIdx.x == 0) part_rr[blockIdx.x] = srr;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc[F_ITER] = -1.0;
 }
 
 // partials of z.r and z.Ap
@@ -394,7 +396,9 @@ __global__ __launch_bounds__(TB) void fcg_dots(const double *__restrict__ z,
                                                const double *__restrict__ r,
                                                const double *__restrict__ Ap,
                                                double *__restrict__ part_rz,
-                                               double *__restrict__ part_zap, int64_t n) {
+                                               double *__restrict__ part_zap, double *__restrict__ sc,
+                                               int64_t n) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc[F_ITER] += 1.0;  // read by the kernels AFTER this one
     double a = 0.0, c = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
         const double zi = z[i];
@@ -500,7 +504,7 @@ int amg_fcg_solve_ex(nodal_ctx *h, const double *b, bool do_setup, int32_t *info
             return -2;  // singular: caller fills NaNs
         }
     }
-    fcg_init<<<gv, TB, 0, st>>>(b, x, r, part_rr, n);
+    fcg_init<<<gv, TB, 0, st>>>(b, x, r, part_rr, sc, n);
     NODAL_HIP_TRY(h, hipGetLastError());
 
     const double tol = 1e-13;
@@ -517,13 +521,12 @@ int amg_fcg_solve_ex(nodal_ctx *h, const double *b, bool do_setup, int32_t *info
     // every check interval runs eagerly with HIP events around the SpMV (roofline).
     auto iteration = [&](bool timed) -> int {
         NODAL_TRY(amg_apply(h, r, z));
-        fcg_dots<<<gv, TB, 0, st>>>(z, r, Ap, part_rz, part_zap, n);
+        fcg_dots<<<gv, TB, 0, st>>>(z, r, Ap, part_rz, part_zap, sc, n);
         fcg_direction<<<gv, TB, 0, st>>>(z, p, part_rz, part_zap, part_rr, (int)gv, sc, n);
         if (timed) NODAL_HIP_TRY(h, hipEventRecord(e0, st));
         pcg_spmv<<<gs, TB, 0, st>>>(indptr, indices, data, p, Ap, part_pap, n);
         if (timed) NODAL_HIP_TRY(h, hipEventRecord(e1, st));
         fcg_update<<<gv, TB, 0, st>>>(x, r, p, Ap, part_pap, (int)gs, part_rr, sc, n);
-        fcg_advance<<<1, 1, 0, st>>>(sc);
         NODAL_HIP_TRY(h, hipGetLastError());
         return NODAL_OK;
     };
