@@ -1,0 +1,457 @@
+// Dense block elimination with explicitly inverted diagonal blocks: the passive (SPD) dense
+// path and the presolved systems of dense_lu.hip's dispatcher.
+#include <cstdlib>
+
+#include "dense_common.h"
+
+namespace {
+
+constexpr int W = 256;             // default block width (K of the bulk update)
+// ---------------------------------------------------------------------------------
+// Passive networks (B == 0, every R > 0): G is symmetric positive definite, so block
+// Gaussian elimination with EXPLICITLY INVERTED diagonal blocks needs no pivoting and
+// is stable (the diagonal blocks of an SPD matrix are at least as well conditioned as
+// the matrix).  Per 256-column block k:
+//     Q    = A11^-1                      (small chain on the high-priority stream)
+//     A12 <- Q A12                       (GEMM; includes the right-hand sides)
+//     A22 <- A22 - A21 A12               (GEMM, the bulk of the flops)
+// A21 is never touched: there is no tall-skinny panel factorisation, the critical
+// path per block is one 256 x 256 inverse, and that runs while the previous block's
+// big GEMM is still busy (its diagonal block is updated first).  Back substitution is
+// x1 = A12[:, rhs] - A12[:, rest] x2, block by block: no triangular solves.
+//
+// Q for w = 256 comes from the 2 x 2 Schur-complement formula on 128 x 128 quadrants:
+//     [A B]^-1   [A^-1 + T1 S^-1 T2   -T1 S^-1]     T1 = A^-1 B, T2 = C A^-1,
+//     [C D]    = [-S^-1 T2             S^-1   ]     S  = D - C T1
+// with the two 128 x 128 inverses by in-register Gauss-Jordan (one workgroup, the
+// block distributed 4 x 4 per thread, pivot row / column broadcast through LDS).
+
+constexpr int GJ = 128;
+constexpr int BI_MAX = 512;        // largest block width of the block elimination
+
+// dst (m x m, ldd) = inverse of src (m x m, lds_), m <= 128.  No pivoting.  A zero or
+// NaN pivot records its 1-based global index in *dinfo (first one wins).
+__global__ __launch_bounds__(1024) void gj128(const double *__restrict__ src, int64_t lds_, int m,
+                                               double *__restrict__ dst, int64_t ldd,
+                                               int32_t *__restrict__ dinfo, int base) {
+    __shared__ double rowb[2][GJ], colb[2][GJ];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    double a[4][4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int r = ty + 32 * ii, c = tx + 32 * jj;
+            a[ii][jj] = (r < m && c < m) ? src[(int64_t)c * lds_ + r] : (r == c ? 1.0 : 0.0);
+        }
+    // Step k: the owners of column k publish it (with a zero in row k) and clear their
+    // copy; the owners of row k publish the scaled row (1/p in column k) and keep it as
+    // the new row k.  After the barrier every element takes the SAME update
+    // a -= col[i] * row[j]: rows other than k get a_ij - a_ik a_kj / p, column k gets
+    // 0 - a_ik / p, and row k is left alone by its zero multiplier.
+    // (The loop over k is split as k = 32 kb + kr with kb unrolled, so that the register
+    // index of row / column k is a compile-time constant.)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        for (int kr = 0; kr < 32; ++kr) {
+            const int k = 32 * kb + kr, buf = kr & 1;
+            if (k >= m) break;
+            const bool rowowner = ty == kr, colowner = tx == kr;
+            double rv[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) rv[jj] = a[kb][jj];
+            if (colowner) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    colb[buf][ty + 32 * ii] = (ii == kb && rowowner) ? 0.0 : a[ii][kb];
+                    a[ii][kb] = 0.0;
+                }
+            }
+            if (rowowner) {
+                // the pivot sits in lane tx == kr of this half-wave, register rv[kb]
+                const double p = __shfl(rv[kb], (int)(threadIdx.x & 32u) + kr, 64);
+                if (tx == 0 && !(p != 0.0 && p == p) && *dinfo == 0) *dinfo = base + k + 1;
+                double ip = __builtin_amdgcn_rcp(p);
+                ip = fma(fma(-p, ip, 1.0), ip, ip);  // one Newton step: full double accuracy
+                ip = fma(fma(-p, ip, 1.0), ip, ip);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    rv[jj] = (tx + 32 * jj) == k ? ip : rv[jj] * ip;
+                    rowb[buf][tx + 32 * jj] = rv[jj];
+                    a[kb][jj] = rv[jj];
+                }
+            }
+            __syncthreads();
+            double rr[4], ff[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) rr[jj] = rowb[buf][tx + 32 * jj];
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) ff[ii] = colb[buf][ty + 32 * ii];
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) a[ii][jj] = fma(-ff[ii], rr[jj], a[ii][jj]);
+        }
+    }
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int r = ty + 32 * ii, c = tx + 32 * jj;
+            if (r < m && c < m) dst[(int64_t)c * ldd + r] = a[ii][jj];
+        }
+}
+
+// The same inverse with RANK-4 steps on the matrix cores (v_mfma_f64_4x4x4_4b_f64), 32
+// block steps instead of 128 scalar ones.  The 128 x 128 block lives in accumulator
+// registers in the MFMA result layout: wave w owns the 32 x 32 tile (tr = w & 3, tc = w >> 2),
+// acc[mi][c8] lane l = element (32 tr + 16 mi + (l & 15), 32 tc + 4 c8 + (l >> 4)).
+// Block step p, pivots k0 = 4p .. 4p+3 (block Gauss-Jordan, no pivoting):
+//   1. the owners publish the four pivot rows and the four pivot columns (raw) through LDS
+//      and clear their copy of the pivot columns;
+//   2. one wave inverts the 4 x 4 pivot block P;
+//   3. row panel  Rp = P^-1 [pivot rows]  with P^-1 itself in the pivot columns,
+//      column panel Lp = -[pivot columns] with zeros in the pivot rows;
+//   4. every wave: acc += Lp Rp (16 MFMAs; the cleared pivot columns become -L P^-1, the
+//      pivot rows are untouched by their zero multipliers) and the row owners take Rp as
+//      their new pivot rows.
+constexpr int RP_S = 132;  // row panel stride (doubles): the 4 k of a fragment on disjoint banks
+constexpr int CP_S = 144;  // column panel stride
+
+__device__ __forceinline__ double rcp_f64(double p) {
+    double ip = __builtin_amdgcn_rcp(p);
+    ip = fma(fma(-p, ip, 1.0), ip, ip);
+    return fma(fma(-p, ip, 1.0), ip, ip);
+}
+
+__global__ __launch_bounds__(1024) void gj128_mfma(const double *__restrict__ src, int64_t lds_, int m,
+                                                    double *__restrict__ dst, int64_t ldd,
+                                                    int32_t *__restrict__ dinfo, int base) {
+    __shared__ double rowraw[4][128], colraw[4][128], pinv[16];
+    __shared__ double rowpan[4][RP_S], colpan[4][CP_S];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tr = wave & 3, tc = wave >> 2;
+    const int lr = lane & 15, lc = lane >> 4, lq = lane & 3;
+    double acc0[8], acc1[8];  // two separate arrays: a select between them cannot be turned
+                              // into a dynamically indexed (scratch-resident) array access
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+        const int r0 = 32 * tr + lr, r1 = r0 + 16, c = 32 * tc + 4 * c8 + lc;
+        acc0[c8] = (r0 < m && c < m) ? src[(int64_t)c * lds_ + r0] : (r0 == c ? 1.0 : 0.0);
+        acc1[c8] = (r1 < m && c < m) ? src[(int64_t)c * lds_ + r1] : (r1 == c ? 1.0 : 0.0);
+    }
+    const int nsteps = (m + 3) / 4;
+    for (int p = 0; p < nsteps; ++p) {
+        const int k0 = 4 * p, tp = p >> 3, mip = (p >> 2) & 1, ro = 4 * (p & 3), c8p = p & 7;
+        // ---- 1. publish ----
+        if (tr == tp && lr >= ro && lr < ro + 4) {
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8)
+                rowraw[lr - ro][32 * tc + 4 * c8 + lc] = mip == 0 ? acc0[c8] : acc1[c8];
+        }
+        if (tc == tp) {  // uniform per wave; static register indices, uniform selects
+            double v0 = acc0[0], v1 = acc1[0];
+#pragma unroll
+            for (int c8 = 1; c8 < 8; ++c8) {
+                v0 = c8 == c8p ? acc0[c8] : v0;
+                v1 = c8 == c8p ? acc1[c8] : v1;
+            }
+            colraw[lc][32 * tr + lr] = v0;
+            colraw[lc][32 * tr + 16 + lr] = v1;
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                acc0[c8] = c8 == c8p ? 0.0 : acc0[c8];
+                acc1[c8] = c8 == c8p ? 0.0 : acc1[c8];
+            }
+        }
+        __syncthreads();
+        // ---- 2. invert the pivot block (wave 0, every lane redundantly) ----
+        if (wave == 0) {
+            double a[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[i][j] = rowraw[i][k0 + j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double pv = a[k][k];
+                if (lane == 0 && !(pv != 0.0 && pv == pv) && *dinfo == 0) *dinfo = base + k0 + k + 1;
+                const double ip = rcp_f64(pv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[k][j] = j == k ? ip : a[k][j] * ip;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i == k) continue;
+                    const double f = a[i][k];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[i][j] = j == k ? -f * ip : fma(-f, a[k][j], a[i][j]);
+                }
+            }
+            if (lane < 16) {
+                double v = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (lane == 4 * i + j) v = a[i][j];
+                pinv[lane] = v;
+            }
+        }
+        __syncthreads();
+        // ---- 3. panels ----
+        {
+            const int t = threadIdx.x & 511, k = t >> 7, x = t & 127;
+            if (threadIdx.x < 512) {
+                double v;
+                if (x >= k0 && x < k0 + 4) v = pinv[4 * k + (x - k0)];
+                else {
+                    v = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v = fma(pinv[4 * k + j], rowraw[j][x], v);
+                }
+                rowpan[k][x] = v;
+            } else {
+                colpan[k][x] = (x >= k0 && x < k0 + 4) ? 0.0 : -colraw[k][x];
+            }
+        }
+        __syncthreads();
+        // ---- 4. rank-4 update ----
+        {
+            double bf[2], af[8];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) bf[mi] = colpan[lc][32 * tr + 16 * mi + lr];
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) af[c8] = rowpan[lc][32 * tc + 4 * c8 + lq];
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                acc0[c8] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[c8], bf[0], acc0[c8], 0, 0, 0);
+                acc1[c8] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[c8], bf[1], acc1[c8], 0, 0, 0);
+            }
+            if (tr == tp && lr >= ro && lr < ro + 4) {
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    const double v = rowpan[lr - ro][32 * tc + 4 * c8 + lc];
+                    acc0[c8] = mip == 0 ? v : acc0[c8];
+                    acc1[c8] = mip == 1 ? v : acc1[c8];
+                }
+            }
+        }
+        // (the next step's publish writes rowraw / colraw only; the panels are rewritten
+        // after two more barriers)
+    }
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+        const int r0 = 32 * tr + lr, r1 = r0 + 16, c = 32 * tc + 4 * c8 + lc;
+        if (r0 < m && c < m) dst[(int64_t)c * ldd + r0] = acc0[c8];
+        if (r1 < m && c < m) dst[(int64_t)c * ldd + r1] = acc1[c8];
+    }
+}
+
+// dst (rows x cols, ldd) = src (rows x cols, lds_): four columns per workgroup pass,
+// whole lines moved
+__global__ __launch_bounds__(256) void copy_block(const double *__restrict__ src, int64_t lds_,
+                                                  double *__restrict__ dst, int64_t ldd, int rows,
+                                                  int64_t cols) {
+    for (int64_t c = (int64_t)blockIdx.x * 4; c < cols; c += (int64_t)gridDim.x * 4)
+        for (int r = threadIdx.x; r < rows; r += 256) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = c + u < cols ? src[(c + u) * lds_ + r] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c + u < cols) dst[(c + u) * ldd + r] = v[u];
+        }
+}
+
+// Back substitution for the block-inverse form: x[j0:j1] = y[j0:j1] is final; the rows
+// above lose A[0:j0, j0:j1] x[j0:j1].  A workgroup owns 64 rows (one per lane); its four
+// waves split the block's columns, 16 independent loads in flight each, and meet in
+// LDS.  blockIdx.y = right-hand side.
+__global__ __launch_bounds__(256) void bs_block(const double *__restrict__ A, int64_t lda,
+                                                double *__restrict__ y, double *__restrict__ xout,
+                                                int64_t ldx, int j0, int j1) {
+    __shared__ double xs[BI_MAX];
+    __shared__ double part[3][64];
+    y += (int64_t)blockIdx.y * lda;
+    xout += (int64_t)blockIdx.y * ldx;
+    const int w = j1 - j0, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = threadIdx.x; t < w; t += 256) xs[t] = y[j0 + t];
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int t = threadIdx.x; t < w; t += 256) xout[j0 + t] = xs[t];
+    const int per = (w + 3) / 4, s0 = wave * per, s1 = s0 + per < w ? s0 + per : w;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < j0; base += (int64_t)gridDim.x * 64) {
+        const int64_t i = base + lane;
+        double acc = 0.0;
+        if (i < j0) {
+            const double *col = A + (int64_t)j0 * lda + i;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int s = s0;
+            for (; s + 16 <= s1; s += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = col[(int64_t)(s + u) * lda];
+#pragma unroll
+                for (int u = 0; u < 16; u += 4) {
+                    a0 = fma(v[u + 0], xs[s + u + 0], a0);
+                    a1 = fma(v[u + 1], xs[s + u + 1], a1);
+                    a2 = fma(v[u + 2], xs[s + u + 2], a2);
+                    a3 = fma(v[u + 3], xs[s + u + 3], a3);
+                }
+            }
+            for (; s < s1; ++s) a0 = fma(col[(int64_t)s * lda], xs[s], a0);
+            acc = (a0 + a1) + (a2 + a3);
+        }
+        if (wave > 0) part[wave - 1][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && i < j0) y[i] -= (acc + part[0][lane]) + (part[1][lane] + part[2][lane]);
+        __syncthreads();
+    }
+}
+
+// Q (ld ldq) = inverse of the w x w block at D (ld lda), w <= BI_MAX; D itself is overwritten.
+// w <= 128: one Gauss-Jordan workgroup; otherwise the 2 x 2 Schur-complement formula with the
+// leading m1 = 128 (w <= 256) or 256 columns, recursively.  `scratch` holds 2 * m1 * m2 doubles
+// per recursion level (T1, T2).
+int invert_diag(nodal_ctx *h, hipStream_t sp, double *D, int64_t lda, int w, double *Q, int64_t ldq,
+                double *scratch, int32_t *dinfo, int base) {
+    if (w <= GJ) {
+        if (h->gj_scalar) gj128<<<1, 1024, 0, sp>>>(D, lda, w, Q, ldq, dinfo, base);
+        else gj128_mfma<<<1, 1024, 0, sp>>>(D, lda, w, Q, ldq, dinfo, base);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        return NODAL_OK;
+    }
+    const int m1 = w <= 2 * GJ ? GJ : 2 * GJ, m2 = w - m1;
+    double *T1 = scratch, *T2 = scratch + (size_t)m1 * m2, *deeper = T2 + (size_t)m1 * m2;
+    double *Bq = D + (int64_t)m1 * lda, *Cq = D + m1, *Dq = D + (int64_t)m1 * lda + m1;
+    double *Q11 = Q, *Q12 = Q + (int64_t)m1 * ldq, *Q21 = Q + m1, *Q22 = Q + (int64_t)m1 * ldq + m1;
+    NODAL_TRY(invert_diag(h, sp, D, lda, m1, Q11, ldq, deeper, dinfo, base));
+    NODAL_TRY(gemm_pair_f64(h, sp, GEMM_SET, GemmProblem{T1, m1, Q11, ldq, Bq, lda, m1, m2, m1},    // T1 = A^-1 B
+                            GemmProblem{T2, m2, Cq, lda, Q11, ldq, m2, m1, m1}));                  // T2 = C A^-1
+    NODAL_TRY(gemm_f64(h, sp, GEMM_SUB, Dq, lda, Cq, lda, T1, m1, m2, m2, m1));                    // S = D - C T1
+    NODAL_TRY(invert_diag(h, sp, Dq, lda, m2, Q22, ldq, deeper, dinfo, base + m1));                // S^-1
+    NODAL_TRY(gemm_pair_f64(h, sp, GEMM_SETNEG, GemmProblem{Q12, ldq, T1, m1, Q22, ldq, m1, m2, m2},  // -T1 S^-1
+                            GemmProblem{Q21, ldq, Q22, ldq, T2, m2, m2, m1, m2}));                    // -S^-1 T2
+    NODAL_TRY(gemm_f64(h, sp, GEMM_SUB, Q11, ldq, Q12, ldq, T2, m2, m1, m1, m2));                  // + T1 S^-1 T2
+    return NODAL_OK;
+}
+
+int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncols, int32_t *dinfo,
+                    GemmTimer &tm, int64_t wb) {
+    // Three streams.  Per block k = [J0, J1), next block [J1, J2), once A12(k) <- Q(k) A12(k)
+    // (called W(k) below) is done and the previous bulk update has retired:
+    //   sp (high priority): diag   A[J1:J2, J1:J2] -= A[J1:J2, J0:J1] W(k)       (small)
+    //                       Q(k+1) = inv(A[J1:J2, J1:J2])                         (chain)
+    //                       W(k+1), first FIRST columns  (after the strip)
+    //   s3:                 strip  A[J1:J2, J2:]   -= A[J1:J2, J0:J1] W(k)       (block row k+1)
+    //                       W(k+1), remaining columns    (after Q(k+1))
+    //   sg:                 rest   A[J2:,   J1:]   -= A[J2:,   J0:J1] W(k)       (the bulk)
+    // The critical path per block is diag -> inverse -> first columns of W -> next diag; the
+    // strip, the wide part of W and the bulk update run beside it.
+    static const bool full_mask = getenv("NODAL_BI_MASKED") == nullptr;  // bulk updates on all CUs
+    hipStream_t sp = h->stream, sg = full_mask ? h->stream3 : h->stream2;
+    hipStream_t s3 = full_mask ? h->stream2 : h->stream3;
+    hipEvent_t ev_wfirst = h->ev_bi[0], ev_strip = h->ev_bi[1], ev_wrest = h->ev_bi[2],
+               ev_start = h->ev_bi[3], ev_done = h->ev_bi[4], ev_q = h->ev_bi[5], ev_rest = nullptr;
+    const int64_t FIRST = 2 * wb;  // columns of W(k) that the next two diagonal blocks need
+    // scratch: Q[2] (wb x wb), the inverse's T1 / T2 per recursion level, S1 (wb x FIRST), S (wb x ncols)
+    const size_t qb = (size_t)wb * wb, tb = 2 * (size_t)(2 * GJ) * (2 * GJ) + 2 * (size_t)GJ * GJ;
+    NODAL_HIP_TRY(h, h->work.reserve((2 * qb + tb + (size_t)wb * FIRST + (size_t)wb * (size_t)ncols) * 8 + 256));
+    double *Q[2] = {h->work.as<double>(), h->work.as<double>() + qb};
+    double *T = Q[1] + qb, *S1 = T + tb, *S = S1 + (size_t)wb * FIRST;
+
+    // A12 <- Q A12 for the block [J0, J1): columns [c0, c1) on stream st through scratch buf
+    auto scale_cols = [&](hipStream_t st, const double *Qk, double *buf, int64_t J0, int64_t J1, int64_t c0,
+                          int64_t c1) -> int {
+        if (c1 <= c0) return NODAL_OK;
+        const int w = (int)(J1 - J0);
+        copy_block<<<blocks_for(c1 - c0, 4), 256, 0, st>>>(A + c0 * lda + J0, lda, buf, wb, w, c1 - c0);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        return gemm_f64(h, st, GEMM_SET, A + c0 * lda + J0, lda, Qk, wb, buf, wb, w, c1 - c0, w);
+    };
+    auto first_end = [&](int64_t J1) { return J1 + FIRST < ncols ? J1 + FIRST : ncols; };
+
+    NODAL_HIP_TRY(h, hipEventRecord(ev_start, sp));  // the matrix was prepared on the main stream
+    NODAL_HIP_TRY(h, hipStreamWaitEvent(sg, ev_start, 0));
+    NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_start, 0));
+    {
+        const int64_t J1 = n < wb ? n : wb;
+        NODAL_TRY(invert_diag(h, sp, A, lda, (int)J1, Q[0], wb, T, dinfo, 0));
+        NODAL_HIP_TRY(h, hipEventRecord(ev_q, sp));
+        NODAL_TRY(scale_cols(sp, Q[0], S1, 0, J1, J1, first_end(J1)));
+        NODAL_HIP_TRY(h, hipEventRecord(ev_wfirst, sp));
+        NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_q, 0));
+        NODAL_TRY(scale_cols(s3, Q[0], S, 0, J1, first_end(J1), ncols));
+        NODAL_HIP_TRY(h, hipEventRecord(ev_wrest, s3));
+    }
+    int blk = 0;
+    for (int64_t J0 = 0; J0 < n; J0 += wb, ++blk) {
+        const int64_t J1 = J0 + wb < n ? J0 + wb : n;
+        const int w = (int)(J1 - J0);
+        if (J1 >= n) break;
+        const int64_t J2 = J1 + wb < n ? J1 + wb : n;
+        const double *L = A + J0 * lda, *U = A + J1 * lda + J0;  // A[:, J0:J1] and W(k)
+        double *Qn = Q[(blk + 1) & 1];
+        if (ev_rest) {  // block row k+1 was last written by the previous bulk update
+            NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_rest, 0));
+            NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_rest, 0));
+        }
+        NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_wfirst, 0));
+        NODAL_HIP_TRY(h, hipStreamWaitEvent(sg, ev_wfirst, 0));
+        NODAL_HIP_TRY(h, hipStreamWaitEvent(sg, ev_wrest, 0));
+        // sp: diag + inverse chain
+        NODAL_TRY(gemm_sub_f64(h, sp, A + J1 * lda + J1, lda, L + J1, lda, U, lda, J2 - J1, J2 - J1, w));
+        NODAL_TRY(invert_diag(h, sp, A + J1 * lda + J1, lda, (int)(J2 - J1), Qn, wb, T, dinfo, (int)J1));
+        NODAL_HIP_TRY(h, hipEventRecord(ev_q, sp));
+        // s3: strip
+        NODAL_TRY(gemm_sub_f64(h, s3, A + J2 * lda + J1, lda, L + J1, lda, U + (J2 - J1) * lda, lda,
+                               J2 - J1, ncols - J2, w));
+        NODAL_HIP_TRY(h, hipEventRecord(ev_strip, s3));
+        // sg: rest
+        if (J2 < n) {
+            NODAL_TRY(tm.begin(sg));
+            NODAL_TRY(gemm_sub_f64(h, sg, A + J1 * lda + J2, lda, L + J2, lda, U, lda, n - J2, ncols - J1, w));
+            NODAL_TRY(tm.end(sg, 2.0 * (double)w * (double)(n - J2) * (double)(ncols - J1)));
+            ev_rest = tm.last_end();  // the timing event doubles as the dependency (one packet less)
+        } else ev_rest = nullptr;
+        // W(k+1): the first columns on the critical stream, the wide remainder beside it
+        NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_strip, 0));
+        NODAL_TRY(scale_cols(sp, Qn, S1, J1, J2, J2, first_end(J2)));
+        NODAL_HIP_TRY(h, hipEventRecord(ev_wfirst, sp));
+        NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_q, 0));
+        NODAL_TRY(scale_cols(s3, Qn, S, J1, J2, first_end(J2), ncols));
+        NODAL_HIP_TRY(h, hipEventRecord(ev_wrest, s3));
+    }
+    NODAL_HIP_TRY(h, hipEventRecord(ev_done, sg));
+    NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_done, 0));
+    NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_wrest, 0));
+    return NODAL_OK;
+}
+
+}  // namespace
+
+// Factor-and-solve by block elimination: A is the column-major augmented matrix (n + nrhs
+// columns, leading dimension lda); the solutions go to xout (column c at xout + c * ldx).
+int dense_block_elimination(nodal_ctx *h, double *A, int64_t n, int64_t lda, int32_t nrhs, double *xout,
+                            int64_t ldx, int32_t *dinfo) {
+    const int64_t ncols = n + nrhs;
+    hipStream_t st = h->stream;
+    GemmTimer tm{h};  // (reset and collected by the caller, dense_factor_solve_multi)
+    // Block width 256.  (512 is implemented -- NODAL_BI_WIDTH=512 -- and was measured on
+    // config 2: the K = 512 bulk updates run at 43 instead of 38 TFLOP/s, 13.1 instead of
+    // 15.9 ms in total, but their 150-us tiles make every launch of the inverse chain wait
+    // longer for a free CU: 20.4 ms per solve against 20.5.)
+    int64_t wb = W;
+    if (const char *e = getenv("NODAL_BI_WIDTH")) wb = atoi(e) == 512 ? 512 : 256;
+    NODAL_TRY(factor_blockinv(h, A, n, lda, ncols, dinfo, tm, wb));
+    double *y = A + n * lda;
+    for (int64_t j1 = n; j1 > 0;) {
+        const int64_t j0 = ((j1 - 1) / wb) * wb;
+        dim3 grid(blocks_for(j0 > 0 ? j0 : 1, 64), (unsigned)nrhs);
+        if (grid.x > 256 && nrhs > 1) grid.x = 256;  // many columns: fewer workgroups per column
+        bs_block<<<grid, 256, 0, st>>>(A, lda, y, xout, ldx, (int)j0, (int)j1);
+        j1 = j0;
+    }
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
+}

@@ -48,6 +48,8 @@ struct nodal_ctx {
     hipEvent_t ev_la[2] = {nullptr, nullptr};
     hipStream_t stream3 = nullptr;   // bulk stream of the block-inverse elimination (all CUs)
     hipEvent_t ev_bi[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t gt_used = 0;              // GemmTimer (dense_common.h): timed launches, their flops
+    double gt_flops = 0.0;
     bool optimistic_nopivot = false; // dense: block elimination although not passive (caller verifies the answer)
     bool gj_scalar = false;          // NODAL_GJ_SCALAR=1: scalar Gauss-Jordan instead of the rank-4 MFMA one
     bool dense_blockinv = true;      // passive dense systems: block elimination (NODAL_DENSE_BLOCKINV=0: LU)
@@ -181,6 +183,9 @@ static inline int64_t dense_lda(int64_t n) {
     return l;
 }
 int dense_factor_solve(nodal_ctx *h, int32_t *info);
+// block elimination with inverted diagonal blocks (block_elim.hip): factor + back substitution
+int dense_block_elimination(nodal_ctx *h, double *A, int64_t n, int64_t lda, int32_t nrhs, double *xout,
+                            int64_t ldx, int32_t *dinfo);
 int dense_factor_solve_multi(nodal_ctx *h, int32_t nrhs, double *xout, int64_t ldx, int32_t *info);
 int dense_prepare(nodal_ctx *h);
 int dense_prepare_pairs(nodal_ctx *h, int32_t nrhs, const int32_t *ia, const int32_t *ib);
