@@ -63,10 +63,10 @@ class LazyComponents(Mapping):
         return comp
 
     def __iter__(self):
-        return iter(self._nl._row_of)
+        return iter(self._nl.component_keys)  # names are unique on a vectorised netlist
 
     def __len__(self):
-        return len(self._nl._row_of)
+        return len(self._nl.component_keys)
 
 
 # ---- native tokenizer (csrc/fastcsv.cpp -> libnodal_csv.so), optional -------------------------
@@ -116,7 +116,7 @@ def _finish_fast(nl, name, type_names, value, nfields, acode, bcode, labels):
     nl._nfields = nfields
     nl._acode, nl._bcode = acode, bcode
     nl.component_keys = name.tolist()
-    nl._row_of = dict(zip(nl.component_keys, range(len(name))))
+    nl.__dict__.pop("_row_of", None)  # name -> row, built on first use (Netlist.__getattr__)
     nl.components = LazyComponents(nl)
     nl.degrees = dict(zip(labels, deg.tolist()))
     is_anom = np.isin(type_names.astype(str), c.NODE_TYPES_ANOM) if not hasattr(nl, "_tidx") \
@@ -155,16 +155,16 @@ def _read_native(netlist, path, lib):
             raise Irregular(f"{_CSV_REASONS.get(status, status)} (line {res.bad_line + 1})")
         n, m = res.nrows, res.nnodes
 
-        def arr(ptr, count, dtype):
-            return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dtype, copy=True)
+        def arr(ptr, count):  # one copy out of the library's buffers (freed below)
+            return np.array(np.ctypeslib.as_array(ptr, shape=(count,)))
 
-        line_off = arr(res.line_off, n, np.int64)
-        line_len = arr(res.line_len, n, np.int32)
-        tidx = arr(res.type_idx, n, np.uint8)
-        nfields = arr(res.nfields, n, np.int64)
-        value = arr(res.value, n, np.float64)
-        acode = arr(res.acode, n, np.int64)
-        bcode = arr(res.bcode, n, np.int64)
+        line_off = arr(res.line_off, n)
+        line_len = arr(res.line_len, n)
+        tidx = arr(res.type_idx, n)
+        nfields = arr(res.nfields, n)
+        value = arr(res.value, n)
+        acode = arr(res.acode, n)
+        bcode = arr(res.bcode, n)
         try:
             names = C.string_at(res.names_blob, res.names_bytes).decode().split("\n")
             labels = C.string_at(res.labels_blob, res.labels_bytes).decode().split("\n")
@@ -185,6 +185,19 @@ def _read_native(netlist, path, lib):
 
 def read_fast(netlist, path):
     """Fill `netlist` (a Netlist whose `_reset()` has run) from the CSV at `path`."""
+    import gc
+    # millions of small objects (names, labels, dict entries) are created and all survive:
+    # the cyclic collector would only rescan them over and over
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        return _read_fast(netlist, path)
+    finally:
+        if was_enabled:
+            gc.enable()
+
+
+def _read_fast(netlist, path):
     lib = _load_csv_lib()
     if lib:
         return _read_native(netlist, path, lib)

@@ -143,6 +143,14 @@ class Netlist:
         self.nodenum = {}
         self.opmodel_equivalents = []
 
+    def __getattr__(self, name):
+        # vectorised netlists build their name -> row map only when somebody asks for it
+        if name == "_row_of" and self.__dict__.get("_fast"):
+            row_of = dict(zip(self.component_keys, range(len(self.component_keys))))
+            self.__dict__["_row_of"] = row_of
+            return row_of
+        raise AttributeError(name)
+
     @classmethod
     def from_rows(cls, rows):
         self = cls.__new__(cls)
