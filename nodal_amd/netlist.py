@@ -151,6 +151,40 @@ class Netlist:
             return row_of
         raise AttributeError(name)
 
+    def __deepcopy__(self, memo):
+        """equivalent_resistance deep-copies the netlist before adding its probe source.  A
+        vectorised netlist keeps its big columns in arrays that are REPLACED, never mutated,
+        when a row is appended (fastparse.append_row), so the copy shares them and only the
+        small mutable containers are duplicated (2e6 rows: 0.3 s instead of 8 s)."""
+        import copy
+        if not self.__dict__.get("_fast"):
+            clone = self.__class__.__new__(self.__class__)
+            memo[id(self)] = clone
+            for key, value in self.__dict__.items():
+                clone.__dict__[key] = copy.deepcopy(value, memo)
+            return clone
+        clone = self.__class__.__new__(self.__class__)
+        memo[id(self)] = clone
+        shared = {"_raw", "_line_off", "_line_len", "_tidx", "_df", "_name", "_type", "_value", "_nfields",
+                  "_acode", "_bcode", "_is_anom", "_node_index"}
+        for key, value in self.__dict__.items():
+            if key == "_row_of":
+                continue  # rebuilt on demand
+            if key in shared:
+                clone.__dict__[key] = value
+            elif key == "components":
+                from . import fastparse
+                comps = fastparse.LazyComponents(clone)
+                comps._cache = dict(value._cache)
+                clone.__dict__[key] = comps
+            elif isinstance(value, dict):
+                clone.__dict__[key] = dict(value)
+            elif isinstance(value, list):
+                clone.__dict__[key] = [list(v) if isinstance(v, list) else v for v in value]
+            else:
+                clone.__dict__[key] = copy.deepcopy(value, memo)
+        return clone
+
     @classmethod
     def from_rows(cls, rows):
         self = cls.__new__(cls)
