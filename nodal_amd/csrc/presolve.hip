@@ -19,9 +19,9 @@
 // voltage-defined branches form a forest on their lead nodes (no loops of sources); every
 // tree is rooted at ground if it touches ground and every other node of it is a pivot,
 // defined through the branch to its parent.  Chains resolve by substitution (stacked
-// sources add up, a control node that is itself a pivot is replaced by its expression) as
-// long as every pivot ends with at most one control term on surviving nodes.  Dependent
-// sources without a branch of their own (CCCS) must not be controlled by a pivot.
+// sources add up, a control node that is itself a pivot is replaced by its expression, for
+// the branch-less dependent sources (CCCS) too) as long as every pivot ends with at most
+// one control term on surviving nodes and no substituted control carries a term itself.
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -147,8 +147,8 @@ struct DevTableOut {
 
 // keep[i] = 1: component survives unchanged (up to node renumbering);
 // hit[i]  = 1: it touches an eliminated node and is rewritten by the host;
-// branch components are dropped.  A dependent source controlled by a pivot node makes
-// the pattern unsupported (*invalid = 1).
+// (a lead OR a control node; the control's expression is substituted); branch components
+// are dropped.  (*invalid is kept for patterns the host cannot rewrite.)
 __global__ __launch_bounds__(TB) void classify(DevTable t, int64_t nc,
                                                const int32_t *__restrict__ newidx,
                                                uint32_t *__restrict__ keep,
@@ -160,11 +160,12 @@ __global__ __launch_bounds__(TB) void classify(DevTable t, int64_t nc,
         if (ty == NODAL_T_R || ty == NODAL_T_A || ty == NODAL_T_CCCS || ty == NODAL_T_GM) {
             const int a = t.a[i], b = t.b[i];
             const bool touched = (a >= 0 && newidx[a] < 0) || (b >= 0 && newidx[b] < 0);
+            bool control_eliminated = false;
             if (ty == NODAL_T_CCCS || ty == NODAL_T_GM) {
                 const int c = t.c[i], d = t.d[i];
-                if ((c >= 0 && newidx[c] < 0) || (d >= 0 && newidx[d] < 0)) *invalid = 1;
+                control_eliminated = (c >= 0 && newidx[c] < 0) || (d >= 0 && newidx[d] < 0);
             }
-            if (touched) ht = 1; else kp = 1;
+            if (touched || control_eliminated) ht = 1; else kp = 1;  // the host substitutes
         }
         keep[i] = kp;
         hit[i] = ht;
@@ -397,7 +398,7 @@ struct Extras {
     std::vector<double> value;
     std::vector<int32_t> a, b, c, d;
 };
-static void rewrite_hits(const nodal_ctx *h, const double *value, const PresolvePlan &plan,
+static bool rewrite_hits(const nodal_ctx *h, const double *value, const PresolvePlan &plan,
                          const std::vector<int32_t> &hits, Extras &x) {
     const HostTable &t = h->host;
     std::vector<std::pair<int32_t, int32_t>> by_pivot(plan.exprs.size());
@@ -436,11 +437,17 @@ static void rewrite_hits(const nodal_ctx *h, const double *value, const Presolve
             const Side sa = side(t.a[i]), sb = side(t.b[i]);
             if (sa.base != sb.base) emit(NODAL_T_A, v, sa.base, sb.base, -1, -1);
         } else if (ty == NODAL_T_CCCS || ty == NODAL_T_GM) {
+            // gm (e_c - e_d) flowing a -> b, with eliminated leads AND controls substituted
             const double gm = ty == NODAL_T_CCCS ? v / value[t.drv[i]] : v;
-            const Side sa = side(t.a[i]), sb = side(t.b[i]);
-            if (sa.base != sb.base) emit(NODAL_T_GM, gm, sa.base, sb.base, t.c[i], t.d[i]);
+            const Side sa = side(t.a[i]), sb = side(t.b[i]), rc = side(t.c[i]), rd = side(t.d[i]);
+            if (rc.g != 0.0 || rd.g != 0.0) return false;  // a control with its own control term
+            if (sa.base == sb.base) continue;
+            const double cst = gm * (rc.cst - rd.cst);
+            if (cst != 0.0) emit(NODAL_T_A, cst, sb.base, sa.base, -1, -1);
+            if (rc.base != rd.base) emit(NODAL_T_GM, gm, sa.base, sb.base, rc.base, rd.base);
         }
     }
+    return true;
 }
 
 // Build the reduced component table directly in the child context's device arrays.
@@ -508,7 +515,7 @@ static int presolve_build_reduced(nodal_ctx *h, nodal_ctx *r, const double *valu
         NODAL_HIP_TRY(h, hipMemcpyAsync(hits.data(), h->ps_hits.p, (size_t)nhit * 4, hipMemcpyDeviceToHost, st));
     NODAL_HIP_TRY(h, hipStreamSynchronize(st));
     Extras x;
-    rewrite_hits(h, value_host, plan, hits, x);
+    if (!rewrite_hits(h, value_host, plan, hits, x)) return NODAL_OK;  // not expressible: fall back
     const int64_t nx = (int64_t)x.type.size();
     if (nx) {
         std::vector<int32_t> minus((size_t)nx, -1);

@@ -185,6 +185,8 @@ def _stacked_source_rows(side, dependent):
         rows += [
             ["v1", "VCVS", "3.0", "700", "g", "40", "900"],   # controlled by an eliminated node
             ["h1", "CCVS", "2.0", "800", "801", str(side + 2), str(side + 3), "rh1_1"],  # its driver's leads
+            # CCCS sensing the current of a resistor that hangs on a source node (control = pivot "5")
+            ["f1", "CCCS", "0.5", "1000", "g", "5", "6", "rh0_4"],
         ]
     return rows
 
@@ -200,7 +202,7 @@ def test_presolve_resolves_chains_of_sources(side, dense, monkeypatch, capfd):
     from oracle import nodal_oracle as oracle
     monkeypatch.setenv("NODAL_TRACE", "1")
     table = lowering.lower(n.Netlist.from_rows(_stacked_source_rows(side, not dense)))
-    assert table.B == (5 if dense else 7)
+    assert table.B == (5 if dense else 8)
     h = _ffi.Handle(0)
     h.upload(table)
     h.assemble_symbolic()
