@@ -91,15 +91,38 @@ struct Hierarchy {
     int sweeps0 = 2;    // Jacobi sweeps before / after the coarse correction at level 0 (NODAL_AMG_SWEEPS0=1: one)
     TailDesc tdesc;
     DevBuf tail_image;
+    // Level objects and scratch buffers outlive a setup: a solve rebuilds the hierarchy for new
+    // matrix values, and ~80 hipMalloc / hipFree pairs per setup cost more than the kernels.
+    std::vector<Level *> pool;  // every Level ever created; `levels` is the active prefix
+    Level scratch[2];           // intermediate pair graphs of the matching passes
+    DevBuf pass_map, members_none, members_rows;
     ~Hierarchy() { clear(); }
+    static void release_level(Level *l) {
+        DevBuf *bufs[] = {&l->indptr, &l->indices, &l->rowidx, &l->data, &l->diag_pos, &l->cptr,
+                          &l->contrib, &l->dinv, &l->agg, &l->memptr, &l->mem, &l->vec, &l->part};
+        for (DevBuf *b : bufs) b->release();
+    }
+    Level *take(size_t i) {  // the i-th level object, buffers kept from earlier setups
+        while (pool.size() <= i) pool.push_back(new Level());
+        pool[i]->nc = 0;
+        return pool[i];
+    }
+    void begin_setup() {
+        levels.clear();
+        tail = -1;
+        coarse_direct = false;
+    }
     void clear() {
-        for (Level *l : levels) {
-            DevBuf *bufs[] = {&l->indptr, &l->indices, &l->rowidx, &l->data, &l->diag_pos, &l->cptr,
-                              &l->contrib, &l->dinv, &l->agg, &l->memptr, &l->mem, &l->vec, &l->part};
-            for (DevBuf *b : bufs) b->release();
+        for (Level *l : pool) {
+            release_level(l);
             delete l;
         }
+        pool.clear();
         levels.clear();
+        for (Level &t : scratch) release_level(&t);
+        pass_map.release();
+        members_none.release();
+        members_rows.release();
         coarse_inv.release();
         tail_image.release();
         tail = -1;
@@ -191,7 +214,8 @@ __global__ __launch_bounds__(TB) void compose_map(int64_t n, int32_t *__restrict
 
 // grouping enumerators (group.h)
 struct CoarseEntries {  // fine entry e -> (agg[row], agg[col])
-    [[maybe_unused]] static constexpr int SLOTS = 1;
+    static constexpr int SLOTS = 1;
+    static constexpr bool EXACT = true;  // one tuple per fine entry
     const int32_t *rowidx, *indices, *agg;
     int64_t nitems;
     template <class F>
@@ -200,7 +224,8 @@ struct CoarseEntries {  // fine entry e -> (agg[row], agg[col])
     }
 };
 struct Members {  // node i -> (agg[i], 0): one entry per aggregate, members ascending
-    [[maybe_unused]] static constexpr int SLOTS = 1;
+    static constexpr int SLOTS = 1;
+    static constexpr bool EXACT = true;  // one tuple per node
     const int32_t *agg;
     int64_t nitems;
     template <class F>
@@ -864,16 +889,19 @@ int amg_setup(nodal_ctx *h, double *flag) {
 int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
                   const int32_t *indices, const int32_t *rowidx, const double *data,
                   const int32_t *diag_pos, double *flag) {
-    amg_destroy(h);
-    Hierarchy *H = new Hierarchy();
-    h->amg = H;
+    Hierarchy *H = static_cast<Hierarchy *>(h->amg);
+    if (!H) {
+        H = new Hierarchy();
+        h->amg = H;
+    }
+    H->begin_setup();
     if (const char *e = getenv("NODAL_AMG_KMAX")) H->kmax = atoi(e);
     if (const char *e = getenv("NODAL_AMG_PASSES0")) H->passes0 = atoi(e);
     if (const char *e = getenv("NODAL_AMG_SWEEPS0")) H->sweeps0 = atoi(e);
     if (const char *e = getenv("NODAL_AMG_PASSES1")) H->passes1 = atoi(e);
     hipStream_t st = h->stream;
 
-    Level *l0 = new Level();
+    Level *l0 = H->take(0);
     H->levels.push_back(l0);
     l0->A.n = n0;
     l0->A.nnz = nnz0;
@@ -890,19 +918,19 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
         // PASSES matching passes; the intermediate pair graphs live in scratch levels
         NODAL_HIP_TRY(h, fine->agg.reserve((size_t)n * 4 + 8));
         int32_t *agg = fine->agg.as<int32_t>();
-        Level tmp[2];
+        Level *tmp = H->scratch;
         Csr cur = fine->A;
         int64_t nc = n;
-        DevBuf pass_map;
+        DevBuf &pass_map = H->pass_map;
         bool stalled = false;
-        Level *coarse = new Level();
+        Level *coarse = H->take(H->levels.size());
         const int passes = (int)H->levels.size() == 1 ? H->passes0 : H->passes1;
         for (int p = 0; p < passes; ++p) {
             NODAL_HIP_TRY(h, pass_map.reserve((size_t)cur.n * 4 + 8));
             int32_t *map = p == 0 ? agg : pass_map.as<int32_t>();
             int64_t na = 0;
             int s = matching_pass(h, cur, map, &na);
-            if (s != NODAL_OK) { delete coarse; return s; }
+            if (s != NODAL_OK) return s;
             if (p == 0 && na > (int64_t)(0.8 * (double)n)) { stalled = true; break; }
             if (p > 0) {
                 compose_map<<<grid_for(n), TB, 0, st>>>(n, agg, map);
@@ -911,32 +939,21 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
             const bool last = (p == passes - 1) || na <= COARSEST_MAX || na > (int64_t)(0.9 * (double)cur.n);
             Level *dst = last ? coarse : &tmp[p & 1];
             s = galerkin(h, cur, map, na, dst);
-            if (s != NODAL_OK) { delete coarse; return s; }
+            if (s != NODAL_OK) return s;
             cur = dst->A;
             nc = na;
             if (last) break;
         }
-        for (Level &t : tmp) {
-            DevBuf *bufs[] = {&t.indptr, &t.indices, &t.rowidx, &t.data, &t.diag_pos, &t.cptr, &t.contrib};
-            for (DevBuf *b : bufs) b->release();
-        }
-        pass_map.release();
-        if (stalled) { delete coarse; break; }
+        if (stalled) break;
         fine->nc = nc;
         // aggregate -> members
         {
             Members en{agg, n};
             int64_t nent = 0, ncon = 0;
-            DevBuf none, rowi;
-            int s = grp::build_lists(h, en, nc, &nent, &ncon, none, rowi, fine->memptr, fine->cptr,
-                                     nullptr, nullptr);
-            none.release();
-            rowi.release();
-            if (s != NODAL_OK) { delete coarse; return s; }
-            if (nent != nc || ncon != n) {
-                delete coarse;
-                return nodal_fail(h, NODAL_E_INVALID, "amg: empty aggregate");
-            }
+            int s = grp::build_lists(h, en, nc, &nent, &ncon, H->members_none, H->members_rows, fine->memptr,
+                                     fine->cptr, nullptr, nullptr, /*known_nent=*/nc);  // one entry per aggregate
+            if (s != NODAL_OK) return s;
+            if (nent != nc || ncon != n) return nodal_fail(h, NODAL_E_INVALID, "amg: empty aggregate");
             NODAL_HIP_TRY(h, fine->mem.reserve((size_t)n * 4 + 8));
             unpack_members<<<grid_for(n), TB, 0, st>>>(fine->cptr.as<uint32_t>(),
                                                       fine->mem.as<int32_t>(), n);

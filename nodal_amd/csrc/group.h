@@ -15,6 +15,7 @@
 //              template <class F> __device__ void for_each(int64_t item, F f) const; }
 //   with f(int slot, int row, int col) called for every tuple of `item`.
 #pragma once
+#include <type_traits>
 #include "ctx.h"
 
 namespace {
@@ -228,13 +229,24 @@ __global__ __launch_bounds__(TB) void fill_i32(int32_t *p, int32_t v, int64_t n)
 
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Enumerators that emit exactly SLOTS tuples for every item declare
+// `static constexpr bool EXACT = true`: the number of contributions is then known on the
+// host and build_lists saves a device round trip (the multigrid setup calls it ~20 times
+// per solve; each round trip idles the GPU for ~100 us).
+template <class E, class = void>
+struct emits_exactly : std::false_type {};
+template <class E>
+struct emits_exactly<E, std::void_t<decltype(E::EXACT)>> : std::bool_constant<E::EXACT> {};
+
 // Group one family of stamps (matrix or rhs) into entries.  On return:
 //   *nent entries, *ncon contributions; rowidx / cptr / contrib filled;
 //   indices, indptr, diag_pos filled when non-null.
+// `known_nent` >= 0: the caller knows the number of entries (e.g. one per aggregate): no
+// round trip for it either.
 template <class E>
 int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int64_t *ncon_out,
                 DevBuf &indices, DevBuf &rowidx, DevBuf &cptr, DevBuf &contrib, DevBuf *indptr,
-                DevBuf *diag_pos) {
+                DevBuf *diag_pos, int64_t known_nent = -1) {
     hipStream_t st = h->stream;
     if (en.nitems >= (1ll << 29) || nrows >= (1ll << 31) - 2)
         return nodal_fail(h, NODAL_E_UNSUPPORTED, "too many items for 32-bit grouping keys");
@@ -255,10 +267,15 @@ int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int
     count_rows<E><<<grid_for(en.nitems), TB, 0, st>>>(en, rowstart);
     NODAL_HIP_TRY(h, hipGetLastError());
     NODAL_TRY(scan_exclusive_u32(h, rowstart, rowstart, nrows + 1, &counts[2], w + off_scan));
-    uint32_t C32 = 0;
-    NODAL_HIP_TRY(h, hipMemcpyAsync(&C32, &counts[2], 4, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
-    const int64_t C = C32;
+    int64_t C;
+    if constexpr (emits_exactly<E>::value) {
+        C = en.nitems * E::SLOTS;
+    } else {
+        uint32_t C32 = 0;
+        NODAL_HIP_TRY(h, hipMemcpyAsync(&C32, &counts[2], 4, hipMemcpyDeviceToHost, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        C = C32;
+    }
     if (C > 0x7fffffffll)
         return nodal_fail(h, NODAL_E_UNSUPPORTED, "more than 2^31 stamps");
     *ncon_out = C;
@@ -299,18 +316,16 @@ int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int
     sort_rows_short<<<grid_for(nrows), TB, 0, st>>>(rowstart, skey, nrows, medium_list, long_list,
                                                    counts);
     NODAL_HIP_TRY(h, hipGetLastError());
-    uint32_t lc[2] = {0, 0};
-    NODAL_HIP_TRY(h, hipMemcpyAsync(lc, counts, 8, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
-    if (lc[0] > 0) {
-        sort_rows_medium<<<lc[0] > 2048 ? 2048 : lc[0], TB, 0, st>>>(rowstart, skey, medium_list,
-                                                                    counts);
+    // The medium / long row lists are counted on the device (counts[0], counts[1]) and both
+    // kernels loop over them with a grid stride: launched unconditionally with a bounded grid
+    // (an empty list costs two idle launches, a round trip to learn the counts ~100 us).
+    {
+        const unsigned gm = (unsigned)(nrows < 1024 ? (nrows > 0 ? nrows : 1) : 1024);
+        sort_rows_medium<<<gm, TB, 0, st>>>(rowstart, skey, medium_list, counts);
         NODAL_HIP_TRY(h, hipGetLastError());
-    }
-    if (lc[1] > 0) {
-        NODAL_HIP_TRY(h, h->work3.reserve((size_t)C * 16));  // padded scratch
-        sort_rows_long<<<lc[1] > 256 ? 256 : lc[1], 1024, 0, st>>>(
-            rowstart, skey, h->work3.as<uint64_t>(), long_list, counts);
+        NODAL_HIP_TRY(h, h->work3.reserve((size_t)C * 16));  // padded scratch of the long sort
+        sort_rows_long<<<gm < 128 ? gm : 128, 1024, 0, st>>>(rowstart, skey, h->work3.as<uint64_t>(),
+                                                            long_list, counts);
         NODAL_HIP_TRY(h, hipGetLastError());
     }
 
@@ -319,10 +334,13 @@ int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int
     // scanned over C+1 slots: slot C (zero) receives the number of entries
     NODAL_HIP_TRY(h, hipMemsetAsync(head + C, 0, 4, st));
     NODAL_TRY(scan_exclusive_u32(h, head, eidx, C + 1, nullptr, w2 + o_scan2));
-    uint32_t nent32 = 0;
-    NODAL_HIP_TRY(h, hipMemcpyAsync(&nent32, eidx + C, 4, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
-    const int64_t nent = nent32;
+    int64_t nent = known_nent;
+    if (nent < 0) {
+        uint32_t nent32 = 0;
+        NODAL_HIP_TRY(h, hipMemcpyAsync(&nent32, eidx + C, 4, hipMemcpyDeviceToHost, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        nent = nent32;
+    }
     *nent_out = nent;
 
     NODAL_HIP_TRY(h, indices.reserve((size_t)nent * 4 + 4));

@@ -16,6 +16,10 @@
 // Singular systems: x is filled with NaN and info > 0, without an error status,
 // because the reference's sparse path warns and returns NaNs (SURVEY.md section 0
 // quirk 3).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include "ctx.h"
 #include "spmv_stream.h"
 
@@ -488,9 +492,16 @@ int amg_fcg_solve_ex(nodal_ctx *h, const double *b, bool do_setup, int32_t *info
     const unsigned gv = grid_rows(n, 1), gs = stream::grid_for_rows(n, MAX_PARTIALS);
     NODAL_HIP_TRY(h, hipMemsetAsync(sc, 0, F_COUNT * 8, st));
     NODAL_HIP_TRY(h, hipMemsetAsync(part_zap, 0, MAX_PARTIALS * 8, st));
+    static const bool trace = getenv("NODAL_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     if (do_setup) {
         NODAL_TRY(amg_setup(h, sc + F_FLAG));
         h->amg_levels = amg_num_levels(h);
+        if (trace) {
+            NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+            fprintf(stderr, "[amg] hierarchy %.2f ms\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+        }
         // structurally singular (a floating island): the reference's spsolve returns
         // NaNs; CG would happily return one of the infinitely many solutions
         NODAL_HIP_TRY(h, h->work3.reserve((size_t)n + 256));
@@ -503,6 +514,12 @@ int amg_fcg_solve_ex(nodal_ctx *h, const double *b, bool do_setup, int32_t *info
             *resid = 0.0;
             return -2;  // singular: caller fills NaNs
         }
+    }
+    if (trace) {
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        fprintf(stderr, "[amg] setup + structural check %.2f ms (%d levels)\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(),
+                h->amg_levels);
     }
     fcg_init<<<gv, TB, 0, st>>>(b, x, r, part_rr, sc, n);
     NODAL_HIP_TRY(h, hipGetLastError());
