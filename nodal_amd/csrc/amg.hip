@@ -29,7 +29,10 @@ using grp::grid_for;
 using grp::TB;
 
 constexpr int PASSES = 3;
-constexpr int MATCH_ROUNDS = 5;
+#ifndef NODAL_MATCH_ROUNDS
+#define NODAL_MATCH_ROUNDS 5
+#endif
+constexpr int MATCH_ROUNDS = NODAL_MATCH_ROUNDS;  // propose / confirm rounds per matching pass
 constexpr int COARSEST_MAX = 64;
 constexpr int MAX_LEVELS = 16;
 #ifndef NODAL_OMEGA
