@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun) from the repo root: kernel-trace summaries of the default
-# bench and PMC passes (one counter per pass, no trace domains) for cfg2 / cfg3 / cfg5.
+# bench and PMC passes (one counter per pass, no trace domains) for cfg2 / cfg3 / cfg4 / cfg5.
 # Outputs land under gpurun_out/prof_final/; tools/pmc_summary.py turns the PMC passes into
 # profiles/<round>_pmc_traffic.json afterwards.
 set -e
@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_final
 mkdir -p $O
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/default -o default -- python3 bench.py > $O/bench_default.log 2>&1
-for w in cfg2 cfg3 cfg5; do
+for w in cfg2 cfg3 cfg4 cfg5; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${w}_$c -- python3 bench.py --workload $w --steps 1 --warmup 1 --no-cpu --no-also > $O/pmc_${w}_$c.log 2>&1
   done
