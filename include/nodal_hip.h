@@ -99,10 +99,14 @@ int nodal_export_csr(nodal_handle h, int32_t *indptr, int32_t *indices,
 int nodal_export_dense(nodal_handle h, double *G, double *rhs);
 
 /* ---- solve (replaces Circuit.solve, reference nodal/nodal.py:313-336) ----
- * dense : LU with partial (row) pivoting, as LAPACK dgesv behind
- *         np.linalg.solve (reference nodal/nodal.py:327).  *info > 0: U(info,info)
- *         is exactly zero -> status NODAL_E_SINGULAR (host maps it to LinAlgError /
- *         UnconnectedCircuitError as reference nodal/nodal.py:328-335).
+ * dense : direct solve of the dense system, replacing LAPACK dgesv behind
+ *         np.linalg.solve (reference nodal/nodal.py:327): partial pivoting with dgesv's
+ *         pivot order for small systems, tournament pivoting for large general ones,
+ *         pivot-free block elimination for (presolved) conductance networks -- see
+ *         DESIGN.md section 3.2.  *info > 0: singular matrix (an exactly zero pivot, or
+ *         a floating sub-network of a passive system) -> status NODAL_E_SINGULAR (host
+ *         maps it to LinAlgError / UnconnectedCircuitError as reference
+ *         nodal/nodal.py:328-335).
  * sparse: replaces scipy.sparse.linalg.spsolve (reference nodal/nodal.py:325).
  *         On a singular system x is filled with NaN, *info > 0 and the status is
  *         NODAL_OK: the reference's sparse path warns and returns NaNs, it does
