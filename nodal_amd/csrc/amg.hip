@@ -88,8 +88,10 @@ struct Hierarchy {
     DevBuf coarse_inv;  // dense inverse of the last level
     bool coarse_direct = false;
     int tail = -1;      // first level handled by the LDS tail kernel (-1: none)
-    int kmax = 1;       // K-cycle (two inner FCG steps) down to this coarse level, plain V hand-over below;
-                        // measured: 1 beats 0 and >= 2 on configs 3, 4 and 5 (NODAL_AMG_KMAX to override)
+    int kmax = 1;       // K-cycle (two inner FCG steps) down to this coarse level, plain V hand-over below.
+                        // Set per hierarchy to tail - 2: every level gets the K-cycle except the one right
+                        // above the LDS tail (which runs its own two inner steps).  1e6 nodes: 1, 4e6: 2
+                        // (there 1 needs 108 iterations / 125 ms, 2: 52 / 75 ms).  NODAL_AMG_KMAX overrides.
     int passes0 = PASSES, passes1 = PASSES;  // pairwise matching passes at level 0 / below
     int sweeps0 = 2;    // Jacobi sweeps before / after the coarse correction at level 0 (NODAL_AMG_SWEEPS0=1: one)
     TailDesc tdesc;
@@ -898,7 +900,6 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
         h->amg = H;
     }
     H->begin_setup();
-    if (const char *e = getenv("NODAL_AMG_KMAX")) H->kmax = atoi(e);
     if (const char *e = getenv("NODAL_AMG_PASSES0")) H->passes0 = atoi(e);
     if (const char *e = getenv("NODAL_AMG_SWEEPS0")) H->sweeps0 = atoi(e);
     if (const char *e = getenv("NODAL_AMG_PASSES1")) H->passes1 = atoi(e);
@@ -974,6 +975,8 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
         NODAL_HIP_TRY(h, hipGetLastError());
         NODAL_TRY(build_tail(h, H));
     }
+    if (const char *e = getenv("NODAL_AMG_KMAX")) H->kmax = atoi(e);
+    else H->kmax = H->tail > 0 ? (H->tail - 2 > 1 ? H->tail - 2 : 1) : 1 << 20;
     return NODAL_OK;
 }
 
