@@ -40,6 +40,7 @@ constexpr int MAX_LEVELS = 16;
 #endif
 constexpr double OMEGA = NODAL_OMEGA;  // damped-Jacobi weight (0.7 / 0.85 / 1.0 measured: see DESIGN.md)
 constexpr int DOT_BLOCKS = 128;  // partial sums per dot product
+constexpr int64_t K_MIN_ROWS = 32768;  // coarse levels at least this large get the K-cycle
 constexpr int64_t SPLIT_PROLONG_MIN = 200000;  // levels this large prolong in a separate pass
 
 struct Csr {
@@ -89,9 +90,9 @@ struct Hierarchy {
     bool coarse_direct = false;
     int tail = -1;      // first level handled by the LDS tail kernel (-1: none)
     int kmax = 1;       // K-cycle (two inner FCG steps) down to this coarse level, plain V hand-over below.
-                        // Set per hierarchy to tail - 2: every level gets the K-cycle except the one right
-                        // above the LDS tail (which runs its own two inner steps).  1e6 nodes: 1, 4e6: 2
-                        // (there 1 needs 108 iterations / 125 ms, 2: 52 / 75 ms).  NODAL_AMG_KMAX overrides.
+                        // Set per hierarchy: the last coarse level with >= K_MIN_ROWS rows (at least 1).
+                        // 1e6 nodes: 1, 4e6: 2 (there 1 needs 108 iterations / 125 ms, 2: 52 / 75 ms).
+                        // NODAL_AMG_KMAX overrides.
     int passes0 = PASSES, passes1 = PASSES;  // pairwise matching passes at level 0 / below
     int sweeps0 = 2;    // Jacobi sweeps before / after the coarse correction at level 0 (NODAL_AMG_SWEEPS0=1: one)
     TailDesc tdesc;
@@ -976,7 +977,14 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
         NODAL_TRY(build_tail(h, H));
     }
     if (const char *e = getenv("NODAL_AMG_KMAX")) H->kmax = atoi(e);
-    else H->kmax = H->tail > 0 ? (H->tail - 2 > 1 ? H->tail - 2 : 1) : 1 << 20;
+    else {
+        // K-cycle on the coarse levels that are still large (>= K_MIN_ROWS rows), plain V
+        // hand-over below, where a V-cycle over a few thousand rows (and the tail's own two
+        // inner steps) is accurate enough and every K level would double the launches
+        H->kmax = 1;
+        for (int l = 2; l < (int)H->levels.size(); ++l)
+            if (H->levels[l]->A.n >= K_MIN_ROWS) H->kmax = l;
+    }
     return NODAL_OK;
 }
 
