@@ -239,3 +239,26 @@ def test_dense_dependent_sources_take_presolve_and_optimistic_elimination(monkey
     xo, _ = oracle.solve(G.tocsr(), A, True)
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
     h.close()
+
+
+@pytest.mark.parametrize("side", [9, 12, 25, 40, 64])
+def test_multigrid_path_on_small_networks(side):
+    """Small passive networks take the direct solve by default; the multigrid-preconditioned
+    CG is still exercised on them explicitly (tiny hierarchies, levels that all fit the LDS
+    tail, the Jacobi-CG fallback below the multigrid's minimum size)."""
+    from nodal_amd import generators as gen
+    from oracle import nodal_oracle as oracle
+    import random
+    rng = random.Random(side)
+    vals = [10.0 ** rng.uniform(-1, 1) for _ in range(gen.grid_resistor_count(side))]
+    table = gen.grid_table(side, vals)
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    x, info, iters, relres = h.solve_sparse(method=_ffi.SPARSE_PCG)
+    assert info == 0 and iters > 0 and h.residual() <= 1e-12
+    G, A = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(G.tocsr(), A, True)
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    h.close()
