@@ -525,7 +525,8 @@ int amg_fcg_solve_ex(nodal_ctx *h, const double *b, bool do_setup, int32_t *info
     NODAL_HIP_TRY(h, hipGetLastError());
 
     const double tol = 1e-13;
-    const int64_t maxit = 500;
+    // chain-like networks need ~1000 iterations; beyond the cap: Jacobi-CG fallback
+    const int64_t maxit = getenv("NODAL_FCG_MAXIT") ? atoll(getenv("NODAL_FCG_MAXIT")) : 5000;
     const int check = 4;
     double hs[F_COUNT];
     int64_t it = 0;
