@@ -94,6 +94,7 @@ struct Hierarchy {
                         // 1e6 nodes: 1, 4e6: 2 (there 1 needs 108 iterations / 125 ms, 2: 52 / 75 ms).
                         // NODAL_AMG_KMAX overrides.
     int passes0 = PASSES, passes1 = PASSES;  // pairwise matching passes at level 0 / below
+    bool passes_forced = false;              // NODAL_AMG_PASSES0/1 given: no per-level adaptation
     int sweeps0 = 2;    // Jacobi sweeps before / after the coarse correction at level 0 (NODAL_AMG_SWEEPS0=1: one)
     TailDesc tdesc;
     DevBuf tail_image;
@@ -901,9 +902,9 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
         h->amg = H;
     }
     H->begin_setup();
-    if (const char *e = getenv("NODAL_AMG_PASSES0")) H->passes0 = atoi(e);
+    if (const char *e = getenv("NODAL_AMG_PASSES0")) { H->passes0 = atoi(e); H->passes_forced = true; }
     if (const char *e = getenv("NODAL_AMG_SWEEPS0")) H->sweeps0 = atoi(e);
-    if (const char *e = getenv("NODAL_AMG_PASSES1")) H->passes1 = atoi(e);
+    if (const char *e = getenv("NODAL_AMG_PASSES1")) { H->passes1 = atoi(e); H->passes_forced = true; }
     hipStream_t st = h->stream;
 
     Level *l0 = H->take(0);
@@ -929,7 +930,11 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
         DevBuf &pass_map = H->pass_map;
         bool stalled = false;
         Level *coarse = H->take(H->levels.size());
-        const int passes = (int)H->levels.size() == 1 ? H->passes0 : H->passes1;
+        // aggregates of ~8 (three pairwise passes) suit 2-D-connected networks; along a wire
+        // (fewer than 4 entries per row) piecewise constants over 8 nodes correct too little:
+        // two passes there (ladder of 1e5 sections: 460 instead of 1140 iterations)
+        int passes = (int)H->levels.size() == 1 ? H->passes0 : H->passes1;
+        if (!H->passes_forced && fine->A.nnz < 4 * n) passes = passes < 2 ? passes : 2;
         for (int p = 0; p < passes; ++p) {
             NODAL_HIP_TRY(h, pass_map.reserve((size_t)cur.n * 4 + 8));
             int32_t *map = p == 0 ? agg : pass_map.as<int32_t>();
