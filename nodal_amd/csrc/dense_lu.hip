@@ -6,28 +6,29 @@
 // columns: column n is the right-hand side, so the row interchanges and the
 // forward substitution L y = P b happen as part of the blocked factorisation.
 //
-// Two regimes:
-//   n <= GEPP_MAX  classic partial pivoting, one pivot search per column with the
-//                  LAPACK idamax rule (first row of maximal |a|): the same pivot
-//                  sequence as dgetrf, for the small circuits whose printed digits
-//                  users compare with the reference.
-//   n >  GEPP_MAX  two-level blocking for the matrix cores.  Outer panels of W = 256
-//                  columns feed a K = 256 trailing update (gemm_f64.hip; 32 flop per
-//                  byte of C traffic, MFMA-bound).  Inside an outer panel, blocks of
-//                  32 columns are pivoted by a tournament (communication-avoiding
-//                  LU, Grigori/Demmel/Xiang): every 256-row slab elects 32 candidate
-//                  rows by partial pivoting on a register-resident copy, candidates
-//                  are merged 8 slabs at a time, and the winners' LU is the block's
-//                  L11/U11.  That replaces 2 launches per COLUMN by ~7 per 32 columns;
-//                  its stability is that of partial pivoting in practice and the
-//                  solution is checked by the scaled residual.
-//   passive        resistors + current sources only, all R > 0 (B == 0): G is column
-//   networks       diagonally dominant, and on such matrices partial pivoting never
-//   (n > GEPP_MAX) interchanges -- the diagonal is a maximal entry of its column, idamax
-//                  resolves ties to the first row, which IS the diagonal, and Schur
-//                  complements of column diagonally dominant matrices stay so.  The
-//                  pivot search is skipped: same pivot sequence as dgetrf, none of its
-//                  latency.  (BASELINE.json configs 2 and 4.)
+// Dispatch (dense_factor_solve_multi):
+//   passive, n > 256   conductance networks (resistors + current sources, all R > 0, B == 0) are
+//                      symmetric positive definite: block elimination with inverted diagonal
+//                      blocks, no pivoting -- block_elim.hip.  Systems with voltage-defined
+//                      branches are first reduced to such a network by presolve.hip (api.hip).
+//   n <= GEPP_MAX      classic partial pivoting, one pivot search per column with the
+//                      LAPACK idamax rule (first row of maximal |a|): the same pivot
+//                      sequence as dgetrf, for the small circuits whose printed digits
+//                      users compare with the reference.
+//   n >  GEPP_MAX      two-level blocking for the matrix cores.  Outer panels of W = 256
+//                      columns feed a K = 256 trailing update (gemm_f64.hip).  Inside an outer
+//                      panel, blocks of 32 columns are pivoted by a tournament
+//                      (communication-avoiding LU, Grigori/Demmel/Xiang): every 256-row slab
+//                      elects 32 candidate rows by partial pivoting on a register-resident
+//                      copy, candidates are merged 8 slabs at a time, and the winners' LU is
+//                      the block's L11/U11.  That replaces 2 launches per COLUMN by ~7 per 32
+//                      columns; its stability is that of partial pivoting in practice and the
+//                      solution is checked by the scaled residual.
+//   NODAL_DENSE_BLOCKINV=0  passive networks through a no-pivot LU with the same blocking (on
+//                      column diagonally dominant matrices partial pivoting never
+//                      interchanges: the diagonal is a maximal entry of its column, idamax
+//                      resolves ties to the first row, which IS the diagonal, and Schur
+//                      complements stay dominant).  Kept as a cross-check of block_elim.hip.
 // An exactly zero pivot sets info = column + 1 (LAPACK convention).
 #include <cstdlib>
 
