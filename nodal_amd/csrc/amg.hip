@@ -10,16 +10,21 @@
 //     to its strongest free neighbour, (weight, symmetric edge hash) breaks ties the
 //     same way from both ends, mutual proposals are matched; leftovers join the
 //     aggregate of their strongest matched neighbour.  PASSES passes per level (the
-//     graph of pairs is matched again) give aggregates of ~10 nodes.
+//     graph of pairs is matched again) give aggregates of ~10 nodes; chain-like levels
+//     (fewer than 4 entries per row) use two passes.
 //   * coarse matrices A_c = P^T A P (P piecewise constant) are formed by the same
 //     grouping pipeline as the stamping (group.h): tuples (agg[row], agg[col]) of the
 //     fine entries are bucketed, sorted and summed in a fixed order.
 //   * coarsening stops at <= COARSEST_MAX nodes; that matrix is inverted densely.
+//   * level objects and scratch are kept across setups (a solve re-runs the setup for new
+//     matrix values; re-allocating ~80 buffers cost more than the setup kernels).
 // Cycle: unsmoothed aggregation needs the K-cycle for mesh-independent convergence
-// (V-cycle iteration counts grow with the number of levels): at every level the
-// coarse problem is solved by two steps of flexible CG preconditioned by the next
-// level's cycle.  One damped-Jacobi pre- and post-smoothing step, fused with the
-// residual / prolongation so a level visit costs three kernels.
+// (V-cycle iteration counts grow with the number of levels): on every coarse level of at
+// least K_MIN_ROWS rows the coarse problem is solved by two steps of flexible CG
+// preconditioned by the next level's cycle; smaller levels get a plain V hand-over down to
+// the LDS-resident tail, which runs its own two inner steps.  Damped-Jacobi pre- and
+// post-smoothing (two sweeps at level 0, one below), fused with the residual /
+// prolongation so a level visit costs three kernels.
 #include "group.h"
 #include "spmv_stream.h"
 

@@ -1,13 +1,13 @@
 // Sparse path of Circuit.solve (replaces scipy.sparse.linalg.spsolve,
 // reference nodal/nodal.py:325) on the CSR matrix built by stamp.hip.
 //
-//   * B == 0 (resistors and current sources only): G is a symmetric weighted
-//     graph Laplacian plus ground conductances -> preconditioned conjugate
-//     gradients in fp64.  Three kernels per iteration, no atomics, no host
-//     round trip: dot products are block partials that the NEXT kernel's
-//     prologue reduces (every workgroup redundantly, in a fixed order, so the
-//     result is deterministic).  The SpMV gives each row to a sub-wave group of
-//     LPR lanes and reduces with wavefront shuffles.
+//   * B == 0 (resistors and current sources only), more than 4096 unknowns: G is a
+//     symmetric weighted graph Laplacian plus ground conductances -> flexible conjugate
+//     gradients in fp64 preconditioned by the aggregation multigrid of amg.hip (Jacobi-CG
+//     as the fallback).  No atomics, no host round trip per iteration: dot products are
+//     block partials that the NEXT kernel's prologue reduces (every workgroup redundantly,
+//     in a fixed order, so the result is deterministic).  Row kernels are CSR-stream
+//     (spmv_stream.h).  Smaller passive systems are solved directly (block_elim.hip).
 //   * otherwise (branch equations present: zero diagonals, non-symmetric): small
 //     systems are scattered into a dense column-major panel and factorised by
 //     the dense LU (dense_lu.hip); large ones go to the block-preconditioned flexible
