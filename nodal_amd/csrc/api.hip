@@ -107,13 +107,18 @@ void nodal_free_buffers(nodal_ctx *h) {
         delete h->reduced;
         h->reduced = nullptr;
     }
+    if (h->lowdeg) {
+        nodal_free_buffers(h->lowdeg);
+        delete h->lowdeg;
+        h->lowdeg = nullptr;
+    }
     DevBuf *bufs[] = {&h->type, &h->value, &h->a, &h->b, &h->c, &h->d, &h->drv, &h->k,
                       &h->values_batch, &h->indptr, &h->indices, &h->rowidx, &h->cptr,
                       &h->contrib, &h->rhs_row, &h->rhs_cptr, &h->rhs_contrib, &h->diag_pos,
                       &h->data, &h->rhs, &h->status, &h->x, &h->dense, &h->piv, &h->work,
                       &h->work2, &h->work3, &h->solver, &h->krylov, &h->gn_indptr, &h->gn_indices,
                       &h->gn_rowidx, &h->gn_data, &h->gn_diag, &h->schur, &h->ps_buf, &h->ps_newidx,
-                      &h->ps_hits};
+                      &h->ps_hits, &h->grounded, &h->ld_newidx, &h->ld_work};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
     h->evpool.clear();

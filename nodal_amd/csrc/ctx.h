@@ -71,6 +71,13 @@ struct nodal_ctx {
     bool use_presolve = true;
     bool use_graphs = false;       // hipGraph replay of the FCG iteration: measured no gain (kernels are not host-bound)
     DevBuf ps_buf, ps_newidx, ps_hits;
+    // exact elimination of nodes with <= 2 neighbours (lowdeg.hip): the reduced network is a
+    // matrix-only context (no component table) that inherits the grounded-node flags
+    nodal_ctx *lowdeg = nullptr;
+    bool csr_only = false;
+    DevBuf grounded;        // u8[n]
+    DevBuf ld_newidx, ld_work;
+    int ld_rounds = 0, ld_slow_rounds = 0;  // rounds that led to this context (all / those removing < 1/32)
 
     // ---- symbolic assembly results ----
     bool have_symbolic = false;
@@ -206,6 +213,11 @@ int csr_has_floating_component(nodal_ctx *h, const uint8_t *grounded, int32_t *f
 
 // u8[n] flags: 1 where a resistor connects the node to ground (stamp.hip)
 int stamp_grounded_flags(nodal_ctx *h, uint8_t *flags_dev);
+// the same for any context, matrix-only ones included (lowdeg.hip)
+int grounded_flags(nodal_ctx *h, uint8_t *flags_dev);
+int csr_to_dense(nodal_ctx *h, double *G_dev, int64_t ld);
+int csr_small_floating_check(nodal_ctx *h, int32_t *floating);
+int lowdeg_solve(nodal_ctx *h, int min_share, bool *done, int32_t *info, int32_t *iters, double *resid);
 
 // ---- sparse solvers (sparse_*.hip) ----
 int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, double *resid);

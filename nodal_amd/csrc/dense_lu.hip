@@ -731,7 +731,7 @@ int dense_factor_solve(nodal_ctx *h, int32_t *info) {
         if (!(scaled <= 1e-9)) {
             int32_t floating = 0;
             NODAL_HIP_TRY(h, h->work3.reserve((size_t)h->n + 256));
-            NODAL_TRY(stamp_grounded_flags(h, h->work3.as<uint8_t>()));
+            NODAL_TRY(grounded_flags(h, h->work3.as<uint8_t>()));
             NODAL_TRY(csr_has_floating_component(h, h->work3.as<uint8_t>(), &floating));
             if (floating) *info = (int32_t)h->n;
         }

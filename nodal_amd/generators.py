@@ -204,3 +204,80 @@ def cfg5_table(N, seed=5):
     return _table(types, vals, cat(ga, a, np.int64), cat(gb, b, np.int64),
                   cat(none, cc, np.int64), cat(none, dd, np.int64), cat(none, drv, np.int64),
                   last)
+
+
+# ---------------------------------------------------------------------------
+# Chain-like passive networks (tests and tools/topologies.py): the cases the sparse path
+# solves by exact elimination of low-degree nodes (csrc/lowdeg.hip) rather than by multigrid.
+# ---------------------------------------------------------------------------
+
+def passive_table(a, b, values, source_node, ground):
+    """Resistors a[i]-b[i] plus a 1 A source from `source_node` to `ground` (largest id)."""
+    import numpy as np
+    n = len(a)
+    types = np.zeros(n + 1, dtype=np.uint8)
+    types[-1] = 1
+    vals = np.append(np.asarray(values, dtype=np.float64), 1.0)
+    a = np.append(np.asarray(a, dtype=np.int64), source_node)
+    b = np.append(np.asarray(b, dtype=np.int64), ground)
+    none = np.full(n + 1, -1, dtype=np.int64)
+    return _table(types, vals, a, b, none, none, none, ground)
+
+
+def ladder_table(n, seed=1, island=0):
+    """n resistors in series, a shunt to ground at every tenth node; `island` > 0 adds a chain
+    of that many nodes that touches nothing else (a floating sub-network: singular)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    ground = n + 1 + island
+    k = np.arange(n, dtype=np.int64)
+    taps = np.arange(0, n + 1, 10, dtype=np.int64)
+    a = [k, taps]
+    b = [k + 1, np.full(len(taps), ground, dtype=np.int64)]
+    vals = [rng.uniform(0.5, 2.0, n), rng.uniform(0.5e4, 2e4, len(taps))]
+    if island > 1:
+        isl = np.arange(n + 1, n + island, dtype=np.int64)
+        a.append(isl)
+        b.append(isl + 1)
+        vals.append(rng.uniform(0.5, 2.0, len(isl)))
+    return passive_table(np.concatenate(a), np.concatenate(b), np.concatenate(vals), n, ground)
+
+
+def chain_table(n, seed=1):
+    """n resistors in series, grounded at one end only (condition number ~ n^2)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    ground = n + 1
+    k = np.arange(n, dtype=np.int64)
+    return passive_table(np.append(k, 0), np.append(k + 1, ground), rng.uniform(0.5, 2.0, n + 1), n, ground)
+
+
+def binary_tree_table(n, seed=1):
+    """Complete binary tree of n nodes, the root tied to ground, the source at the last leaf."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    child = np.arange(1, n, dtype=np.int64)
+    return passive_table(np.append((child - 1) // 2, 0), np.append(child, n), rng.uniform(0.5, 2.0, n),
+                         n - 1, n)
+
+
+def grid_with_wires_table(side, wire, seed=1):
+    """side x side grid; a wire of `wire` resistors hangs off every node of the top row and
+    ends in a resistor to ground."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    ga, gb, _ = _grid_arrays(side)
+    nn = side * side
+    a, b = [ga], [gb]
+    nxt = nn
+    for c in range(side):
+        ids = np.arange(nxt, nxt + wire, dtype=np.int64)
+        a.append(np.append(c, ids[:-1]))
+        b.append(ids)
+        nxt += wire
+    ground = nxt
+    ends = np.arange(nn + wire - 1, nxt, wire, dtype=np.int64)
+    a.append(ends)
+    b.append(np.full(len(ends), ground, dtype=np.int64))
+    a, b = np.concatenate(a), np.concatenate(b)
+    return passive_table(a, b, rng.uniform(0.5, 2.0, len(a)), nn - 1, ground)

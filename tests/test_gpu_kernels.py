@@ -262,3 +262,64 @@ def test_multigrid_path_on_small_networks(side):
     xo, _ = oracle.solve(G.tocsr(), A, True)
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
     h.close()
+
+
+def _chainlike_table(kind):
+    from nodal_amd import generators as gen
+    return {"ladder": lambda: gen.ladder_table(30000),
+            "chain": lambda: gen.chain_table(6000),
+            "tree": lambda: gen.binary_tree_table(50000),
+            "wires": lambda: gen.grid_with_wires_table(40, 120)}[kind]()
+
+
+@pytest.mark.parametrize("kind", ["ladder", "chain", "tree", "wires"])
+def test_sparse_low_degree_elimination(kind, monkeypatch, capfd):
+    """Ladders, chains, trees and grids with dangling wires: the sparse passive path removes
+    the nodes with one or two neighbours exactly, round by round (csrc/lowdeg.hip), and hands
+    what is left to the direct solve or the multigrid.  Same answer as SuperLU and as the
+    multigrid on the unreduced network."""
+    from oracle import nodal_oracle as oracle
+    table = _chainlike_table(kind)
+    G, A = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(G.tocsr(), A, True)
+    scale = np.abs(xo).max()
+    monkeypatch.setenv("NODAL_TRACE", "1")
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    capfd.readouterr()
+    x, info, iters, relres = h.solve_sparse()
+    assert "[lowdeg]" in capfd.readouterr().err
+    assert info == 0 and h.residual() <= 1e-12
+    assert np.abs(x - xo).max() <= 1e-9 * scale
+    monkeypatch.setenv("NODAL_LOWDEG", "0")
+    x1, info1, iters1, _ = h.solve_sparse()
+    assert "[lowdeg]" not in capfd.readouterr().err
+    assert info1 == 0 and iters1 > 0
+    assert np.abs(x1 - xo).max() <= 1e-9 * scale
+    h.close()
+
+
+@pytest.mark.parametrize("island", [2, 3, 700])
+def test_sparse_low_degree_elimination_reports_floating_chain(island):
+    """A chain that touches nothing else collapses to a single node without neighbours and
+    without a path to ground: singular, like the structural test of the multigrid path says."""
+    from nodal_amd import generators as gen
+    table = gen.ladder_table(20000, island=island)
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    x, info, iters, relres = h.solve_sparse()
+    assert info > 0 and np.isnan(x).all()
+    h.close()
+    # regular without the island
+    table = gen.ladder_table(20000)
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    x, info, iters, relres = h.solve_sparse()
+    assert info == 0 and np.isfinite(x).all()
+    h.close()

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Sparse passive path on topologies other than the benchmark grids: iterations, time and the
+distance from the CPU oracle (scipy SuperLU) for ladders, trees, grids with dangling wires,
+high-contrast grids.  Run on the GPU box:
+
+    python tools/topologies.py [name ...]          # NODAL_LOWDEG=0 switches the elimination off
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from nodal_amd import _ffi  # noqa: E402
+from nodal_amd import generators as gen  # noqa: E402
+
+
+def contrast_grid(side, decades, seed=1):
+    rng = np.random.default_rng(seed)
+    vals = 10.0 ** rng.uniform(-decades / 2, decades / 2, gen.grid_resistor_count(side))
+    return gen.grid_table(side, vals)
+
+
+CASES = {
+    "ladder5e3": lambda: gen.ladder_table(5000),
+    "ladder2e4": lambda: gen.ladder_table(20000),
+    "ladder1e5": lambda: gen.ladder_table(100000),
+    "ladder1e6": lambda: gen.ladder_table(1000000),
+    "chain1e5": lambda: gen.chain_table(100000),
+    "tree1e5": lambda: gen.binary_tree_table(100000),
+    "tree1e6": lambda: gen.binary_tree_table(1000000),
+    "wires300x200": lambda: gen.grid_with_wires_table(300, 200),
+    "grid300": lambda: gen.grid_table(300),
+    "contrast300d4": lambda: contrast_grid(300, 4),
+}
+
+
+def run(name, oracle_check=True):
+    table = CASES[name]()
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        x, info, iters, relres = h.solve_sparse()
+        dt = (time.perf_counter() - t0) * 1e3
+        best = dt if best is None else min(best, dt)
+    res = h.residual()
+    err = float("nan")
+    if oracle_check:
+        from oracle import nodal_oracle as oracle
+        G, A = oracle.assemble_fast(table)
+        xo, _ = oracle.solve(G.tocsr(), A, True)
+        err = float(np.abs(x - xo).max() / np.abs(xo).max())
+    print(f"{name:16s} n={len(x):8d} info={info} iters={iters:5d} {best:8.2f} ms  residual {res:.1e}  "
+          f"vs SuperLU {err:.1e}", flush=True)
+    h.close()
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CASES)
+    for nm in names:
+        run(nm)
