@@ -711,7 +711,7 @@ int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, do
         // (208 -> 52 iterations, the count of the bare grid).  Before a direct solve only
         // a round that removes 1/8 of the unknowns is cheaper than solving them.
         bool done = false;
-        NODAL_TRY(lowdeg_solve(h, n > densify_max ? 256 : 8, &done, info, iters, resid));
+        NODAL_TRY(lowdeg_solve(h, n > densify_max ? 512 : 8, &done, info, iters, resid));
         if (done) {
             if (*info > 0) NODAL_TRY(dense_fill_nan(h, h->x.as<double>(), n));
             h->have_x = true;
