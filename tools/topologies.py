@@ -15,6 +15,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from nodal_amd import _ffi  # noqa: E402
 from nodal_amd import generators as gen  # noqa: E402
 
+if os.environ.get("NODAL_LIB"):  # a library built with other compile-time constants (experiments)
+    _ffi.LIB_PATH = os.path.abspath(os.environ["NODAL_LIB"])
+
 
 def contrast_grid(side, decades, seed=1):
     rng = np.random.default_rng(seed)
@@ -32,7 +35,9 @@ CASES = {
     "tree1e6": lambda: gen.binary_tree_table(1000000),
     "wires300x200": lambda: gen.grid_with_wires_table(300, 200),
     "grid300": lambda: gen.grid_table(300),
+    "contrast300d2": lambda: contrast_grid(300, 2),
     "contrast300d4": lambda: contrast_grid(300, 4),
+    "contrast300d6": lambda: contrast_grid(300, 6),
 }
 
 
