@@ -34,7 +34,7 @@ typedef enum {
     NODAL_E_ZERO_RESISTANCE = 3,  /* -> ValueError   (reference nodal/models.py:14-17) */
     NODAL_E_STAMP_COLLISION = 4,  /* -> AssertionError (reference nodal/models.py:43,47,
                                       66,70,168,172,176,193,197: `assert G[i, j] == 0`) */
-    NODAL_E_SINGULAR = 5,         /* exact zero pivot / non-finite solution          */
+    NODAL_E_SINGULAR = 5,         /* zero pivot / floating sub-network / non-finite x */
     NODAL_E_NOMEM = 6,
     NODAL_E_UNSUPPORTED = 7
 } nodal_status;

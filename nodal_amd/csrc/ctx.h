@@ -190,6 +190,7 @@ static inline int64_t dense_lda(int64_t n) {
     return l;
 }
 int dense_factor_solve(nodal_ctx *h, int32_t *info);
+int dense_fill_nan(nodal_ctx *h, double *x, int64_t n);
 // block elimination with inverted diagonal blocks (block_elim.hip): factor + back substitution
 int dense_block_elimination(nodal_ctx *h, double *A, int64_t n, int64_t lda, int32_t nrhs, double *xout,
                             int64_t ldx, int32_t *dinfo);

@@ -323,3 +323,35 @@ def test_sparse_low_degree_elimination_reports_floating_chain(island):
     x, info, iters, relres = h.solve_sparse()
     assert info == 0 and np.isfinite(x).all()
     h.close()
+
+
+def test_dense_entry_point_eliminates_low_degree_nodes_too(monkeypatch, capfd):
+    """`Circuit(netlist)` is dense by default: a passive ladder is still reduced by the exact
+    elimination before anything is formed densely, with the same answer as LAPACK on the full
+    matrix; a floating chain is reported singular."""
+    from nodal_amd import generators as gen
+    from oracle import nodal_oracle as oracle
+    table = gen.ladder_table(3000)
+    G, A = oracle.assemble_fast(table)
+    xo = np.linalg.solve(G.toarray(), A)
+    monkeypatch.setenv("NODAL_TRACE", "1")
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    capfd.readouterr()
+    x, info = h.solve_dense()
+    assert "[lowdeg]" in capfd.readouterr().err
+    assert info == 0 and np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    monkeypatch.setenv("NODAL_LOWDEG", "0")
+    x1, info1 = h.solve_dense()
+    assert info1 == 0 and np.abs(x1 - xo).max() <= 1e-9 * np.abs(xo).max()
+    h.close()
+    monkeypatch.delenv("NODAL_LOWDEG")
+    h = _ffi.Handle(0)
+    h.upload(gen.ladder_table(3000, island=40))
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    x, info = h.solve_dense()
+    assert info > 0
+    h.close()
