@@ -995,6 +995,11 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
         for (int l = 2; l < (int)H->levels.size(); ++l)
             if (H->levels[l]->A.n >= K_MIN_ROWS) H->kmax = l;
     }
+    if (getenv("NODAL_TRACE")) {
+        fprintf(stderr, "[amg] levels (rows/entries):");
+        for (const Level *l : H->levels) fprintf(stderr, " %lld/%lld", (long long)l->A.n, (long long)l->A.nnz);
+        fprintf(stderr, "  kmax %d tail %d\n", H->kmax, H->tail);
+    }
     return NODAL_OK;
 }
 
