@@ -492,3 +492,23 @@ def test_cli_scripts(tmp_path, capsys):
     with pytest.raises(SystemExit) as e:
         solver.main([str(path)])
     assert e.value.code == 1
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_ladder_through_the_front_end(sparse):
+    """A resistor ladder (series resistors, a shunt to ground at every fifth node) through
+    Netlist / Circuit / solve: both entry points reduce it by exact elimination of the
+    low-degree nodes (csrc/lowdeg.hip) and agree with the oracle's LAPACK / SuperLU answer."""
+    rng = random.Random(11)
+    sections = 2500
+    rows = []
+    for k in range(sections):
+        rows.append([f"rs{k}", "R", repr(rng.uniform(0.5, 2.0)), f"n{k}", f"n{k + 1}"])
+        if k % 5 == 0:
+            rows.append([f"rp{k}", "R", repr(rng.uniform(50.0, 200.0)), f"n{k}", "g"])
+    rows.append(["a1", "A", "0.25", f"n{sections}", "g"])
+    nl = n.Netlist.from_rows(rows)
+    x = n.Circuit(nl, sparse=sparse).solve().result
+    Go, Ao, _ = oracle.build_model(nl, sparse)
+    xo, _ = oracle.solve(Go, Ao, sparse)
+    assert normwise(x, xo) <= TOL
