@@ -355,3 +355,40 @@ def test_dense_entry_point_eliminates_low_degree_nodes_too(monkeypatch, capfd):
     x, info = h.solve_dense()
     assert info > 0
     h.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_sparse_low_degree_elimination_on_random_networks(seed):
+    """Random trees with a few extra edges (cycles), subdivided edges (wires), parallel
+    resistors and several ties to ground: every mix of one- and two-neighbour nodes, fill that
+    lands on existing entries, rounds that stop early.  Against SuperLU."""
+    from nodal_amd import generators as gen
+    from oracle import nodal_oracle as oracle
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(1500, 12000))
+    parent = np.array([rng.integers(max(0, i - 1 - int(rng.integers(0, 50))), i) for i in range(1, n)],
+                      dtype=np.int64)
+    a = [parent, ]
+    b = [np.arange(1, n, dtype=np.int64)]
+    extra = int(n * rng.uniform(0.0, 0.3))
+    ea, eb = rng.integers(0, n, extra), rng.integers(0, n, extra)
+    keep = ea != eb
+    a.append(ea[keep]); b.append(eb[keep])
+    dup = rng.integers(0, n - 1, n // 20)          # parallel resistors on tree edges
+    a.append(parent[dup]); b.append(dup + 1)
+    ground = n
+    ties = rng.integers(0, n, max(1, n // 200))
+    a.append(ties); b.append(np.full(len(ties), ground, dtype=np.int64))
+    a, b = np.concatenate(a), np.concatenate(b)
+    vals = 10.0 ** rng.uniform(-1.5, 1.5, len(a))
+    table = gen.passive_table(a, b, vals, int(rng.integers(0, n)), ground)
+    G, A = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(G.tocsr(), A, True)
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    x, info, iters, relres = h.solve_sparse()
+    assert info == 0 and h.residual() <= 1e-12
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    h.close()
