@@ -386,7 +386,19 @@ int nodal_solve_pairs(nodal_handle h, int32_t dense, int32_t npairs, const int32
         for (int32_t q = 0; q < npairs; ++q) resistance[q] = 0.0;
         return NODAL_OK;
     }
-    if (dense || n <= 64 || !(h->B == 0 && h->passive_network)) {
+    bool reduced = false;
+    if (n > 1024 && h->B == 0 && h->passive_network && !h->force_pivoting) {
+        // chains / ladders / trees: exact elimination of the low-degree nodes per pair (lowdeg.hip)
+        NODAL_TRY(lowdeg_solve_pairs(h, npairs, ia, ib, res, &reduced, info));
+        if (reduced && *info > 0) {
+            if (dense) return nodal_fail(h, NODAL_E_SINGULAR, "singular matrix: a floating sub-network");
+            for (int32_t q = 0; q < npairs; ++q) resistance[q] = __builtin_nan("");
+            return NODAL_OK;
+        }
+    }
+    if (reduced) {
+        // results are in `res`
+    } else if (dense || n <= 64 || !(h->B == 0 && h->passive_network)) {
         // one LU for up to CHUNK pairs: they are extra right-hand-side columns
         const int32_t CHUNK = 512;
         for (int32_t q0 = 0; q0 < npairs; q0 += CHUNK) {

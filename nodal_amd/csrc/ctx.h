@@ -199,6 +199,8 @@ int dense_prepare(nodal_ctx *h);
 int dense_prepare_pairs(nodal_ctx *h, int32_t nrhs, const int32_t *ia, const int32_t *ib);
 int sparse_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const int32_t *ib,
                        double *res_dev, int32_t *info);
+int lowdeg_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const int32_t *ib, double *res_dev,
+                       bool *done, int32_t *info);
 
 // ---- aggregation multigrid preconditioner (amg.hip) ----
 int amg_setup(nodal_ctx *h, double *flag_dev);

@@ -17,6 +17,7 @@
 // because the reference's sparse path warns and returns NaNs (SURVEY.md section 0
 // quirk 3).
 #include <chrono>
+#include <utility>
 #include <cstdio>
 #include <cstdlib>
 
@@ -677,6 +678,42 @@ int sparse_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const in
         pair_read<<<1, 1, 0, st>>>(h->x.as<double>(), ia[q], ib[q], res_dev + q);
     }
     NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
+}
+
+// Pair sweep on a passive network made of chains / ladders / trees: every pair goes through the
+// exact elimination of lowdeg.hip (the probe pair only changes the right-hand side, but a
+// reduction costs a few ms where the multigrid needs hundreds of iterations on such networks).
+// *done = false: the network has too few low-degree nodes, nothing was computed.
+int lowdeg_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const int32_t *ib, double *res_dev,
+                       bool *done, int32_t *info) {
+    *done = false;
+    *info = 0;
+    const int64_t n = h->n;
+    hipStream_t st = h->stream;
+    NODAL_HIP_TRY(h, h->ps_buf.reserve((size_t)n * 8 + 64));
+    for (int32_t q = 0; q < npairs; ++q) {
+        NODAL_HIP_TRY(h, hipMemsetAsync(h->ps_buf.p, 0, (size_t)n * 8, st));
+        pair_rhs<<<1, 1, 0, st>>>(h->ps_buf.as<double>(), ia[q], ib[q]);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        bool d = false;
+        int32_t inf = 0, it = 0;
+        double rs = 0.0;
+        std::swap(h->rhs, h->ps_buf);  // the elimination reads the context's right-hand side
+        const int s = lowdeg_solve(h, n > 4096 ? 512 : 8, &d, &inf, &it, &rs);
+        std::swap(h->rhs, h->ps_buf);
+        if (s != NODAL_OK) return s;
+        if (!d) return q == 0 ? NODAL_OK : nodal_fail(h, NODAL_E_INVALID, "pair sweep: elimination not repeatable");
+        if (inf > 0) {  // floating sub-network: every pair is singular, as in the reference
+            *done = true;
+            *info = 1;
+            return NODAL_OK;
+        }
+        h->last_iterations = it;
+        pair_read<<<1, 1, 0, st>>>(h->x.as<double>(), ia[q], ib[q], res_dev + q);
+        NODAL_HIP_TRY(h, hipGetLastError());
+    }
+    *done = true;
     return NODAL_OK;
 }
 

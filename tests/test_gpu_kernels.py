@@ -392,3 +392,38 @@ def test_sparse_low_degree_elimination_on_random_networks(seed):
     assert info == 0 and h.residual() <= 1e-12
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
     h.close()
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_pair_sweep_on_a_ladder_uses_the_elimination(dense, monkeypatch, capfd):
+    """Equivalent resistances between nodes of a long ladder (nodal_solve_pairs): every pair
+    goes through the exact elimination instead of hundreds of multigrid iterations (sparse)
+    or a dense factorisation of the whole ladder (dense); same numbers as SuperLU."""
+    from nodal_amd import generators as gen
+    from oracle import nodal_oracle as oracle
+    import scipy.sparse.linalg as spla
+    table = gen.ladder_table(20000 if not dense else 6000)
+    G, _ = oracle.assemble_fast(table)
+    lu = spla.splu(G.tocsc())
+    n = G.shape[0]
+    ia = np.array([0, 17, n - 1, 5], dtype=np.int32)
+    ib = np.array([n - 1, 4000, -1, 6], dtype=np.int32)   # -1: the ground node
+    want = []
+    for a, b in zip(ia, ib):
+        rhs = np.zeros(n)
+        rhs[a] += 1.0
+        if b >= 0:
+            rhs[b] -= 1.0
+        x = lu.solve(rhs)
+        want.append(x[a] - (x[b] if b >= 0 else 0.0))
+    monkeypatch.setenv("NODAL_TRACE", "1")
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    capfd.readouterr()
+    got, info = h.solve_pairs(ia, ib, dense)
+    assert "[lowdeg]" in capfd.readouterr().err
+    assert info == 0
+    assert np.abs(got - np.array(want)).max() <= 1e-9 * np.abs(want).max()
+    h.close()
