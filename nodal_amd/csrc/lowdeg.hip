@@ -15,10 +15,10 @@
 // (`h->lowdeg`, matrix only, no component table) that goes through sparse_solve again:
 // further rounds while enough nodes can be removed (sparse_solve sets the bar), then the dense
 // direct solve or the multigrid CG.  A ladder of 1e5 sections is solved
-// exactly in ~10 rounds instead of 460 CG iterations.
+// exactly in 7 rounds and a small dense solve (2.4 ms) instead of 208 CG iterations (31 ms).
 //
-// Everything is deterministic: F is chosen by a hash priority (a candidate is taken if it
-// beats every candidate neighbour), the kept nodes keep their relative order, and S is
+// Everything is deterministic: F is chosen by a fixed priority (odd index first, then a hash: a
+// candidate is taken if it beats every candidate neighbour), the kept nodes keep their relative order, and S is
 // grouped by group.h like every other matrix here (contributions summed in a fixed order,
 // S bitwise symmetric).
 //
@@ -40,12 +40,16 @@ struct View {
     const double *data;
 };
 
+// Total order on the nodes: odd indices first, a hash among equals.  Netlists number the nodes
+// of a wire consecutively more often than not (first appearance in the file, and a round keeps
+// the order of the nodes it keeps), and then every other node of the wire is taken -- half of
+// it per round instead of the third a purely random order gives.
 __device__ __forceinline__ uint64_t node_priority(uint32_t i) {
     uint64_t h = (uint64_t)i * 0x9E3779B97F4A7C15ull;
     h ^= h >> 31;
     h *= 0xBF58476D1CE4E5B9ull;
     h ^= h >> 29;
-    return (h & 0xFFFFFFFF00000000ull) | i;  // distinct for distinct nodes
+    return ((uint64_t)(i & 1u) << 63) | ((h >> 1) & 0x7FFFFFFF00000000ull) | i;  // distinct for distinct nodes
 }
 
 // 1 or 2 neighbours and a positive diagonal
