@@ -427,3 +427,40 @@ def test_pair_sweep_on_a_ladder_uses_the_elimination(dense, monkeypatch, capfd):
     assert info == 0
     assert np.abs(got - np.array(want)).max() <= 1e-9 * np.abs(want).max()
     h.close()
+
+
+@pytest.mark.parametrize("side,wire", [(40, 120), (80, 60)])
+def test_floating_island_survives_the_elimination_rounds(side, wire):
+    """A floating 30 x 30 grid next to a grid with dangling wires: the rounds shorten the wires,
+    the island (no low-degree nodes) stays, and whichever solver gets the remainder -- the
+    dense one with its LDS connectivity check (<= 4096 unknowns left) or the multigrid with
+    the inherited 'touches ground' flags -- must report the network singular."""
+    from nodal_amd import generators as gen
+    rng = np.random.default_rng(3)
+    ga, gb, _ = gen._grid_arrays(side)
+    nn = side * side
+    a, b = [ga], [gb]
+    nxt = nn
+    for c in range(side):
+        ids = np.arange(nxt, nxt + wire, dtype=np.int64)
+        a.append(np.append(c, ids[:-1])); b.append(ids)
+        nxt += wire
+    ends = np.arange(nn + wire - 1, nxt, wire, dtype=np.int64)
+    ia_, ib_, _ = gen._grid_arrays(30)
+    island0 = nxt
+    ground = island0 + 900
+    for tie in (False, True):
+        aa = a + [ends, ia_ + island0] + ([np.array([island0 + 17])] if tie else [])
+        bb = b + [np.full(len(ends), ground, dtype=np.int64), ib_ + island0] + ([np.array([ground])] if tie else [])
+        aa, bb = np.concatenate(aa), np.concatenate(bb)
+        table = gen.passive_table(aa, bb, rng.uniform(0.5, 2.0, len(aa)), nn - 1, ground)
+        h = _ffi.Handle(0)
+        h.upload(table)
+        h.assemble_symbolic()
+        assert h.assemble_numeric()[0] == _ffi.OK
+        x, info, iters, relres = h.solve_sparse()
+        if tie:   # island tied to ground: regular
+            assert info == 0 and np.isfinite(x).all() and h.residual() <= 1e-12
+        else:
+            assert info > 0 and np.isnan(x).all()
+        h.close()
