@@ -78,6 +78,14 @@ struct nodal_ctx {
     DevBuf grounded;        // u8[n]
     DevBuf ld_newidx, ld_work;
     int ld_rounds = 0, ld_slow_rounds = 0;  // rounds that led to this context (all / those removing < 1/32)
+    // The choice of the eliminated set and the pattern of the reduced matrix depend on the
+    // STRUCTURE of this context's matrix only: kept while struct_epoch stands (value sweeps,
+    // pair sweeps, repeated solves), so that a later round is three kernels and no read-back.
+    uint64_t struct_epoch = 1;     // bumped whenever the CSR pattern of this context is rebuilt
+    uint64_t ld_epoch = 0;         // struct_epoch the cached decision below belongs to
+    int ld_state = 0;              // 1 too few candidates, 2 child built, 3 child built and singular (leftover)
+    int ld_share = 0;              // the bar (n / share nodes) the decision was taken with
+    int64_t ld_n = 0, ld_nnz = 0;
 
     // ---- symbolic assembly results ----
     bool have_symbolic = false;

@@ -310,6 +310,25 @@ int lowdeg_solve(nodal_ctx *h, int min_share, bool *done, int32_t *info, int32_t
     hipStream_t st = h->stream;
     const View A = view_of(h);
     const auto t0 = std::chrono::steady_clock::now();
+    if (const char *e = getenv("NODAL_LOWDEG_SHARE")) min_share = atoi(e) > 0 ? atoi(e) : min_share;
+    const bool cached = h->ld_state != 0 && h->ld_epoch == h->struct_epoch && h->ld_share == min_share &&
+                        h->ld_n == n && h->ld_nnz == A.nnz && (h->ld_state == 1 || h->lowdeg);
+    auto remember = [&](int state) {
+        h->ld_state = state;
+        h->ld_epoch = h->struct_epoch;
+        h->ld_share = min_share;
+        h->ld_n = n;
+        h->ld_nnz = A.nnz;
+    };
+    if (cached && h->ld_state == 1) return NODAL_OK;
+    if (cached && h->ld_state == 3) {
+        *done = true;
+        *info = 1;
+        *iters = 0;
+        *resid = 0.0;
+        return NODAL_OK;
+    }
+    const bool build = !cached;
 
     // independent set of low-degree nodes
     const size_t a_keep = grp::align_up((size_t)(n + 1) * 4);
@@ -319,26 +338,31 @@ int lowdeg_solve(nodal_ctx *h, int min_share, bool *done, int32_t *info, int32_t
     uint32_t *pos = reinterpret_cast<uint32_t *>(h->ld_work.as<char>() + a_keep);
     uint32_t *count = reinterpret_cast<uint32_t *>(h->ld_work.as<char>() + 2 * a_keep);
     void *scan_tmp = h->ld_work.as<char>() + 2 * a_keep + 256;
-    NODAL_HIP_TRY(h, hipMemsetAsync(count, 0, 8, st));
-    select_nodes<<<grid_for(n), TB, 0, st>>>(A, keep, count);
-    NODAL_HIP_TRY(h, hipGetLastError());
-    uint32_t nelim = 0;
-    NODAL_HIP_TRY(h, hipMemcpyAsync(&nelim, count, 4, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
-    if (const char *e = getenv("NODAL_LOWDEG_SHARE")) min_share = atoi(e) > 0 ? atoi(e) : min_share;
-    if ((int64_t)nelim * min_share < n) return NODAL_OK;
-    // low-yield rounds are worth their ~0.3 ms while wires are being shortened (each round takes
-    // a third of every wire); a network that keeps yielding a trickle of candidates is cut off
-    const bool slow = (int64_t)nelim * 32 < n;
-    if (h->ld_rounds >= 48 || (slow && h->ld_slow_rounds >= 12)) return NODAL_OK;
-    const int64_t nk = n - (int64_t)nelim;
-    if (nk < 1) return NODAL_OK;
-
-    NODAL_HIP_TRY(h, hipMemsetAsync(keep + n, 0, 4, st));
-    NODAL_TRY(scan_exclusive_u32(h, keep, pos, n + 1, nullptr, scan_tmp));
     int32_t *newidx = h->ld_newidx.as<int32_t>();
-    finish_newidx<<<grid_for(n), TB, 0, st>>>(n, keep, pos, newidx);
-    NODAL_HIP_TRY(h, hipGetLastError());
+    bool slow = false;
+    int64_t nk = build ? 0 : h->lowdeg->n;
+    if (build) {
+        h->ld_state = 0;
+        NODAL_HIP_TRY(h, hipMemsetAsync(count, 0, 8, st));
+        select_nodes<<<grid_for(n), TB, 0, st>>>(A, keep, count);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        uint32_t nelim = 0;
+        NODAL_HIP_TRY(h, hipMemcpyAsync(&nelim, count, 4, hipMemcpyDeviceToHost, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        // low-yield rounds are worth their ~0.3 ms while wires are being shortened (each round takes
+        // a third to a half of every wire); a network that keeps yielding a trickle of candidates is cut off
+        slow = (int64_t)nelim * 32 < n;
+        nk = n - (int64_t)nelim;
+        if ((int64_t)nelim * min_share < n || nk < 1 || h->ld_rounds >= 48 ||
+            (slow && h->ld_slow_rounds >= 12)) {
+            remember(1);
+            return NODAL_OK;
+        }
+        NODAL_HIP_TRY(h, hipMemsetAsync(keep + n, 0, 4, st));
+        NODAL_TRY(scan_exclusive_u32(h, keep, pos, n + 1, nullptr, scan_tmp));
+        finish_newidx<<<grid_for(n), TB, 0, st>>>(n, keep, pos, newidx);
+        NODAL_HIP_TRY(h, hipGetLastError());
+    }
 
     // the context of the reduced network: a matrix, a right-hand side and grounded flags
     if (!h->lowdeg) {
@@ -361,37 +385,39 @@ int lowdeg_solve(nodal_ctx *h, int min_share, bool *done, int32_t *info, int32_t
     c->gj_scalar = h->gj_scalar;
     c->use_graphs = h->use_graphs;
     c->amg_min_n = h->amg_min_n;
-    c->ld_rounds = h->ld_rounds + 1;
-    c->ld_slow_rounds = h->ld_slow_rounds + (slow ? 1 : 0);
-    c->n = nk;
-    c->K = (int32_t)nk;
-    c->B = 0;
     c->have_x = false;
     c->have_numeric = false;
+    int64_t nent = c->nnz;
+    if (build) {
+        c->ld_rounds = h->ld_rounds + 1;
+        c->ld_slow_rounds = h->ld_slow_rounds + (slow ? 1 : 0);
+        c->n = nk;
+        c->K = (int32_t)nk;
+        c->B = 0;
+        ++c->struct_epoch;  // whatever the child had cached about its own matrix is void
 
-    SchurEntries en;
-    en.nitems = A.nnz;
-    en.indptr = A.indptr;
-    en.indices = A.indices;
-    en.rowidx = A.rowidx;
-    en.newidx = newidx;
-    int64_t nent = 0, ncon = 0;
-    // (grouping scratch in the child's work buffers: the parent's may hold live data of the caller)
-    {
+        SchurEntries en;
+        en.nitems = A.nnz;
+        en.indptr = A.indptr;
+        en.indices = A.indices;
+        en.rowidx = A.rowidx;
+        en.newidx = newidx;
+        int64_t ncon = 0;
+        // (grouping scratch in the child's work buffers: the parent's may hold live data of the caller)
         const int bs = grp::build_lists(c, en, nk, &nent, &ncon, c->indices, c->rowidx, c->cptr, c->contrib,
                                         &c->indptr, &c->diag_pos);
         if (bs != NODAL_OK) {
             h->err = c->err;
             return bs;
         }
+        c->nnz = nent;
+        c->ncontrib = ncon;
+        NODAL_HIP_TRY(h, c->data.reserve((size_t)nent * 8 + 8));
+        NODAL_HIP_TRY(h, c->rhs.reserve((size_t)nk * 8 + 8));
+        NODAL_HIP_TRY(h, c->x.reserve((size_t)nk * 8 + 8));
+        NODAL_HIP_TRY(h, c->grounded.reserve((size_t)nk + 256));
+        NODAL_HIP_TRY(h, h->grounded.reserve((size_t)n + 256));
     }
-    c->nnz = nent;
-    c->ncontrib = ncon;
-    NODAL_HIP_TRY(h, c->data.reserve((size_t)nent * 8 + 8));
-    NODAL_HIP_TRY(h, c->rhs.reserve((size_t)nk * 8 + 8));
-    NODAL_HIP_TRY(h, c->x.reserve((size_t)nk * 8 + 8));
-    NODAL_HIP_TRY(h, c->grounded.reserve((size_t)nk + 256));
-    NODAL_HIP_TRY(h, h->grounded.reserve((size_t)n + 256));
     if (nent > 0) {
         schur_values<<<grid_for(nent), TB, 0, st>>>(A, c->cptr.as<int32_t>(), c->contrib.as<uint32_t>(),
                                                    c->data.as<double>(), nent);
@@ -401,22 +427,26 @@ int lowdeg_solve(nodal_ctx *h, int min_share, bool *done, int32_t *info, int32_t
     if (!h->csr_only) NODAL_TRY(stamp_grounded_flags(h, flags));  // a child already holds its own
     reduce_rhs<<<grid_for(n), TB, 0, st>>>(A, newidx, h->rhs.as<double>(), flags, c->rhs.as<double>(),
                                           c->grounded.as<uint8_t>());
-    find_floating_leftovers<<<grid_for(nk), TB, 0, st>>>(nk, c->indptr.as<int32_t>(), c->grounded.as<uint8_t>(),
-                                                        count + 1);
     NODAL_HIP_TRY(h, hipGetLastError());
     c->have_numeric = true;
-    uint32_t leftover = 0;
-    NODAL_HIP_TRY(h, hipMemcpyAsync(&leftover, count + 1, 4, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
-    if (leftover) {
-        if (trace) fprintf(stderr, "[lowdeg] a floating sub-network collapsed to a single node: singular\n");
-        *done = true;
-        *info = 1;
-        *iters = 0;
-        *resid = 0.0;
-        return NODAL_OK;
+    if (build) {
+        find_floating_leftovers<<<grid_for(nk), TB, 0, st>>>(nk, c->indptr.as<int32_t>(),
+                                                            c->grounded.as<uint8_t>(), count + 1);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        uint32_t leftover = 0;
+        NODAL_HIP_TRY(h, hipMemcpyAsync(&leftover, count + 1, 4, hipMemcpyDeviceToHost, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        remember(leftover ? 3 : 2);
+        if (leftover) {
+            if (trace) fprintf(stderr, "[lowdeg] a floating sub-network collapsed to a single node: singular\n");
+            *done = true;
+            *info = 1;
+            *iters = 0;
+            *resid = 0.0;
+            return NODAL_OK;
+        }
     }
-    if (trace) {
+    if (trace && build) {
         NODAL_HIP_TRY(h, hipStreamSynchronize(st));
         fprintf(stderr, "[lowdeg] %lld -> %lld unknowns, %lld -> %lld entries (%.2f ms)\n", (long long)n,
                 (long long)nk, (long long)A.nnz, (long long)nent,

@@ -261,6 +261,7 @@ Table table_of(nodal_ctx *h) {
 int stamp_symbolic(nodal_ctx *h) {
     if (!h->have_table) return nodal_fail(h, NODAL_E_INVALID, "no component table uploaded");
     h->have_symbolic = h->have_numeric = h->have_x = false;
+    ++h->struct_epoch;
     const int64_t n = h->n;
     const Table tb = table_of(h);
     NODAL_TRY(grp::build_lists(h, MatrixStamps{tb, tb.ncomp}, n, &h->nnz, &h->ncontrib, h->indices,

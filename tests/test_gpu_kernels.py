@@ -464,3 +464,48 @@ def test_floating_island_survives_the_elimination_rounds(side, wire):
         else:
             assert info > 0 and np.isnan(x).all()
         h.close()
+
+
+def test_low_degree_elimination_structure_is_reused_across_a_value_sweep(monkeypatch, capfd):
+    """One ladder topology, several sets of resistances on one handle: the eliminated sets and
+    the patterns of the reduced matrices are kept from the first member on (no '[lowdeg]'
+    build lines afterwards), the values are not -- every member against SuperLU.  A different
+    circuit uploaded to the same handle rebuilds everything."""
+    from nodal_amd import generators as gen
+    from nodal_amd.lowering import ComponentTable  # noqa: F401  (table type of the generators)
+    from oracle import nodal_oracle as oracle
+    import copy
+    rng = np.random.default_rng(9)
+    table = gen.ladder_table(12000)
+    members = 4
+    vals = np.tile(table.value, (members, 1))
+    for m in range(1, members):
+        vals[m, :-1] = table.value[:-1] * 10.0 ** rng.uniform(-1.0, 1.0, table.ncomp - 1)
+    monkeypatch.setenv("NODAL_TRACE", "1")
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    h.upload_values(vals)
+    for m in range(members):
+        assert h.assemble_numeric(m)[0] == _ffi.OK
+        capfd.readouterr()
+        x, info, iters, _ = h.solve_sparse()
+        err = capfd.readouterr().err
+        assert ("[lowdeg]" in err) == (m == 0)
+        tm = copy.copy(table)
+        tm.value = vals[m]
+        G, A = oracle.assemble_fast(tm)
+        xo, _ = oracle.solve(G.tocsr(), A, True)
+        assert info == 0 and np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    # another circuit of the same size class on the same handle
+    other = gen.binary_tree_table(12002)
+    h.upload(other)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    capfd.readouterr()
+    x, info, iters, _ = h.solve_sparse()
+    assert "[lowdeg]" in capfd.readouterr().err
+    G, A = oracle.assemble_fast(other)
+    xo, _ = oracle.solve(G.tocsr(), A, True)
+    assert info == 0 and np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    h.close()

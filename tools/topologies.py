@@ -47,12 +47,14 @@ def run(name, oracle_check=True):
     h.upload(table)
     h.assemble_symbolic()
     assert h.assemble_numeric()[0] == _ffi.OK
-    best = None
-    for _ in range(3):
+    # the first solve builds whatever depends on the topology only (elimination sets, reduced
+    # patterns); repeated solves on the same handle reuse it
+    times = []
+    for _ in range(4):
         t0 = time.perf_counter()
         x, info, iters, relres = h.solve_sparse()
-        dt = (time.perf_counter() - t0) * 1e3
-        best = dt if best is None else min(best, dt)
+        times.append((time.perf_counter() - t0) * 1e3)
+    first, best = times[0], min(times[1:])
     res = h.residual()
     err = float("nan")
     if oracle_check:
@@ -60,7 +62,7 @@ def run(name, oracle_check=True):
         G, A = oracle.assemble_fast(table)
         xo, _ = oracle.solve(G.tocsr(), A, True)
         err = float(np.abs(x - xo).max() / np.abs(xo).max())
-    print(f"{name:16s} n={len(x):8d} info={info} iters={iters:5d} {best:8.2f} ms  residual {res:.1e}  "
+    print(f"{name:16s} n={len(x):8d} info={info} iters={iters:5d} first {first:7.2f} ms, then {best:7.2f} ms  residual {res:.1e}  "
           f"vs SuperLU {err:.1e}", flush=True)
     h.close()
 
