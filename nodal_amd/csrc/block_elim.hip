@@ -129,6 +129,9 @@ __global__ __launch_bounds__(1024) void gj128_mfma(const double *__restrict__ sr
                                                     int32_t *__restrict__ dinfo, int base) {
     __shared__ double rowraw[4][128], colraw[4][128], pinv[16];
     __shared__ double rowpan[4][RP_S], colpan[4][CP_S];
+    // on the critical chain, usually sharing its CU with a workgroup of the bulk update: its
+    // waves go first at instruction issue
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tr = wave & 3, tc = wave >> 2;
     const int lr = lane & 15, lc = lane >> 4, lq = lane & 3;

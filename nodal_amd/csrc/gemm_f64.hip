@@ -202,6 +202,7 @@ __device__ __forceinline__ void gemm_small_body(double *__restrict__ C, int64_t 
                                                 const double *__restrict__ B, int64_t ldb, int M,
                                                 int N, int K) {
     __shared__ double part[3][4][64][4];
+    __builtin_amdgcn_s_setprio(3);  // chain kernels: ahead of the bulk update's waves on a shared CU
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
