@@ -509,3 +509,44 @@ def test_low_degree_elimination_structure_is_reused_across_a_value_sweep(monkeyp
     xo, _ = oracle.solve(G.tocsr(), A, True)
     assert info == 0 and np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
     h.close()
+
+
+@pytest.mark.parametrize("shape", ["star", "double_star", "caterpillar", "ring"])
+def test_sparse_low_degree_elimination_extreme_shapes(shape):
+    """Networks that collapse to one or two unknowns in a single round (a hub with thousands of
+    leaves), that alternate leaves and a spine, or that are one big cycle."""
+    from nodal_amd import generators as gen
+    from oracle import nodal_oracle as oracle
+    rng = np.random.default_rng(5)
+    m = 5000
+    if shape == "star":            # hub 0, leaves 1..m, hub tied to ground
+        a = np.append(np.zeros(m, dtype=np.int64), 0)
+        b = np.append(np.arange(1, m + 1, dtype=np.int64), m + 1)
+        src, ground = m, m + 1
+    elif shape == "double_star":   # two hubs joined by a resistor, each with m/2 leaves
+        half = m // 2
+        a = np.concatenate([np.zeros(half, dtype=np.int64), np.ones(half, dtype=np.int64), [0], [1]])
+        b = np.concatenate([np.arange(2, 2 + half), np.arange(2 + half, 2 + 2 * half), [1], [2 + 2 * half]])
+        src, ground = 2, 2 + 2 * half
+    elif shape == "caterpillar":   # spine 0..m-1, one leaf per spine node, both ends grounded
+        spine = np.arange(m - 1, dtype=np.int64)
+        a = np.concatenate([spine, np.arange(m, dtype=np.int64), [0], [m - 1]])
+        b = np.concatenate([spine + 1, np.arange(m, 2 * m, dtype=np.int64), [2 * m], [2 * m]])
+        src, ground = 2 * m - 1, 2 * m
+    else:                          # ring of m nodes, one tie to ground
+        ring = np.arange(m, dtype=np.int64)
+        a = np.append(ring, 0)
+        b = np.append((ring + 1) % m, m)
+        src, ground = m // 2, m
+    table = gen.passive_table(a, b, rng.uniform(0.5, 2.0, len(a)), src, ground)
+    G, A = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(G.tocsr(), A, True)
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    for _ in range(2):  # second solve: cached elimination structure
+        x, info, iters, relres = h.solve_sparse()
+        assert info == 0 and h.residual() <= 1e-12
+        assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    h.close()
