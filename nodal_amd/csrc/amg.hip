@@ -61,6 +61,8 @@ struct Level {
     int64_t nc = 0;       // size of the next level
     DevBuf agg;           // i32[n]: node -> aggregate
     DevBuf memptr, mem;   // aggregate -> member nodes (ascending)
+    DevBuf binv, boff;  // block smoother: inverses of the aggregates' diagonal blocks (see block_*)
+    bool block = false;
     DevBuf vec;           // work vectors, see V_* below
     DevBuf part;          // dot-product partials: 5 x DOT_BLOCKS
     double *v(int which) const { return vec.as<double>() + (int64_t)which * ((A.n + 31) & ~31ll); }
@@ -100,6 +102,7 @@ struct Hierarchy {
                         // NODAL_AMG_KMAX overrides.
     int passes0 = PASSES, passes1 = PASSES;  // pairwise matching passes at level 0 / below
     bool passes_forced = false;              // NODAL_AMG_PASSES0/1 given: no per-level adaptation
+    bool block_smoother = false;  // NODAL_AMG_BLOCK=1: aggregate-block Jacobi on the levels above the LDS tail
     int sweeps0 = 2;    // Jacobi sweeps before / after the coarse correction at level 0 (NODAL_AMG_SWEEPS0=1: one)
     TailDesc tdesc;
     DevBuf tail_image;
@@ -111,12 +114,14 @@ struct Hierarchy {
     ~Hierarchy() { clear(); }
     static void release_level(Level *l) {
         DevBuf *bufs[] = {&l->indptr, &l->indices, &l->rowidx, &l->data, &l->diag_pos, &l->cptr,
-                          &l->contrib, &l->dinv, &l->agg, &l->memptr, &l->mem, &l->vec, &l->part};
+                          &l->contrib, &l->dinv, &l->agg, &l->memptr, &l->mem, &l->vec, &l->part,
+                          &l->binv, &l->boff};
         for (DevBuf *b : bufs) b->release();
     }
     Level *take(size_t i) {  // the i-th level object, buffers kept from earlier setups
         while (pool.size() <= i) pool.push_back(new Level());
         pool[i]->nc = 0;
+        pool[i]->block = false;
         return pool[i];
     }
     void begin_setup() {
@@ -368,6 +373,188 @@ __global__ __launch_bounds__(TB) void smooth_again(Csr A, const double *__restri
             x2[i] = fma(OMEGA * dinv[i], r[i], x[i]);
             r2[i] = b[i] - sum;
         });
+}
+
+// ---- aggregate-block smoother ---------------------------------------------------------
+// B = blockdiag(A restricted to each aggregate).  Point Jacobi cannot damp an error that is
+// constant on a strongly coupled cluster INSIDE an aggregate (D is dominated by the strong
+// links); B^-1 treats every aggregate exactly.  Binv is stored aggregate by aggregate, m x m
+// row-major at boff[I] (m = members of I, in the order of the member list).
+__global__ __launch_bounds__(TB) void block_sizes(int64_t nc, const int32_t *__restrict__ memptr,
+                                                  uint32_t *__restrict__ sq) {
+    for (int64_t I = (int64_t)blockIdx.x * TB + threadIdx.x; I <= nc; I += (int64_t)gridDim.x * TB) {
+        const uint32_t m = I < nc ? (uint32_t)(memptr[I + 1] - memptr[I]) : 0u;
+        sq[I] = m * m;
+    }
+}
+
+// number of nodes with one link that carries more than `share` of their diagonal: the networks
+// on which point Jacobi fails (see above) have many
+__global__ __launch_bounds__(TB) void count_dominated(Csr A, double share, uint32_t *__restrict__ count) {
+    uint32_t mine = 0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        double d = 0.0, mx = 0.0;
+        for (int32_t e = A.indptr[i]; e < A.indptr[i + 1]; ++e) {
+            const double v = A.data[e];
+            if (A.indices[e] == (int)i) d = v;
+            else mx = fmax(mx, fabs(v));
+        }
+        mine += mx > share * d ? 1u : 0u;
+    }
+    __shared__ uint32_t total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    if (mine) atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && total) atomicAdd(count, total);
+}
+
+__global__ __launch_bounds__(TB) void block_stats(int64_t nc, const int32_t *__restrict__ memptr,
+                                                  uint32_t *__restrict__ out) {  // [0] m>16, [1] m>32, [2] max m
+    for (int64_t I = (int64_t)blockIdx.x * TB + threadIdx.x; I < nc; I += (int64_t)gridDim.x * TB) {
+        const uint32_t m = (uint32_t)(memptr[I + 1] - memptr[I]);
+        if (m > 16) atomicAdd(&out[0], 1u);
+        if (m > 32) atomicAdd(&out[1], 1u);
+        atomicMax(&out[2], m);
+    }
+}
+
+// Blocks of up to W nodes (W = 16: ~95 % of them, W = 32: the rest but a handful): W lanes per
+// aggregate, lane r holds row r in registers, Gauss-Jordan without pivoting (SPD) with the pivot
+// row broadcast by shuffles.  Handles the aggregates with LO < m <= W.
+template <int W, int LO>
+__global__ __launch_bounds__(TB) void block_build_reg(Csr A, int64_t nc, const int32_t *__restrict__ agg,
+                                                      const int32_t *__restrict__ memptr,
+                                                      const int32_t *__restrict__ mem,
+                                                      const uint32_t *__restrict__ boff,
+                                                      double *__restrict__ binv, double *__restrict__ flag) {
+    const int r = threadIdx.x & (W - 1);
+    constexpr int SH = W == 16 ? 4 : 5;
+    const int64_t groups = ((int64_t)gridDim.x * TB) >> SH;
+    const int64_t rounds = (nc + groups - 1) / groups;  // every lane runs the same number of rounds (shuffles)
+    for (int64_t t = 0; t < rounds; ++t) {
+        const int64_t I = t * groups + (((int64_t)blockIdx.x * TB + threadIdx.x) >> SH);
+        const bool have = I < nc;
+        const int32_t p0 = have ? memptr[I] : 0;
+        const int m = have ? memptr[I + 1] - p0 : 0;
+        const bool ours = m > LO && m <= W;
+        if (!__any(ours)) continue;  // wave-uniform: nothing for this wave in this round
+        double row[W];
+#pragma unroll
+        for (int c = 0; c < W; ++c) row[c] = 0.0;
+        const bool mine = ours && r < m;
+        if (mine) {
+            const int i = mem[p0 + r];
+            for (int32_t e = A.indptr[i]; e < A.indptr[i + 1]; ++e) {
+                const int j = A.indices[e];
+                if (agg[j] != (int32_t)I) continue;
+                int c = 0;
+                while (mem[p0 + c] != j) ++c;
+                const double v = A.data[e];
+#pragma unroll
+                for (int cc = 0; cc < W; ++cc) row[cc] = cc == c ? v : row[cc];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const bool step = ours && k < m;   // uniform over the W lanes of an aggregate
+            const double d = __shfl(row[k], k, W);
+            if (step && r == k && !(d > 0.0)) *flag = 1.0;
+            const double piv = 1.0 / d;
+            if (step && r == k) {
+                row[k] = 1.0;
+#pragma unroll
+                for (int c = 0; c < W; ++c) row[c] *= piv;
+            }
+            const double f = row[k];
+            double pk[W];
+#pragma unroll
+            for (int c = 0; c < W; ++c) pk[c] = __shfl(row[c], k, W);
+            if (step && mine && r != k) {
+                row[k] = 0.0;
+#pragma unroll
+                for (int c = 0; c < W; ++c) row[c] = fma(-f, pk[c], row[c]);
+            }
+        }
+        if (mine) {
+            double *B = binv + boff[I] + (int64_t)r * m;
+#pragma unroll
+            for (int c = 0; c < W; ++c)
+                if (c < m) B[c] = row[c];
+        }
+    }
+}
+
+// anything larger: one thread each, in global memory
+__global__ __launch_bounds__(TB) void block_build_large(Csr A, int64_t nc, const int32_t *__restrict__ agg,
+                                                        const int32_t *__restrict__ memptr,
+                                                        const int32_t *__restrict__ mem,
+                                                        const uint32_t *__restrict__ boff,
+                                                        double *__restrict__ binv,
+                                                        double *__restrict__ flag) {
+    for (int64_t I = (int64_t)blockIdx.x * TB + threadIdx.x; I < nc; I += (int64_t)gridDim.x * TB) {
+        const int32_t p0 = memptr[I];
+        const int m = memptr[I + 1] - p0;
+        if (m <= 32) continue;
+        double *B = binv + boff[I];
+        for (int t = 0; t < m * m; ++t) B[t] = 0.0;
+        for (int r = 0; r < m; ++r) {
+            const int i = mem[p0 + r];
+            for (int32_t e = A.indptr[i]; e < A.indptr[i + 1]; ++e) {
+                const int j = A.indices[e];
+                if (agg[j] != (int32_t)I) continue;
+                int c = 0;
+                while (mem[p0 + c] != j) ++c;
+                B[r * m + c] = A.data[e];
+            }
+        }
+        for (int k = 0; k < m; ++k) {
+            const double d = B[k * m + k];
+            if (!(d > 0.0)) *flag = 1.0;
+            const double piv = 1.0 / d;
+            B[k * m + k] = 1.0;
+            for (int j = 0; j < m; ++j) B[k * m + j] *= piv;
+            for (int i = 0; i < m; ++i) {
+                if (i == k) continue;
+                const double f = B[i * m + k];
+                B[i * m + k] = 0.0;
+                for (int j = 0; j < m; ++j) B[i * m + j] = fma(-f, B[k * m + j], B[i * m + j]);
+            }
+        }
+    }
+}
+
+// out = base + w * Binv v   (base == nullptr: out = w * Binv v).  One thread per member
+// position: the lanes of an aggregate read consecutive entries of a column of its
+// (symmetric) inverse and the same entries of v.
+__global__ __launch_bounds__(TB) void block_apply(int64_t n, const int32_t *__restrict__ agg,
+                                                  const int32_t *__restrict__ memptr,
+                                                  const int32_t *__restrict__ mem,
+                                                  const uint32_t *__restrict__ boff,
+                                                  const double *__restrict__ binv,
+                                                  const double *__restrict__ v,
+                                                  const double *__restrict__ base,
+                                                  double *__restrict__ out, double w) {
+    for (int64_t p = (int64_t)blockIdx.x * TB + threadIdx.x; p < n; p += (int64_t)gridDim.x * TB) {
+        const int i = mem[p];
+        const int I = agg[i];
+        const int32_t p0 = memptr[I];
+        const int m = memptr[I + 1] - p0;
+        const double *col = binv + boff[I] + (p - p0);
+        double s = 0.0;
+        for (int c = 0; c < m; ++c) s = fma(col[(int64_t)c * m], v[mem[p0 + c]], s);
+        out[i] = base ? fma(w, s, base[i]) : w * s;
+    }
+}
+
+// r = b - A x  (CSR-stream)
+__global__ __launch_bounds__(TB) void residual_vec(Csr A, const double *__restrict__ b,
+                                                   const double *__restrict__ x,
+                                                   double *__restrict__ r) {
+    stream::for_rows(
+        A.indptr, A.indices, A.data, A.n,
+        [&](int32_t, int32_t col, double val) { return val * x[col]; },
+        [&](int64_t i, double sum) { r[i] = b[i] - sum; });
 }
 
 // rc[I] = sum of r over the members of aggregate I (fixed order)
@@ -798,6 +985,44 @@ int galerkin(nodal_ctx *h, const Csr &A, const int32_t *agg, int64_t nc, Level *
     return NODAL_OK;
 }
 
+// inverses of the aggregates' diagonal blocks of level L (block smoother)
+int build_blocks(nodal_ctx *h, Level *L, double *flag) {
+    hipStream_t st = h->stream;
+    const int64_t nc = L->nc;
+    NODAL_HIP_TRY(h, L->boff.reserve((size_t)(nc + 1) * 4 + 64));
+    NODAL_HIP_TRY(h, h->work.reserve(scan_tmp_bytes(nc + 1) + 256));
+    uint32_t *boff = L->boff.as<uint32_t>();
+    uint32_t *total_dev = reinterpret_cast<uint32_t *>(h->work.as<char>());
+    block_sizes<<<grid_for(nc + 1), TB, 0, st>>>(nc, L->memptr.as<int32_t>(), boff);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    NODAL_TRY(scan_exclusive_u32(h, boff, boff, nc + 1, total_dev, h->work.as<char>() + 256));
+    uint32_t total = 0;
+    NODAL_HIP_TRY(h, hipMemcpyAsync(&total, total_dev, 4, hipMemcpyDeviceToHost, st));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    NODAL_HIP_TRY(h, L->binv.reserve((size_t)total * 8 + 64));
+    block_build_reg<16, 0><<<grid_for(nc * 16), TB, 0, st>>>(L->A, nc, L->agg.as<int32_t>(),
+                                                            L->memptr.as<int32_t>(), L->mem.as<int32_t>(), boff,
+                                                            L->binv.as<double>(), flag);
+    block_build_reg<32, 16><<<grid_for(nc * 32), TB, 0, st>>>(L->A, nc, L->agg.as<int32_t>(),
+                                                             L->memptr.as<int32_t>(), L->mem.as<int32_t>(), boff,
+                                                             L->binv.as<double>(), flag);
+    block_build_large<<<grid_for(nc), TB, 0, st>>>(L->A, nc, L->agg.as<int32_t>(), L->memptr.as<int32_t>(),
+                                                  L->mem.as<int32_t>(), boff, L->binv.as<double>(), flag);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    L->block = true;
+    if (getenv("NODAL_TRACE")) {
+        uint32_t *st3 = reinterpret_cast<uint32_t *>(h->work.as<char>());
+        NODAL_HIP_TRY(h, hipMemsetAsync(st3, 0, 12, st));
+        block_stats<<<grid_for(nc), TB, 0, st>>>(nc, L->memptr.as<int32_t>(), st3);
+        uint32_t hs3[3];
+        NODAL_HIP_TRY(h, hipMemcpyAsync(hs3, st3, 12, hipMemcpyDeviceToHost, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        fprintf(stderr, "[amg] blocks: %lld aggregates, %u larger than 16, %u larger than 32, largest %u, %u doubles\n",
+                (long long)nc, hs3[0], hs3[1], hs3[2], total);
+    }
+    return NODAL_OK;
+}
+
 int finish_level(nodal_ctx *h, Level *l, const int32_t *diag_pos, double *flag) {
     const int64_t n = l->A.n;
     NODAL_HIP_TRY(h, l->dinv.reserve((size_t)n * 8 + 8));
@@ -921,6 +1146,25 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
     l0->A.rowidx = rowidx;
     l0->A.data = data;
     NODAL_TRY(finish_level(h, l0, diag_pos, flag));
+    // Smoother: point Jacobi, or -- where a tenth of the nodes hang on one dominant link
+    // (resistances spread over several decades) -- Jacobi over the aggregates' diagonal blocks.
+    // NODAL_AMG_BLOCK=0 / 1 forces the choice.
+    if (const char *e = getenv("NODAL_AMG_BLOCK")) {
+        H->block_smoother = atoi(e) != 0;
+    } else {
+        NODAL_HIP_TRY(h, h->work.reserve(256));
+        uint32_t *cnt = h->work.as<uint32_t>();
+        NODAL_HIP_TRY(h, hipMemsetAsync(cnt, 0, 4, st));
+        count_dominated<<<grid_for(n0), TB, 0, st>>>(l0->A, 0.9, cnt);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        uint32_t dominated = 0;
+        NODAL_HIP_TRY(h, hipMemcpyAsync(&dominated, cnt, 4, hipMemcpyDeviceToHost, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        H->block_smoother = (int64_t)dominated * 10 >= n0;
+        if (getenv("NODAL_TRACE"))
+            fprintf(stderr, "[amg] %u of %lld nodes hang on one link (> 0.9 of the diagonal): %s smoother\n", dominated,
+                    (long long)n0, H->block_smoother ? "aggregate-block" : "point Jacobi");
+    }
 
     while ((int)H->levels.size() < MAX_LEVELS) {
         Level *fine = H->levels.back();
@@ -995,6 +1239,11 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
         for (int l = 2; l < (int)H->levels.size(); ++l)
             if (H->levels[l]->A.n >= K_MIN_ROWS) H->kmax = l;
     }
+    if (H->block_smoother) {
+        const int nl = (int)H->levels.size();
+        const int upto = H->tail >= 0 ? H->tail : nl - 1;  // levels [0, upto) run through cycle()
+        for (int l = 0; l < upto; ++l) NODAL_TRY(build_blocks(h, H->levels[l], flag));
+    }
     if (getenv("NODAL_TRACE")) {
         fprintf(stderr, "[amg] levels (rows/entries):");
         for (const Level *l : H->levels) fprintf(stderr, " %lld/%lld", (long long)l->A.n, (long long)l->A.nnz);
@@ -1031,8 +1280,16 @@ int cycle(nodal_ctx *h, Hierarchy *H, int l, const double *b, double *out) {
     const double *dinv = L->dinv.as<double>();
     double *x = L->v(V_X), *r = L->v(V_R);
     double *rc = C->v(V_RC), *c1 = C->v(V_C1), *c2 = C->v(V_C2);
-    smooth_residual<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, dinv, b, x, r);
-    const bool two_sweeps = l == 0 && H->sweeps0 == 2;  // level 0 only: bandwidth-bound there, latency-bound below
+    const int32_t *agg_ = L->agg.as<int32_t>(), *memptr_ = L->memptr.as<int32_t>(), *mem_ = L->mem.as<int32_t>();
+    if (L->block) {
+        // x = w Binv b ;  r = b - A x
+        block_apply<<<grid_for(n), TB, 0, st>>>(n, agg_, memptr_, mem_, L->boff.as<uint32_t>(),
+                                               L->binv.as<double>(), b, nullptr, x, OMEGA);
+        residual_vec<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, b, x, r);
+    } else {
+        smooth_residual<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, dinv, b, x, r);
+    }
+    const bool two_sweeps = !L->block && l == 0 && H->sweeps0 == 2;  // level 0 only: bandwidth-bound there, latency-bound below
     if (two_sweeps) {
         double *x2 = L->v(V_V1), *r2 = L->v(V_V2);  // (the K-cycle vectors of level 0 are never used)
         smooth_again<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, dinv, b, x, r, x2, r2);
@@ -1067,7 +1324,14 @@ int cycle(nodal_ctx *h, Hierarchy *H, int l, const double *b, double *out) {
                                     part + 2 * DOT_BLOCKS, part + 4 * DOT_BLOCKS);
         NODAL_HIP_TRY(h, hipGetLastError());
     }
-    if (n >= SPLIT_PROLONG_MIN) {
+    if (L->block) {
+        // xp = x + P (s1 c1 + s2 c2) ;  out = xp + w Binv (b - A xp)
+        double *xp = r, *r2 = x;  // r is dead after the restriction, x after the prolongation
+        prolong_add<<<grid_for(n), TB, 0, st>>>(n, x, agg_, c1, c2, C->part.as<double>(), nparts, xp);
+        residual_vec<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, b, xp, r2);
+        block_apply<<<grid_for(n), TB, 0, st>>>(n, agg_, memptr_, mem_, L->boff.as<uint32_t>(),
+                                               L->binv.as<double>(), r2, xp, out, OMEGA);
+    } else if (n >= SPLIT_PROLONG_MIN) {
         double *xp = r;  // the residual vector is dead after the restriction
         prolong_add<<<grid_for(n), TB, 0, st>>>(n, x, L->agg.as<int32_t>(), c1, c2,
                                                C->part.as<double>(), nparts, xp);
