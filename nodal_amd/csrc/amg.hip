@@ -24,7 +24,9 @@
 // preconditioned by the next level's cycle; smaller levels get a plain V hand-over down to
 // the LDS-resident tail, which runs its own two inner steps.  Damped-Jacobi pre- and
 // post-smoothing (two sweeps at level 0, one below), fused with the residual /
-// prolongation so a level visit costs three kernels.
+// prolongation so a level visit costs three kernels.  Networks in which many nodes hang on
+// one dominant link (resistances over several decades) get Jacobi over the aggregates'
+// diagonal blocks instead, on every level above the tail (block_* kernels below).
 #include "group.h"
 #include "spmv_stream.h"
 
@@ -1228,7 +1230,7 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
         NODAL_HIP_TRY(h, H->coarse_inv.reserve((size_t)last->A.n * last->A.n * 8 + 8));
         coarsest_inverse<<<1, 256, 0, st>>>(last->A, H->coarse_inv.as<double>(), flag);
         NODAL_HIP_TRY(h, hipGetLastError());
-        NODAL_TRY(build_tail(h, H));
+        if (!getenv("NODAL_AMG_NOTAIL")) NODAL_TRY(build_tail(h, H));
     }
     if (const char *e = getenv("NODAL_AMG_KMAX")) H->kmax = atoi(e);
     else {
