@@ -380,8 +380,9 @@ __global__ __launch_bounds__(TB) void smooth_again(Csr A, const double *__restri
 // ---- aggregate-block smoother ---------------------------------------------------------
 // B = blockdiag(A restricted to each aggregate).  Point Jacobi cannot damp an error that is
 // constant on a strongly coupled cluster INSIDE an aggregate (D is dominated by the strong
-// links); B^-1 treats every aggregate exactly.  Binv is stored aggregate by aggregate, m x m
-// row-major at boff[I] (m = members of I, in the order of the member list).
+// links); B^-1 treats every aggregate exactly.  Binv is stored aggregate by aggregate at
+// boff[I], m x m (m = members of I, in the order of the member list), TRANSPOSED: the general
+// path's node block is not symmetric.
 __global__ __launch_bounds__(TB) void block_sizes(int64_t nc, const int32_t *__restrict__ memptr,
                                                   uint32_t *__restrict__ sq) {
     for (int64_t I = (int64_t)blockIdx.x * TB + threadIdx.x; I <= nc; I += (int64_t)gridDim.x * TB) {
@@ -478,11 +479,11 @@ __global__ __launch_bounds__(TB) void block_build_reg(Csr A, int64_t nc, const i
                 for (int c = 0; c < W; ++c) row[c] = fma(-f, pk[c], row[c]);
             }
         }
-        if (mine) {
-            double *B = binv + boff[I] + (int64_t)r * m;
+        if (mine) {  // stored transposed (column r of the image = row r of the inverse): see block_apply
+            double *B = binv + boff[I] + r;
 #pragma unroll
             for (int c = 0; c < W; ++c)
-                if (c < m) B[c] = row[c];
+                if (c < m) B[(int64_t)c * m] = row[c];
         }
     }
 }
@@ -523,12 +524,18 @@ __global__ __launch_bounds__(TB) void block_build_large(Csr A, int64_t nc, const
                 for (int j = 0; j < m; ++j) B[i * m + j] = fma(-f, B[k * m + j], B[i * m + j]);
             }
         }
+        for (int i = 0; i < m; ++i)  // stored transposed, like the register kernels
+            for (int j = i + 1; j < m; ++j) {
+                const double t = B[i * m + j];
+                B[i * m + j] = B[j * m + i];
+                B[j * m + i] = t;
+            }
     }
 }
 
 // out = base + w * Binv v   (base == nullptr: out = w * Binv v).  One thread per member
-// position: the lanes of an aggregate read consecutive entries of a column of its
-// (symmetric) inverse and the same entries of v.
+// position: the image holds the inverse TRANSPOSED, so the lanes of an aggregate (row r of
+// the inverse each) read consecutive entries, and all of them the same entries of v.
 __global__ __launch_bounds__(TB) void block_apply(int64_t n, const int32_t *__restrict__ agg,
                                                   const int32_t *__restrict__ memptr,
                                                   const int32_t *__restrict__ mem,
