@@ -25,6 +25,15 @@ def contrast_grid(side, decades, seed=1):
     return gen.grid_table(side, vals)
 
 
+def general_contrast(side, decades, seed=1):
+    """config 5 (grid + 1 % voltage / dependent sources) with the resistances spread over decades"""
+    rng = np.random.default_rng(seed)
+    table = gen.cfg5_table(side)
+    res = table.type == 0
+    table.value[res] = 10.0 ** rng.uniform(-decades / 2, decades / 2, int(res.sum()))
+    return table
+
+
 CASES = {
     "ladder5e3": lambda: gen.ladder_table(5000),
     "ladder2e4": lambda: gen.ladder_table(20000),
@@ -41,6 +50,8 @@ CASES = {
     "contrast300d4": lambda: contrast_grid(300, 4),
     "contrast300d6": lambda: contrast_grid(300, 6),
     "contrast1000d4": lambda: contrast_grid(1000, 4),
+    "general300d0": lambda: gen.cfg5_table(300),
+    "general300d4": lambda: general_contrast(300, 4),
 }
 
 
@@ -71,6 +82,6 @@ def run(name, oracle_check=True):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or [c for c in CASES if c != "contrast1000d4"]
+    names = sys.argv[1:] or [c for c in CASES if c not in ("contrast1000d4", "general300d4", "general300d0")]
     for nm in names:
         run(nm, oracle_check=os.environ.get("NODAL_TOPO_NO_ORACLE") is None)
