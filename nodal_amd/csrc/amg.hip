@@ -69,7 +69,7 @@ struct Level {
     DevBuf part;          // dot-product partials: 5 x DOT_BLOCKS
     double *v(int which) const { return vec.as<double>() + (int64_t)which * ((A.n + 31) & ~31ll); }
 };
-enum { V_X = 0, V_R = 1, V_RC = 2, V_C1 = 3, V_C2 = 4, V_V1 = 5, V_V2 = 6, V_R2 = 7, V_COUNT = 8 };
+enum { V_X = 0, V_R = 1, V_RC = 2, V_C1 = 3, V_C2 = 4, V_V1 = 5, V_V2 = 6, V_R2 = 7, V_T = 8, V_COUNT = 9 };
 
 // ---- LDS-resident tail --------------------------------------------------------
 // All levels from `tail` down fit in one CU's LDS (160 KB): their matrices are packed
@@ -613,6 +613,30 @@ __global__ __launch_bounds__(TB) void prolong_smooth(Csr A, const double *__rest
         A.indptr, A.indices, A.data, A.n,
         [&](int32_t, int32_t col, double val) { return val * corrected(col); },
         [&](int64_t i, double sum) { out[i] = fma(OMEGA * dinv[i], b[i] - sum, corrected(i)); });
+}
+
+// coarse correction fused with the residual (CSR-stream; small and medium levels, block mode):
+//   xp = x + P (s1 c1 + s2 c2) ;  r = b - A xp      (xp_j is recomputed per entry)
+__global__ __launch_bounds__(TB) void prolong_residual(Csr A, const double *__restrict__ b,
+                                                       const double *__restrict__ x,
+                                                       const int32_t *__restrict__ agg,
+                                                       const double *__restrict__ c1,
+                                                       const double *__restrict__ c2,
+                                                       const double *__restrict__ part, int nparts,
+                                                       double *__restrict__ xp, double *__restrict__ r) {
+    const KCoef k = kcycle_coefficients(part, nparts);
+    const bool two = nparts != 0;
+    auto corrected = [&](int64_t j) {
+        const int J = agg[j];
+        return x[j] + k.s1 * c1[J] + (two ? k.s2 * c2[J] : 0.0);
+    };
+    stream::for_rows(
+        A.indptr, A.indices, A.data, A.n,
+        [&](int32_t, int32_t col, double val) { return val * corrected(col); },
+        [&](int64_t i, double sum) {
+            xp[i] = corrected(i);
+            r[i] = b[i] - sum;
+        });
 }
 
 // The same in two launches for large levels, where gathering agg / c1 / c2 once per
@@ -1338,8 +1362,14 @@ int cycle(nodal_ctx *h, Hierarchy *H, int l, const double *b, double *out) {
     if (L->block) {
         // xp = x + P (s1 c1 + s2 c2) ;  out = xp + w Binv (b - A xp)
         double *xp = r, *r2 = x;  // r is dead after the restriction, x after the prolongation
-        prolong_add<<<grid_for(n), TB, 0, st>>>(n, x, agg_, c1, c2, C->part.as<double>(), nparts, xp);
-        residual_vec<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, b, xp, r2);
+        if (n >= SPLIT_PROLONG_MIN) {
+            prolong_add<<<grid_for(n), TB, 0, st>>>(n, x, agg_, c1, c2, C->part.as<double>(), nparts, xp);
+            residual_vec<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, b, xp, r2);
+        } else {  // one launch: x is read per entry there, so the residual goes to a third vector
+            r2 = L->v(V_T);
+            prolong_residual<<<stream::grid_for_rows(n), TB, 0, st>>>(L->A, b, x, agg_, c1, c2,
+                                                                     C->part.as<double>(), nparts, xp, r2);
+        }
         block_apply<<<grid_for(n), TB, 0, st>>>(n, agg_, memptr_, mem_, L->boff.as<uint32_t>(),
                                                L->binv.as<double>(), r2, xp, out, OMEGA);
     } else if (n >= SPLIT_PROLONG_MIN) {
