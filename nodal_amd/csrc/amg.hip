@@ -402,7 +402,7 @@ __global__ __launch_bounds__(TB) void count_dominated(Csr A, double share, uint3
             if (A.indices[e] == (int)i) d = v;
             else mx = fmax(mx, fabs(v));
         }
-        mine += mx > share * d ? 1u : 0u;
+        mine += (d > 0.0 && mx > share * d) ? 1u : 0u;
     }
     __shared__ uint32_t total;
     if (threadIdx.x == 0) total = 0;
