@@ -25,8 +25,10 @@
 // the LDS-resident tail, which runs its own two inner steps.  Damped-Jacobi pre- and
 // post-smoothing (two sweeps at level 0, one below), fused with the residual /
 // prolongation so a level visit costs three kernels.  Networks in which many nodes hang on
-// one dominant link (resistances over several decades) get Jacobi over the aggregates'
-// diagonal blocks instead, on every level above the tail (block_* kernels below).
+// one dominant link (resistances over two decades or more) are set up in "contrast mode":
+// Jacobi over the aggregates' diagonal blocks on every level above the tail (block_* kernels
+// below), free nodes propose only over links of at least a tenth of their strongest one (so
+// that aggregates do not cut strong links), two passes per level.
 #include "group.h"
 #include "spmv_stream.h"
 
