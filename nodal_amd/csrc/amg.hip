@@ -391,11 +391,12 @@ __global__ __launch_bounds__(TB) void smooth_again(Csr A, const double *__restri
 // links); B^-1 treats every aggregate exactly.  Binv is stored aggregate by aggregate at
 // boff[I], m x m (m = members of I, in the order of the member list), TRANSPOSED: the general
 // path's node block is not symmetric.
+constexpr uint32_t BLOCK_MAX = 32;  // dense blocks up to this many nodes (what the register kernels build)
 __global__ __launch_bounds__(TB) void block_sizes(int64_t nc, const int32_t *__restrict__ memptr,
                                                   uint32_t *__restrict__ sq) {
     for (int64_t I = (int64_t)blockIdx.x * TB + threadIdx.x; I <= nc; I += (int64_t)gridDim.x * TB) {
         const uint32_t m = I < nc ? (uint32_t)(memptr[I + 1] - memptr[I]) : 0u;
-        sq[I] = m * m;
+        sq[I] = m <= BLOCK_MAX ? m * m : m;  // larger aggregates: their diagonal only
     }
 }
 
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(TB) void block_stats(int64_t nc, const int32_t *__r
     }
 }
 
-// Blocks of up to W nodes (W = 16: ~95 % of them, W = 32: the rest but a handful): W lanes per
+// Blocks of up to W nodes (W = 16: ~95 % of them, W = 32 = BLOCK_MAX: the rest): W lanes per
 // aggregate, lane r holds row r in registers, Gauss-Jordan without pivoting (SPD) with the pivot
 // row broadcast by shuffles.  Handles the aggregates with LO < m <= W.
 template <int W, int LO>
@@ -496,48 +497,23 @@ __global__ __launch_bounds__(TB) void block_build_reg(Csr A, int64_t nc, const i
     }
 }
 
-// anything larger: one thread each, in global memory
-__global__ __launch_bounds__(TB) void block_build_large(Csr A, int64_t nc, const int32_t *__restrict__ agg,
-                                                        const int32_t *__restrict__ memptr,
-                                                        const int32_t *__restrict__ mem,
-                                                        const uint32_t *__restrict__ boff,
-                                                        double *__restrict__ binv,
-                                                        double *__restrict__ flag) {
-    for (int64_t I = (int64_t)blockIdx.x * TB + threadIdx.x; I < nc; I += (int64_t)gridDim.x * TB) {
+// Aggregates above BLOCK_MAX nodes (a hub that many leftovers joined) keep point Jacobi: only
+// the reciprocals of their diagonal entries are stored (a dense inverse would cost m^3).
+__global__ __launch_bounds__(TB) void block_build_diag(Csr A, int64_t n, const int32_t *__restrict__ agg,
+                                                       const int32_t *__restrict__ memptr,
+                                                       const int32_t *__restrict__ mem,
+                                                       const uint32_t *__restrict__ boff,
+                                                       double *__restrict__ binv, double *__restrict__ flag) {
+    for (int64_t p = (int64_t)blockIdx.x * TB + threadIdx.x; p < n; p += (int64_t)gridDim.x * TB) {
+        const int i = mem[p];
+        const int I = agg[i];
         const int32_t p0 = memptr[I];
-        const int m = memptr[I + 1] - p0;
-        if (m <= 32) continue;
-        double *B = binv + boff[I];
-        for (int t = 0; t < m * m; ++t) B[t] = 0.0;
-        for (int r = 0; r < m; ++r) {
-            const int i = mem[p0 + r];
-            for (int32_t e = A.indptr[i]; e < A.indptr[i + 1]; ++e) {
-                const int j = A.indices[e];
-                if (agg[j] != (int32_t)I) continue;
-                int c = 0;
-                while (mem[p0 + c] != j) ++c;
-                B[r * m + c] = A.data[e];
-            }
-        }
-        for (int k = 0; k < m; ++k) {
-            const double d = B[k * m + k];
-            if (!(d > 0.0)) *flag = 1.0;
-            const double piv = 1.0 / d;
-            B[k * m + k] = 1.0;
-            for (int j = 0; j < m; ++j) B[k * m + j] *= piv;
-            for (int i = 0; i < m; ++i) {
-                if (i == k) continue;
-                const double f = B[i * m + k];
-                B[i * m + k] = 0.0;
-                for (int j = 0; j < m; ++j) B[i * m + j] = fma(-f, B[k * m + j], B[i * m + j]);
-            }
-        }
-        for (int i = 0; i < m; ++i)  // stored transposed, like the register kernels
-            for (int j = i + 1; j < m; ++j) {
-                const double t = B[i * m + j];
-                B[i * m + j] = B[j * m + i];
-                B[j * m + i] = t;
-            }
+        if ((uint32_t)(memptr[I + 1] - p0) <= BLOCK_MAX) continue;
+        double d = 0.0;
+        for (int32_t e = A.indptr[i]; e < A.indptr[i + 1]; ++e)
+            if (A.indices[e] == i) d = A.data[e];
+        if (!(d > 0.0)) *flag = 1.0;
+        binv[boff[I] + (p - p0)] = 1.0 / d;
     }
 }
 
@@ -559,7 +535,9 @@ __global__ __launch_bounds__(TB) void block_apply(int64_t n, const int32_t *__re
         const int m = memptr[I + 1] - p0;
         const double *col = binv + boff[I] + (p - p0);
         double s = 0.0;
-        for (int c = 0; c < m; ++c) s = fma(col[(int64_t)c * m], v[mem[p0 + c]], s);
+        if ((uint32_t)m > BLOCK_MAX) s = col[0] * v[i];  // diagonal only
+        else
+            for (int c = 0; c < m; ++c) s = fma(col[(int64_t)c * m], v[mem[p0 + c]], s);
         out[i] = base ? fma(w, s, base[i]) : w * s;
     }
 }
@@ -1047,8 +1025,9 @@ int build_blocks(nodal_ctx *h, Level *L, double *flag) {
     block_build_reg<32, 16><<<grid_for(nc * 32), TB, 0, st>>>(L->A, nc, L->agg.as<int32_t>(),
                                                              L->memptr.as<int32_t>(), L->mem.as<int32_t>(), boff,
                                                              L->binv.as<double>(), flag);
-    block_build_large<<<grid_for(nc), TB, 0, st>>>(L->A, nc, L->agg.as<int32_t>(), L->memptr.as<int32_t>(),
-                                                  L->mem.as<int32_t>(), boff, L->binv.as<double>(), flag);
+    block_build_diag<<<grid_for(L->A.n), TB, 0, st>>>(L->A, L->A.n, L->agg.as<int32_t>(),
+                                                     L->memptr.as<int32_t>(), L->mem.as<int32_t>(), boff,
+                                                     L->binv.as<double>(), flag);
     NODAL_HIP_TRY(h, hipGetLastError());
     L->block = true;
     if (getenv("NODAL_TRACE")) {

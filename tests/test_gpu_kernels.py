@@ -573,7 +573,7 @@ def test_multigrid_block_smoother_on_high_contrast_grid(decades, monkeypatch, ca
     assert h.assemble_numeric()[0] == _ffi.OK
     capfd.readouterr()
     x, info, iters, _ = h.solve_sparse()
-    assert "aggregate-block smoother" in capfd.readouterr().err
+    assert "[amg] blocks:" in capfd.readouterr().err  # contrast mode (chosen by the setup, or forced)
     assert info == 0 and h.residual() <= 1e-12
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
     monkeypatch.setenv("NODAL_AMG_BLOCK", "0")
@@ -601,3 +601,38 @@ def test_multigrid_block_smoother_forced_on_uniform_and_general_networks(monkeyp
         assert info == 0 and iters > 0 and h.residual() <= 1e-12
         assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
         h.close()
+
+
+def test_multigrid_contrast_mode_with_a_hub(monkeypatch, capfd):
+    """A hub tied by strong links to 300 nodes of a grid: those nodes refuse weak matches and
+    join the hub's pair, whose aggregate then exceeds the 32 nodes a dense smoother block may
+    have -- it keeps point Jacobi (diagonal fallback) while the rest of the network gets
+    blocks."""
+    from nodal_amd import generators as gen
+    from oracle import nodal_oracle as oracle
+    side = 80
+    rng = np.random.default_rng(21)
+    ga, gb, _ = gen._grid_arrays(side)
+    nn = side * side
+    hub = nn
+    spokes = rng.choice(nn, 300, replace=False)
+    a = np.concatenate([ga, np.full(300, hub, dtype=np.int64), [0]])
+    b = np.concatenate([gb, spokes.astype(np.int64), [nn + 1]])
+    vals = np.concatenate([rng.uniform(0.5, 2.0, len(ga)), rng.uniform(0.005, 0.02, 300), [1.0]])  # ohms
+    table = gen.passive_table(a, b, vals, nn - 1, nn + 1)
+    G, A = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(G.tocsr(), A, True)
+    monkeypatch.setenv("NODAL_TRACE", "1")
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    capfd.readouterr()
+    x, info, iters, _ = h.solve_sparse()
+    err = capfd.readouterr().err
+    import re
+    m = re.search(r"\[amg\] blocks: \d+ aggregates, \d+ larger than 16, (\d+) larger than 32, largest (\d+)", err)
+    assert m and int(m.group(1)) >= 1 and int(m.group(2)) > 32  # level 0: the hub's aggregate
+    assert info == 0 and h.residual() <= 1e-12
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    h.close()
