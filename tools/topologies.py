@@ -51,6 +51,7 @@ CASES = {
     "contrast300d6": lambda: contrast_grid(300, 6),
     "contrast1000d4": lambda: contrast_grid(1000, 4),
     "contrast1000d6": lambda: contrast_grid(1000, 6),
+    "contrast3000d4": lambda: contrast_grid(3000, 4),
     "general300d0": lambda: gen.cfg5_table(300),
     "general300d4": lambda: general_contrast(300, 4),
 }
@@ -83,6 +84,6 @@ def run(name, oracle_check=True):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or [c for c in CASES if c not in ("contrast1000d4", "contrast1000d6", "general300d4", "general300d0")]
+    names = sys.argv[1:] or [c for c in CASES if c not in ("contrast1000d4", "contrast1000d6", "contrast3000d4", "general300d4", "general300d0")]
     for nm in names:
         run(nm, oracle_check=os.environ.get("NODAL_TOPO_NO_ORACLE") is None)
