@@ -1428,6 +1428,16 @@ int amg_has_floating_component(nodal_ctx *h, const uint8_t *grounded0, int32_t *
     int32_t *label = reinterpret_cast<int32_t *>(h->work2.as<char>() + 2 * half);
     int32_t *root_ok = reinterpret_cast<int32_t *>(h->work2.as<char>() + 2 * half + a4);
     int32_t *flags = reinterpret_cast<int32_t *>(h->work2.as<char>() + 2 * half + 2 * a4);  // changed, floating
+    if (nl <= 4096) {
+        // the usual case (a last level of a few dozen nodes): components and verdict in ONE
+        // single-workgroup launch (lowdeg.hip) instead of a host round trip per propagation step
+        NODAL_HIP_TRY(h, hipMemsetAsync(flags + 1, 0, 4, st));
+        NODAL_TRY(csr_floating_check_small(h, nl, last->A.indptr, last->A.indices, cur,
+                                           reinterpret_cast<uint32_t *>(flags + 1)));
+        NODAL_HIP_TRY(h, hipMemcpyAsync(floating, flags + 1, 4, hipMemcpyDeviceToHost, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        return NODAL_OK;
+    }
     cc_init<<<grid_for(nl), TB, 0, st>>>(nl, label);
     for (int it = 0; it < 4096; ++it) {
         NODAL_HIP_TRY(h, hipMemsetAsync(flags, 0, 4, st));

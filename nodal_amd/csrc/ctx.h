@@ -228,6 +228,8 @@ int stamp_grounded_flags(nodal_ctx *h, uint8_t *flags_dev);
 int grounded_flags(nodal_ctx *h, uint8_t *flags_dev);
 int csr_to_dense(nodal_ctx *h, double *G_dev, int64_t ld);
 int csr_small_floating_check(nodal_ctx *h, int32_t *floating);
+int csr_floating_check_small(nodal_ctx *h, int64_t n, const int32_t *indptr, const int32_t *indices,
+                             const uint8_t *grounded, uint32_t *flag_dev);
 int lowdeg_solve(nodal_ctx *h, int min_share, bool *done, int32_t *info, int32_t *iters, double *resid);
 
 // ---- sparse solvers (sparse_*.hip) ----

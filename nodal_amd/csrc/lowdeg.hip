@@ -289,6 +289,24 @@ int csr_small_floating_check(nodal_ctx *h, int32_t *floating) {
     return NODAL_OK;
 }
 
+// The same test for any small CSR graph (the last level of a multigrid hierarchy): launched on
+// the context's stream, *flag_dev (zeroed by the caller) is set if a component is floating.
+int csr_floating_check_small(nodal_ctx *h, int64_t n, const int32_t *indptr, const int32_t *indices,
+                             const uint8_t *grounded, uint32_t *flag_dev) {
+    if (n > CC_MAX) return nodal_fail(h, NODAL_E_INVALID, "csr_floating_check_small: too many nodes");
+    View A;
+    A.n = n;
+    A.nnz = 0;
+    A.indptr = indptr;
+    A.indices = indices;
+    A.rowidx = nullptr;
+    A.diag_pos = nullptr;
+    A.data = nullptr;
+    small_floating_check<<<1, 1024, 0, h->stream>>>(A, grounded, flag_dev);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
+}
+
 // G of a matrix-only context as a column-major dense panel
 int csr_to_dense(nodal_ctx *h, double *G_dev, int64_t ld) {
     const int64_t n = h->n;
