@@ -1054,14 +1054,44 @@ int finish_level(nodal_ctx *h, Level *l, const int32_t *diag_pos, double *flag) 
 }
 
 
+__global__ __launch_bounds__(TB) void max_row_length(int64_t n, const int32_t *__restrict__ indptr,
+                                                     int32_t *__restrict__ out) {
+    int32_t m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        const int32_t len = indptr[i + 1] - indptr[i];
+        m = len > m ? len : m;
+    }
+    if (m > 0) atomicMax(out, m);
+}
+
 // Choose the first level from which everything fits in LDS and pack its image.
 int build_tail(nodal_ctx *h, Hierarchy *H) {
     const int L = (int)H->levels.size() - 1;
     H->tail = -1;
     auto up16 = [](int x) { return (x + 15) & ~15; };
+    // The tail kernel gives every row to one thread: a hub row of hundreds of entries makes that
+    // thread the whole kernel (406 instead of 25 us with a 5000-spoke hub on level 0).  Levels with
+    // such rows stay outside the tail, where the CSR-stream kernels sum long rows cooperatively.
+    constexpr int32_t TAIL_MAX_ROW = 128;
+    int32_t longest[MAX_LEVELS] = {0};
+    {
+        NODAL_HIP_TRY(h, h->work.reserve(MAX_LEVELS * 4 + 64));
+        int32_t *dev = h->work.as<int32_t>();
+        NODAL_HIP_TRY(h, hipMemsetAsync(dev, 0, MAX_LEVELS * 4, h->stream));
+        for (int t = 1; t < L; ++t)
+            if (H->levels[t]->A.n <= 65535)
+                max_row_length<<<grid_for(H->levels[t]->A.n), TB, 0, h->stream>>>(
+                    H->levels[t]->A.n, H->levels[t]->A.indptr, dev + t);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        NODAL_HIP_TRY(h, hipMemcpyAsync(longest, dev, MAX_LEVELS * 4, hipMemcpyDeviceToHost, h->stream));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
     for (int t = 1; t < L; ++t) {  // level 0 and the coarsest alone never form a tail
         if (L - t + 1 > TAIL_MAX_LEVELS) continue;
         if (H->levels[t]->A.n > 65535 || H->levels[t]->A.nnz > (1 << 22)) continue;
+        bool hub = false;
+        for (int k = t; k < L; ++k) hub = hub || longest[k] > TAIL_MAX_ROW;
+        if (hub) continue;
         TailDesc d;
         memset(&d, 0, sizeof d);
         d.nlev = L - t + 1;

@@ -7,8 +7,8 @@
 // contiguous range of entries: every lane multiplies consecutive entries (fully
 // coalesced 8-byte value and 4-byte index loads), the products are staged in LDS,
 // and after a barrier lane t sums row t's products from LDS and runs the row
-// epilogue.  Row blocks with more than STREAM_CAP entries (hub nodes) fall back to
-// a lane-per-row loop.
+// epilogue.  Row blocks with more than STREAM_CAP entries (hub nodes) are walked in chunks,
+// long rows summed by the whole workgroup.
 //
 //   entry(e, col, val) -> double   value staged for entry e (e.g. val * x[col])
 //   row(r, sum)                    consumes the sum of the staged values of row r
@@ -21,6 +21,7 @@ namespace stream {
 
 constexpr int TB = 256;           // threads = rows per block
 constexpr int STREAM_CAP = 3072;  // staged entries per row block (24 KB of LDS)
+constexpr int LONG_PART = 96;     // longer parts of a row inside a chunk are summed by the whole workgroup
 
 inline unsigned grid_for_rows(int64_t n, unsigned cap = 8192) {
     int64_t g = (n + TB - 1) / TB;
@@ -51,10 +52,50 @@ __device__ __forceinline__ void for_rows(const int32_t *__restrict__ indptr,
                 row(r, s);
             }
             __syncthreads();
-        } else if (r < r1) {
-            double s = 0.0;
-            for (int32_t e = indptr[r]; e < indptr[r + 1]; ++e) s += entry(e, indices[e], data[e]);
-            row(r, s);
+        } else {
+            // A row block with more than STREAM_CAP entries holds a hub (a node with thousands of
+            // neighbours).  The entry range is walked in chunks of STREAM_CAP: lane t keeps the
+            // running sum of row t; the part of a row inside a chunk is summed by its lane if it
+            // is short and by the whole workgroup if it is long (a lane walking 5000 staged values
+            // alone made every row kernel ~1 ms).
+            __shared__ int long_lane[TB], long_a[TB], long_b[TB];
+            __shared__ int long_count;
+            __shared__ double wave_part[TB / 64];
+            const int32_t ra = r < r1 ? indptr[r] : e1, rb = r < r1 ? indptr[r + 1] : e1;
+            double acc = 0.0;
+            for (int32_t c0 = e0; c0 < e1; c0 += STREAM_CAP) {
+                const int32_t c1 = c0 + STREAM_CAP < e1 ? c0 + STREAM_CAP : e1;
+                if (threadIdx.x == 0) long_count = 0;
+                for (int32_t e = c0 + (int32_t)threadIdx.x; e < c1; e += TB)
+                    staged[e - c0] = entry(e, indices[e], data[e]);
+                __syncthreads();
+                const int32_t a = ra > c0 ? ra : c0, b = rb < c1 ? rb : c1;
+                if (b - a > LONG_PART) {
+                    const int k = atomicAdd(&long_count, 1);  // (order irrelevant: every row is summed on its own)
+                    long_lane[k] = (int)threadIdx.x;
+                    long_a[k] = a - c0;
+                    long_b[k] = b - c0;
+                } else {
+                    for (int32_t p = a; p < b; ++p) acc += staged[p - c0];
+                }
+                __syncthreads();
+                const int nlong = long_count;
+                for (int k = 0; k < nlong; ++k) {
+                    double part = 0.0;
+                    for (int p = long_a[k] + (int)threadIdx.x; p < long_b[k]; p += TB) part += staged[p];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+                    if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = part;
+                    __syncthreads();
+                    if ((int)threadIdx.x == long_lane[k]) {
+#pragma unroll
+                        for (int w = 0; w < TB / 64; ++w) acc += wave_part[w];
+                    }
+                    __syncthreads();
+                }
+                __syncthreads();  // everyone has read long_count / staged before the next chunk resets them
+            }
+            if (r < r1) row(r, acc);
         }
     }
 }
