@@ -58,7 +58,8 @@ __device__ __forceinline__ void for_rows(const int32_t *__restrict__ indptr,
             // running sum of row t; the part of a row inside a chunk is summed by its lane if it
             // is short and by the whole workgroup if it is long (a lane walking 5000 staged values
             // alone made every row kernel ~1 ms).
-            __shared__ int long_lane[TB], long_a[TB], long_b[TB];
+            constexpr int MAX_LONG = STREAM_CAP / LONG_PART;  // long parts that fit in one chunk
+            __shared__ int long_lane[MAX_LONG], long_a[MAX_LONG], long_b[MAX_LONG];  // (small: LDS sets the occupancy)
             __shared__ int long_count;
             __shared__ double wave_part[TB / 64];
             const int32_t ra = r < r1 ? indptr[r] : e1, rb = r < r1 ? indptr[r + 1] : e1;

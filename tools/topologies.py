@@ -44,6 +44,7 @@ CASES = {
     "tree1e6": lambda: gen.binary_tree_table(1000000),
     "wires300x200": lambda: gen.grid_with_wires_table(300, 200),
     "grid300": lambda: gen.grid_table(300),
+    "grid1000": lambda: gen.grid_table(1000),
     "contrast300d1": lambda: contrast_grid(300, 1),
     "contrast300d2": lambda: contrast_grid(300, 2),
     "contrast300d3": lambda: contrast_grid(300, 3),
@@ -84,6 +85,6 @@ def run(name, oracle_check=True):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or [c for c in CASES if c not in ("contrast1000d4", "contrast1000d6", "contrast3000d4", "general300d4", "general300d0")]
+    names = sys.argv[1:] or [c for c in CASES if c not in ("grid1000", "contrast1000d4", "contrast1000d6", "contrast3000d4", "general300d4", "general300d0")]
     for nm in names:
         run(nm, oracle_check=os.environ.get("NODAL_TOPO_NO_ORACLE") is None)
