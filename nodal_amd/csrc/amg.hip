@@ -552,16 +552,17 @@ __global__ __launch_bounds__(TB) void residual_vec(Csr A, const double *__restri
         [&](int64_t i, double sum) { r[i] = b[i] - sum; });
 }
 
-// rc[I] = sum of r over the members of aggregate I (fixed order)
+// rc[I] = sum of r over the members of aggregate I (fixed order).  CSR-stream over the member
+// lists: a hub's aggregate can have tens of thousands of members (every leftover spoke joins
+// it), which one thread per aggregate would walk alone.
 __global__ __launch_bounds__(TB) void restrict_sum(int64_t nc, const int32_t *__restrict__ memptr,
                                                    const int32_t *__restrict__ mem,
                                                    const double *__restrict__ r,
                                                    double *__restrict__ rc) {
-    for (int64_t I = (int64_t)blockIdx.x * TB + threadIdx.x; I < nc; I += (int64_t)gridDim.x * TB) {
-        double s = 0.0;
-        for (int32_t p = memptr[I]; p < memptr[I + 1]; ++p) s += r[mem[p]];
-        rc[I] = s;
-    }
+    stream::for_rows(
+        memptr, mem, static_cast<const double *>(nullptr), nc,
+        [&](int32_t, int32_t node, double) { return r[node]; },
+        [&](int64_t I, double sum) { rc[I] = sum; });
 }
 
 // K-cycle coefficients from the five dot products of the two inner FCG steps
@@ -1371,7 +1372,7 @@ int cycle(nodal_ctx *h, Hierarchy *H, int l, const double *b, double *out) {
         x = x2;
         r = r2;
     }
-    restrict_sum<<<grid_for(nc), TB, 0, st>>>(nc, L->memptr.as<int32_t>(), L->mem.as<int32_t>(), r, rc);
+    restrict_sum<<<stream::grid_for_rows(nc), TB, 0, st>>>(nc, L->memptr.as<int32_t>(), L->mem.as<int32_t>(), r, rc);
     NODAL_HIP_TRY(h, hipGetLastError());
     int nparts = 0;
     const bool coarse_is_last = (l + 1 == (int)H->levels.size() - 1);

@@ -10,7 +10,8 @@
 // epilogue.  Row blocks with more than STREAM_CAP entries (hub nodes) are walked in chunks,
 // long rows summed by the whole workgroup.
 //
-//   entry(e, col, val) -> double   value staged for entry e (e.g. val * x[col])
+//   entry(e, col, val) -> double   value staged for entry e (e.g. val * x[col]); `data` may be
+//                                  null (pattern-only sums: val = 0)
 //   row(r, sum)                    consumes the sum of the staged values of row r
 #pragma once
 #include <hip/hip_runtime.h>
@@ -43,7 +44,7 @@ __device__ __forceinline__ void for_rows(const int32_t *__restrict__ indptr,
         const int64_t r = r0 + threadIdx.x;
         if (e1 - e0 <= STREAM_CAP) {  // uniform over the workgroup
             for (int32_t e = e0 + (int32_t)threadIdx.x; e < e1; e += TB)
-                staged[e - e0] = entry(e, indices[e], data[e]);
+                staged[e - e0] = entry(e, indices[e], data ? data[e] : 0.0);
             __syncthreads();
             if (r < r1) {
                 double s = 0.0;
@@ -68,7 +69,7 @@ __device__ __forceinline__ void for_rows(const int32_t *__restrict__ indptr,
                 const int32_t c1 = c0 + STREAM_CAP < e1 ? c0 + STREAM_CAP : e1;
                 if (threadIdx.x == 0) long_count = 0;
                 for (int32_t e = c0 + (int32_t)threadIdx.x; e < c1; e += TB)
-                    staged[e - c0] = entry(e, indices[e], data[e]);
+                    staged[e - c0] = entry(e, indices[e], data ? data[e] : 0.0);
                 __syncthreads();
                 const int32_t a = ra > c0 ? ra : c0, b = rb < c1 ? rb : c1;
                 if (b - a > LONG_PART) {

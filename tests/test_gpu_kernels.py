@@ -670,3 +670,30 @@ def test_expander_like_network_keeps_the_jacobi_preconditioner(monkeypatch, capf
     assert info == 0 and 0 < iters < 200 and h.residual() <= 1e-12
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
     h.close()
+
+
+def test_hub_node_with_thousands_of_neighbours():
+    """A node tied to 4000 nodes of a grid: its row block exceeds what the CSR-stream kernels
+    stage at once (chunked walk, the hub's row summed by the whole workgroup), its aggregate
+    has thousands of members (restriction through the same pattern), and its coarse images
+    keep their levels out of the LDS tail."""
+    from nodal_amd import generators as gen
+    from oracle import nodal_oracle as oracle
+    side = 120
+    rng = np.random.default_rng(33)
+    ga, gb, _ = gen._grid_arrays(side)
+    nn = side * side
+    spokes = rng.choice(nn, 4000, replace=False).astype(np.int64)
+    a = np.concatenate([ga, np.full(4000, nn, dtype=np.int64), [0]])
+    b = np.concatenate([gb, spokes, [nn + 1]])
+    table = gen.passive_table(a, b, rng.uniform(0.5, 2.0, len(a)), nn - 1, nn + 1)
+    G, A = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(G.tocsr(), A, True)
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    x, info, iters, _ = h.solve_sparse()
+    assert info == 0 and iters > 0 and h.residual() <= 1e-12
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    h.close()
