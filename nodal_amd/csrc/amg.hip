@@ -24,8 +24,8 @@
 // preconditioned by the next level's cycle; smaller levels get a plain V hand-over down to
 // the LDS-resident tail, which runs its own two inner steps.  Damped-Jacobi pre- and
 // post-smoothing (two sweeps at level 0, one below), fused with the residual /
-// prolongation so a level visit costs three kernels.  Networks in which many nodes hang on
-// one dominant link (resistances over two decades or more) are set up in "contrast mode":
+// prolongation so a level visit costs three kernels.  Networks in which many nodes have
+// graded links (resistances over a decade or more, anisotropy) are set up in "contrast mode":
 // Jacobi over the aggregates' diagonal blocks on every level above the tail (block_* kernels
 // below), free nodes propose only over links of at least a tenth of their strongest one (so
 // that aggregates do not cut strong links), two passes per level.
@@ -400,18 +400,23 @@ __global__ __launch_bounds__(TB) void block_sizes(int64_t nc, const int32_t *__r
     }
 }
 
-// number of nodes with one link that carries more than `share` of their diagonal: the networks
-// on which point Jacobi fails (see above) have many
-__global__ __launch_bounds__(TB) void count_dominated(Csr A, double share, uint32_t *__restrict__ count) {
+// Number of nodes whose links are graded: the strongest one carries more than `share` of the
+// diagonal, or is more than `spread` times the weakest one (anisotropy: two strong links and two
+// weak ones).  These are the networks on which point Jacobi and plain matching fail (see above).
+__global__ __launch_bounds__(TB) void count_dominated(Csr A, double share, double spread,
+                                                      uint32_t *__restrict__ count) {
     uint32_t mine = 0;
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
-        double d = 0.0, mx = 0.0;
+        double d = 0.0, mx = 0.0, mn = 1e300;
         for (int32_t e = A.indptr[i]; e < A.indptr[i + 1]; ++e) {
             const double v = A.data[e];
             if (A.indices[e] == (int)i) d = v;
-            else mx = fmax(mx, fabs(v));
+            else if (v != 0.0) {
+                mx = fmax(mx, fabs(v));
+                mn = fmin(mn, fabs(v));
+            }
         }
-        mine += (d > 0.0 && mx > share * d) ? 1u : 0u;
+        mine += (d > 0.0 && (mx > share * d || mx > spread * mn)) ? 1u : 0u;
     }
     __shared__ uint32_t total;
     if (threadIdx.x == 0) total = 0;
@@ -1197,10 +1202,10 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
     l0->A.rowidx = rowidx;
     l0->A.data = data;
     NODAL_TRY(finish_level(h, l0, diag_pos, flag));
-    // Smoother: point Jacobi, or -- where at least 1 % of the nodes hang on one dominant link
-    // (resistances spread over two decades or more: 1.9 % at two decades, where the block
-    // smoother already wins 10.9 against 15.1 ms on a 300 x 300 grid, 15 % at three, 28 % at
-    // four) -- Jacobi over the aggregates' diagonal blocks.
+    // Smoother: point Jacobi, or -- where at least 1 % of the nodes have graded links (one link
+    // above 0.9 of the diagonal, or the strongest above 8 x the weakest: resistances spread over
+    // a decade or more -- 5 % of the nodes at one decade, 75 % at two -- or anisotropy) -- Jacobi
+    // over the aggregates' diagonal blocks.
     // NODAL_AMG_BLOCK=0 / 1 forces the choice.
     if (const char *e = getenv("NODAL_AMG_BLOCK")) {
         H->block_smoother = atoi(e) != 0;
@@ -1208,14 +1213,14 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
         NODAL_HIP_TRY(h, h->work.reserve(256));
         uint32_t *cnt = h->work.as<uint32_t>();
         NODAL_HIP_TRY(h, hipMemsetAsync(cnt, 0, 4, st));
-        count_dominated<<<grid_for(n0), TB, 0, st>>>(l0->A, 0.9, cnt);
+        count_dominated<<<grid_for(n0), TB, 0, st>>>(l0->A, 0.9, 8.0, cnt);
         NODAL_HIP_TRY(h, hipGetLastError());
         uint32_t dominated = 0;
         NODAL_HIP_TRY(h, hipMemcpyAsync(&dominated, cnt, 4, hipMemcpyDeviceToHost, st));
         NODAL_HIP_TRY(h, hipStreamSynchronize(st));
         H->block_smoother = (int64_t)dominated * 100 >= n0;
         if (getenv("NODAL_TRACE"))
-            fprintf(stderr, "[amg] %u of %lld nodes hang on one link (> 0.9 of the diagonal): %s smoother\n", dominated,
+            fprintf(stderr, "[amg] %u of %lld nodes have graded links (one > 0.9 of the diagonal, or > 8 x the weakest): %s smoother\n", dominated,
                     (long long)n0, H->block_smoother ? "aggregate-block" : "point Jacobi");
     }
     // With dominant links around, aggregates must not cut them: a free node whose strong

@@ -697,3 +697,31 @@ def test_hub_node_with_thousands_of_neighbours():
     assert info == 0 and iters > 0 and h.residual() <= 1e-12
     assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
     h.close()
+
+
+def test_multigrid_contrast_mode_on_anisotropic_grid(monkeypatch, capfd):
+    """Vertical resistors 1000 x the horizontal ones: every node has two strong links and two
+    weak ones (none carries 0.9 of the diagonal, but the links are graded 1000 : 1), the setup
+    must pick the contrast mode, which needs a fraction of the iterations of point Jacobi."""
+    from nodal_amd import generators as gen
+    from oracle import nodal_oracle as oracle
+    side = 90
+    ga, gb, _ = gen._grid_arrays(side)
+    vals = np.where(gb == ga + 1, 1.0, 1000.0)
+    table = gen.grid_table(side, vals)
+    G, A = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(G.tocsr(), A, True)
+    monkeypatch.setenv("NODAL_TRACE", "1")
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    capfd.readouterr()
+    x, info, iters, _ = h.solve_sparse()
+    assert "[amg] blocks:" in capfd.readouterr().err
+    assert info == 0 and h.residual() <= 1e-12
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    monkeypatch.setenv("NODAL_AMG_BLOCK", "0")
+    x0, info0, iters0, _ = h.solve_sparse()
+    assert info0 == 0 and iters0 > 2 * iters
+    h.close()

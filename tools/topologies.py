@@ -25,6 +25,12 @@ def contrast_grid(side, decades, seed=1):
     return gen.grid_table(side, vals)
 
 
+def anisotropic_grid(side, ratio):
+    """vertical resistors `ratio` times the horizontal ones"""
+    ga, gb, _ = gen._grid_arrays(side)
+    return gen.grid_table(side, np.where(gb == ga + 1, 1.0, float(ratio)))
+
+
 def general_contrast(side, decades, seed=1):
     """config 5 (grid + 1 % voltage / dependent sources) with the resistances spread over decades"""
     rng = np.random.default_rng(seed)
@@ -50,6 +56,8 @@ CASES = {
     "contrast300d3": lambda: contrast_grid(300, 3),
     "contrast300d4": lambda: contrast_grid(300, 4),
     "contrast300d6": lambda: contrast_grid(300, 6),
+    "aniso300r10": lambda: anisotropic_grid(300, 10),
+    "aniso300r1000": lambda: anisotropic_grid(300, 1000),
     "contrast1000d4": lambda: contrast_grid(1000, 4),
     "contrast1000d6": lambda: contrast_grid(1000, 6),
     "contrast3000d4": lambda: contrast_grid(3000, 4),
