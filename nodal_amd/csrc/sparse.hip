@@ -328,7 +328,9 @@ int pcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
     NODAL_HIP_TRY(h, hipGetLastError());
 
     const double tol = 1e-13;
-    const int64_t maxit = 20 * (int64_t)(n < 1000 ? 1000 : n);
+    // Jacobi-CG needs ~5.5 sqrt(n) iterations on a grid; ten times that and it is not going to
+    // converge (the old cap of 20 n iterations meant minutes of silence at 1e5 unknowns)
+    const int64_t maxit = 1000 + (int64_t)(50.0 * sqrt((double)n));
     const int check = 50;
     double hs[S_COUNT];
     int64_t it = 0;
@@ -365,6 +367,7 @@ int pcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
     // algorithmic bytes of one SpMV launch: matrix once, x and y once
     h->kern_alg = 12.0 * (double)h->nnz + 4.0 * (double)(n + 1) + 16.0 * (double)n;
     if (status == 2) return -1;  // not SPD / singular: caller falls back
+    if (status == 3) return -1;  // not converged: never hand back an unconverged vector as a solution
     *info = 0;
     return NODAL_OK;
 }

@@ -58,6 +58,9 @@ CASES = {
     "contrast300d6": lambda: contrast_grid(300, 6),
     "aniso300r10": lambda: anisotropic_grid(300, 10),
     "aniso300r1000": lambda: anisotropic_grid(300, 1000),
+    "contrast300d8": lambda: contrast_grid(300, 8),
+    "contrast300d10": lambda: contrast_grid(300, 10),
+    "contrast300d12": lambda: contrast_grid(300, 12),
     "contrast1000d4": lambda: contrast_grid(1000, 4),
     "contrast1000d6": lambda: contrast_grid(1000, 6),
     "contrast3000d4": lambda: contrast_grid(3000, 4),
@@ -93,6 +96,6 @@ def run(name, oracle_check=True):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or [c for c in CASES if c not in ("grid1000", "contrast1000d4", "contrast1000d6", "contrast3000d4", "general300d4", "general300d0")]
+    names = sys.argv[1:] or [c for c in CASES if c not in ("grid1000", "contrast300d8", "contrast300d10", "contrast300d12", "contrast1000d4", "contrast1000d6", "contrast3000d4", "general300d4", "general300d0")]
     for nm in names:
         run(nm, oracle_check=os.environ.get("NODAL_TOPO_NO_ORACLE") is None)
