@@ -14,3 +14,4 @@ for w in cfg2 cfg3 cfg4 cfg5; do
   done
 done
 tail -1 $O/bench_default.log
+# (a plain `python bench.py > gpurun_out/bench_plain.log` gives profiles/<round>_bench_default.json)
