@@ -1202,7 +1202,7 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
     l0->A.rowidx = rowidx;
     l0->A.data = data;
     NODAL_TRY(finish_level(h, l0, diag_pos, flag));
-    // Smoother: point Jacobi, or -- where at least 1 % of the nodes have graded links (one link
+    // Smoother: point Jacobi, or -- where at least 32 nodes (1 % in small networks) have graded links (one link
     // above 0.9 of the diagonal, or the strongest above 8 x the weakest: resistances spread over
     // a decade or more -- 5 % of the nodes at one decade, 75 % at two -- or anisotropy) -- Jacobi
     // over the aggregates' diagonal blocks.
@@ -1218,7 +1218,10 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
         uint32_t dominated = 0;
         NODAL_HIP_TRY(h, hipMemcpyAsync(&dominated, cnt, 4, hipMemcpyDeviceToHost, st));
         NODAL_HIP_TRY(h, hipStreamSynchronize(st));
-        H->block_smoother = (int64_t)dominated * 100 >= n0;
+        // (a count, not a share: every such node is a near-null mode the Krylov iteration has to
+        // find by itself -- 100 near-shorts in a 90 000-node grid cost point Jacobi 880 iterations)
+        const int64_t bar = n0 / 100 < 32 ? (n0 / 100 > 0 ? n0 / 100 : 1) : 32;
+        H->block_smoother = (int64_t)dominated >= bar;
         if (getenv("NODAL_TRACE"))
             fprintf(stderr, "[amg] %u of %lld nodes have graded links (one > 0.9 of the diagonal, or > 8 x the weakest): %s smoother\n", dominated,
                     (long long)n0, H->block_smoother ? "aggregate-block" : "point Jacobi");

@@ -725,3 +725,29 @@ def test_multigrid_contrast_mode_on_anisotropic_grid(monkeypatch, capfd):
     x0, info0, iters0, _ = h.solve_sparse()
     assert info0 == 0 and iters0 > 2 * iters
     h.close()
+
+
+def test_a_few_near_shorts_select_the_contrast_mode(monkeypatch, capfd):
+    """A uniform grid in which 60 resistors are replaced by 0.1 milli-ohm wires: a fraction of a
+    percent of the nodes, but each pair joined by a short is a near-null mode point Jacobi cannot
+    damp -- the setup counts them (not their share) and picks the contrast mode."""
+    from nodal_amd import generators as gen
+    from oracle import nodal_oracle as oracle
+    side = 100
+    rng = np.random.default_rng(8)
+    vals = rng.uniform(0.5, 2.0, gen.grid_resistor_count(side))
+    vals[rng.choice(len(vals), 60, replace=False)] = 1e-4  # (micro-ohms would put kappa beyond the 1e-9 bar)
+    table = gen.grid_table(side, vals)
+    G, A = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(G.tocsr(), A, True)
+    monkeypatch.setenv("NODAL_TRACE", "1")
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    capfd.readouterr()
+    x, info, iters, _ = h.solve_sparse()
+    assert "[amg] blocks:" in capfd.readouterr().err
+    assert info == 0 and iters <= 80 and h.residual() <= 1e-12
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    h.close()
