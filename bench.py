@@ -3,33 +3,38 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-A step is one pass of the hot path (symbolic + numeric assembly + solve, the
-equivalent of the reference's `Circuit(netlist, sparse)` + `.solve()`,
-nodal/nodal.py:306-336) over one batch of synthetic circuits per GPU.  Inputs
-are uploaded before the timed region; nothing is cached between steps.
+A step is one pass of the hot path over one batch of synthetic circuits per GPU: for every
+circuit symbolic + numeric assembly + solve, the equivalent of the reference's
+`Circuit(netlist, sparse)` + `.solve()` (reference nodal/nodal.py:306-336).  Inputs are
+uploaded before the timed region; nothing is cached between circuits or steps.
 
 Workloads (BASELINE.json `configs`):
-    cfg2  100x100 resistor grid, dense G, fp64 LU           (default, configs[1])
-    cfg3  1000x1000 resistor grid, sparse CSR path
-    cfg4  batch of 100x100 grids with per-member values, sparse path, shared
-          symbolic phase inside each step
+    cfg3  1000x1000 resistor grid (1e6 nodes), sparse CSR path        default at N = 1
+          (the configuration north_star's ">= 50x scipy.sparse" target is quoted on)
+    cfg4  batch of 100x100 grids with per-member values, 128 members per GPU, solved as
+          one block-diagonal system per rank and gathered over RCCL   default at N > 1
+    cfg2  100x100 resistor grid, dense G, fp64 block elimination / LU
     cfg5  1000x1000 grid + 1% E + CCCS/VCVS, sparse path
-With N > 1 every rank runs the same per-GPU work on its own members (weak
-scaling, no data-path collective: independent circuits).
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel of the
-workload, timed with HIP events on the library's stream; `cpu_baseline` is the
-oracle (the reference's algorithm restated, same numpy/scipy calls) timed on
-this box's host cores; `also` carries the other single-GPU configurations.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N rank processes itself
+(fresh children, before this process touches the GPU); under torchrun (WORLD_SIZE set) it
+is a rank.  cfg4 is the path that shards (weak scaling: 128 members per GPU); cfg2 / cfg3 /
+cfg5 are single-GPU problems and run as independent replicas when asked for with N > 1.
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel of the workload,
+timed with HIP events on the library's stream, plus the end-to-end figure of SURVEY.md
+section 8d; `cpu_baseline` is the oracle (the reference's algorithm restated, same numpy /
+scipy calls) timed on this box's host cores; `also` carries the other configurations, each
+with its own cpu_baseline.
 """
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -42,247 +47,431 @@ FP64_MFMA_444_TF = 73.0     # v_mfma_f64_4x4x4_4b_f64 -- the instruction gemm_f6
 FP64_MFMA_INSTR_TF = 36.2   # v_mfma_f64_16x16x4_f64, 138 cycles/instruction/wave
 FP64_VALU_FMA_TF = 59.3     # v_fma_f64
 
+CIRCUITS_PER_STEP = {"cfg3": 32, "cfg5": 16, "cfg2": 8, "cfg4": 128}
+PROFILE_ROUND = "r02"
+
 
 def pmc_traffic(workload):
-    """HBM bytes per launch of the workload's dominant kernel from the committed
-    rocprofv3 PMC summary (FETCH_SIZE x2 + WRITE_SIZE, separate passes; see
-    profiles/r01_pmc_traffic.json).  None if that workload was not profiled."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f)["dominant"][workload]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    """HBM bytes per launch of the workload's dominant kernel from the committed rocprofv3
+    PMC summary (FETCH_SIZE x2 + WRITE_SIZE, separate passes; profiles/<round>_pmc_traffic.json).
+    None if that workload was not profiled."""
+    for rnd in (PROFILE_ROUND, "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")) as f:
+                return json.load(f)["dominant"][workload]["hbm_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
 
 
-def build_workload(name, rank, per_gpu):
-    """Returns (table, values or None, dense, circuits_per_step, description)."""
-    from nodal_amd import generators as gen
-    if name == "cfg2":
-        table = gen.grid_table(100)
-        vals = np.ones((per_gpu, table.ncomp))
-        for i in range(per_gpu):  # distinct members per rank, same topology
-            member = rank * per_gpu + i
-            if member > 0:
-                vals[i, :-1] = gen.cfg4_values(member, 100)
-        return table, vals, True, per_gpu, "grid(100) 1e4 nodes, dense G, fp64 LU"
-    if name == "cfg4":
-        from nodal_amd.batch import replicate_table
-        table = gen.grid_table(100)
-        vals = np.ones((per_gpu, table.ncomp))
-        for i in range(per_gpu):
-            vals[i, :-1] = gen.cfg4_values(rank * per_gpu + i, 100)
-        # the shard's members are assembled and solved as ONE block-diagonal system
-        return (replicate_table(table, vals), None, False, 1,
-                f"batch of {per_gpu} grid(100) value sweeps per GPU, sparse CSR, block-diagonal")
-    if name == "cfg3":
-        return gen.grid_table(1000), None, False, 1, "grid(1000) 1e6 nodes, sparse CSR"
-    if name == "cfg5":
-        return gen.cfg5_table(1000), None, False, 1, "grid(1000)+1% E+CCCS/VCVS, sparse"
-    raise SystemExit(f"unknown workload {name}")
+def alg_bytes(table, n, nnz):
+    """SURVEY.md section 8d: B_asm = sum of record bytes + 12 nnz + 4(n+1) + 8n;
+    B_solve,min = 12 nnz + 4(n+1) + 16n."""
+    import numpy as np
+    dependent = int(np.count_nonzero(table.type >= 3))
+    records = 17 * (table.ncomp - dependent) + 29 * dependent
+    b_asm = records + 12 * nnz + 4 * (n + 1) + 8 * n
+    b_solve = 12 * nnz + 4 * (n + 1) + 16 * n
+    return b_asm, b_solve
 
 
-def run_step(h, dense, members):
-    for i in range(members):
-        info = h.run(dense, member=i, reuse_symbolic=(i > 0))
-        if info != 0:
-            raise RuntimeError(f"solver reported info={info}")
+# ---------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------
 
+class SingleCircuits:
+    """cfg2 / cfg3 / cfg5: `per_step` independent circuits per step, one after the other on
+    one handle; every circuit runs symbolic + numeric + solve."""
 
-def time_workload(name, rank, world, steps, warmup, per_gpu, dist, concurrent=1):
-    """`concurrent` > 1 (independent-circuit workloads): the step's circuits are spread over that
-    many handles, each driven by its own host thread -- independent solves overlap on the GPU
-    (one circuit's latency-bound phases run beside another's bulk updates)."""
-    import torch
-    from concurrent.futures import ThreadPoolExecutor
-    from nodal_amd import _ffi
-    table, vals, dense, members, desc = build_workload(name, rank, per_gpu)
-    concurrent = max(1, min(concurrent, members)) if name == "cfg2" else 1
-    handles = []
-    for _ in range(concurrent):
-        hh = _ffi.Handle(torch.cuda.current_device())
-        hh.upload(table)
-        if vals is not None:
-            hh.upload_values(vals)
-        handles.append(hh)
-    h = handles[0]
-    pool = ThreadPoolExecutor(max_workers=concurrent) if concurrent > 1 else None
+    def __init__(self, name, rank, per_step, device):
+        import numpy as np
+        from nodal_amd import _ffi
+        from nodal_amd import generators as gen
+        self.name, self.per_step = name, per_step
+        self.dense = name == "cfg2"
+        if name == "cfg2":
+            self.table = gen.grid_table(100)
+            self.desc = "grid(100) 1e4 nodes, dense G, fp64 block elimination"
+        elif name == "cfg3":
+            self.table = gen.grid_table(1000)
+            self.desc = "grid(1000) 1e6 nodes, sparse CSR path"
+        else:
+            self.table = gen.cfg5_table(1000)
+            self.desc = "grid(1000) + 1% E + CCCS/VCVS (non-symmetric MNA), sparse path"
+        self.h = _ffi.Handle(device)
+        t0 = time.perf_counter()
+        self.h.upload(self.table)
+        self.h.synchronize()
+        self.h2d_ms = (time.perf_counter() - t0) * 1e3
+        self.phase = np.zeros(3)
+        self.kern_ms = self.kern_n = 0
+        self.kern_alg = 0.0
+        self.circuits_done = 0
 
-    def run_share(idx, first):
-        # circuits idx, idx + concurrent, ... on handle idx; one symbolic assembly per step
-        hh = handles[idx]
-        for j, i in enumerate(range(idx, members, concurrent)):
-            info = hh.run(dense, member=i, reuse_symbolic=not (first or (idx == 0 and j == 0)))
+    def step(self):
+        h = self.h
+        for _ in range(self.per_step):
+            info = h.run(self.dense, member=0, reuse_symbolic=False)
             if info != 0:
                 raise RuntimeError(f"solver reported info={info}")
+            ms, launches, alg = h.kernel_stats()
+            self.kern_ms += ms
+            self.kern_n += launches
+            self.kern_alg = alg
+            self.phase += h.timings()
+            self.circuits_done += 1
 
-    def step(first=False):
-        if pool is None:
-            run_share(0, first)
-        else:
-            for f in [pool.submit(run_share, idx, first) for idx in range(concurrent)]:
-                f.result()
+    def reset_stats(self):
+        self.phase[:] = 0
+        self.kern_ms = self.kern_n = 0
+        self.circuits_done = 0
 
-    for w in range(warmup):
-        step(first=(w == 0))
-    if warmup == 0:
-        step(first=True)  # every handle needs its symbolic phase once (untimed)
+    def finish(self):
+        import numpy as np
+        h = self.h
+        t0 = time.perf_counter()
+        x = h.download_x()
+        d2h_ms = (time.perf_counter() - t0) * 1e3
+        iterations, levels, _ = h.solve_info()
+        out = dict(resid=h.residual(), x0=float(x[0]), n=h.n, nnz=h.nnz, iterations=iterations,
+                   amg_levels=levels, d2h_ms=d2h_ms, h2d_ms=self.h2d_ms,
+                   h2d_bytes=int(sum(np.asarray(getattr(self.table, f)).nbytes for f in
+                                     ("type", "value", "a", "b", "c", "d", "drv", "k"))),
+                   d2h_bytes=int(x.nbytes))
+        h.close()
+        return out
+
+
+class BatchShard:
+    """cfg4: this rank's 128 members of the value sweep as one block-diagonal system
+    (nodal_run_batch), results gathered from device memory over RCCL when world > 1."""
+
+    def __init__(self, rank, world, per_gpu, device, dist):
+        import numpy as np
+        import torch
+        from nodal_amd import generators as gen
+        from nodal_amd.batch import BatchSolver
+        self.name, self.per_step, self.dist, self.world = "cfg4", per_gpu, dist, world
+        self.dense = False
+        self.table = gen.grid_table(100)
+        self.desc = (f"batch of {per_gpu * world} grid(100) value sweeps, {per_gpu} per GPU as one "
+                     "block-diagonal system, sparse path" + (", all_gather over RCCL" if world > 1 else ""))
+        vals = np.ones((per_gpu, self.table.ncomp))
+        for i in range(per_gpu):
+            vals[i, :-1] = gen.cfg4_values(rank * per_gpu + i, 100)
+        self.solver = BatchSolver(self.table, device)
+        self.solver.h.assemble_symbolic()  # per-member n, nnz for the byte counts (untimed)
+        self.n, self.nnz = self.solver.h.n, self.solver.h.nnz
+        t0 = time.perf_counter()
+        self.solver.upload_values(vals)
+        self.h2d_ms = (time.perf_counter() - t0) * 1e3
+        self.h2d_bytes = int(vals.nbytes)
+        dev = torch.device("cuda", device)
+        self.block = torch.empty((per_gpu, self.table.n), dtype=torch.float64, device=dev)
+        self.gathered = (torch.empty((world * per_gpu, self.table.n), dtype=torch.float64, device=dev)
+                         if world > 1 else None)
+        self.phase = np.zeros(3)
+        self.kern_ms = self.kern_n = 0
+        self.kern_alg = 0.0
+        self.gather_ms = 0.0
+        self.circuits_done = 0
+
+    def step(self):
+        import torch
+        s = self.solver
+        s.run(sparse=True, reuse_symbolic=False, download=False)
+        s.copy_to_device(self.block)
+        if self.gathered is not None:
+            t0 = time.perf_counter()
+            if self.dist.get_backend() == "nccl":
+                self.dist.all_gather_into_tensor(self.gathered, self.block)
+            else:  # rehearsal over gloo: through host memory
+                g = torch.empty(self.gathered.shape, dtype=torch.float64)
+                self.dist.all_gather_into_tensor(g, self.block.cpu())
+                self.gathered.copy_(g)
+            torch.cuda.synchronize()
+            self.gather_ms += (time.perf_counter() - t0) * 1e3
+        ms, launches, alg = s.h.kernel_stats()
+        self.kern_ms += ms
+        self.kern_n += launches
+        self.kern_alg = alg
+        self.phase += s.h.timings()
+        self.circuits_done += self.per_step
+
+    def reset_stats(self):
+        self.phase[:] = 0
+        self.kern_ms = self.kern_n = 0
+        self.gather_ms = 0.0
+        self.circuits_done = 0
+
+    def finish(self):
+        import numpy as np
+        h = self.solver.h
+        t0 = time.perf_counter()
+        x = self.block.cpu().numpy()
+        d2h_ms = (time.perf_counter() - t0) * 1e3
+        iterations, levels, _ = h.solve_info()
+        # every rank must hold every member after the gather
+        gathered_ok = None
+        if self.gathered is not None:
+            g = self.gathered.cpu().numpy()
+            rank = self.dist.get_rank()
+            gathered_ok = bool(np.array_equal(g[rank * self.per_step:(rank + 1) * self.per_step], x)
+                               and np.isfinite(g).all())
+        out = dict(resid=h.residual(), x0=float(x[0, 0]), n=self.n, nnz=self.nnz,
+                   iterations=iterations, amg_levels=levels, d2h_ms=d2h_ms, h2d_ms=self.h2d_ms,
+                   h2d_bytes=self.h2d_bytes, d2h_bytes=int(x.nbytes), gathered_ok=gathered_ok)
+        self.solver.close()
+        return out
+
+
+def make_workload(name, rank, world, device, dist, per_step):
+    if name == "cfg4":
+        return BatchShard(rank, world, per_step, device, dist)
+    return SingleCircuits(name, rank, per_step, device)
+
+
+def time_workload(name, rank, world, device, dist, steps, warmup, per_step):
+    import torch
+    wl = make_workload(name, rank, world, device, dist if world > 1 else None, per_step)
+    for _ in range(max(warmup, 1)):  # at least one untimed pass: buffers grow to their final size
+        wl.step()
+    wl.reset_stats()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    kern_ms = kern_n = 0
-    phase = np.zeros(3)
     for _ in range(steps):
-        step()
-        for hh in handles:
-            ms, launches, alg = hh.kernel_stats()
-            kern_ms += ms
-            kern_n += launches
-        phase += np.array(h.timings())
+        wl.step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    resid = h.residual()
-    x = h.download_x()
-    iterations, amg_levels, _ = h.solve_info()
-    if name == "cfg4":
-        members = per_gpu  # circuits per step (one block-diagonal solve)
-    stats = dict(elapsed=elapsed, members=members, dense=dense, desc=desc, table=table,
-                 kern_ms=kern_ms, kern_n=kern_n, kern_alg=alg, resid=resid, x0=float(x[0]),
-                 phase_ms=(phase / steps).tolist(), n=h.n, nnz=h.nnz, name=name,
-                 iterations=iterations, amg_levels=amg_levels, concurrent=concurrent)
-    for hh in handles:
-        hh.close()
-    if pool is not None:
-        pool.shutdown()
-    return stats
+    st = dict(name=name, desc=wl.desc, dense=wl.dense, elapsed=elapsed, steps=steps,
+              circuits_per_step=wl.per_step, circuits=wl.circuits_done,
+              phase_ms=(wl.phase / max(wl.circuits_done if name != "cfg4" else steps, 1)).tolist(),
+              kern_ms=wl.kern_ms, kern_n=wl.kern_n, kern_alg=wl.kern_alg, table=wl.table,
+              gather_ms=getattr(wl, "gather_ms", 0.0) / max(steps, 1))
+    st.update(wl.finish())
+    return st
 
 
-def roofline_of(stats):
-    if stats["kern_n"] == 0:
-        return None
-    avg_s = stats["kern_ms"] / stats["kern_n"] * 1e-3
-    if stats["dense"]:
-        achieved = stats["kern_alg"] / avg_s / 1e12
-        return {"bound": "mfma", "kernel": "gemm_sub_kernel (K=256 bulk update of the block elimination)",
-                "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": achieved / FP64_MFMA_PEAK_TF, "traffic": pmc_traffic(stats["name"]),
-                "avg_launch_us": avg_s * 1e6, "launches_timed": stats["kern_n"],
-                "alg_flops_per_launch": stats["kern_alg"],
-                "measured_instruction_ceiling": {"v_mfma_f64_4x4x4_4b": FP64_MFMA_444_TF,
-                                                 "v_mfma_f64_16x16x4": FP64_MFMA_INSTR_TF,
-                                                 "v_fma_f64": FP64_VALU_FMA_TF, "unit": "TFLOP/s"}}
-    achieved = stats["kern_alg"] / avg_s / 1e9
-    return {"bound": "hbm", "kernel": "CSR-stream SpMV (pcg_spmv / spmv_kernel)", "achieved": achieved,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(stats["name"]), "avg_launch_us": avg_s * 1e6,
-            "launches_timed": stats["kern_n"], "alg_bytes_per_launch": stats["kern_alg"]}
+# ---------------------------------------------------------------------------------
+# reporting
+# ---------------------------------------------------------------------------------
+
+def roofline_of(st, circuits_per_sec_per_gpu):
+    b_asm, b_solve = alg_bytes(st["table"], st["n"], st["nnz"])
+    out = None
+    if st["kern_n"]:
+        avg_s = st["kern_ms"] / st["kern_n"] * 1e-3
+        if st["dense"]:
+            achieved = st["kern_alg"] / avg_s / 1e12
+            out = {"bound": "mfma", "kernel": "gemm_sub_kernel (K=256 bulk update of the block elimination)",
+                   "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                   "frac": achieved / FP64_MFMA_PEAK_TF, "traffic": pmc_traffic(st["name"]),
+                   "avg_launch_us": avg_s * 1e6, "launches_timed": st["kern_n"],
+                   "alg_flops_per_launch": st["kern_alg"],
+                   "measured_instruction_ceiling": {"v_mfma_f64_4x4x4_4b": FP64_MFMA_444_TF,
+                                                    "v_mfma_f64_16x16x4": FP64_MFMA_INSTR_TF,
+                                                    "v_fma_f64": FP64_VALU_FMA_TF, "unit": "TFLOP/s"}}
+        else:
+            achieved = st["kern_alg"] / avg_s / 1e9
+            out = {"bound": "hbm", "kernel": st.get("kernel_name") or DOMINANT_SPARSE_KERNEL,
+                   "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(st["name"]),
+                   "avg_launch_us": avg_s * 1e6, "launches_timed": st["kern_n"],
+                   "alg_bytes_per_launch": st["kern_alg"]}
+    if out is None:
+        out = {"bound": "mfma" if st["dense"] else "hbm", "kernel": None, "achieved": None,
+               "peak": FP64_MFMA_PEAK_TF if st["dense"] else HBM_PEAK_GBS,
+               "unit": "TFLOP/s" if st["dense"] else "GB/s", "frac": None, "traffic": None}
+    if st["dense"]:
+        flops = 2.0 / 3.0 * st["n"] ** 3 + 2.0 * st["n"] ** 2
+        out["end_to_end"] = {"what": "circuits/s x (2/3 n^3 + 2 n^2) / fp64 matrix peak",
+                             "flops_per_circuit": flops,
+                             "frac": circuits_per_sec_per_gpu * flops / (FP64_MFMA_PEAK_TF * 1e12)}
+    else:
+        out["end_to_end"] = {"what": "circuits/s x B_alg / 8e12 (SURVEY.md 8d primary figure)",
+                             "B_asm": b_asm, "B_solve_min": b_solve, "B_alg": b_asm + b_solve,
+                             "frac": circuits_per_sec_per_gpu * (b_asm + b_solve) / (HBM_PEAK_GBS * 1e9)}
+    return out
 
 
-def cpu_baseline(name, table, members=1):
-    """The oracle (reference algorithm restated; same numpy / scipy calls the
-    reference makes) on this box's host cores, one circuit."""
+DOMINANT_SPARSE_KERNEL = "level-0 matrix pass of the multigrid-preconditioned CG (see DESIGN.md 3.3)"
+
+
+def cpu_baseline(name, table):
+    """The oracle (reference algorithm restated; same numpy / scipy calls the reference
+    makes) on this box's host cores.  One circuit for cfg2 / cfg3 / cfg5, eight members
+    for cfg4; `value` = circuits actually solved / time."""
+    import numpy as np
     from oracle import nodal_oracle as oracle
+    from nodal_amd import generators as gen
     try:
         from threadpoolctl import threadpool_info
         blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         blas_threads = os.cpu_count()
-    t0 = time.perf_counter()
-    G, A = oracle.assemble_fast(table)
-    t_asm = time.perf_counter() - t0
     dense = name == "cfg2"
-    t0 = time.perf_counter()
+    members = 8 if name == "cfg4" else 1
+    t_asm = t_solve = 0.0
+    x0 = None
+    for m in range(members):
+        t = table
+        if name == "cfg4":
+            t = table.truncated(table.ncomp)
+            t.value[:-1] = gen.cfg4_values(m, 100)
+        t0 = time.perf_counter()
+        G, A = oracle.assemble_fast(t)
+        G = G.toarray() if dense else G.tocsr()
+        t_asm += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        x, _ = oracle.solve(G, A, not dense)
+        t_solve += time.perf_counter() - t0
+        x0 = float(x[0]) if x0 is None else x0
     if dense:
-        x, _ = oracle.solve(G.toarray(), A, False)
         cores, what = blas_threads, "numpy.linalg.solve (LAPACK dgesv)"
     else:
-        x, _ = oracle.solve(G.tocsr(), A, True)
         cores, what = 1, "scipy.sparse.linalg.spsolve (SuperLU)"
-    t_solve = time.perf_counter() - t0
     return {"value": members / (t_asm + t_solve), "unit": "circuits/s", "cores": cores, "kind": "port",
             "sample": f"{members} circuit(s) of {name}: vectorised numpy stamping {t_asm:.2f} s + {what} "
-                      f"{t_solve:.2f} s; the reference's own per-component Python stamping is "
-                      "slower (BASELINE.md section 2)",
-            "solve_only_circuits_per_s": members / t_solve, "x0": float(x[0])}
+                      f"{t_solve:.2f} s (host has {os.cpu_count()} cores); the reference's own per-component "
+                      "Python stamping is slower (BASELINE.md section 2)",
+            "solve_only_circuits_per_s": members / t_solve, "seconds": t_asm + t_solve, "x0": x0}
+
+
+def summary(st, world, with_cpu):
+    circuits = st["circuits"] * world
+    value = circuits / st["elapsed"]
+    out = {"workload": f"{st['name']}: {st['desc']}", "circuits_per_sec": value,
+           "ms_per_solve": st["elapsed"] / st["circuits"] * 1e3,
+           "phase_ms": {"symbolic": st["phase_ms"][0], "numeric": st["phase_ms"][1], "solve": st["phase_ms"][2]},
+           "h2d_ms": st["h2d_ms"], "d2h_ms": st["d2h_ms"], "h2d_bytes": st["h2d_bytes"],
+           "d2h_bytes": st["d2h_bytes"], "scaled_residual": st["resid"],
+           "solver": {"iterations": st["iterations"], "amg_levels": st["amg_levels"]},
+           "roofline": roofline_of(st, value / world)}
+    if st["name"] == "cfg4":
+        out["gather_ms_per_step"] = st["gather_ms"]
+        out["gathered_ok"] = st["gathered_ok"]
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(st["name"], st["table"])
+        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        if abs(out["cpu_baseline"]["x0"] - st["x0"]) > 1e-9 * max(1.0, abs(st["x0"])):
+            raise RuntimeError(f"{st['name']}: GPU x[0]={st['x0']!r} differs from the oracle's "
+                               f"{out['cpu_baseline']['x0']!r}")
+    return out
+
+
+# ---------------------------------------------------------------------------------
+# entry
+# ---------------------------------------------------------------------------------
+
+def launch_ranks(n, argv):
+    """Start `n` rank processes of this script (fresh children: this process has made no
+    GPU call), relay rank 0's JSON line, exit with the first failing rank's code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    code = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        code = code or p.returncode
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(code)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
-    ap.add_argument("--per-gpu", type=int, default=0, help="circuits per GPU per step")
-    ap.add_argument("--concurrent", type=int, default=1,
-                    help="cfg2: independent solves in flight per GPU (one handle + host thread each)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--per-step", type=int, default=0, help="circuits per GPU per step")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
+    # NODAL_BENCH_REHEARSE=1: every rank shares GPU 0 and the collectives run over gloo -- a
+    # rehearsal of the launcher, the sharding and the in-loop gather on a one-GPU box (RCCL
+    # refuses two ranks on one device).  Numbers from such a run are not benchmark results.
+    rehearse = os.environ.get("NODAL_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearse:
+            dist_mod.init_process_group("gloo")
+        else:
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local))
         dist = dist_mod
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    per_gpu = args.per_gpu or {"cfg2": 2, "cfg4": 128}.get(args.workload, 1)
-    st = time_workload(args.workload, rank, world, args.steps, args.warmup, per_gpu, dist, args.concurrent)
-    circuits = st["members"] * args.steps * world
+    name = args.workload or ("cfg3" if world == 1 else "cfg4")
+    per_step = args.per_step or CIRCUITS_PER_STEP[name]
+    st = time_workload(name, rank, world, local, dist, args.steps, args.warmup, per_step)
+    head = summary(st, world, with_cpu=(rank == 0 and world == 1 and not args.no_cpu))
     out = {
         "metric": "circuits_per_sec",
-        "value": circuits / st["elapsed"],
+        "value": head["circuits_per_sec"],
         "unit": "circuits/s",
         "n_gpus": world,
+        "world_size": dist.get_world_size() if dist is not None else 1,
+        "backend": (dist.get_backend() + (" (= RCCL)" if dist.get_backend() == "nccl" else " (rehearsal)"))
+                   if dist is not None else None,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": st["elapsed"] / args.steps * 1e3,
-        "ms_per_solve": st["elapsed"] / (st["members"] * args.steps) * 1e3,
+        "ms_per_solve": head["ms_per_solve"],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {st['desc']}", "circuits_per_gpu_per_step":
-                   st["members"], "n": st["n"], "nnz": st["nnz"],
-                   "parallelism": f"independent circuits x{world}",
-                   "concurrent_solves_per_gpu": st["concurrent"]},
-        "phase_ms": {"symbolic": st["phase_ms"][0], "numeric": st["phase_ms"][1],
-                     "solve": st["phase_ms"][2]},
-        "scaled_residual": st["resid"],
-        "solver": {"iterations": st["iterations"], "amg_levels": st["amg_levels"]},
-        "roofline": roofline_of(st),
+        "config": {"workload": head["workload"], "circuits_per_gpu_per_step": st["circuits_per_step"],
+                   "n": st["n"], "nnz": st["nnz"],
+                   "parallelism": ("batch members sharded over ranks, all_gather of x" if name == "cfg4" and world > 1
+                                   else f"independent circuits x{world}")},
     }
-    if rank == 0 and world == 1:
-        if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.workload, st["table"], st["members"])
-            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        if not args.no_also:
-            also = {}
-            for other in ("cfg3", "cfg4", "cfg5"):
-                if other == args.workload:
-                    continue
-                s2 = time_workload(other, 0, 1, 2, 1, {"cfg4": 128}.get(other, 1), None)
-                also[other] = {"workload": s2["desc"],
-                               "circuits_per_sec": s2["members"] * 2 / s2["elapsed"],
-                               "ms_per_solve": s2["elapsed"] / (s2["members"] * 2) * 1e3,
-                               "phase_ms": s2["phase_ms"], "scaled_residual": s2["resid"],
-                               "solver": {"iterations": s2["iterations"], "amg_levels": s2["amg_levels"]},
-                               "roofline": roofline_of(s2)}
-            out["also"] = also
+    for key in ("phase_ms", "h2d_ms", "d2h_ms", "h2d_bytes", "d2h_bytes", "scaled_residual", "solver",
+                "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "gather_ms_per_step", "gathered_ok"):
+        if key in head:
+            out[key] = head[key]
+    if rank == 0 and world == 1 and not args.no_also:
+        also = {}
+        for other in ("cfg4", "cfg5", "cfg2"):
+            if other == name:
+                continue
+            s2 = time_workload(other, 0, 1, local, None, {"cfg4": 6, "cfg5": 2, "cfg2": 1}[other], 1,
+                               {"cfg4": 128, "cfg5": 4, "cfg2": 4}[other])
+            also[other] = summary(s2, 1, with_cpu=not args.no_cpu)
+        out["also"] = also
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -137,6 +137,25 @@ int nodal_residual(nodal_handle h, double *scaled_residual);
 int nodal_run(nodal_handle h, int32_t dense, int32_t member, int32_t reuse_symbolic,
               int32_t *info);
 
+/* ---- batch variant (BASELINE.json config 4) -----------
+ * Replaces a Python loop of `Circuit(netlist, sparse=True)` + `.solve()` (reference
+ * nodal/nodal.py:306-336) over the members [first, first + count) of the value table
+ * uploaded by nodal_upload_values: the members are assembled and solved on the device as
+ * ONE block-diagonal system built from the single topology in HBM (sparse path).
+ * x_out (may be NULL: results stay on the device, see nodal_batch_x_device) receives
+ * count x n doubles, row m = unknown vector of member first + m.  info_out (may be NULL)
+ * receives one int per member: 0 solved; > 0 singular network (row of NaNs, as the
+ * reference's spsolve); < 0 minus the nodal_status the member's assembly failed with
+ * (NODAL_E_ZERO_RESISTANCE, NODAL_E_STAMP_COLLISION; row of NaNs).  When the block system
+ * cannot be solved as a whole the members are solved one by one, so only the offending
+ * members are marked.  reuse_symbolic != 0 keeps the block pattern of the previous call
+ * with the same topology and count. */
+int nodal_run_batch(nodal_handle h, int32_t first, int32_t count, int32_t reuse_symbolic,
+                    double *x_out, int32_t *info_out);
+/* copy the count x n results of the last nodal_run_batch into DEVICE memory of the handle's
+ * GPU (e.g. the send buffer of a collective); capacity_bytes is the size of that buffer */
+int nodal_batch_x_device(nodal_handle h, void *device_dst, int64_t capacity_bytes);
+
 /* ---- timing of the last call, measured with HIP events on the handle's
  *      stream: milliseconds spent in [symbolic, numeric, factor/solve] ----- */
 int nodal_last_timings(nodal_handle h, double *ms3);

@@ -43,6 +43,8 @@ SIGNATURES = {
     "nodal_solve_pairs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _i32p, _i32p, _f64p, _i32p]),
     "nodal_residual": (C.c_int, [C.c_void_p, _f64p]),
     "nodal_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _i32p]),
+    "nodal_run_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p, _i32p]),
+    "nodal_batch_x_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "nodal_last_timings": (C.c_int, [C.c_void_p, _f64p]),
     "nodal_last_kernel_stats": (C.c_int, [C.c_void_p, _f64p, _i64p, _f64p]),
     "nodal_last_solve_info": (C.c_int, [C.c_void_p, _i32p, _i32p, _f64p]),
@@ -125,6 +127,7 @@ class Handle:
                 ("type", "value", "a", "b", "c", "d", "drv", "k")]
         self._keep = cols
         t, v, a, b, c, d, drv, k = cols
+        self.n_members = table.K + table.B
         self._check(self.lib.nodal_upload_components(
             self._h, table.ncomp, _ptr(t, C.c_uint8), _ptr(v, C.c_double),
             _ptr(a, C.c_int32), _ptr(b, C.c_int32), _ptr(c, C.c_int32), _ptr(d, C.c_int32),
@@ -216,6 +219,20 @@ class Handle:
                                        C.byref(info)), allow=(E_SINGULAR,))
         self._refresh_sizes()
         return info.value
+
+    def run_batch(self, first, count, reuse_symbolic=False, download=True):
+        """Members [first, first + count) of the uploaded value table as one block-diagonal
+        system.  Returns ([count, n] array or None, info[count])."""
+        x = np.empty((count, self.n_members), dtype=np.float64) if download else None
+        info = np.zeros(count, dtype=np.int32)
+        self._check(self.lib.nodal_run_batch(self._h, first, count, int(reuse_symbolic),
+                                             _ptr(x, C.c_double) if download else None,
+                                             _ptr(info, C.c_int32)))
+        return x, info
+
+    def batch_x_to_device(self, data_ptr, capacity_bytes):
+        """Copy the last run_batch's results into device memory (a torch tensor's data_ptr())."""
+        self._check(self.lib.nodal_batch_x_device(self._h, C.c_void_p(data_ptr), capacity_bytes))
 
     def timings(self):
         ms = (C.c_double * 3)()

@@ -8,9 +8,17 @@ xGMI; "gloo" on CPU for tests).  Collectives are used only at the edges:
   * optional broadcast of the shared component table from rank 0 (0.5 MB for
     grid(100)) when only rank 0 parsed the netlist;
   * all_gather of the per-rank solution blocks (128 x 9999 x 8 B = 10 MB per
-    GPU for config 4): direct all-to-all traffic over the xGMI mesh, no
-    reduction, no ring.
+    GPU for config 4) straight from device memory: direct all-to-all traffic
+    over the xGMI mesh, no reduction, no ring.
+
+On a GPU the members of a shard are assembled and solved as ONE block-diagonal
+system that `nodal_run_batch` builds on the device from the single topology and
+the `values[batch][ncomp]` table in HBM (csrc/batch.hip); what the reference
+does for the same job is a Python loop of `Circuit(netlist, sparse)` +
+`.solve()` (reference nodal/nodal.py:306-336).
 """
+
+import warnings
 
 import numpy as np
 
@@ -23,14 +31,12 @@ def shard_range(total, rank, world):
 
 
 def replicate_table(table, values):
-    """One block-diagonal system holding every member of a value sweep.
-
-    Independent circuits that share the ground node do not couple (the ground row is
-    eliminated), so M members of a K-node, B-branch topology are one netlist with
-    M*K nodes and M*B branch unknowns.  Solving them together keeps the GPU full
-    (a single 1e4-node circuit occupies a few CUs) and costs one symbolic phase and
-    one multigrid setup.  Unknown layout: member m owns x[m*K:(m+1)*K] and
-    x[M*K + m*B : M*K + (m+1)*B]."""
+    """Host-side statement of the block-diagonal system `nodal_run_batch` builds on the
+    device: M members of a K-node, B-branch topology as one netlist with M*K nodes and
+    M*B branch unknowns (independent circuits that share the ground node do not couple:
+    the ground row is eliminated).  Member m owns x[m*K:(m+1)*K] and
+    x[M*K + m*B : M*K + (m+1)*B].  Kept for tests and tools; the product path does this
+    on the GPU."""
     from .lowering import ComponentTable
     M = values.shape[0]
     nc, K, B = table.ncomp, table.K, table.B
@@ -58,60 +64,136 @@ def split_solution(x, M, K, B):
     return out
 
 
-def solve_members(table, values, sparse=True, device=0, solver=None):
+def _raise_member_errors(info, first=0):
+    """info < 0 is minus the status a member's assembly failed with: raise what
+    `Circuit(netlist)` raises for that member (reference nodal/models.py:14-17 and its
+    bare `assert G[i, j] == 0`).  info > 0 (singular member) is not an error on the sparse
+    path: the row holds NaNs and the caller is warned, as the reference's spsolve does."""
+    from . import _ffi
+    from .circuit import MatrixRankWarning
+    for m, inf in enumerate(np.asarray(info).tolist()):
+        if inf == -_ffi.E_ZERO_RESISTANCE:
+            raise ValueError(f"Model error: resistors can't have null resistance (member {first + m})")
+        if inf == -_ffi.E_STAMP_COLLISION:
+            raise AssertionError(f"stamp collision in member {first + m}")
+    if np.any(np.asarray(info) > 0):
+        warnings.warn("Matrix is exactly singular", MatrixRankWarning, stacklevel=3)
+
+
+class BatchSolver:
+    """One device context kept alive across calls (creating one costs ~30 ms: four HIP
+    streams, a dozen events) with the topology resident in HBM.  `solve` uploads a value
+    table and returns the [members, n] solutions; `solve_into` leaves them in a device
+    buffer (the send buffer of the gather)."""
+
+    def __init__(self, table, device=0):
+        from . import _ffi
+        self.table = table
+        self.device = device
+        self.h = _ffi.Handle(device)
+        self.h.upload(table)
+        self._fresh = True  # no block pattern yet for this topology
+        self.last_info = None
+
+    def close(self):
+        if self.h is not None:
+            self.h.close()
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def upload_values(self, values):
+        self.h.upload_values(values)
+        self.members = values.shape[0]
+
+    def run(self, sparse=True, reuse_symbolic=False, download=True):
+        """Solve the uploaded members.  Returns [members, n] (or None with download=False:
+        the results stay on the device for `copy_to_device`)."""
+        h = self.h
+        M = self.members
+        if sparse:
+            x, info = h.run_batch(0, M, reuse_symbolic=reuse_symbolic and not self._fresh,
+                                  download=download)
+            self._fresh = False
+            self.last_info = info
+            _raise_member_errors(info)
+            return x
+        # dense members: one LU each (the dense path has no block form)
+        out = np.empty((M, self.table.n))
+        h.assemble_symbolic()
+        for i in range(M):
+            status, _bad = h.assemble_numeric(i)
+            _raise_member_errors([-status], first=i)
+            x, info = h.solve_dense()
+            if info > 0:
+                raise np.linalg.LinAlgError("Singular matrix")
+            out[i] = x
+        return out
+
+    def solve(self, values, sparse=True):
+        self.upload_values(np.ascontiguousarray(values, dtype=np.float64))
+        return self.run(sparse)
+
+    def copy_to_device(self, tensor):
+        """Results of the last sparse `run` into a torch CUDA tensor of >= members*n doubles."""
+        self.h.batch_x_to_device(tensor.data_ptr(), tensor.numel() * tensor.element_size())
+
+
+def solve_members(table, values, sparse=True, device=0, solver=None, session=None):
     """Solve every row of `values` ([members, ncomp]) on one GPU with a shared
     symbolic phase.  Returns [members, n] float64.  `solver` lets tests inject
-    a stand-in for the HIP handle."""
+    a stand-in for the HIP handle; `session` is a BatchSolver to reuse."""
     if solver is not None:
         return solver(table, values, sparse)
-    from . import _ffi
-    if sparse and values.shape[0] > 1:
-        # all members at once, as one block-diagonal system
-        h = _ffi.Handle(device)
-        try:
-            h.upload(replicate_table(table, values))
-            info = h.run(False)
-            x = h.download_x()
-            return split_solution(x, values.shape[0], table.K, table.B)
-        finally:
-            h.close()
-    h = _ffi.Handle(device)
-    try:
-        h.upload(table)
-        h.upload_values(values)
-        out = None
-        for i in range(values.shape[0]):
-            info = h.run(not sparse, member=i, reuse_symbolic=(i > 0))
-            if out is None:
-                out = np.empty((values.shape[0], h.n))
-            out[i] = h.download_x() if info == 0 else np.nan
-        return out if out is not None else np.empty((0, table.n))
-    finally:
-        h.close()
+    if values.shape[0] == 0:
+        return np.empty((0, table.n))
+    if session is not None:
+        return session.solve(values, sparse)
+    with BatchSolver(table, device) as s:
+        return s.solve(values, sparse)
 
 
-def solve_batch_distributed(table, values, sparse=True, device=None, solver=None, dist=None):
+def solve_batch_distributed(table, values, sparse=True, device=None, solver=None, dist=None,
+                            session=None):
     """Every rank passes the same `table` and the full `values`; each solves its
     shard and all ranks return the gathered [members, n] array."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return solve_members(table, values, sparse, device or 0, solver)
+        return solve_members(table, values, sparse, device or 0, solver, session)
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
-    lo, hi = shard_range(values.shape[0], rank, world)
-    mine = solve_members(table, values[lo:hi], sparse, device if device is not None else rank,
-                         solver)
+    total = values.shape[0]
+    lo, hi = shard_range(total, rank, world)
     use_cuda = dist.get_backend() == "nccl"
-    dev = torch.device("cuda", device if device is not None else rank) if use_cuda else "cpu"
-    # all_gather needs equal block sizes: pad the short shards by one row
-    width = -(-values.shape[0] // world)
+    dev_index = device if device is not None else rank
+    dev = torch.device("cuda", dev_index) if use_cuda else torch.device("cpu")
+    # all_gather needs equal block sizes: short shards are padded with NaN rows
+    width = -(-total // world)
     block = torch.full((width, table.n), float("nan"), dtype=torch.float64, device=dev)
-    block[: hi - lo] = torch.from_numpy(mine).to(dev)
-    blocks = [torch.empty_like(block) for _ in range(world)]
-    dist.all_gather(blocks, block)
-    out = np.empty((values.shape[0], table.n))
-    for r, b in enumerate(blocks):
-        rlo, rhi = shard_range(values.shape[0], r, world)
-        out[rlo:rhi] = b[: rhi - rlo].cpu().numpy()
+    on_device = use_cuda and solver is None and sparse and hi > lo
+    if on_device:
+        # shard solved on this rank's GPU, results handed to RCCL without touching the host
+        own = session if session is not None else BatchSolver(table, dev_index)
+        try:
+            own.upload_values(np.ascontiguousarray(values[lo:hi], dtype=np.float64))
+            own.run(sparse=True, download=False)
+            own.copy_to_device(block)
+        finally:
+            if session is None:
+                own.close()
+    elif hi > lo:
+        mine = solve_members(table, values[lo:hi], sparse, dev_index, solver, session)
+        block[: hi - lo] = torch.from_numpy(np.ascontiguousarray(mine)).to(dev)
+    gathered = torch.empty((world * width, table.n), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(gathered, block)
+    flat = gathered.cpu().numpy()
+    out = np.empty((total, table.n))
+    for r in range(world):
+        rlo, rhi = shard_range(total, r, world)
+        out[rlo:rhi] = flat[r * width: r * width + (rhi - rlo)]
     return out
 
 

@@ -11,8 +11,20 @@ int nodal_upload_internal(nodal_ctx *h, int64_t ncomp, const uint8_t *type, cons
 
 namespace {
 
+// selects the handle's device for the duration of an API call and gives the calling
+// thread its own current device back afterwards
 struct DeviceGuard {
-    explicit DeviceGuard(nodal_ctx *h) { (void)hipSetDevice(h->device); }
+    int prev = -1;
+    explicit DeviceGuard(nodal_ctx *h) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != h->device) (void)hipSetDevice(h->device);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
 
 template <class T>
@@ -102,6 +114,7 @@ int nodal_create(int device_id, nodal_handle *out) {
 
 void nodal_free_buffers(nodal_ctx *h) {
     amg_destroy(h);
+    nodal_free_block_child(h);
     if (h->reduced) {
         nodal_free_buffers(h->reduced);
         delete h->reduced;
@@ -175,6 +188,8 @@ int nodal_upload_internal(nodal_ctx *h, int64_t ncomp, const uint8_t *type, cons
         if (!ok) return nodal_fail(h, NODAL_E_INVALID, "component table row out of range");
     }
     h->have_table = h->have_symbolic = h->have_numeric = h->have_x = false;
+    ++h->table_epoch;
+    h->batch_count = 0;
     h->ncomp = ncomp;
     h->K = K;
     h->B = B;
@@ -308,6 +323,7 @@ int nodal_solve_dense(nodal_handle h, double *x, int32_t *info) {
     DeviceGuard g(h);
     *info = 0;
     h->have_x = false;
+    h->last_batch_block = false;
     h->last_iterations = 0;
     h->amg_levels = 0;
     NODAL_HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
@@ -354,6 +370,7 @@ int nodal_solve_sparse(nodal_handle h, int32_t method, double *x, int32_t *info,
     double rs = 0;
     NODAL_HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
     h->amg_levels = 0;
+    h->last_batch_block = false;
     int s = sparse_solve(h, method, info, &it, &rs);
     h->last_iterations = it;
     h->last_relres = rs;
@@ -431,6 +448,11 @@ int nodal_solve_pairs(nodal_handle h, int32_t dense, int32_t npairs, const int32
 int nodal_residual(nodal_handle h, double *scaled_residual) {
     if (!h || !scaled_residual) return NODAL_E_INVALID;
     DeviceGuard g(h);
+    if (h->last_batch_block && h->blocksys) {  // whole block-diagonal system of the last nodal_run_batch
+        const int s = sparse_residual(h->blocksys, scaled_residual);
+        if (s != NODAL_OK) h->err = h->blocksys->err;
+        return s;
+    }
     return sparse_residual(h, scaled_residual);
 }
 

@@ -63,6 +63,14 @@ struct nodal_ctx {
     DevBuf values_batch;  // [batch][ncomp] doubles
     int32_t batch = 0;
     bool have_table = false;
+    uint64_t table_epoch = 1;      // bumped by every upload_components (topology identity)
+    // value sweeps as one block-diagonal system (batch.hip): child context + [count][n] results
+    nodal_ctx *blocksys = nullptr;
+    uint64_t block_epoch = 0;      // (child) table_epoch of the parent its table was replicated from
+    DevBuf batch_x;
+    int32_t batch_count = 0;
+    bool last_batch_block = false;  // the last solve was a block-diagonal batch (nodal_residual looks at it)
+    hipEvent_t ev_batch[4] = {nullptr, nullptr, nullptr, nullptr};  // phase timing of nodal_run_batch
     HostTable host;
     bool keep_host_table = true;
     int32_t member = 0;            // batch member of the last numeric assembly
@@ -239,3 +247,4 @@ int sparse_residual(nodal_ctx *h, double *scaled);
 int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, double *resid,
                    bool dense_child = false);
 void nodal_free_buffers(nodal_ctx *h);  // api.hip
+void nodal_free_block_child(nodal_ctx *h);  // batch.hip

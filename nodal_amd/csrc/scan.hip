@@ -39,8 +39,9 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *block_
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums(const uint32_t *__restrict__ in,
-                                                               uint32_t *__restrict__ sums,
+// (`in` / `out` carry no __restrict__: the contract of scan_exclusive_u32 is that out may
+// alias in, and every caller scans in place)
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums(const uint32_t *in, uint32_t *sums,
                                                                int64_t n) {
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t s = 0;
@@ -52,10 +53,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums(const uint32_t *_
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_tiles(const uint32_t *__restrict__ in,
-                                                           uint32_t *__restrict__ out,
-                                                           const uint32_t *__restrict__ tile_off,
-                                                           int64_t n, uint32_t *total) {
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tiles(const uint32_t *in, uint32_t *out,
+                                                           const uint32_t *tile_off, int64_t n,
+                                                           uint32_t *total) {
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     uint32_t s = 0;

@@ -456,7 +456,8 @@ def test_value_sweep_batch_reuses_symbolic():
 
 def test_block_diagonal_batch_matches_per_member_oracle():
     """BASELINE.json config 4: a shard's members are solved as one block-diagonal
-    system (nodal_amd.batch); every member must match its own oracle solve."""
+    system built on the device (nodal_run_batch); every member must match its own
+    oracle solve."""
     from nodal_amd import batch
     N, members = 24, 12  # 12 x 575 nodes: above the multigrid threshold
     table = gen.grid_table(N)
@@ -469,6 +470,96 @@ def test_block_diagonal_batch_matches_per_member_oracle():
         Go, Ao = oracle.assemble_fast(gen.grid_table(N, vals[b, :-1]))
         xo, _ = oracle.solve(Go.tocsr(), Ao, True)
         assert normwise(out[b], xo) <= TOL
+
+
+def test_device_block_table_equals_host_statement():
+    """The block-diagonal table nodal_run_batch replicates on the device assembles to the
+    same matrix, bit for bit, as the host statement of it (batch.replicate_table) -- for a
+    topology with every component type (index shifts of a, b, c, d, drv, k)."""
+    from nodal_amd import batch
+    case = next(c for c in CASES if c["name"] == "doc/test_1")
+    table = lower(parse(case))
+    rng = np.random.default_rng(3)
+    members = 5
+    vals = np.tile(table.value, (members, 1)) * rng.uniform(0.5, 2.0, size=(members, table.ncomp))
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.upload_values(vals)
+    x, info = h.run_batch(0, members)
+    h.close()
+    assert (info == 0).all()
+    big = batch.replicate_table(table, vals)
+    Go, Ao = oracle.assemble_fast(big)
+    xo, _ = oracle.solve(Go.tocsr(), Ao, True)
+    want = batch.split_solution(xo, members, table.K, table.B)
+    for m in range(members):
+        t = table.truncated(table.ncomp)
+        t.value[:] = vals[m]
+        Gm, Am = oracle.assemble_fast(t)
+        xm, _ = oracle.solve(Gm.tocsr(), Am, True)
+        assert normwise(want[m], xm) <= 1e-12  # the block statement itself
+        assert normwise(x[m], xm) <= TOL
+
+
+def test_full_size_cfg4_shard():
+    """BASELINE.json config 4 at its real per-GPU size: 128 x grid(100) with cfg4_values as
+    one block-diagonal system (n = 1 279 872).  Member 3 against the reference's golden
+    samples, nine other members against the oracle, all <= 1e-9 norm-wise."""
+    from nodal_amd.batch import BatchSolver
+    N, members = 100, 128
+    table = gen.grid_table(N)
+    vals = np.ones((members, table.ncomp))
+    for b in range(members):
+        vals[b, :-1] = gen.cfg4_values(b, N)
+    with BatchSolver(table, 0) as s:
+        out = s.solve(vals, sparse=True)
+        resid = s.h.residual()
+        again = s.solve(vals, sparse=True)  # second call: buffers and the child context are reused
+    assert out.shape == (members, table.n) and np.isfinite(out).all()
+    assert np.array_equal(out, again)
+    assert resid <= 1e-13
+    case = next(c for c in SYNTH if c["name"] == "cfg4(100,b=3)")
+    idx = np.array(case["x_idx"])
+    ref = np.array(case["x_sparse_samples"])
+    assert np.abs(out[3][idx] - ref).max() / case["x_sparse_absmax"] <= TOL
+    assert abs(out[3][0] - case["e1"]) <= TOL * abs(case["e1"])
+    for b in (0, 1, 2, 17, 31, 64, 100, 126, 127):
+        Go, Ao = oracle.assemble_fast(gen.grid_table(N, vals[b, :-1]))
+        xo, _ = oracle.solve(Go.tocsr(), Ao, True)
+        assert normwise(out[b], xo) <= TOL, b
+
+
+def test_batch_isolates_offending_members():
+    """One singular member must not spoil the shard: only its row is NaN (with the
+    reference's MatrixRankWarning), as a loop of per-circuit spsolve calls would give; a
+    zero resistance in one member raises the reference's ValueError."""
+    from nodal_amd.batch import BatchSolver
+    # (1 - gain) e1 = 0: singular iff gain == 1 (reference nodal/models.py:53-78)
+    rows = [["r1", "R", "1", "1", "g"], ["r2", "R", "2", "1", "2"], ["r3", "R", "1", "2", "g"],
+            ["a1", "A", "1", "1", "g"], ["d1", "VCVS", "0.5", "1", "g", "1", "g"]]
+    nl = n.Netlist.from_rows(rows)
+    table = lower(nl)
+    members = 6
+    vals = np.tile(table.value, (members, 1))
+    gains = [0.5, 2.0, 1.0, -3.0, 1.0, 0.25]
+    vals[:, 4] = gains
+    with BatchSolver(table, 0) as s:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            out = s.solve(vals, sparse=True)
+        assert any(issubclass(x.category, MatrixRankWarning) for x in w)
+        assert list(s.last_info > 0) == [g == 1.0 for g in gains]
+        for m, g in enumerate(gains):
+            if g == 1.0:
+                assert np.isnan(out[m]).all()
+                continue
+            rows_m = [r[:2] + [repr(float(v))] + r[3:] for r, v in zip(rows, vals[m])]
+            Go, Ao, _ = oracle.build_model(n.Netlist.from_rows(rows_m), True)
+            xo, _ = oracle.solve(Go, Ao, True)
+            assert normwise(out[m], xo) <= TOL
+        vals[3, 1] = 0.0
+        with pytest.raises(ValueError, match="null resistance"):
+            s.solve(vals, sparse=True)
 
 
 def test_cli_scripts(tmp_path, capsys):
