@@ -114,6 +114,7 @@ int nodal_create(int device_id, nodal_handle *out) {
 
 void nodal_free_buffers(nodal_ctx *h) {
     amg_destroy(h);
+    sagg_destroy(h);
     nodal_free_block_child(h);
     if (h->reduced) {
         nodal_free_buffers(h->reduced);

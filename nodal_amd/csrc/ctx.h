@@ -141,6 +141,7 @@ struct nodal_ctx {
     std::vector<hipEvent_t> evpool;  // HIP-event pairs around the dominant kernel
 
     void *amg = nullptr;  // multigrid hierarchy (amg.hip)
+    void *sagg = nullptr; // smoothed-aggregation hierarchy (sagg.hip)
     int32_t last_iterations = 0;
     double last_relres = 0;
     int32_t amg_levels = 0;
@@ -227,6 +228,10 @@ int amg_apply(nodal_ctx *h, const double *r, double *z);
 int amg_num_levels(nodal_ctx *h);
 int64_t amg_level_size(nodal_ctx *h, int level);
 void amg_destroy(nodal_ctx *h);
+void sagg_destroy(nodal_ctx *h);
+// smoothed-aggregation FCG (sagg.hip): NODAL_OK, -1 breakdown, -2 structurally singular,
+// -3 declined (not this hierarchy's kind of network: use amg.hip)
+int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, int32_t *iters, double *resid);
 int amg_has_floating_component(nodal_ctx *h, const uint8_t *grounded0, int32_t *floating);
 int csr_has_floating_component(nodal_ctx *h, const uint8_t *grounded, int32_t *floating);
 

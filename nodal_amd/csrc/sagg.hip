@@ -1,0 +1,1284 @@
+// Smoothed-aggregation multigrid for the sparse SPD path (passive networks: G is a weighted
+// graph Laplacian plus ground conductances) -- the preconditioner of the flexible CG that
+// replaces scipy.sparse.linalg.spsolve (reference nodal/nodal.py:325) on large resistor
+// networks whose links are not graded (the benchmark grids; graded networks, hubs and
+// expanders keep the plain-aggregation hierarchy of amg.hip, which this path hands over to
+// by declining at setup).
+//
+// Why a second hierarchy: with piecewise-constant interpolation (amg.hip) the iteration
+// count is set by the coarse correction -- 60 FCG iterations on the 1e6-node grid, each
+// with a K-cycle of ~35 launches.  Smoothing the prolongator, P = (I - w D^-1 A) P_tent,
+// halves the count (29) with K-cycling at the first coarse level only.
+//
+// Layout: every level stores its matrix in column-major ELL with a per-row length
+// (slot s of row i at [s * ld + i]): one thread per row, every load of a wave is a
+// contiguous 256/512-byte segment, no LDS staging, no barriers.  P has at most PW = 4
+// entries per fine row (own aggregate + the neighbours' aggregates, the rest lumped into
+// the own one: row sums are kept), R = P^T is stored by coarse row.
+//
+// Setup per level, all on the device, deterministic (no floating-point atomics):
+//   1. aggregation: distance-2 maximal independent set by hashed priorities (Bell, Dalton,
+//      Olson: two neighbour-max passes per round), roots + their neighbours form the
+//      aggregates, the nodes at distance 2 join the aggregate of their strongest assigned
+//      neighbour;
+//   2. P rows in registers; R by integer counting + per-row sort of (node, slot) keys;
+//   3. Galerkin product A_c = R A P: one wavefront per coarse row -- pass 1 collects the
+//      row's column set in an LDS hash set and sorts it with wave shuffles, pass 2
+//      regenerates the products in (R entry, A slot, P slot) order, stages them in LDS and
+//      every lane sums the products of "its" column in that fixed order.
+// One host round trip per level (the number of aggregates sizes the next level).
+#include "group.h"
+
+int grounded_flags(nodal_ctx *h, uint8_t *flags_dev);  // lowdeg.hip
+
+namespace {
+
+using grp::TB;
+constexpr int PW = 4;            // prolongation entries per fine row
+constexpr int ACAP = 64;         // row cap of a coarse matrix: one lane per column in the Galerkin kernel
+constexpr int RCAP = 96;         // row cap of R
+constexpr int W0_MAX = 32;       // level-0 rows longer than this (hubs): decline
+constexpr int COARSEST = 64;     // dense inverse below this
+constexpr int MAX_LEVELS = 12;
+constexpr int MIS_ROUNDS = 6;     // 0.5 % of the nodes are still undecided then: they join or found small aggregates
+constexpr int TAIL_MAX_N = 1024; // levels this small run inside the single-workgroup tail kernel
+constexpr int TAIL_LEVELS = 6;
+constexpr int TAIL_LDS_BUDGET = 150 * 1024;
+constexpr int APAD = 32;         // the Galerkin kernel zero-pads every coarse row up to this many slots
+constexpr int DOT_BLOCKS = 1024;   // partial sums per dot product of the K-cycle
+#ifndef NODAL_SA_OMEGA
+#define NODAL_SA_OMEGA 0.85
+#endif
+constexpr double OMEGA = NODAL_SA_OMEGA;      // damped-Jacobi smoother
+constexpr double OMEGA_P = 2.0 / 3.0;         // prolongator smoothing (rho(D^-1 A) <= 2 for an M-matrix)
+
+inline unsigned grid_for(int64_t n, unsigned cap = 8192) {
+    int64_t g = (n + TB - 1) / TB;
+    if (g < 1) g = 1;
+    return (unsigned)(g > cap ? cap : g);
+}
+inline int64_t pad64(int64_t n) { return (n + 63) & ~(int64_t)63; }
+
+struct Ell {
+    int64_t n = 0, ld = 0;
+    int32_t width = 0;
+    const int32_t *col = nullptr;
+    const double *val = nullptr;
+    const int32_t *len = nullptr;
+};
+
+enum { ST_MAXLEN = 0, ST_GRADED = 1, ST_BADDIAG = 2, ST_OVERFLOW = 3, ST_NNZ = 4, ST_UNASSIGNED = 5,
+       ST_MAXR = 6, ST_COUNT = 8 };
+
+struct SLevel {
+    int64_t n = 0, ld = 0, nc = 0;
+    int32_t width = 0;       // slots allocated for A
+    int32_t maxlen = 0;      // longest row of A (host copy)
+    int32_t wfix = 0;        // > 0: every row is zero-padded to this many slots (unrolled row kernels)
+    int64_t nnz = 0;
+    DevBuf acol, aval, alen, dinv;
+    DevBuf agg, pcol, pval;
+    DevBuf rcol, rval, rlen;
+    int64_t rld = 0;
+    DevBuf vec, part, gflag;
+    Ell A() const {
+        Ell e;
+        e.n = n; e.ld = ld; e.width = width;
+        e.col = acol.as<int32_t>(); e.val = aval.as<double>(); e.len = alen.as<int32_t>();
+        return e;
+    }
+    double *v(int which) const { return vec.as<double>() + (int64_t)which * ld; }
+};
+enum { V_X = 0, V_R = 1, V_XP = 2, V_RC = 3, V_C1 = 4, V_C2 = 5, V_V1 = 6, V_V2 = 7, V_R2 = 8, V_COUNT = 9 };
+
+struct TailLevelDesc {
+    int n, nc, ld, rld, width, nq, lpr;  // width: longest row of A; nq: blocks of 8 per row of R; lpr: lanes per row
+    const int32_t *acol, *pcol, *rcol, *rlen;
+    const double *aval, *dinv, *pval, *rval;
+    int o_aval, o_acol, o_dinv, o_pval, o_pcol, o_rval, o_rcol, o_B, o_X, o_Y, o_R;  // LDS offsets (bytes)
+};
+struct TailDesc {
+    int nlev;  // tail levels; the last one is solved with its dense inverse / diagonal
+    TailLevelDesc lv[TAIL_LEVELS];
+    const double *inv;
+    int image_bytes;  // matrices and transfer operators (packed once per setup)
+    int lds_bytes;    // image + vectors
+};
+
+struct SHierarchy {
+    std::vector<SLevel *> pool;
+    int nlev = 0;
+    int tail = -1;          // first level inside the tail kernel
+    bool ready = false;
+    bool kcycle = true;          // two inner FCG steps at the first coarse level
+    bool dense_coarsest = true;  // last level: dense inverse; false: nothing but isolated nodes (diagonal)
+    DevBuf tail_image;
+    DevBuf stats, coarse_inv, mis_t, mis_m, mis_flag, mis_id, agg1, keys, rstart, cursor, lists;
+    TailDesc td;
+    uint64_t *host_stats = nullptr;  // pinned
+    SLevel *level(int l) {
+        while ((int)pool.size() <= l) pool.push_back(new SLevel());
+        return pool[l];
+    }
+    ~SHierarchy() {
+        for (SLevel *l : pool) {
+            DevBuf *b[] = {&l->acol, &l->aval, &l->alen, &l->dinv, &l->agg, &l->pcol, &l->pval, &l->rcol,
+                           &l->rval, &l->rlen, &l->vec, &l->part, &l->gflag};
+            for (DevBuf *x : b) x->release();
+            delete l;
+        }
+        tail_image.release();
+        DevBuf *b[] = {&stats, &coarse_inv, &mis_t, &mis_m, &mis_flag, &mis_id, &agg1, &keys, &rstart, &cursor, &lists};
+        for (DevBuf *x : b) x->release();
+        if (host_stats) (void)hipHostFree(host_stats);
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// level 0: CSR -> ELL
+// ---------------------------------------------------------------------------------
+
+// longest row, number of nodes with graded links (amg.hip's contrast criterion: one link above
+// `share` of the diagonal, or the strongest more than `spread` times the weakest)
+__global__ __launch_bounds__(TB) void row_stats(int64_t n, const int32_t *__restrict__ indptr,
+                                                const int32_t *__restrict__ indices,
+                                                const double *__restrict__ data, double share, double spread,
+                                                unsigned long long *__restrict__ stats) {
+    int32_t mlen = 0;
+    uint32_t graded = 0, bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        const int32_t e0 = indptr[i], e1 = indptr[i + 1];
+        mlen = max(mlen, e1 - e0);
+        double d = 0.0, mx = 0.0, mn = 1e300;
+        for (int32_t e = e0; e < e1; ++e) {
+            const double v = data[e];
+            if (indices[e] == (int32_t)i) d = v;
+            else if (v != 0.0) {
+                mx = fmax(mx, fabs(v));
+                mn = fmin(mn, fabs(v));
+                if (v > 0.0) bad = 1;  // positive off-diagonal: not an M-matrix
+            }
+        }
+        if (!(d > 0.0)) bad = 1;
+        graded += (d > 0.0 && (mx > share * d || mx > spread * mn)) ? 1u : 0u;
+    }
+    __shared__ unsigned int s_len, s_graded, s_bad;
+    if (threadIdx.x == 0) s_len = s_graded = s_bad = 0;
+    __syncthreads();
+    atomicMax(&s_len, (unsigned)mlen);
+    if (graded) atomicAdd(&s_graded, graded);
+    if (bad) atomicOr(&s_bad, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(&stats[ST_MAXLEN], (unsigned long long)s_len);
+        if (s_graded) atomicAdd(&stats[ST_GRADED], (unsigned long long)s_graded);
+        if (s_bad) atomicOr(&stats[ST_BADDIAG], 1ull);
+    }
+}
+
+__global__ __launch_bounds__(TB) void csr_to_ell(int64_t n, int64_t ld, const int32_t *__restrict__ indptr,
+                                                 const int32_t *__restrict__ indices,
+                                                 const double *__restrict__ data, int32_t *__restrict__ col,
+                                                 double *__restrict__ val, int32_t *__restrict__ len,
+                                                 double *__restrict__ dinv, int32_t wpad) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        const int32_t e0 = indptr[i], e1 = indptr[i + 1];
+        double d = 1.0;
+        for (int32_t e = e0; e < e1; ++e) {
+            const int32_t c = indices[e];
+            const double v = data[e];
+            col[(int64_t)(e - e0) * ld + i] = c;
+            val[(int64_t)(e - e0) * ld + i] = v;
+            if (c == (int32_t)i) d = v;
+        }
+        for (int32_t s = e1 - e0; s < wpad; ++s) {  // zero padding up to the fixed width
+            col[(int64_t)s * ld + i] = (int32_t)i;
+            val[(int64_t)s * ld + i] = 0.0;
+        }
+        len[i] = e1 - e0;
+        dinv[i] = 1.0 / d;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// aggregation: distance-2 maximal independent set
+// ---------------------------------------------------------------------------------
+// T[i] = state << 30 | hash30(i) ; state 3 root, 1 undecided, T = 0 out.  (Two nodes within
+// distance 2 with equal hashes -- about one pair in 1e8 -- both become roots: harmless, the
+// aggregates are a little smaller there.)
+
+__device__ __forceinline__ uint32_t hash30(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x & 0x3fffffffu;
+}
+
+__global__ __launch_bounds__(TB) void mis_init(int64_t n, uint32_t *__restrict__ T) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        T[i] = (1u << 30) | hash30((uint32_t)i);
+}
+
+// m[i] = max of v over the closed neighbourhood of i
+__global__ __launch_bounds__(TB) void mis_max(Ell A, const uint32_t *__restrict__ v, uint32_t *__restrict__ m) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        uint32_t best = v[i];
+        const int32_t l = A.len[i];
+        for (int32_t s = 0; s < l; ++s) {
+            const uint32_t t = v[A.col[(int64_t)s * A.ld + i]];
+            best = t > best ? t : best;
+        }
+        m[i] = best;
+    }
+}
+
+// second neighbour-max + state update: an undecided node that is the maximum of its distance-2
+// neighbourhood becomes a root; one that sees a root there drops out.  (No count of the nodes left
+// undecided: 15 000 wavefronts adding to one word cost 150 us, ten times the kernel.)
+__global__ __launch_bounds__(TB) void mis_update(Ell A, uint32_t *__restrict__ T, const uint32_t *__restrict__ m1) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        const uint32_t own = T[i];
+        if ((own >> 30) != 1) continue;
+        uint32_t best = m1[i];
+        const int32_t l = A.len[i];
+        for (int32_t s = 0; s < l; ++s) {
+            const uint32_t t = m1[A.col[(int64_t)s * A.ld + i]];
+            best = t > best ? t : best;
+        }
+        if (best == own) T[i] = own | (2u << 30);
+        else if ((best >> 30) == 3) T[i] = 0;
+    }
+}
+
+// tracing only: nodes still undecided
+__global__ __launch_bounds__(TB) void mis_count(int64_t n, const uint32_t *__restrict__ T,
+                                                unsigned long long *__restrict__ out) {
+    uint32_t left = 0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        left += (T[i] >> 30) == 1 ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) left += __shfl_down(left, off, 64);
+    if ((threadIdx.x & 63) == 0 && left) atomicAdd(out, (unsigned long long)left);
+}
+
+// roots, plus the nodes still undecided after the last round that have no root next to them
+__global__ __launch_bounds__(TB) void mis_flag_roots(Ell A, const uint32_t *__restrict__ T,
+                                                     uint32_t *__restrict__ flag) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i <= A.n; i += (int64_t)gridDim.x * TB) {
+        uint32_t f = 0;
+        if (i < A.n) {
+            const uint32_t own = T[i];
+            if ((own >> 30) == 3) f = 1;
+            else if ((own >> 30) == 1) {
+                bool near = false;
+                const int32_t l = A.len[i];
+                for (int32_t s = 0; s < l; ++s) near = near || (T[A.col[(int64_t)s * A.ld + i]] >> 30) == 3;
+                f = near ? 0u : 1u;
+            }
+        }
+        flag[i] = f;
+    }
+}
+
+// roots and their neighbours (the root of highest priority if there are several)
+__global__ __launch_bounds__(TB) void assign_near(Ell A, const uint32_t *__restrict__ T,
+                                                  const uint32_t *__restrict__ flag,
+                                                  const uint32_t *__restrict__ id, int32_t *__restrict__ agg1) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        int32_t a = -1;
+        if (flag[i]) a = (int32_t)id[i];
+        else {
+            uint32_t best = 0;
+            const int32_t l = A.len[i];
+            for (int32_t s = 0; s < l; ++s) {
+                const int32_t j = A.col[(int64_t)s * A.ld + i];
+                if (j == (int32_t)i || !flag[j]) continue;
+                const uint32_t t = T[j] | (3u << 30);
+                if (t > best) { best = t; a = (int32_t)id[j]; }
+            }
+        }
+        agg1[i] = a;
+    }
+}
+
+// the rest joins the aggregate of its strongest assigned neighbour
+__global__ __launch_bounds__(TB) void assign_far(Ell A, const int32_t *__restrict__ agg1, int32_t *__restrict__ agg,
+                                                 unsigned long long *__restrict__ stats) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        int32_t a = agg1[i];
+        if (a < 0) {
+            double bw = -1.0;
+            const int32_t l = A.len[i];
+            for (int32_t s = 0; s < l; ++s) {
+                const int32_t j = A.col[(int64_t)s * A.ld + i];
+                const int32_t aj = agg1[j];
+                if (j == (int32_t)i || aj < 0) continue;
+                const double w = fabs(A.val[(int64_t)s * A.ld + i]);
+                if (w > bw) { bw = w; a = aj; }
+            }
+            if (a < 0) stats[ST_UNASSIGNED] = 1;  // benign race
+        }
+        agg[i] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// P = (I - w D^-1 A) P_tent, at most PW entries per row (the rest lumped into the own aggregate)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(TB) void build_P(Ell A, const double *__restrict__ dinv,
+                                              const int32_t *__restrict__ agg, int32_t *__restrict__ pcol,
+                                              double *__restrict__ pval) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        int32_t c[PW];
+        double v[PW];
+#pragma unroll
+        for (int k = 0; k < PW; ++k) { c[k] = -1; v[k] = 0.0; }
+        const int32_t own = agg[i];
+        c[0] = own;
+        v[0] = 1.0;
+        const double wd = OMEGA_P * dinv[i];
+        const int32_t l = A.len[i];
+        for (int32_t s = 0; s < l; ++s) {
+            const int32_t J = agg[A.col[(int64_t)s * A.ld + i]];
+            const double t = -wd * A.val[(int64_t)s * A.ld + i];
+            bool placed = false;
+#pragma unroll
+            for (int k = 0; k < PW; ++k) {
+                if (!placed && c[k] == J) { v[k] += t; placed = true; }
+            }
+#pragma unroll
+            for (int k = 1; k < PW; ++k) {
+                if (!placed && c[k] < 0) { c[k] = J; v[k] = t; placed = true; }
+            }
+            if (!placed) v[0] += t;  // a fifth aggregate: lumped (row sum kept)
+        }
+#pragma unroll
+        for (int k = 0; k < PW; ++k) {
+            pcol[(int64_t)k * A.ld + i] = c[k];
+            pval[(int64_t)k * A.ld + i] = v[k];
+        }
+    }
+}
+
+// ---- R = P^T by coarse row: count, scan, fill, sort each row's (node << 2 | slot) keys ----
+__global__ __launch_bounds__(TB) void r_count(int64_t n, int64_t ld, const int32_t *__restrict__ pcol,
+                                              uint32_t *__restrict__ cnt) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+#pragma unroll
+        for (int k = 0; k < PW; ++k) {
+            const int32_t J = pcol[(int64_t)k * ld + i];
+            if (J >= 0) atomicAdd(&cnt[J], 1u);
+        }
+    }
+}
+__global__ __launch_bounds__(TB) void r_fill(int64_t n, int64_t ld, const int32_t *__restrict__ pcol,
+                                             const uint32_t *__restrict__ rstart, uint32_t *__restrict__ cursor,
+                                             uint64_t *__restrict__ keys) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+#pragma unroll
+        for (int k = 0; k < PW; ++k) {
+            const int32_t J = pcol[(int64_t)k * ld + i];
+            if (J >= 0) keys[rstart[J] + atomicAdd(&cursor[J], 1u)] = ((uint64_t)i << 2) | (uint64_t)k;
+        }
+    }
+}
+__global__ __launch_bounds__(TB) void r_to_ell(int64_t nc, int64_t rld, const uint32_t *__restrict__ rstart,
+                                               const uint64_t *__restrict__ keys, int64_t ld,
+                                               const double *__restrict__ pval, int32_t *__restrict__ rcol,
+                                               double *__restrict__ rval, int32_t *__restrict__ rlen,
+                                               unsigned long long *__restrict__ stats) {
+    uint32_t mlen = 0;
+    for (int64_t I = (int64_t)blockIdx.x * TB + threadIdx.x; I < nc; I += (int64_t)gridDim.x * TB) {
+        const uint32_t s0 = rstart[I];
+        uint32_t l = rstart[I + 1] - s0;
+        mlen = l > mlen ? l : mlen;
+        if (l > (uint32_t)RCAP) l = RCAP;
+        for (uint32_t t = 0; t < l; ++t) {
+            const uint64_t key = keys[s0 + t];
+            const int64_t i = (int64_t)(key >> 2);
+            const int64_t at = ((int64_t)(t >> 3) * rld + I) * 8 + (t & 7);  // blocks of 8 (k_restrict)
+            rcol[at] = (int32_t)i;
+            rval[at] = pval[(int64_t)(key & 3) * ld + i];
+        }
+        // zero padding: to the end of the last block of 8, and on small levels (the LDS tail copies
+        // whole rows without looking at their length) up to RCAP
+        const uint32_t upto = nc <= 4096 ? (uint32_t)RCAP : ((l + 7u) & ~7u);
+        for (uint32_t t = l; t < upto; ++t) {
+            const int64_t at = ((int64_t)(t >> 3) * rld + I) * 8 + (t & 7);
+            rcol[at] = 0;
+            rval[at] = 0.0;
+        }
+        rlen[I] = (int32_t)l;
+    }
+    if (mlen > (uint32_t)RCAP) atomicOr(&stats[ST_OVERFLOW], 2ull);
+    if (mlen) atomicMax(&stats[ST_MAXR], (unsigned long long)mlen);
+}
+
+// ---------------------------------------------------------------------------------
+// Galerkin product A_c = R A P: one wavefront (= one 64-thread workgroup) per coarse row
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_excl_scan(int v, int *total) {
+    const int lane = threadIdx.x & 63;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    *total = __shfl(incl, 63, 64);
+    return incl - v;
+}
+
+// Products of the R entries [t0, t0 + tn) of coarse row I, in (R entry, A slot, P slot) order, into
+// the LDS list (lJ, lV); returns their number.  The (node, slot, weight) pairs are laid out in
+// LDS first, so that no lane idles on the slots a short row does not have and every global
+// load of a step is independent of the others of that step: four dependent round trips per
+// group (R entry -> row length -> A entry -> P entries).
+__device__ __forceinline__ int galerkin_products(const Ell &A, const int32_t *__restrict__ pcol,
+                                                 const double *__restrict__ pval, int64_t rld,
+                                                 const int32_t *__restrict__ rcol, const double *__restrict__ rval,
+                                                 int64_t I, int t0, int tn, int32_t *pi, int32_t *psa, double *pw,
+                                                 int32_t *lJ, double *lV) {
+    const int lane = threadIdx.x;
+    int32_t i = 0, len = 0;
+    double w = 0.0;
+    if (lane < tn) {
+        const int t = t0 + lane;
+        const int64_t rat = ((int64_t)(t >> 3) * rld + I) * 8 + (t & 7);
+        i = rcol[rat];
+        w = rval[rat];
+        len = A.len[i];
+    }
+    int npairs = 0;
+    const int poff = wave_excl_scan(len, &npairs);
+    for (int sa = 0; sa < len; ++sa) {
+        pi[poff + sa] = i;
+        psa[poff + sa] = sa;
+        pw[poff + sa] = w;
+    }
+    __syncthreads();
+    int np = 0;
+    for (int base = 0; base < npairs; base += 64) {
+        const int idx = base + lane;
+        int32_t pj[PW];
+        double pv[PW];
+        int c = 0;
+        if (idx < npairs) {
+            const int32_t ii = pi[idx], sa = psa[idx];
+            const int32_t k = A.col[(int64_t)sa * A.ld + ii];
+            const double wa = pw[idx] * A.val[(int64_t)sa * A.ld + ii];
+            int32_t J[PW];
+            double pp[PW];
+#pragma unroll
+            for (int sp = 0; sp < PW; ++sp) {
+                J[sp] = pcol[(int64_t)sp * A.ld + k];
+                pp[sp] = pval[(int64_t)sp * A.ld + k];
+            }
+#pragma unroll
+            for (int sp = 0; sp < PW; ++sp)
+                if (J[sp] >= 0) {
+                    pj[c] = J[sp];
+                    pv[c] = wa * pp[sp];
+                    ++c;
+                }
+        }
+        int chunk = 0;
+        const int o = np + wave_excl_scan(c, &chunk);
+#pragma unroll
+        for (int q = 0; q < PW; ++q)
+            if (q < c) {
+                lJ[o + q] = pj[q];
+                lV[o + q] = pv[q];
+            }
+        np += chunk;
+    }
+    __syncthreads();
+    return np;
+}
+
+// G: R entries per group (G * longest row of A pairs and four times as many products fit in LDS)
+__global__ __launch_bounds__(64) void galerkin(Ell A, const int32_t *__restrict__ pcol,
+                                               const double *__restrict__ pval, int64_t nc, int64_t rld,
+                                               const int32_t *__restrict__ rcol, const double *__restrict__ rval,
+                                               const int32_t *__restrict__ rlen, int64_t cld,
+                                               int32_t *__restrict__ ccol, double *__restrict__ cval,
+                                               int32_t *__restrict__ clen, double *__restrict__ cdinv,
+                                               unsigned long long *__restrict__ stats, int G) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    const int paircap = G * A.width;
+    int32_t *set = reinterpret_cast<int32_t *>(gsm);                         // [256]
+    double *pw = reinterpret_cast<double *>(gsm + 1024);                     // [paircap]
+    double *lV = pw + paircap;                                               // [4 paircap]
+    int32_t *pi = reinterpret_cast<int32_t *>(lV + 4 * paircap);             // [paircap]
+    int32_t *psa = pi + paircap;                                             // [paircap]
+    int32_t *lJ = psa + paircap;                                             // [4 paircap]
+    const int lane = threadIdx.x;
+    uint32_t my_max = 0, my_nnz = 0, my_flags = 0;
+    for (int64_t I = blockIdx.x; I < nc; I += gridDim.x) {
+        for (int k = lane; k < 256; k += 64) set[k] = -1;
+        __syncthreads();
+        const int rl = rlen[I];
+        const int ngroups = (rl + G - 1) / G;
+        // pass 1: the set of columns
+        int np = 0;
+        for (int g = 0; g < ngroups; ++g) {
+            np = galerkin_products(A, pcol, pval, rld, rcol, rval, I, g * G, min(G, rl - g * G), pi, psa, pw, lJ, lV);
+            for (int p = lane; p < np; p += 64) {
+                const int32_t J = lJ[p];
+                uint32_t hsh = ((uint32_t)J * 2654435761u) >> 24;
+                for (int probe = 0; probe < 256; ++probe) {
+                    const int32_t old = atomicCAS(&set[hsh], -1, J);
+                    if (old == -1 || old == J) break;
+                    hsh = (hsh + 1) & 255u;
+                    if (probe == 255) my_flags |= 1u;
+                }
+            }
+            __syncthreads();
+        }
+        // compact the set (each lane owns 4 slots), sort it with wave shuffles
+        int32_t mine[4];
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mine[q] = set[lane * 4 + q];
+            cnt += mine[q] >= 0 ? 1 : 0;
+        }
+        int total = 0;
+        int off = wave_excl_scan(cnt, &total);
+        __syncthreads();
+        // (the compacted columns go through `set` itself: every lane has read its slots)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (mine[q] >= 0) set[off++] = mine[q];
+        __syncthreads();
+        if (total > ACAP) {
+            my_flags |= 1u;
+            total = ACAP;
+        }
+        int32_t myJ = lane < total ? set[lane] : 0x7fffffff;
+        __syncthreads();
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const int32_t other = __shfl_xor(myJ, j, 64);
+                const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+                const int32_t lo = myJ < other ? myJ : other, hi = myJ < other ? other : myJ;
+                myJ = (lower == up) ? lo : hi;
+            }
+        }
+        // pass 2: lane l sums the products of column myJ in list order; a row of one group still has
+        // its products in LDS, longer rows regenerate them group by group
+        double acc = 0.0;
+        for (int g = 0; g < ngroups; ++g) {
+            if (ngroups > 1)
+                np = galerkin_products(A, pcol, pval, rld, rcol, rval, I, g * G, min(G, rl - g * G), pi, psa, pw, lJ, lV);
+            // eight products per step, loaded unconditionally (a compare-then-load loop pays the LDS
+            // latency twice per product: 12 us for a row of 200 products); +0.0 for the others
+            // leaves the sum, and its order, unchanged
+            for (int p = lane + np; p < ((np + 7) & ~7); p += 64) lJ[p] = -1;  // pad (capacity is a multiple of 8)
+            __syncthreads();
+            for (int p = 0; p < np; p += 8) {
+                int32_t j8[8];
+                double v8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    j8[u] = lJ[p + u];
+                    v8[u] = lV[p + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += j8[u] == myJ ? v8[u] : 0.0;
+            }
+            __syncthreads();
+        }
+        if (lane >= total && lane < APAD) {  // zero padding: fixed-trip-count row loops (tail, unrolled kernels)
+            ccol[(int64_t)lane * cld + I] = (int32_t)I;
+            cval[(int64_t)lane * cld + I] = 0.0;
+        }
+        if (lane < total) {
+            ccol[(int64_t)lane * cld + I] = myJ;
+            cval[(int64_t)lane * cld + I] = acc;
+            if (myJ == (int32_t)I) {
+                if (!(acc > 0.0)) my_flags |= 4u;
+                cdinv[I] = acc > 0.0 ? 1.0 / acc : 1.0;
+            }
+        }
+        if (lane == 0) {
+            clen[I] = total;
+            my_max = (uint32_t)total > my_max ? (uint32_t)total : my_max;
+            my_nnz += (uint32_t)total;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        if (my_max) atomicMax(&stats[ST_MAXLEN], (unsigned long long)my_max);
+        if (my_nnz) atomicAdd(&stats[ST_NNZ], (unsigned long long)my_nnz);
+    }
+    if (my_flags & 1u) atomicOr(&stats[ST_OVERFLOW], 1ull);
+    if (my_flags & 4u) atomicOr(&stats[ST_BADDIAG], 1ull);
+}
+
+// dense inverse of the coarsest matrix (n <= COARSEST) by Gauss-Jordan in LDS; SPD, no pivoting
+__global__ __launch_bounds__(256) void coarsest_inverse(Ell A, double *__restrict__ inv,
+                                                        unsigned long long *__restrict__ stats) {
+    __shared__ double M[COARSEST][2 * COARSEST + 1];
+    const int n = (int)A.n;
+    for (int t = threadIdx.x; t < n * 2 * n; t += 256) {
+        const int r = t / (2 * n), c = t % (2 * n);
+        M[r][c] = (c >= n && c - n == r) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < n; r += 256)
+        for (int s = 0; s < A.len[r]; ++s) M[r][A.col[(int64_t)s * A.ld + r]] = A.val[(int64_t)s * A.ld + r];
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        const double pv = M[k][k];
+        if (!(pv > 0.0)) {
+            if (threadIdx.x == 0) atomicOr(&stats[ST_BADDIAG], 2ull);
+            return;  // uniform: every thread reads the same pivot
+        }
+        const double rp = 1.0 / pv;
+        __syncthreads();
+        for (int c = threadIdx.x; c < 2 * n; c += 256) M[k][c] *= rp;
+        __syncthreads();
+        for (int t = threadIdx.x; t < n * 2 * n; t += 256) {
+            const int r = t / (2 * n), c = t % (2 * n);
+            if (r != k && c != k) M[r][c] = fma(-M[r][k], M[k][c], M[r][c]);
+        }
+        __syncthreads();
+        for (int r = threadIdx.x; r < n; r += 256)
+            if (r != k) M[r][k] = 0.0;
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < n * n; t += 256) inv[t] = M[t / n][n + t % n];
+}
+
+// ---- structural singularity: "touches ground" flags OR-ed up the hierarchy, components of the
+//      last level by label propagation in one workgroup ------------------------------------
+__global__ __launch_bounds__(TB) void flags_up(int64_t n, const int32_t *__restrict__ agg,
+                                               const uint8_t *__restrict__ fine, uint8_t *__restrict__ coarse) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        if (fine[i]) coarse[agg[i]] = 1;  // benign race: every writer stores 1
+}
+__global__ __launch_bounds__(64) void last_level_floating(Ell A, const uint8_t *__restrict__ grounded,
+                                                          uint32_t *__restrict__ floating) {
+    __shared__ int label[COARSEST];
+    __shared__ int changed;
+    const int n = (int)A.n, i = threadIdx.x;
+    if (i < n) label[i] = i;
+    __syncthreads();
+    for (int it = 0; it < COARSEST; ++it) {
+        if (i == 0) changed = 0;
+        __syncthreads();
+        int best = i < n ? label[i] : 0;
+        if (i < n)
+            for (int s = 0; s < A.len[i]; ++s) {
+                const int l = label[A.col[(int64_t)s * A.ld + i]];
+                best = l < best ? l : best;
+            }
+        __syncthreads();
+        if (i < n && best < label[i]) {
+            label[i] = best;
+            changed = 1;
+        }
+        __syncthreads();
+        if (!changed) break;
+        __syncthreads();
+    }
+    __shared__ int ok[COARSEST];
+    if (i < n) ok[i] = 0;
+    __syncthreads();
+    if (i < n && grounded[i]) ok[label[i]] = 1;
+    __syncthreads();
+    if (i < n && label[i] == i && !ok[i]) *floating = 1;
+}
+
+// diagonal last level: every node is a component of its own
+__global__ __launch_bounds__(TB) void any_unflagged(int64_t n, const uint8_t *__restrict__ grounded,
+                                                    uint32_t *__restrict__ floating) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        if (!grounded[i]) *floating = 1;  // benign race
+}
+
+}  // namespace
+
+#include "sagg_cycle.h"
+
+// ---------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------
+namespace {
+
+constexpr int SAGG_DECLINED = -3;  // not this path's kind of network: the caller takes amg.hip
+
+// smallest unrolled width class >= maxlen (0: none)
+int width_class(int maxlen) {
+    static const int classes[] = {4, 5, 6, 8, 12, 16, 20, 24, 32};
+    for (int c : classes)
+        if (maxlen <= c) return c;
+    return 0;
+}
+// padded rows pay when the padding is small, or when the level is so small that latency is all
+int choose_wfix(int maxlen, int64_t n, int64_t nnz, int pad_limit) {
+    const int c = width_class(maxlen);
+    if (c == 0 || c > pad_limit) return 0;
+    if ((double)c * (double)n <= 1.3 * (double)nnz || n <= 32768) return c;
+    return 0;
+}
+
+SHierarchy *hierarchy_of(nodal_ctx *h) {
+    if (!h->sagg) h->sagg = new SHierarchy();
+    return static_cast<SHierarchy *>(h->sagg);
+}
+
+struct SolveBufs {
+    double *r, *z, *p, *Ap, *x0, *part_rz, *part_zap, *part_rr, *part_pap, *sc;
+    int g0;  // grid of the level-0 kernels that produce / consume dot partials
+};
+
+// one aggregation + transfer operators + Galerkin product: level l -> l + 1.
+// *stop: the level cannot be coarsened (every node is its own aggregate).
+int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool *declined, bool *stop) {
+    hipStream_t st = h->stream;
+    SLevel *L = H->level(l);
+    const int64_t n = L->n, ld = L->ld;
+    Ell A = L->A();
+    A.width = L->maxlen;  // pair enumeration of the Galerkin kernel: slots actually in use
+    unsigned long long *dstats = H->stats.as<unsigned long long>();
+
+    NODAL_HIP_TRY(h, H->mis_t.reserve((size_t)n * 8 + 64));
+    NODAL_HIP_TRY(h, H->mis_m.reserve((size_t)n * 8 + 64));
+    NODAL_HIP_TRY(h, H->mis_flag.reserve((size_t)(n + 1) * 4 + 64));
+    NODAL_HIP_TRY(h, H->mis_id.reserve((size_t)(n + 1) * 4 + 64 + scan_tmp_bytes(n + 1)));
+    NODAL_HIP_TRY(h, H->agg1.reserve((size_t)n * 4 + 64));
+    NODAL_HIP_TRY(h, L->agg.reserve((size_t)n * 4 + 64));
+    NODAL_HIP_TRY(h, H->cursor.reserve((MIS_ROUNDS + 2) * 8 + 64));
+    uint32_t *T = H->mis_t.as<uint32_t>(), *M = H->mis_m.as<uint32_t>();
+    uint32_t *flag = H->mis_flag.as<uint32_t>(), *id = H->mis_id.as<uint32_t>();
+    unsigned long long *cnt = H->cursor.as<unsigned long long>();
+    void *scan_tmp = H->mis_id.as<char>() + (((size_t)(n + 1) * 4 + 63) & ~(size_t)63);
+
+    const unsigned g = grid_for(n);
+    static const bool trace_mis = getenv("NODAL_TRACE") != nullptr;
+    if (trace_mis) NODAL_HIP_TRY(h, hipMemsetAsync(cnt, 0, (MIS_ROUNDS + 2) * 8, st));
+    mis_init<<<g, TB, 0, st>>>(n, T);
+    for (int r = 0; r < MIS_ROUNDS; ++r) {
+        mis_max<<<g, TB, 0, st>>>(A, T, M);
+        mis_update<<<g, TB, 0, st>>>(A, T, M);
+        if (trace_mis) mis_count<<<g, TB, 0, st>>>(n, T, cnt + r + 1);
+    }
+    mis_flag_roots<<<grid_for(n + 1), TB, 0, st>>>(A, T, flag);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    NODAL_TRY(scan_exclusive_u32(h, flag, id, n + 1, nullptr, scan_tmp));
+    // the one round trip of this level: the number of aggregates, and what the Galerkin kernel
+    // of the level above recorded about THIS level's matrix
+    uint32_t nc32 = 0;
+    NODAL_HIP_TRY(h, hipMemcpyAsync(&nc32, id + n, 4, hipMemcpyDeviceToHost, st));
+    NODAL_HIP_TRY(h, hipMemcpyAsync(hs, dstats, (size_t)MAX_LEVELS * ST_COUNT * 8, hipMemcpyDeviceToHost, st));
+    unsigned long long hcnt[MIS_ROUNDS + 1] = {0};
+    if (trace_mis) NODAL_HIP_TRY(h, hipMemcpyAsync(hcnt, cnt, sizeof hcnt, hipMemcpyDeviceToHost, st));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    if (trace_mis) {
+        fprintf(stderr, "[sagg] level %d: undecided after each MIS round:", l);
+        for (int r = 1; r <= MIS_ROUNDS; ++r) fprintf(stderr, " %llu", hcnt[r]);
+        fprintf(stderr, "\n");
+    }
+    const int64_t nc = nc32;
+    if (l > 0) {  // what the Galerkin kernel of the level above recorded about this level's matrix
+        const unsigned long long *s = hs + (size_t)l * ST_COUNT;
+        L->maxlen = (int32_t)s[ST_MAXLEN];
+        L->nnz = (int64_t)s[ST_NNZ];
+        A.width = L->maxlen;
+        if (s[ST_OVERFLOW] || s[ST_BADDIAG] || hs[(size_t)(l - 1) * ST_COUNT + ST_OVERFLOW] ||
+            hs[(size_t)(l - 1) * ST_COUNT + ST_UNASSIGNED]) {
+            *declined = true;
+            return NODAL_OK;
+        }
+    }
+    if (nc >= n || L->maxlen <= 1) {  // nothing but isolated nodes (one per independent circuit): last level
+        *stop = true;
+        return NODAL_OK;
+    }
+    if (nc * 2 > n || nc < 1) {  // coarsening too slow to pay: not this path's kind of graph
+        *declined = true;
+        return NODAL_OK;
+    }
+    L->nc = nc;
+    assign_near<<<g, TB, 0, st>>>(A, T, flag, id, H->agg1.as<int32_t>());
+    assign_far<<<g, TB, 0, st>>>(A, H->agg1.as<int32_t>(), L->agg.as<int32_t>(), dstats + (size_t)l * ST_COUNT);
+    NODAL_HIP_TRY(h, L->pcol.reserve((size_t)PW * ld * 4 + 64));
+    NODAL_HIP_TRY(h, L->pval.reserve((size_t)PW * ld * 8 + 64));
+    build_P<<<g, TB, 0, st>>>(A, L->dinv.as<double>(), L->agg.as<int32_t>(), L->pcol.as<int32_t>(),
+                             L->pval.as<double>());
+    NODAL_HIP_TRY(h, hipGetLastError());
+
+    // R = P^T by coarse row
+    const size_t a4 = (((size_t)(nc + 1) * 4) + 255) & ~(size_t)255;
+    NODAL_HIP_TRY(h, H->rstart.reserve(2 * a4 + 256 + scan_tmp_bytes(nc + 1)));
+    NODAL_HIP_TRY(h, H->keys.reserve((size_t)PW * n * 8 + 64));
+    NODAL_HIP_TRY(h, H->lists.reserve(2 * a4 + 64));
+    char *rs = H->rstart.as<char>();
+    uint32_t *rstart = reinterpret_cast<uint32_t *>(rs);
+    uint32_t *cursor = reinterpret_cast<uint32_t *>(rs + a4);
+    uint32_t *counts = reinterpret_cast<uint32_t *>(rs + 2 * a4);
+    void *scan_tmp2 = rs + 2 * a4 + 256;
+    NODAL_HIP_TRY(h, hipMemsetAsync(rs, 0, 2 * a4 + 256, st));
+    r_count<<<g, TB, 0, st>>>(n, ld, L->pcol.as<int32_t>(), rstart);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    NODAL_TRY(scan_exclusive_u32(h, rstart, rstart, nc + 1, nullptr, scan_tmp2));
+    uint64_t *keys = H->keys.as<uint64_t>();
+    r_fill<<<g, TB, 0, st>>>(n, ld, L->pcol.as<int32_t>(), rstart, cursor, keys);
+    int32_t *medium_list = H->lists.as<int32_t>();
+    int32_t *long_list = reinterpret_cast<int32_t *>(H->lists.as<char>() + a4);
+    grp::sort_rows_short<<<grid_for(nc), TB, 0, st>>>(rstart, keys, nc, medium_list, long_list, counts);
+    {
+        const unsigned gm = (unsigned)(nc < 1024 ? nc : 1024);
+        grp::sort_rows_medium<<<gm, TB, 0, st>>>(rstart, keys, medium_list, counts);
+        NODAL_HIP_TRY(h, h->work3.reserve((size_t)PW * n * 16 + 64));  // padded scratch of the long sort
+        grp::sort_rows_long<<<gm < 128 ? gm : 128, 1024, 0, st>>>(rstart, keys, h->work3.as<uint64_t>(), long_list,
+                                                                 counts);
+    }
+    NODAL_HIP_TRY(h, hipGetLastError());
+
+    SLevel *C = H->level(l + 1);
+    C->n = nc;
+    C->ld = pad64(nc);
+    C->width = ACAP;
+    C->nc = 0;
+    L->rld = C->ld;
+    NODAL_HIP_TRY(h, L->rcol.reserve((size_t)RCAP * C->ld * 4 + 64));
+    NODAL_HIP_TRY(h, L->rval.reserve((size_t)RCAP * C->ld * 8 + 64));
+    NODAL_HIP_TRY(h, L->rlen.reserve((size_t)C->ld * 4 + 64));
+    r_to_ell<<<grid_for(nc), TB, 0, st>>>(nc, L->rld, rstart, keys, ld, L->pval.as<double>(),
+                                         L->rcol.as<int32_t>(), L->rval.as<double>(), L->rlen.as<int32_t>(),
+                                         dstats + (size_t)l * ST_COUNT);
+    NODAL_HIP_TRY(h, C->acol.reserve((size_t)ACAP * C->ld * 4 + 64));
+    NODAL_HIP_TRY(h, C->aval.reserve((size_t)ACAP * C->ld * 8 + 64));
+    NODAL_HIP_TRY(h, C->alen.reserve((size_t)C->ld * 4 + 64));
+    NODAL_HIP_TRY(h, C->dinv.reserve((size_t)C->ld * 8 + 64));
+    {
+        // R entries per group: pairs (G x longest row of A) and products (4 x pairs) of a group live in LDS;
+        // small budget where there are many coarse rows (occupancy), larger where rows are few and long
+        const int paircap = nc > 50000 ? 192 : 512;
+        int G = paircap / (A.width > 0 ? A.width : 1);
+        G = (G < 8 ? 8 : (G > 64 ? 64 : G)) & ~1;  // even: the product list's capacity is a multiple of 8
+        const size_t lds = 1024 + (size_t)G * A.width * 64;
+        NODAL_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(galerkin),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds > 65536 ? lds : 65536)));
+        galerkin<<<(unsigned)(nc < 32768 ? nc : 32768), 64, lds, st>>>(
+            A, L->pcol.as<int32_t>(), L->pval.as<double>(), nc, L->rld, L->rcol.as<int32_t>(), L->rval.as<double>(),
+            L->rlen.as<int32_t>(), C->ld, C->acol.as<int32_t>(), C->aval.as<double>(), C->alen.as<int32_t>(),
+            C->dinv.as<double>(), dstats + (size_t)(l + 1) * ST_COUNT, G);
+    }
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
+}
+
+int build_tail(nodal_ctx *h, SHierarchy *H, const unsigned long long *hs) {
+    H->tail = -1;
+    const int last = H->nlev - 1;
+    auto up16 = [](int x) { return (x + 15) & ~15; };
+    for (int t = 1; t <= last; ++t) {
+        if (H->pool[t]->n > TAIL_MAX_N || last - t + 1 > TAIL_LEVELS) continue;
+        TailDesc d;
+        memset(&d, 0, sizeof d);
+        d.nlev = last - t + 1;
+        int off = 0;
+        bool ok = true;
+        for (int k = 0; k < d.nlev; ++k) {  // image part
+            const SLevel *L = H->pool[t + k];
+            TailLevelDesc &q = d.lv[k];
+            q.n = (int)L->n; q.nc = (int)L->nc; q.ld = (int)L->ld; q.rld = (int)L->rld; q.width = L->maxlen;
+            q.acol = L->acol.as<int32_t>(); q.aval = L->aval.as<double>();
+            q.dinv = L->dinv.as<double>();
+            q.pcol = L->pcol.as<int32_t>(); q.pval = L->pval.as<double>();
+            q.rcol = L->rcol.as<int32_t>(); q.rval = L->rval.as<double>(); q.rlen = L->rlen.as<int32_t>();
+            if (k == d.nlev - 1) {  // dense inverse (n^2) or diagonal (n)
+                q.o_aval = off; off = up16(off + (H->dense_coarsest ? q.n * q.n : q.n) * 8);
+                continue;
+            }
+            // rows of A are zero-padded by the Galerkin kernel up to APAD slots only
+            if (q.width > APAD) ok = false;
+            const int maxr = (int)hs[(size_t)(t + k) * ST_COUNT + ST_MAXR];
+            q.nq = (maxr + 7) / 8;
+            q.lpr = 1;
+            while (q.lpr < 8 && q.n * q.lpr * 2 <= 1024) q.lpr *= 2;
+            q.o_aval = off; off = up16(off + q.n * q.width * 8);
+            q.o_acol = off; off = up16(off + q.n * q.width * 2);
+            q.o_dinv = off; off = up16(off + q.n * 8);
+            q.o_pval = off; off = up16(off + q.n * PW * 8);
+            q.o_pcol = off; off = up16(off + q.n * PW * 2);
+            q.o_rval = off; off = up16(off + q.nq * q.nc * 8 * 8);
+            q.o_rcol = off; off = up16(off + q.nq * q.nc * 8 * 2);
+        }
+        d.image_bytes = off;
+        for (int k = 0; k < d.nlev; ++k) {  // vectors
+            TailLevelDesc &q = d.lv[k];
+            q.o_B = off; off = up16(off + q.n * 8);
+            q.o_X = off; off = up16(off + q.n * 8);
+            if (k == d.nlev - 1) continue;
+            q.o_Y = off; off = up16(off + q.n * 8);
+            q.o_R = off; off = up16(off + q.n * 8);
+        }
+        d.inv = H->dense_coarsest ? H->coarse_inv.as<double>() : nullptr;
+        d.lds_bytes = off;
+        if (!ok || off > TAIL_LDS_BUDGET) continue;
+        NODAL_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_tail),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, off));
+        NODAL_HIP_TRY(h, H->tail_image.reserve((size_t)d.image_bytes + 256));
+        k_tail_pack<<<1, 1024, 0, h->stream>>>(d, H->tail_image.as<char>());
+        NODAL_HIP_TRY(h, hipGetLastError());
+        H->td = d;
+        H->tail = t;
+        break;
+    }
+    return NODAL_OK;
+}
+
+}  // namespace
+
+void sagg_destroy(nodal_ctx *h) {
+    delete static_cast<SHierarchy *>(h->sagg);
+    h->sagg = nullptr;
+}
+
+// Build the hierarchy for the context's CSR matrix.  *accepted = false: the network is not of
+// the kind this path handles (graded links, hub rows, positive off-diagonals, a coarse row
+// beyond the caps): nothing is kept, the caller uses amg.hip.  *floating: a connected
+// component without a resistor to ground (structurally singular; the reference's spsolve
+// returns NaNs).
+int sagg_setup(nodal_ctx *h, bool *accepted, int32_t *floating) {
+    *accepted = false;
+    *floating = 0;
+    static const bool enabled = !(getenv("NODAL_SAGG") && atoi(getenv("NODAL_SAGG")) == 0);
+    static const bool trace = getenv("NODAL_TRACE") != nullptr;
+    if (!enabled) return NODAL_OK;
+    SHierarchy *H = hierarchy_of(h);
+    H->ready = false;
+    hipStream_t st = h->stream;
+    const int64_t n0 = h->n;
+    if (n0 >= (1ll << 30)) return NODAL_OK;
+    NODAL_HIP_TRY(h, H->stats.reserve((size_t)MAX_LEVELS * ST_COUNT * 8 + 64));
+    if (!H->host_stats)
+        NODAL_HIP_TRY(h, hipHostMalloc(reinterpret_cast<void **>(&H->host_stats), (size_t)MAX_LEVELS * ST_COUNT * 8 + 64));
+    unsigned long long *dstats = H->stats.as<unsigned long long>();
+    unsigned long long *hs = reinterpret_cast<unsigned long long *>(H->host_stats);
+    NODAL_HIP_TRY(h, hipMemsetAsync(dstats, 0, (size_t)MAX_LEVELS * ST_COUNT * 8, st));
+    row_stats<<<grid_for(n0), TB, 0, st>>>(n0, h->indptr.as<int32_t>(), h->indices.as<int32_t>(),
+                                          h->data.as<double>(), 0.9, 8.0, dstats);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    NODAL_HIP_TRY(h, hipMemcpyAsync(hs, dstats, ST_COUNT * 8, hipMemcpyDeviceToHost, st));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    const int64_t bar = n0 / 100 < 32 ? (n0 / 100 > 0 ? n0 / 100 : 1) : 32;  // amg.hip's contrast criterion
+    if (hs[ST_MAXLEN] > (unsigned long long)W0_MAX || hs[ST_MAXLEN] == 0 || hs[ST_BADDIAG] ||
+        (int64_t)hs[ST_GRADED] >= bar) {
+        if (trace)
+            fprintf(stderr, "[sagg] declined: longest row %llu, graded nodes %llu (bar %lld), M-matrix %s\n",
+                    hs[ST_MAXLEN], hs[ST_GRADED], (long long)bar, hs[ST_BADDIAG] ? "no" : "yes");
+        return NODAL_OK;
+    }
+    SLevel *L0 = H->level(0);
+    L0->n = n0;
+    L0->ld = pad64(n0);
+    L0->maxlen = (int32_t)hs[ST_MAXLEN];
+    L0->nnz = h->nnz;
+    L0->wfix = choose_wfix(L0->maxlen, n0, h->nnz, 8);
+    L0->width = L0->wfix ? L0->wfix : L0->maxlen;
+    NODAL_HIP_TRY(h, L0->acol.reserve((size_t)L0->width * L0->ld * 4 + 64));
+    NODAL_HIP_TRY(h, L0->aval.reserve((size_t)L0->width * L0->ld * 8 + 64));
+    NODAL_HIP_TRY(h, L0->alen.reserve((size_t)L0->ld * 4 + 64));
+    NODAL_HIP_TRY(h, L0->dinv.reserve((size_t)L0->ld * 8 + 64));
+    csr_to_ell<<<grid_for(n0), TB, 0, st>>>(n0, L0->ld, h->indptr.as<int32_t>(), h->indices.as<int32_t>(),
+                                           h->data.as<double>(), L0->acol.as<int32_t>(), L0->aval.as<double>(),
+                                           L0->alen.as<int32_t>(), L0->dinv.as<double>(), L0->wfix);
+    NODAL_HIP_TRY(h, hipGetLastError());
+
+    int l = 0;
+    bool diag_last = false;
+    for (;; ++l) {
+        SLevel *L = H->level(l);
+        if (L->n <= COARSEST && l > 0) break;
+        if (l + 1 >= MAX_LEVELS) {
+            if (trace) fprintf(stderr, "[sagg] declined: more than %d levels\n", MAX_LEVELS);
+            return NODAL_OK;
+        }
+        bool declined = false, stop = false;
+        NODAL_TRY(build_level(h, H, l, hs, &declined, &stop));
+        if (declined) {
+            if (trace)
+                fprintf(stderr, "[sagg] declined at level %d (%lld rows): does not coarsen / over a cap / not positive\n",
+                        l, (long long)L->n);
+            return NODAL_OK;
+        }
+        if (stop) {
+            diag_last = true;
+            break;
+        }
+    }
+    H->nlev = l + 1;
+    SLevel *last = H->level(l);
+    if (H->nlev < 2) return NODAL_OK;  // too small for a hierarchy: the caller's other paths
+    // statistics of the last level (its Galerkin kernel ran after the last round trip)
+    NODAL_HIP_TRY(h, hipMemcpyAsync(hs, dstats, (size_t)MAX_LEVELS * ST_COUNT * 8, hipMemcpyDeviceToHost, st));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    for (int k = 0; k < H->nlev; ++k) {
+        const unsigned long long *s = hs + (size_t)k * ST_COUNT;
+        if (k > 0) {
+            H->pool[k]->maxlen = (int32_t)s[ST_MAXLEN];
+            H->pool[k]->nnz = (int64_t)s[ST_NNZ];
+            H->pool[k]->wfix = choose_wfix(H->pool[k]->maxlen, H->pool[k]->n, H->pool[k]->nnz, APAD);
+        }
+        if (s[ST_OVERFLOW] || (k > 0 && s[ST_BADDIAG]) || s[ST_UNASSIGNED]) {
+            if (trace) fprintf(stderr, "[sagg] declined: level %d over a cap / not positive\n", k);
+            return NODAL_OK;
+        }
+    }
+    diag_last = last->maxlen <= 1;
+    H->dense_coarsest = !diag_last;
+    if (H->dense_coarsest) {
+        if (last->n > COARSEST) return NODAL_OK;
+        NODAL_HIP_TRY(h, H->coarse_inv.reserve((size_t)last->n * last->n * 8 + 64));
+        coarsest_inverse<<<1, 256, 0, st>>>(last->A(), H->coarse_inv.as<double>(),
+                                            dstats + (size_t)l * ST_COUNT);
+        NODAL_HIP_TRY(h, hipGetLastError());
+    }
+    for (int k = 0; k < H->nlev; ++k) {
+        SLevel *L = H->pool[k];
+        NODAL_HIP_TRY(h, L->vec.reserve((size_t)V_COUNT * L->ld * 8 + 256));
+        NODAL_HIP_TRY(h, L->part.reserve(5 * DOT_BLOCKS * 8 + 256));
+    }
+    NODAL_TRY(build_tail(h, H, hs));
+
+    // structural singularity: OR the "touches ground" flags up, look at the last level
+    {
+        NODAL_HIP_TRY(h, H->level(0)->gflag.reserve((size_t)n0 + 64));
+        NODAL_TRY(grounded_flags(h, H->level(0)->gflag.as<uint8_t>()));
+        for (int k = 0; k + 1 < H->nlev; ++k) {
+            SLevel *L = H->pool[k], *C = H->pool[k + 1];
+            NODAL_HIP_TRY(h, C->gflag.reserve((size_t)C->n + 64));
+            NODAL_HIP_TRY(h, hipMemsetAsync(C->gflag.p, 0, (size_t)C->n, st));
+            flags_up<<<grid_for(L->n), TB, 0, st>>>(L->n, L->agg.as<int32_t>(), L->gflag.as<uint8_t>(),
+                                                   C->gflag.as<uint8_t>());
+        }
+        uint32_t *fl = reinterpret_cast<uint32_t *>(dstats + (size_t)(MAX_LEVELS - 1) * ST_COUNT + ST_COUNT - 1);
+        NODAL_HIP_TRY(h, hipMemsetAsync(fl, 0, 8, st));
+        if (H->dense_coarsest) last_level_floating<<<1, 64, 0, st>>>(last->A(), last->gflag.as<uint8_t>(), fl);
+        else any_unflagged<<<grid_for(last->n), TB, 0, st>>>(last->n, last->gflag.as<uint8_t>(), fl);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        NODAL_HIP_TRY(h, hipMemcpyAsync(hs, dstats, (size_t)MAX_LEVELS * ST_COUNT * 8, hipMemcpyDeviceToHost, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        if (hs[(size_t)l * ST_COUNT + ST_BADDIAG] & 2ull) {  // coarsest pivot not positive
+            if (trace) fprintf(stderr, "[sagg] declined: coarsest matrix not positive definite\n");
+            return NODAL_OK;
+        }
+        *floating = hs[(size_t)(MAX_LEVELS - 1) * ST_COUNT + ST_COUNT - 1] != 0 ? 1 : 0;
+    }
+    if (trace) {
+        fprintf(stderr, "[sagg] levels (rows/entries/longest row/padded width):");
+        for (int k = 0; k < H->nlev; ++k)
+            fprintf(stderr, " %lld/%lld/%d/%d", (long long)H->pool[k]->n, (long long)H->pool[k]->nnz,
+                    H->pool[k]->maxlen, H->pool[k]->wfix);
+        fprintf(stderr, "  tail %d  coarsest %s\n", H->tail, H->dense_coarsest ? "dense" : "diagonal");
+    }
+    H->ready = true;
+    *accepted = true;
+    return NODAL_OK;
+}
+
+namespace {
+
+// out ~= A_l^-1 b.  At level 0 the post-smoothing kernel also leaves the partial dot products
+// out.b and out.Ap of the outer iteration (sb != nullptr).
+int cycle(nodal_ctx *h, SHierarchy *H, int l, const double *b, const double *x0, double *out, const SolveBufs *sb) {
+    hipStream_t st = h->stream;
+    SLevel *L = H->pool[l];
+    const int64_t n = L->n;
+    if (l == H->tail) {
+        k_tail<<<1, 1024, (size_t)H->td.lds_bytes, st>>>(H->td, H->tail_image.as<char>(), b, out);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        return NODAL_OK;
+    }
+    if (l == H->nlev - 1) {
+        k_coarsest<<<grid_for(n), TB, 0, st>>>(n, H->dense_coarsest ? H->coarse_inv.as<double>() : nullptr,
+                                               L->dinv.as<double>(), b, out);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        return NODAL_OK;
+    }
+    SLevel *C = H->pool[l + 1];
+    const int64_t nc = C->n;
+    const Ell A = L->A();
+    const double *dinv = L->dinv.as<double>();
+    const double *x = x0;  // the pre-smoothed iterate w D^-1 b, from the producer of b
+    double *r = L->v(V_R), *xp = L->v(V_XP);
+    double *rc = C->v(V_RC), *c1 = C->v(V_C1), *c2 = C->v(V_C2);
+    const unsigned g = sb ? (unsigned)sb->g0 : grid_for(n);
+    SAGG_DISPATCH_W(L->wfix, (k_smooth_residual<W><<<g, TB, 0, st>>>(A, b, x0, r)));
+    double *x0c = C->v(V_X);
+    k_restrict<<<grid_for(nc * RL), TB, 0, st>>>(nc, L->rld, L->rcol.as<int32_t>(), L->rval.as<double>(),
+                                                L->rlen.as<int32_t>(), r, rc, C->dinv.as<double>(), x0c);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    int nparts = 0;
+    // K-cycle (two flexible-CG steps on the coarse problem) at the first coarse level only, when
+    // that level is large enough to be outside the tail; plain V hand-over everywhere else
+    const bool kcycle = l == 0 && H->kcycle && l + 1 != H->tail && l + 1 != H->nlev - 1;
+    if (kcycle) {
+        double *v1 = C->v(V_V1), *v2 = C->v(V_V2), *r2 = C->v(V_R2);
+        double *part = C->part.as<double>();
+        const Ell Ac = C->A();
+        const unsigned gd = grid_for(nc, DOT_BLOCKS);  // (grid-stride beyond DOT_BLOCKS x TB rows)
+        nparts = (int)gd;
+        NODAL_TRY(cycle(h, H, l + 1, rc, x0c, c1, nullptr));
+        SAGG_DISPATCH_W(C->wfix, (k_spmv_dots<W><<<gd, TB, 0, st>>>(Ac, c1, v1, rc, nullptr, part + 0 * DOT_BLOCKS,
+                                                                    part + 1 * DOT_BLOCKS, nullptr)));
+        k_second_residual<<<grid_for(nc), TB, 0, st>>>(nc, rc, v1, part, nparts, r2, C->dinv.as<double>(), x0c);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        NODAL_TRY(cycle(h, H, l + 1, r2, x0c, c2, nullptr));
+        SAGG_DISPATCH_W(C->wfix, (k_spmv_dots<W><<<gd, TB, 0, st>>>(Ac, c2, v2, v1, r2, part + 3 * DOT_BLOCKS,
+                                                                    part + 2 * DOT_BLOCKS, part + 4 * DOT_BLOCKS)));
+        NODAL_HIP_TRY(h, hipGetLastError());
+    } else {
+        NODAL_TRY(cycle(h, H, l + 1, rc, x0c, c1, nullptr));
+    }
+    const double *coef = nullptr;
+    if (nparts) {  // s1, s2 once, instead of five reductions in every workgroup of the prolongation
+        double *cf = C->part.as<double>() + 5 * DOT_BLOCKS;
+        k_kcoef<<<1, 320, 0, st>>>(C->part.as<double>(), nparts, cf);
+        coef = cf;
+    }
+    k_prolong<<<grid_for(n), TB, 0, st>>>(n, L->ld, L->pcol.as<int32_t>(), L->pval.as<double>(), x, c1, c2, coef,
+                                         xp);
+    if (sb) {
+        SAGG_DISPATCH_W(L->wfix, (k_post<W, true><<<g, TB, 0, st>>>(A, dinv, b, xp, out, sb->Ap, sb->part_rz,
+                                                                    sb->part_zap)));
+    } else {
+        SAGG_DISPATCH_W(L->wfix, (k_post<W, false><<<g, TB, 0, st>>>(A, dinv, b, xp, out, nullptr, nullptr, nullptr)));
+    }
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
+}
+
+__global__ void f_set_scalars(double *__restrict__ sc, double tol2) {
+    for (int k = 0; k < F_COUNT; ++k) sc[k] = 0.0;
+    sc[F_TOL2] = tol2;
+}
+
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+// Flexible CG preconditioned by the hierarchy.  Return: NODAL_OK (converged, *info = 0); -2 the
+// network is structurally singular (caller fills NaNs); -1 breakdown / no convergence (caller
+// falls back); SAGG_DECLINED (-3) the hierarchy does not take this matrix; > 0 a status.
+int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, int32_t *iters, double *resid) {
+    static const bool trace = getenv("NODAL_TRACE") != nullptr;
+    const int64_t n = h->n;
+    hipStream_t st = h->stream;
+    SHierarchy *H = hierarchy_of(h);
+    if (do_setup) {
+        bool accepted = false;
+        int32_t floating = 0;
+        NODAL_TRY(sagg_setup(h, &accepted, &floating));
+        if (!accepted) return SAGG_DECLINED;
+        if (floating) {
+            *info = 1;
+            *iters = 0;
+            *resid = 0.0;
+            return -2;
+        }
+    }
+    if (!H->ready || H->pool[0]->n != n) return SAGG_DECLINED;
+    h->amg_levels = H->nlev;
+    static const int kc = getenv("NODAL_SA_KCYCLE") ? atoi(getenv("NODAL_SA_KCYCLE")) : 1;
+    H->kcycle = kc != 0;
+
+    const size_t vec = align_up((size_t)n * 8);
+    NODAL_HIP_TRY(h, h->solver.reserve(5 * vec + 4 * MAX_PARTIALS * 8 + F_COUNT * 8 + 256));
+    char *base = h->solver.as<char>();
+    SolveBufs sb;
+    sb.r = reinterpret_cast<double *>(base);
+    sb.z = reinterpret_cast<double *>(base + vec);
+    sb.p = reinterpret_cast<double *>(base + 2 * vec);
+    sb.Ap = reinterpret_cast<double *>(base + 3 * vec);
+    sb.x0 = reinterpret_cast<double *>(base + 4 * vec);
+    sb.part_rz = reinterpret_cast<double *>(base + 5 * vec);
+    sb.part_zap = sb.part_rz + MAX_PARTIALS;
+    sb.part_rr = sb.part_zap + MAX_PARTIALS;
+    sb.part_pap = sb.part_rr + MAX_PARTIALS;
+    sb.sc = sb.part_pap + MAX_PARTIALS;
+    sb.g0 = (int)grid_for(n, MAX_PARTIALS);
+    double *x = h->x.as<double>();
+    const Ell A0 = H->pool[0]->A();
+
+    const double tol = 1e-13;
+    f_set_scalars<<<1, 1, 0, st>>>(sb.sc, tol * tol);
+    const double *dinv0 = H->pool[0]->dinv.as<double>();
+    f_init<<<sb.g0, TB, 0, st>>>(b, x, sb.r, sb.Ap, dinv0, sb.x0, sb.part_rr, n);
+    NODAL_HIP_TRY(h, hipGetLastError());
+
+    const int64_t maxit = getenv("NODAL_FCG_MAXIT") ? atoll(getenv("NODAL_FCG_MAXIT")) : 2000;
+    hipEvent_t e0 = h->ev[2], e1 = h->ev[3];
+    h->kern_ms = 0;
+    h->kern_launches = 0;
+    double hs[F_COUNT];
+    int64_t enqueued = 0;
+    int batch = 6;   // iterations enqueued before the first look at the residual
+    int status = 0;  // 0 running, 1 converged, 2 breakdown, 3 maxit
+    double rr_prev = -1.0;
+    int64_t it_prev = 0;
+    int polls = 0;
+    while (status == 0) {
+        for (int c = 0; c < batch; ++c, ++enqueued) {
+            const int it = (int)enqueued;
+            NODAL_TRY(cycle(h, H, 0, sb.r, sb.x0, sb.z, &sb));
+            f_direction<<<sb.g0, TB, 0, st>>>(sb.z, sb.p, sb.part_rz, sb.part_zap, sb.part_rr, sb.g0, sb.sc, it, n);
+            const bool timed = c == 0;
+            if (timed) NODAL_HIP_TRY(h, hipEventRecord(e0, st));
+            SAGG_DISPATCH_W(H->pool[0]->wfix, (f_spmv<W><<<sb.g0, TB, 0, st>>>(A0, sb.p, sb.Ap, sb.part_pap, sb.sc, it)));
+            if (timed) NODAL_HIP_TRY(h, hipEventRecord(e1, st));
+            f_update<<<sb.g0, TB, 0, st>>>(x, sb.r, sb.p, sb.Ap, sb.part_pap, sb.g0, dinv0, sb.x0, sb.part_rr, sb.sc, it, n);
+            NODAL_HIP_TRY(h, hipGetLastError());
+        }
+        NODAL_HIP_TRY(h, hipMemcpyAsync(hs, sb.sc, F_COUNT * 8, hipMemcpyDeviceToHost, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        ++polls;
+        const bool conv = hs[F_CONV + ((enqueued - 1) & 1)] != 0.0;
+        float ms = 0;
+        // (the timed launch did its work unless the iteration had converged before it)
+        if (!(conv && hs[F_ITERS] <= (double)(enqueued - batch)) && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+            h->kern_ms += ms;
+            h->kern_launches += 1;
+        }
+        if (hs[F_FLAG] != 0.0 || !(hs[F_RR] == hs[F_RR])) status = 2;
+        else if (conv) status = 1;
+        else if (enqueued >= maxit) status = 3;
+        else {
+            // remaining iterations from the observed reduction per iteration, one less than the
+            // estimate: an iteration past convergence still runs its multigrid cycle (only the CG
+            // kernels return at once), a poll costs ~20 us
+            int next = 2;
+            const double target = tol * tol * hs[F_BB];
+            const double rr_ref = rr_prev > 0.0 ? rr_prev : hs[F_BB];
+            const int64_t it_ref = rr_prev > 0.0 ? it_prev : 0;
+            if (hs[F_RR] > 0.0 && hs[F_RR] < rr_ref && enqueued > it_ref) {
+                const double rate = log(hs[F_RR] / rr_ref) / (double)(enqueued - it_ref);  // < 0
+                next = (int)floor(log(target / hs[F_RR]) / rate);
+            }
+            batch = next < 1 ? 1 : (next > 32 ? 32 : next);
+            rr_prev = hs[F_RR];
+            it_prev = enqueued;
+        }
+    }
+    const int64_t its = status == 1 ? (int64_t)hs[F_ITERS] : enqueued;
+    *iters = (int32_t)its;
+    *resid = hs[F_BB] > 0 ? sqrt(hs[F_RR] / hs[F_BB]) : 0.0;
+    const SLevel *L0 = H->pool[0];
+    h->kern_alg = 12.0 * (double)L0->nnz + 4.0 * (double)n + 16.0 * (double)n;
+    if (trace)
+        fprintf(stderr, "[sagg] %d iterations (%lld enqueued, %d polls), relative residual %.2e, status %d\n", *iters,
+                (long long)enqueued, polls, *resid, status);
+    if (status != 1) return -1;
+    *info = 0;
+    return NODAL_OK;
+}

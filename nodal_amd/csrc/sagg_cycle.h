@@ -1,0 +1,556 @@
+// Cycle kernels, setup driver and flexible-CG driver of the smoothed-aggregation path
+// (second half of sagg.hip; included there, same translation unit).
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------------------------
+// row kernels on ELL: one thread per row, four slots in flight
+// ---------------------------------------------------------------------------------
+template <class XF>
+__device__ __forceinline__ double ell_row(const int32_t *__restrict__ col, const double *__restrict__ val,
+                                          int64_t ld, int32_t len, int64_t i, XF xf) {
+    double acc = 0.0;
+    for (int32_t s0 = 0; s0 < len; s0 += 4) {
+        int32_t c[4];
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool ok = s0 + q < len;
+            const int64_t at = (int64_t)(ok ? s0 + q : 0) * ld + i;  // slot 0 exists: len > 0 here
+            c[q] = col[at];
+            v[q] = ok ? val[at] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = fma(v[q], xf(c[q]), acc);
+    }
+    return acc;
+}
+
+// W > 0: every row holds exactly W slots (zero-padded): all loads issued at once, no length load
+// in front of them; W == 0: per-row length.
+template <int W, class XF>
+__device__ __forceinline__ double ell_row_w(const Ell &A, int64_t i, XF xf) {
+    if constexpr (W == 0) {
+        return ell_row(A.col, A.val, A.ld, A.len[i], i, xf);
+    } else {
+        int32_t c[W];
+        double v[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            c[q] = A.col[(int64_t)q * A.ld + i];
+            v[q] = A.val[(int64_t)q * A.ld + i];
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < W; ++q) acc = fma(v[q], xf(c[q]), acc);
+        return acc;
+    }
+}
+
+#define SAGG_DISPATCH_W(w, CALL)                         \
+    switch (w) {                                         \
+    case 4: { constexpr int W = 4; CALL; } break;        \
+    case 5: { constexpr int W = 5; CALL; } break;        \
+    case 6: { constexpr int W = 6; CALL; } break;        \
+    case 8: { constexpr int W = 8; CALL; } break;        \
+    case 12: { constexpr int W = 12; CALL; } break;      \
+    case 16: { constexpr int W = 16; CALL; } break;      \
+    case 20: { constexpr int W = 20; CALL; } break;      \
+    case 24: { constexpr int W = 24; CALL; } break;      \
+    case 32: { constexpr int W = 32; CALL; } break;      \
+    default: { constexpr int W = 0; CALL; } break;       \
+    }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double block_sum(double v) {  // TB threads; valid in every thread
+    __shared__ double ws[TB / 64];
+    __syncthreads();
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < TB / 64; ++w) s += ws[w];
+    return s;
+}
+// every workgroup reduces the same partial array in the same order: deterministic, no atomics
+__device__ __forceinline__ double reduce_partials(const double *__restrict__ part, int count) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += TB) s += part[i];
+    return block_sum(s);
+}
+
+// r = b - A x0, where x0 = w D^-1 b is the pre-smoothed iterate from a zero guess.  x0 comes from
+// whoever produced b (f_init / f_update, k_restrict, k_second_residual): the row sum then gathers
+// one vector, not D^-1 and b.
+template <int W>
+__global__ __launch_bounds__(TB) void k_smooth_residual(Ell A, const double *__restrict__ b,
+                                                        const double *__restrict__ x0, double *__restrict__ r) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        const double s = ell_row_w<W>(A, i, [&](int32_t j) { return x0[j]; });
+        r[i] = b[i] - s;
+    }
+}
+
+// rc = R r.  R is stored in blocks of RL = 8 entries per coarse row, block q of row I at
+// [(q * rld + I) * 8 .. +8): the eight lanes of a row read one contiguous block per step, a
+// wavefront eight consecutive rows = 64 contiguous entries.  (One thread per row walked its
+// 17-40 entries alone: 10-20 dependent round trips, 15-20 us whatever the level's size.)
+constexpr int RL = 8;
+__global__ __launch_bounds__(TB) void k_restrict(int64_t nc, int64_t rld, const int32_t *__restrict__ rcol,
+                                                 const double *__restrict__ rval, const int32_t *__restrict__ rlen,
+                                                 const double *__restrict__ r, double *__restrict__ rc,
+                                                 const double *__restrict__ cdinv, double *__restrict__ x0c) {
+    const int sub = threadIdx.x & (RL - 1);
+    const int64_t rows_per_pass = (int64_t)gridDim.x * (TB / RL);
+    for (int64_t I0 = (int64_t)blockIdx.x * (TB / RL); I0 < nc; I0 += rows_per_pass) {
+        const int64_t I = I0 + threadIdx.x / RL;
+        double s = 0.0;
+        if (I < nc) {
+            const int32_t len = rlen[I];
+            for (int32_t q = 0; q * RL < len; ++q) {
+                const int64_t at = ((int64_t)q * rld + I) * RL + sub;
+                if (q * RL + sub < len) s = fma(rval[at], r[rcol[at]], s);
+            }
+        }
+#pragma unroll
+        for (int off = RL >> 1; off > 0; off >>= 1) s += __shfl_down(s, off, RL);
+        if (I < nc && sub == 0) {
+            rc[I] = s;
+            if (x0c) x0c[I] = OMEGA * cdinv[I] * s;  // pre-smoothed iterate of the coarse visit
+        }
+    }
+}
+
+// K-cycle coefficients from the five dot products of the two inner FCG steps
+struct KCoef { double s1, s2; };
+__device__ __forceinline__ KCoef kcycle_coefficients(const double *__restrict__ part, int nparts) {
+    if (nparts == 0) return KCoef{1.0, 0.0};  // plain V hand-over
+    const double rho1 = reduce_partials(part + 0 * DOT_BLOCKS, nparts);
+    const double alpha1 = reduce_partials(part + 1 * DOT_BLOCKS, nparts);
+    const double gamma = reduce_partials(part + 2 * DOT_BLOCKS, nparts);
+    const double beta = reduce_partials(part + 3 * DOT_BLOCKS, nparts);
+    const double alpha2 = reduce_partials(part + 4 * DOT_BLOCKS, nparts);
+    if (!(rho1 > 0.0)) return KCoef{0.0, 0.0};
+    const double rho2 = beta - gamma * gamma / rho1;
+    if (!(rho2 > 0.0)) return KCoef{alpha1 / rho1, 0.0};
+    return KCoef{alpha1 / rho1 - gamma * alpha2 / (rho1 * rho2), alpha2 / rho2};
+}
+
+// s1, s2 of the K-cycle, once per cycle: one workgroup of five wavefronts, one per dot product
+__global__ __launch_bounds__(320) void k_kcoef(const double *__restrict__ part, int nparts, double *__restrict__ coef) {
+    __shared__ double d[5];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double s = 0.0;
+    for (int i = lane; i < nparts; i += 64) s += part[w * DOT_BLOCKS + i];
+    s = wave_sum(s);
+    if (lane == 0) d[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double rho1 = d[0], alpha1 = d[1], gamma = d[2], beta = d[3], alpha2 = d[4];
+        double s1 = 0.0, s2 = 0.0;
+        if (rho1 > 0.0) {
+            const double rho2 = beta - gamma * gamma / rho1;
+            if (rho2 > 0.0) {
+                s1 = alpha1 / rho1 - gamma * alpha2 / (rho1 * rho2);
+                s2 = alpha2 / rho2;
+            } else {
+                s1 = alpha1 / rho1;
+            }
+        }
+        coef[0] = s1;
+        coef[1] = s2;
+    }
+}
+
+// xp = x + P (s1 c1 + s2 c2)   (coef == nullptr: plain V hand-over, xp = x + P c1)
+__global__ __launch_bounds__(TB) void k_prolong(int64_t n, int64_t ld, const int32_t *__restrict__ pcol,
+                                                const double *__restrict__ pval, const double *__restrict__ x,
+                                                const double *__restrict__ c1, const double *__restrict__ c2,
+                                                const double *__restrict__ coef, double *__restrict__ xp) {
+    const bool two = coef != nullptr;
+    const double s1 = two ? coef[0] : 1.0, s2 = two ? coef[1] : 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        double s = x[i];
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+            const int32_t J = pcol[(int64_t)q * ld + i];
+            if (J >= 0) {
+                const double e = two ? s1 * c1[J] + s2 * c2[J] : c1[J];
+                s = fma(pval[(int64_t)q * ld + i], e, s);
+            }
+        }
+        xp[i] = s;
+    }
+}
+
+// out = xp + w D^-1 (b - A xp); DOTS: partial sums of out.b and out.u (the outer iteration's z.r, z.Ap)
+template <int W, bool DOTS>
+__global__ __launch_bounds__(TB) void k_post(Ell A, const double *__restrict__ dinv, const double *__restrict__ b,
+                                             const double *__restrict__ xp, double *__restrict__ out,
+                                             const double *__restrict__ u, double *__restrict__ p_ob,
+                                             double *__restrict__ p_ou) {
+    double a0 = 0.0, a1 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        const double s = ell_row_w<W>(A, i, [&](int32_t j) { return xp[j]; });
+        const double bi = b[i];
+        const double o = fma(OMEGA * dinv[i], bi - s, xp[i]);
+        out[i] = o;
+        if (DOTS) {
+            a0 = fma(o, bi, a0);
+            a1 = fma(o, u[i], a1);
+        }
+    }
+    if (DOTS) {
+        a0 = block_sum(a0);
+        a1 = block_sum(a1);
+        if (threadIdx.x == 0) {
+            p_ob[blockIdx.x] = a0;
+            p_ou[blockIdx.x] = a1;
+        }
+    }
+}
+
+// v = A c and the partial dot products c.v, c.u1 (and c.u2 when given)
+template <int W>
+__global__ __launch_bounds__(TB) void k_spmv_dots(Ell A, const double *__restrict__ c, double *__restrict__ v,
+                                                  const double *__restrict__ u1, const double *__restrict__ u2,
+                                                  double *__restrict__ p_cv, double *__restrict__ p_cu1,
+                                                  double *__restrict__ p_cu2) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        const double s = ell_row_w<W>(A, i, [&](int32_t j) { return c[j]; });
+        v[i] = s;
+        const double ci = c[i];
+        a0 = fma(ci, s, a0);
+        a1 = fma(ci, u1[i], a1);
+        if (u2) a2 = fma(ci, u2[i], a2);
+    }
+    a0 = block_sum(a0);
+    a1 = block_sum(a1);
+    a2 = block_sum(a2);
+    if (threadIdx.x == 0) {
+        p_cv[blockIdx.x] = a0;
+        p_cu1[blockIdx.x] = a1;
+        if (p_cu2) p_cu2[blockIdx.x] = a2;
+    }
+}
+
+// r2 = rc - (alpha1 / rho1) v1
+__global__ __launch_bounds__(TB) void k_second_residual(int64_t n, const double *__restrict__ rc,
+                                                        const double *__restrict__ v1,
+                                                        const double *__restrict__ part, int nparts,
+                                                        double *__restrict__ r2, const double *__restrict__ dinv,
+                                                        double *__restrict__ x0) {
+    const double rho1 = reduce_partials(part + 0 * DOT_BLOCKS, nparts);
+    const double alpha1 = reduce_partials(part + 1 * DOT_BLOCKS, nparts);
+    const double t = rho1 > 0.0 ? alpha1 / rho1 : 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+    {
+        const double v = fma(-t, v1[i], rc[i]);
+        r2[i] = v;
+        x0[i] = OMEGA * dinv[i] * v;
+    }
+}
+
+// coarsest level outside the tail kernel: dense inverse (n <= COARSEST) or a diagonal matrix
+__global__ __launch_bounds__(TB) void k_coarsest(int64_t n, const double *__restrict__ inv,
+                                                 const double *__restrict__ dinv, const double *__restrict__ b,
+                                                 double *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        double s = 0.0;
+        if (inv)
+            for (int64_t j = 0; j < n; ++j) s = fma(inv[i * n + j], b[j], s);
+        else
+            s = dinv[i] * b[i];
+        out[i] = s;
+    }
+}
+
+// ---- tail: the smallest levels in ONE 1024-thread workgroup, matrices and vectors in LDS -------
+// A level visit of separate launches costs 4-7 us per kernel whatever its size (two to three
+// dependent memory round trips + the launch); here the levels' matrices (f64 values, u16 columns,
+// rows padded to the level's longest), transfer operators and vectors are copied into LDS once
+// per launch and the V-cycle -- TAIL_NU Jacobi sweeps before and after each coarse correction,
+// cheap at LDS latency -- runs between workgroup barriers.  The last level is solved with its
+// dense inverse (or its diagonal: nothing but isolated nodes).
+constexpr int TAIL_NU = 2;
+
+// row i of an LDS-resident ELL matrix times x, by the `lpr` (power of two) adjacent lanes that
+// share the row: lane `sub` takes the slots sub, sub + lpr, ...; four slots in flight; every lane
+// of the group returns the sum
+__device__ __forceinline__ double lds_row(const double *aval, const uint16_t *acol, int n, int width, int i,
+                                          int sub, int lpr, const double *x) {
+    double s0 = 0.0, s1 = 0.0;
+    int t = sub;
+    for (; t + 3 * lpr < width; t += 4 * lpr) {
+        const double v0 = aval[t * n + i], v1 = aval[(t + lpr) * n + i], v2 = aval[(t + 2 * lpr) * n + i],
+                     v3 = aval[(t + 3 * lpr) * n + i];
+        const int c0 = acol[t * n + i], c1 = acol[(t + lpr) * n + i], c2 = acol[(t + 2 * lpr) * n + i],
+                  c3 = acol[(t + 3 * lpr) * n + i];
+        s0 = fma(v0, x[c0], s0);
+        s1 = fma(v1, x[c1], s1);
+        s0 = fma(v2, x[c2], s0);
+        s1 = fma(v3, x[c3], s1);
+    }
+    for (; t < width; t += lpr) s0 = fma(aval[t * n + i], x[acol[t * n + i]], s0);
+    double s = s0 + s1;
+    for (int off = lpr >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    return s;
+}
+
+// the tail levels' matrices and transfer operators, packed once per setup into a global image
+// laid out exactly like the LDS copy
+__global__ __launch_bounds__(1024) void k_tail_pack(TailDesc d, char *__restrict__ image) {
+    const int tid = threadIdx.x;
+    const int last = d.nlev - 1;
+    auto f64 = [&](int off) { return reinterpret_cast<double *>(image + off); };
+    auto u16 = [&](int off) { return reinterpret_cast<uint16_t *>(image + off); };
+    auto copy_f64 = [&](double *dst, const double *src, int rows, int64_t ld, int slots) {
+        for (int e = tid; e < rows * slots; e += 1024) {  // dst[t * rows + i] = src[t * ld + i]
+            const int t = e / rows, i = e - t * rows;
+            dst[e] = src[(int64_t)t * ld + i];
+        }
+    };
+    auto copy_u16 = [&](uint16_t *dst, const int32_t *src, int rows, int64_t ld, int slots) {
+        for (int e = tid; e < rows * slots; e += 1024) {
+            const int t = e / rows, i = e - t * rows;
+            const int32_t v = src[(int64_t)t * ld + i];
+            dst[e] = (uint16_t)(v < 0 ? 0 : v);
+        }
+    };
+    for (int k = 0; k < last; ++k) {
+        const TailLevelDesc &L = d.lv[k];
+        copy_f64(f64(L.o_aval), L.aval, L.n, L.ld, L.width);  // (rows are zero-padded by the Galerkin kernel)
+        copy_u16(u16(L.o_acol), L.acol, L.n, L.ld, L.width);
+        copy_f64(f64(L.o_dinv), L.dinv, L.n, L.ld, 1);
+        copy_f64(f64(L.o_pval), L.pval, L.n, L.ld, PW);       // (empty slots: value 0, column -1 -> 0)
+        copy_u16(u16(L.o_pcol), L.pcol, L.n, L.ld, PW);
+        // R: block q of row I at [(q * rld + I) * 8 ..): nq "slots" of nc * 8 contiguous entries
+        copy_f64(f64(L.o_rval), L.rval, L.nc * RL, (int64_t)L.rld * RL, L.nq);
+        copy_u16(u16(L.o_rcol), L.rcol, L.nc * RL, (int64_t)L.rld * RL, L.nq);
+    }
+    const TailLevelDesc &L = d.lv[last];
+    if (d.inv) copy_f64(f64(L.o_aval), d.inv, L.n * L.n, L.n * L.n, 1);
+    else copy_f64(f64(L.o_aval), L.dinv, L.n, L.n, 1);
+}
+
+__global__ __launch_bounds__(1024) void k_tail(TailDesc d, const char *__restrict__ image,
+                                               const double *__restrict__ rc, double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int last = d.nlev - 1;
+    auto f64 = [&](int off) { return reinterpret_cast<double *>(smem + off); };
+    auto u16 = [&](int off) { return reinterpret_cast<uint16_t *>(smem + off); };
+    {   // image -> LDS: 16-byte pieces, eight in flight per lane (one round trip for ~128 KB)
+        const int4 *src = reinterpret_cast<const int4 *>(image);
+        int4 *dst = reinterpret_cast<int4 *>(smem);
+        const int pieces = d.image_bytes / 16;
+        for (int e0 = tid; e0 < pieces; e0 += 8 * 1024) {
+            int4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[e0 + u * 1024 < pieces ? e0 + u * 1024 : 0];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u * 1024 < pieces) dst[e0 + u * 1024] = v[u];
+        }
+    }
+    for (int i = tid; i < d.lv[0].n; i += 1024) f64(d.lv[0].o_B)[i] = rc[i];
+    __syncthreads();
+    // ---- down ----
+    for (int k = 0; k < last; ++k) {
+        const TailLevelDesc &L = d.lv[k];
+        const double *aval = f64(L.o_aval), *dinv = f64(L.o_dinv), *B = f64(L.o_B);
+        const uint16_t *acol = u16(L.o_acol);
+        double *X = f64(L.o_X), *Y = f64(L.o_Y), *R = f64(L.o_R);
+        const int lpr = L.lpr, sub = tid & (lpr - 1), rows = 1024 / lpr;  // lpr lanes share a row
+        for (int i = tid; i < L.n; i += 1024) X[i] = OMEGA * dinv[i] * B[i];
+        __syncthreads();
+        for (int sweep = 1; sweep < TAIL_NU; ++sweep) {
+            for (int i0 = 0; i0 < L.n; i0 += rows) {
+                const int i = i0 + tid / lpr, ii = i < L.n ? i : L.n - 1;
+                const double ax = lds_row(aval, acol, L.n, L.width, ii, sub, lpr, X);
+                if (i < L.n && sub == 0) Y[i] = fma(OMEGA * dinv[i], B[i] - ax, X[i]);
+            }
+            __syncthreads();
+            double *t = X; X = Y; Y = t;
+        }
+        for (int i0 = 0; i0 < L.n; i0 += rows) {
+            const int i = i0 + tid / lpr, ii = i < L.n ? i : L.n - 1;
+            const double ax = lds_row(aval, acol, L.n, L.width, ii, sub, lpr, X);
+            if (i < L.n && sub == 0) R[i] = B[i] - ax;
+        }
+        __syncthreads();
+        // (X holds the smoothed iterate: remember which buffer via the parity of TAIL_NU below)
+        const double *rval = f64(L.o_rval);
+        const uint16_t *rcol = u16(L.o_rcol);
+        double *Bc = f64(d.lv[k + 1].o_B);
+        for (int I0 = 0; I0 < L.nc; I0 += 1024 / RL) {  // eight lanes per coarse row
+            const int I = I0 + tid / RL, r8 = tid & (RL - 1);
+            double s = 0.0;
+            if (I < L.nc)
+                for (int q = 0; q < L.nq; ++q) {
+                    const int e = (q * L.nc + I) * RL + r8;
+                    s = fma(rval[e], R[rcol[e]], s);
+                }
+#pragma unroll
+            for (int off = RL >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (I < L.nc && r8 == 0) Bc[I] = s;
+        }
+        __syncthreads();
+    }
+    {
+        const TailLevelDesc &L = d.lv[last];
+        const double *inv = f64(L.o_aval), *B = f64(L.o_B);
+        double *E = f64(L.o_X);
+        for (int i = tid; i < L.n; i += 1024) {
+            double s = 0.0;
+            if (d.inv)
+                for (int j = 0; j < L.n; ++j) s = fma(inv[i * L.n + j], B[j], s);
+            else
+                s = inv[i] * B[i];
+            E[i] = s;
+        }
+        __syncthreads();
+    }
+    // ---- up ----
+    const double *Ec = f64(d.lv[last].o_X);
+    for (int k = last - 1; k >= 0; --k) {
+        const TailLevelDesc &L = d.lv[k];
+        const double *aval = f64(L.o_aval), *dinv = f64(L.o_dinv), *B = f64(L.o_B), *pval = f64(L.o_pval);
+        const uint16_t *acol = u16(L.o_acol), *pcol = u16(L.o_pcol);
+        double *X = f64((TAIL_NU & 1) ? L.o_X : L.o_Y), *Y = f64((TAIL_NU & 1) ? L.o_Y : L.o_X);  // X: pre-smoothed iterate
+        for (int i = tid; i < L.n; i += 1024) {
+            double s = X[i];
+#pragma unroll
+            for (int q = 0; q < PW; ++q) s = fma(pval[q * L.n + i], Ec[pcol[q * L.n + i]], s);
+            Y[i] = s;
+        }
+        __syncthreads();
+        const int lpr = L.lpr, sub = tid & (lpr - 1), rows = 1024 / lpr;
+        for (int sweep = 0; sweep < TAIL_NU; ++sweep) {
+            for (int i0 = 0; i0 < L.n; i0 += rows) {
+                const int i = i0 + tid / lpr, ii = i < L.n ? i : L.n - 1;
+                const double ax = lds_row(aval, acol, L.n, L.width, ii, sub, lpr, Y);
+                if (i < L.n && sub == 0) X[i] = fma(OMEGA * dinv[i], B[i] - ax, Y[i]);
+            }
+            __syncthreads();
+            double *t = X; X = Y; Y = t;
+        }
+        Ec = Y;  // the last sweep's result
+    }
+    for (int i = tid; i < d.lv[0].n; i += 1024) out[i] = Ec[i];
+}
+
+// ---------------------------------------------------------------------------------
+// flexible CG (Polak-Ribiere beta: the K-cycle is a mildly non-linear operator)
+// ---------------------------------------------------------------------------------
+// Scalars on the device.  The host passes the iteration number to every kernel, and the words an
+// iteration hands to the next one live in slots indexed by its parity, so a kernel never writes
+// a word that other workgroups of the SAME kernel read (they may start later):
+//   RZ[it&1], CONV[it&1]  written by f_direction(it);  ALPHA[it&1] by f_update(it).
+// Once an iteration has converged, CONV stays raised (f_direction hands it on) and the CG
+// kernels of every later iteration return at once.
+enum { F_RZ = 0, F_ALPHA = 2, F_CONV = 4, F_RR = 6, F_BB = 7, F_FLAG = 8, F_ITERS = 9, F_TOL2 = 10, F_COUNT = 16 };
+constexpr int MAX_PARTIALS = 1024;
+
+__global__ __launch_bounds__(TB) void f_init(const double *__restrict__ b, double *__restrict__ x,
+                                             double *__restrict__ r, double *__restrict__ Ap,
+                                             const double *__restrict__ dinv, double *__restrict__ x0,
+                                             double *__restrict__ part_rr, int64_t n) {
+    double srr = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        const double ri = b[i];
+        x[i] = 0.0;
+        r[i] = ri;
+        x0[i] = OMEGA * dinv[i] * ri;
+        Ap[i] = 0.0;
+        srr = fma(ri, ri, srr);
+    }
+    srr = block_sum(srr);
+    if (threadIdx.x == 0) part_rr[blockIdx.x] = srr;
+}
+
+// beta from the dots of the cycle's last kernel; p = z + beta p; convergence test on |r|^2
+__global__ __launch_bounds__(TB) void f_direction(const double *__restrict__ z, double *__restrict__ p,
+                                                  const double *__restrict__ part_rz,
+                                                  const double *__restrict__ part_zap,
+                                                  const double *__restrict__ part_rr, int nparts,
+                                                  double *__restrict__ sc, int iter, int64_t n) {
+    const int cur = iter & 1, prev = cur ^ 1;
+    if (iter > 0 && sc[F_CONV + prev] != 0.0) {  // converged earlier: hand the flag on
+        if (blockIdx.x == 0 && threadIdx.x == 0) sc[F_CONV + cur] = 1.0;
+        return;
+    }
+    const double rz_new = reduce_partials(part_rz, nparts);
+    const double zap = reduce_partials(part_zap, nparts);
+    const double rr = reduce_partials(part_rr, nparts);
+    const double rz_old = iter > 0 ? sc[F_RZ + prev] : 1.0;
+    const double beta = (iter > 0 && rz_old != 0.0) ? -sc[F_ALPHA + prev] * zap / rz_old : 0.0;
+    const double bb = iter == 0 ? rr : sc[F_BB];
+    const bool bad = !(rz_new >= 0.0) || !(rr == rr);  // preconditioner not positive / NaN
+    const bool converged = bb == 0.0 || rr <= sc[F_TOL2] * bb || bad;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc[F_RZ + cur] = rz_new;
+        sc[F_RR] = rr;
+        if (iter == 0) sc[F_BB] = rr;
+        if (bad) sc[F_FLAG] = 1.0;
+        sc[F_CONV + cur] = converged ? 1.0 : 0.0;
+        if (converged) sc[F_ITERS] = (double)iter;
+    }
+    if (converged) return;  // uniform over the grid: every workgroup reduces the same partials
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        p[i] = iter > 0 ? fma(beta, p[i], z[i]) : z[i];
+}
+
+// Ap = A p, partials of p.Ap
+template <int W>
+__global__ __launch_bounds__(TB) void f_spmv(Ell A, const double *__restrict__ p, double *__restrict__ Ap,
+                                             double *__restrict__ part_pap, const double *__restrict__ sc,
+                                             int iter) {
+    if (sc[F_CONV + (iter & 1)] != 0.0) return;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        const double s = ell_row_w<W>(A, i, [&](int32_t j) { return p[j]; });
+        Ap[i] = s;
+        acc = fma(p[i], s, acc);
+    }
+    acc = block_sum(acc);
+    if (threadIdx.x == 0) part_pap[blockIdx.x] = acc;
+}
+
+// alpha = rz / pAp; x += alpha p; r -= alpha Ap; partials of |r|^2
+__global__ __launch_bounds__(TB) void f_update(double *__restrict__ x, double *__restrict__ r,
+                                               const double *__restrict__ p, const double *__restrict__ Ap,
+                                               const double *__restrict__ part_pap, int nparts,
+                                               const double *__restrict__ dinv, double *__restrict__ x0,
+                                               double *__restrict__ part_rr, double *__restrict__ sc, int iter,
+                                               int64_t n) {
+    const int cur = iter & 1;
+    if (sc[F_CONV + cur] != 0.0) return;
+    const double pap = reduce_partials(part_pap, nparts);
+    const double rz = sc[F_RZ + cur];
+    const bool bad = !(pap > 0.0) && rz != 0.0;  // breakdown (indefinite or singular G)
+    const double alpha = (pap > 0.0) ? rz / pap : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc[F_ALPHA + cur] = alpha;
+        if (bad) sc[F_FLAG] = 1.0;
+    }
+    double srr = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        x[i] = fma(alpha, p[i], x[i]);
+        const double ri = fma(-alpha, Ap[i], r[i]);
+        r[i] = ri;
+        x0[i] = OMEGA * dinv[i] * ri;  // the next cycle's pre-smoothed iterate
+        srr = fma(ri, ri, srr);
+    }
+    srr = block_sum(srr);
+    if (threadIdx.x == 0) part_rr[blockIdx.x] = srr;
+}
+
+}  // namespace

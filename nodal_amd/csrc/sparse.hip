@@ -474,6 +474,10 @@ __global__ __launch_bounds__(TB) void fcg_update(double *__restrict__ x, double 
 // over right-hand sides, nodal_solve_pairs).
 int amg_fcg_solve_ex(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, int32_t *iters,
                      double *resid) {
+    {   // networks without graded links / hubs: smoothed aggregation (sagg.hip); it declines the rest
+        const int s = sagg_fcg_solve(h, b, do_setup, info, iters, resid);
+        if (s != -3) return s;
+    }
     const int64_t n = h->n;
     hipStream_t st = h->stream;
     const size_t vec = align_up((size_t)n * 8);
