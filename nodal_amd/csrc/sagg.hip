@@ -89,7 +89,8 @@ struct SLevel {
     }
     double *v(int which) const { return vec.as<double>() + (int64_t)which * ld; }
 };
-enum { V_X = 0, V_R = 1, V_XP = 2, V_RC = 3, V_C1 = 4, V_C2 = 5, V_V1 = 6, V_V2 = 7, V_R2 = 8, V_COUNT = 9 };
+enum { V_X = 0, V_R = 1, V_XP = 2, V_RC = 3, V_C1 = 4, V_C2 = 5, V_V1 = 6, V_V2 = 7, V_R2 = 8, V_X1 = 9, V_T = 10,
+       V_COUNT = 11 };
 
 struct TailLevelDesc {
     int n, nc, ld, rld, width, nq, lpr;  // width: longest row of A; nq: blocks of 8 per row of R; lpr: lanes per row
@@ -111,8 +112,10 @@ struct SHierarchy {
     int tail = -1;          // first level inside the tail kernel
     bool ready = false;
     bool kcycle = true;          // two inner FCG steps at the first coarse level
+    int nu[3] = {1, 1, 1};       // Jacobi sweeps before and after the coarse correction: level 0 / 1 / deeper
+                                 // (NODAL_SA_NU=212: 28 instead of 32 iterations on the 1e6-node grid, but 16.9 instead of 14.9 ms)
     bool dense_coarsest = true;  // last level: dense inverse; false: nothing but isolated nodes (diagonal)
-    DevBuf tail_image;
+    DevBuf tail_image, apcol, apval, aplen, bstat;
     DevBuf stats, coarse_inv, mis_t, mis_m, mis_flag, mis_id, agg1, keys, rstart, cursor, lists;
     TailDesc td;
     uint64_t *host_stats = nullptr;  // pinned
@@ -128,6 +131,10 @@ struct SHierarchy {
             delete l;
         }
         tail_image.release();
+        bstat.release();
+        apcol.release();
+        apval.release();
+        aplen.release();
         DevBuf *b[] = {&stats, &coarse_inv, &mis_t, &mis_m, &mis_flag, &mis_id, &agg1, &keys, &rstart, &cursor, &lists};
         for (DevBuf *x : b) x->release();
         if (host_stats) (void)hipHostFree(host_stats);
@@ -138,12 +145,39 @@ struct SHierarchy {
 // level 0: CSR -> ELL
 // ---------------------------------------------------------------------------------
 
+// Statistics leave a kernel as one plain store per workgroup into bstat[0][block] (a maximum) and
+// bstat[1][block] (a sum); reduce_bstat folds them into the level's statistics words.  (Tens of
+// thousands of workgroups adding to ONE word serialise at ~11 ns each: 1.4 ms for the Galerkin
+// kernel's 65 536 workgroups, ten times the kernel itself.)
+constexpr int BSTAT_MAX = 65536;
+__global__ __launch_bounds__(1024) void reduce_bstat(int nblocks, const uint32_t *__restrict__ bstat,
+                                                     unsigned long long *__restrict__ stats, int slot_max,
+                                                     int slot_sum) {
+    __shared__ unsigned int s_max;
+    __shared__ unsigned long long s_sum;
+    if (threadIdx.x == 0) { s_max = 0; s_sum = 0; }
+    __syncthreads();
+    unsigned int m = 0;
+    unsigned long long t = 0;
+    for (int i = threadIdx.x; i < nblocks; i += 1024) {
+        m = max(m, bstat[i]);
+        t += bstat[BSTAT_MAX + i];
+    }
+    atomicMax(&s_max, m);
+    atomicAdd(&s_sum, t);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (slot_max >= 0) stats[slot_max] = s_max;
+        if (slot_sum >= 0) stats[slot_sum] = s_sum;
+    }
+}
+
 // longest row, number of nodes with graded links (amg.hip's contrast criterion: one link above
 // `share` of the diagonal, or the strongest more than `spread` times the weakest)
 __global__ __launch_bounds__(TB) void row_stats(int64_t n, const int32_t *__restrict__ indptr,
                                                 const int32_t *__restrict__ indices,
                                                 const double *__restrict__ data, double share, double spread,
-                                                unsigned long long *__restrict__ stats) {
+                                                unsigned long long *__restrict__ stats, uint32_t *__restrict__ bstat) {
     int32_t mlen = 0;
     uint32_t graded = 0, bad = 0;
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
@@ -170,9 +204,9 @@ __global__ __launch_bounds__(TB) void row_stats(int64_t n, const int32_t *__rest
     if (bad) atomicOr(&s_bad, 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicMax(&stats[ST_MAXLEN], (unsigned long long)s_len);
-        if (s_graded) atomicAdd(&stats[ST_GRADED], (unsigned long long)s_graded);
-        if (s_bad) atomicOr(&stats[ST_BADDIAG], 1ull);
+        bstat[blockIdx.x] = s_len;
+        bstat[BSTAT_MAX + blockIdx.x] = s_graded;
+        if (s_bad) atomicOr(&stats[ST_BADDIAG], 1ull);  // (rare)
     }
 }
 
@@ -384,36 +418,98 @@ __global__ __launch_bounds__(TB) void r_fill(int64_t n, int64_t ld, const int32_
         }
     }
 }
+// sorted keys -> blocked R (blocks of 8 entries per coarse row, see k_restrict): eight lanes per row,
+// so that the stores of a wavefront are contiguous
 __global__ __launch_bounds__(TB) void r_to_ell(int64_t nc, int64_t rld, const uint32_t *__restrict__ rstart,
                                                const uint64_t *__restrict__ keys, int64_t ld,
                                                const double *__restrict__ pval, int32_t *__restrict__ rcol,
                                                double *__restrict__ rval, int32_t *__restrict__ rlen,
-                                               unsigned long long *__restrict__ stats) {
+                                               unsigned long long *__restrict__ stats, uint32_t *__restrict__ bstat) {
     uint32_t mlen = 0;
-    for (int64_t I = (int64_t)blockIdx.x * TB + threadIdx.x; I < nc; I += (int64_t)gridDim.x * TB) {
+    const int sub = threadIdx.x & 7;
+    const int64_t rows_per_pass = (int64_t)gridDim.x * (TB / 8);
+    for (int64_t I = (int64_t)blockIdx.x * (TB / 8) + threadIdx.x / 8; I < nc; I += rows_per_pass) {
         const uint32_t s0 = rstart[I];
         uint32_t l = rstart[I + 1] - s0;
         mlen = l > mlen ? l : mlen;
         if (l > (uint32_t)RCAP) l = RCAP;
-        for (uint32_t t = 0; t < l; ++t) {
-            const uint64_t key = keys[s0 + t];
-            const int64_t i = (int64_t)(key >> 2);
-            const int64_t at = ((int64_t)(t >> 3) * rld + I) * 8 + (t & 7);  // blocks of 8 (k_restrict)
-            rcol[at] = (int32_t)i;
-            rval[at] = pval[(int64_t)(key & 3) * ld + i];
-        }
         // zero padding: to the end of the last block of 8, and on small levels (the LDS tail copies
         // whole rows without looking at their length) up to RCAP
         const uint32_t upto = nc <= 4096 ? (uint32_t)RCAP : ((l + 7u) & ~7u);
-        for (uint32_t t = l; t < upto; ++t) {
+        for (uint32_t t = sub; t < upto; t += 8) {
             const int64_t at = ((int64_t)(t >> 3) * rld + I) * 8 + (t & 7);
-            rcol[at] = 0;
-            rval[at] = 0.0;
+            if (t < l) {
+                const uint64_t key = keys[s0 + t];
+                const int64_t i = (int64_t)(key >> 2);
+                rcol[at] = (int32_t)i;
+                rval[at] = pval[(int64_t)(key & 3) * ld + i];
+            } else {
+                rcol[at] = 0;
+                rval[at] = 0.0;
+            }
         }
-        rlen[I] = (int32_t)l;
+        if (sub == 0) rlen[I] = (int32_t)l;
     }
-    if (mlen > (uint32_t)RCAP) atomicOr(&stats[ST_OVERFLOW], 2ull);
-    if (mlen) atomicMax(&stats[ST_MAXR], (unsigned long long)mlen);
+    if (mlen > (uint32_t)RCAP) atomicOr(&stats[ST_OVERFLOW], 2ull);  // (rare)
+    __shared__ unsigned int s_max;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_down(mlen, off, 64);
+        mlen = o > mlen ? o : mlen;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(&s_max, mlen);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bstat[blockIdx.x] = s_max;
+        bstat[BSTAT_MAX + blockIdx.x] = 0;
+    }
+}
+
+// per-row sort of the (node << 2 | slot) keys.  Up to 32 keys: one lane per row with a sorting
+// network in registers (grp::sort_rows_short stops at 16, the rows of R average 17, and its
+// workgroup-per-row LDS sort for the rest cost 80 us per 1e5 rows).
+__global__ __launch_bounds__(TB) void r_sort_short(const uint32_t *__restrict__ rstart, uint64_t *__restrict__ keys,
+                                                   int64_t nc) {
+    for (int64_t I = (int64_t)blockIdx.x * TB + threadIdx.x; I < nc; I += (int64_t)gridDim.x * TB) {
+        const uint32_t s0 = rstart[I];
+        const int len = (int)(rstart[I + 1] - s0);
+        if (len < 2) continue;
+        if (len <= 4) grp::sort_short_row<4>(keys + s0, len);
+        else if (len <= 8) grp::sort_short_row<8>(keys + s0, len);
+        else if (len <= 16) grp::sort_short_row<16>(keys + s0, len);
+        else if (len <= 32) grp::sort_short_row<32>(keys + s0, len);
+    }
+}
+// 33..128 keys (the coarser levels): one wavefront per row, bitonic network in LDS.  Longer rows are
+// beyond RCAP: left as they are, the setup declines.  (No work lists: ten thousand rows appending
+// themselves to one list through one counter cost 100 us.)
+__global__ __launch_bounds__(64) void r_sort_medium(const uint32_t *__restrict__ rstart, uint64_t *__restrict__ keys,
+                                                    int64_t nc) {
+    __shared__ uint64_t buf[128];
+    const int lane = threadIdx.x;
+    for (int64_t I = blockIdx.x; I < nc; I += gridDim.x) {
+        const uint32_t s0 = rstart[I];
+        const int len = (int)(rstart[I + 1] - s0);
+        if (len <= 32 || len > 128) continue;  // uniform over the wavefront
+        buf[lane] = lane < len ? keys[s0 + lane] : ~0ull;
+        buf[lane + 64] = lane + 64 < len ? keys[s0 + lane + 64] : ~0ull;
+        __syncthreads();
+        for (int size = 2; size <= 128; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                // 64 compare-exchanges per step: pair (i, i ^ stride) with i the lane's index with bit `stride` clear
+                const int i = ((lane & ~(stride - 1)) << 1) | (lane & (stride - 1));
+                const int j = i | stride;
+                const bool up = (i & size) == 0;
+                const uint64_t a = buf[i], b = buf[j];
+                if ((a > b) == up) { buf[i] = b; buf[j] = a; }
+                __syncthreads();
+            }
+        if (lane < len) keys[s0 + lane] = buf[lane];
+        if (lane + 64 < len) keys[s0 + lane + 64] = buf[lane + 64];
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -431,15 +527,134 @@ __device__ __forceinline__ int wave_excl_scan(int v, int *total) {
     return incl - v;
 }
 
-// Products of the R entries [t0, t0 + tn) of coarse row I, in (R entry, A slot, P slot) order, into
-// the LDS list (lJ, lV); returns their number.  The (node, slot, weight) pairs are laid out in
-// LDS first, so that no lane idles on the slots a short row does not have and every global
-// load of a step is independent of the others of that step: four dependent round trips per
-// group (R entry -> row length -> A entry -> P entries).
-__device__ __forceinline__ int galerkin_products(const Ell &A, const int32_t *__restrict__ pcol,
-                                                 const double *__restrict__ pval, int64_t rld,
-                                                 const int32_t *__restrict__ rcol, const double *__restrict__ rval,
-                                                 int64_t I, int t0, int tn, int32_t *pi, int32_t *psa, double *pw,
+// Step 1: AP = A P, one thread per fine row, at most APW distinct columns per row (the row of
+// A_c an aggregate ends up with is the union of its members' AP rows, so APW = the coarse row
+// cap is always enough; the classes below are picked from the fine row length).  Duplicates are
+// merged in registers (compare chains, no dynamic indexing), in (A slot, P slot) order.
+template <int APW>
+__global__ __launch_bounds__(TB) void ap_rows(Ell A, const int32_t *__restrict__ pcol, const double *__restrict__ pval,
+                                              int32_t *__restrict__ apcol, double *__restrict__ apval,
+                                              int32_t *__restrict__ aplen, unsigned long long *__restrict__ stats) {
+    bool overflow = false;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+        int32_t c[APW];
+        double v[APW];
+#pragma unroll
+        for (int q = 0; q < APW; ++q) { c[q] = -1; v[q] = 0.0; }
+        int cnt = 0;
+        const int32_t l = A.len[i];
+        for (int32_t s = 0; s < l; ++s) {
+            const int32_t k = A.col[(int64_t)s * A.ld + i];
+            const double a = A.val[(int64_t)s * A.ld + i];
+            int32_t J[PW];
+            double pp[PW];
+#pragma unroll
+            for (int sp = 0; sp < PW; ++sp) {
+                J[sp] = pcol[(int64_t)sp * A.ld + k];
+                pp[sp] = pval[(int64_t)sp * A.ld + k];
+            }
+#pragma unroll
+            for (int sp = 0; sp < PW; ++sp) {
+                if (J[sp] < 0) continue;
+                const double t = a * pp[sp];
+                bool placed = false;
+#pragma unroll
+                for (int q = 0; q < APW; ++q)
+                    if (!placed && c[q] == J[sp]) { v[q] += t; placed = true; }
+#pragma unroll
+                for (int q = 0; q < APW; ++q)
+                    if (!placed && c[q] < 0) { c[q] = J[sp]; v[q] = t; placed = true; cnt = q + 1; }
+                if (!placed) overflow = true;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < APW; ++q)
+            if (q < cnt) {  // (the Galerkin kernel reads aplen[i] slots only)
+                apcol[(int64_t)q * A.ld + i] = c[q];
+                apval[(int64_t)q * A.ld + i] = v[q];
+            }
+        aplen[i] = cnt;
+    }
+    if (overflow) atomicOr(&stats[ST_OVERFLOW], 4ull);
+}
+
+// The same for the coarser levels, whose rows reach up to 64 aggregates: compare chains over 64
+// register slots cost 128 predicated operations per product (400 us for 1.4e5 rows); here every
+// lane keeps an open-addressing table of APW slots in LDS (slot-major: the lanes of a wavefront
+// never share a bank), filled in (A slot, P slot) order and written out in slot order.
+template <int APW>
+__global__ __launch_bounds__(64) void ap_rows_lds(Ell A, const int32_t *__restrict__ pcol,
+                                                  const double *__restrict__ pval, int32_t *__restrict__ apcol,
+                                                  double *__restrict__ apval, int32_t *__restrict__ aplen,
+                                                  unsigned long long *__restrict__ stats) {
+    __shared__ int32_t tc[APW * 64];
+    __shared__ double tv[APW * 64];
+    const int lane = threadIdx.x;
+    bool overflow = false;
+    for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < A.n; i0 += (int64_t)gridDim.x * 64) {
+        const int64_t i = i0 + lane;
+#pragma unroll 8
+        for (int q = 0; q < APW; ++q) tc[q * 64 + lane] = -1;
+        int cnt = 0;
+        if (i < A.n) {
+            const int32_t l = A.len[i];
+            for (int32_t s = 0; s < l; ++s) {
+                const int32_t k = A.col[(int64_t)s * A.ld + i];
+                const double a = A.val[(int64_t)s * A.ld + i];
+                int32_t J[PW];
+                double pp[PW];
+#pragma unroll
+                for (int sp = 0; sp < PW; ++sp) {
+                    J[sp] = pcol[(int64_t)sp * A.ld + k];
+                    pp[sp] = pval[(int64_t)sp * A.ld + k];
+                }
+#pragma unroll
+                for (int sp = 0; sp < PW; ++sp) {
+                    if (J[sp] < 0) continue;
+                    const double t = a * pp[sp];
+                    uint32_t slot = ((uint32_t)J[sp] * 2654435761u) >> 16 & (APW - 1);
+                    bool placed = false;
+                    for (int probe = 0; probe < APW && !placed; ++probe) {
+                        const int32_t c = tc[slot * 64 + lane];
+                        if (c == J[sp]) {
+                            tv[slot * 64 + lane] += t;
+                            placed = true;
+                        } else if (c < 0) {
+                            tc[slot * 64 + lane] = J[sp];
+                            tv[slot * 64 + lane] = t;
+                            ++cnt;
+                            placed = true;
+                        }
+                        slot = (slot + 1) & (APW - 1);
+                    }
+                    if (!placed) overflow = true;
+                }
+            }
+            int o = 0;
+            for (int q = 0; q < APW; ++q) {
+                const int32_t c = tc[q * 64 + lane];
+                if (c >= 0) {
+                    apcol[(int64_t)o * A.ld + i] = c;
+                    apval[(int64_t)o * A.ld + i] = tv[q * 64 + lane];
+                    ++o;
+                }
+            }
+            aplen[i] = cnt;
+        }
+    }
+    if (overflow) atomicOr(&stats[ST_OVERFLOW], 4ull);
+}
+
+// Step 2: A_c = R (AP), one wavefront (= one 64-thread workgroup) per coarse row.  The products
+// w_t * AP[i_t, :] of a group of G entries of the R row go to an LDS list in (R entry, AP slot)
+// order; pass 1 collects the row's column set in an LDS hash set, which is sorted with wave
+// shuffles (lane l owns column l); pass 2 walks the list and every lane sums the products of
+// its column in list order.  A row of one group (the usual case) keeps its products in LDS
+// between the passes.  Three dependent round trips per group: R entry -> AP row length / slots.
+__device__ __forceinline__ int galerkin_products(int64_t ld, const int32_t *__restrict__ apcol,
+                                                 const double *__restrict__ apval, const int32_t *__restrict__ aplen,
+                                                 int64_t rld, const int32_t *__restrict__ rcol,
+                                                 const double *__restrict__ rval, int64_t I, int t0, int tn,
                                                  int32_t *lJ, double *lV) {
     const int lane = threadIdx.x;
     int32_t i = 0, len = 0;
@@ -449,71 +664,45 @@ __device__ __forceinline__ int galerkin_products(const Ell &A, const int32_t *__
         const int64_t rat = ((int64_t)(t >> 3) * rld + I) * 8 + (t & 7);
         i = rcol[rat];
         w = rval[rat];
-        len = A.len[i];
+        len = aplen[i];
     }
-    int npairs = 0;
-    const int poff = wave_excl_scan(len, &npairs);
-    for (int sa = 0; sa < len; ++sa) {
-        pi[poff + sa] = i;
-        psa[poff + sa] = sa;
-        pw[poff + sa] = w;
-    }
-    __syncthreads();
     int np = 0;
-    for (int base = 0; base < npairs; base += 64) {
-        const int idx = base + lane;
-        int32_t pj[PW];
-        double pv[PW];
-        int c = 0;
-        if (idx < npairs) {
-            const int32_t ii = pi[idx], sa = psa[idx];
-            const int32_t k = A.col[(int64_t)sa * A.ld + ii];
-            const double wa = pw[idx] * A.val[(int64_t)sa * A.ld + ii];
-            int32_t J[PW];
-            double pp[PW];
+    int o = wave_excl_scan(len, &np);
+    for (int32_t s0 = 0; s0 < len; s0 += 4) {  // four slots in flight
+        int32_t cj[4];
+        double cv[4];
 #pragma unroll
-            for (int sp = 0; sp < PW; ++sp) {
-                J[sp] = pcol[(int64_t)sp * A.ld + k];
-                pp[sp] = pval[(int64_t)sp * A.ld + k];
-            }
-#pragma unroll
-            for (int sp = 0; sp < PW; ++sp)
-                if (J[sp] >= 0) {
-                    pj[c] = J[sp];
-                    pv[c] = wa * pp[sp];
-                    ++c;
-                }
+        for (int q = 0; q < 4; ++q) {
+            const int32_t s = s0 + q < len ? s0 + q : s0;
+            cj[q] = apcol[(int64_t)s * ld + i];
+            cv[q] = apval[(int64_t)s * ld + i];
         }
-        int chunk = 0;
-        const int o = np + wave_excl_scan(c, &chunk);
 #pragma unroll
-        for (int q = 0; q < PW; ++q)
-            if (q < c) {
-                lJ[o + q] = pj[q];
-                lV[o + q] = pv[q];
+        for (int q = 0; q < 4; ++q)
+            if (s0 + q < len) {
+                lJ[o] = cj[q];
+                lV[o] = w * cv[q];
+                ++o;
             }
-        np += chunk;
     }
+    for (int p = lane + np; p < ((np + 7) & ~7); p += 64) lJ[p] = -1;  // pad to a multiple of 8 (accumulation loop)
     __syncthreads();
     return np;
 }
 
-// G: R entries per group (G * longest row of A pairs and four times as many products fit in LDS)
-__global__ __launch_bounds__(64) void galerkin(Ell A, const int32_t *__restrict__ pcol,
-                                               const double *__restrict__ pval, int64_t nc, int64_t rld,
-                                               const int32_t *__restrict__ rcol, const double *__restrict__ rval,
-                                               const int32_t *__restrict__ rlen, int64_t cld,
-                                               int32_t *__restrict__ ccol, double *__restrict__ cval,
+// G: R entries per group (G * APW products fit in the LDS list)
+__global__ __launch_bounds__(64) void galerkin(int64_t ld, const int32_t *__restrict__ apcol,
+                                               const double *__restrict__ apval, const int32_t *__restrict__ aplen,
+                                               int64_t nc, int64_t rld, const int32_t *__restrict__ rcol,
+                                               const double *__restrict__ rval, const int32_t *__restrict__ rlen,
+                                               int64_t cld, int32_t *__restrict__ ccol, double *__restrict__ cval,
                                                int32_t *__restrict__ clen, double *__restrict__ cdinv,
-                                               unsigned long long *__restrict__ stats, int G) {
+                                               unsigned long long *__restrict__ stats, uint32_t *__restrict__ bstat,
+                                               int G, int pcap) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
-    const int paircap = G * A.width;
-    int32_t *set = reinterpret_cast<int32_t *>(gsm);                         // [256]
-    double *pw = reinterpret_cast<double *>(gsm + 1024);                     // [paircap]
-    double *lV = pw + paircap;                                               // [4 paircap]
-    int32_t *pi = reinterpret_cast<int32_t *>(lV + 4 * paircap);             // [paircap]
-    int32_t *psa = pi + paircap;                                             // [paircap]
-    int32_t *lJ = psa + paircap;                                             // [4 paircap]
+    int32_t *set = reinterpret_cast<int32_t *>(gsm);         // [256]
+    double *lV = reinterpret_cast<double *>(gsm + 1024);     // [pcap]
+    int32_t *lJ = reinterpret_cast<int32_t *>(lV + pcap);    // [pcap]
     const int lane = threadIdx.x;
     uint32_t my_max = 0, my_nnz = 0, my_flags = 0;
     for (int64_t I = blockIdx.x; I < nc; I += gridDim.x) {
@@ -524,7 +713,7 @@ __global__ __launch_bounds__(64) void galerkin(Ell A, const int32_t *__restrict_
         // pass 1: the set of columns
         int np = 0;
         for (int g = 0; g < ngroups; ++g) {
-            np = galerkin_products(A, pcol, pval, rld, rcol, rval, I, g * G, min(G, rl - g * G), pi, psa, pw, lJ, lV);
+            np = galerkin_products(ld, apcol, apval, aplen, rld, rcol, rval, I, g * G, min(G, rl - g * G), lJ, lV);
             for (int p = lane; p < np; p += 64) {
                 const int32_t J = lJ[p];
                 uint32_t hsh = ((uint32_t)J * 2654435761u) >> 24;
@@ -569,17 +758,12 @@ __global__ __launch_bounds__(64) void galerkin(Ell A, const int32_t *__restrict_
                 myJ = (lower == up) ? lo : hi;
             }
         }
-        // pass 2: lane l sums the products of column myJ in list order; a row of one group still has
-        // its products in LDS, longer rows regenerate them group by group
+        // pass 2: eight products per step, loaded unconditionally (a compare-then-load loop pays the
+        // LDS latency twice per product); + 0.0 for the others leaves the sum, and its order, unchanged
         double acc = 0.0;
         for (int g = 0; g < ngroups; ++g) {
             if (ngroups > 1)
-                np = galerkin_products(A, pcol, pval, rld, rcol, rval, I, g * G, min(G, rl - g * G), pi, psa, pw, lJ, lV);
-            // eight products per step, loaded unconditionally (a compare-then-load loop pays the LDS
-            // latency twice per product: 12 us for a row of 200 products); +0.0 for the others
-            // leaves the sum, and its order, unchanged
-            for (int p = lane + np; p < ((np + 7) & ~7); p += 64) lJ[p] = -1;  // pad (capacity is a multiple of 8)
-            __syncthreads();
+                np = galerkin_products(ld, apcol, apval, aplen, rld, rcol, rval, I, g * G, min(G, rl - g * G), lJ, lV);
             for (int p = 0; p < np; p += 8) {
                 int32_t j8[8];
                 double v8[8];
@@ -613,10 +797,10 @@ __global__ __launch_bounds__(64) void galerkin(Ell A, const int32_t *__restrict_
         __syncthreads();
     }
     if (lane == 0) {
-        if (my_max) atomicMax(&stats[ST_MAXLEN], (unsigned long long)my_max);
-        if (my_nnz) atomicAdd(&stats[ST_NNZ], (unsigned long long)my_nnz);
+        bstat[blockIdx.x] = my_max;
+        bstat[BSTAT_MAX + blockIdx.x] = my_nnz;
     }
-    if (my_flags & 1u) atomicOr(&stats[ST_OVERFLOW], 1ull);
+    if (my_flags & 1u) atomicOr(&stats[ST_OVERFLOW], 1ull);  // (rare)
     if (my_flags & 4u) atomicOr(&stats[ST_BADDIAG], 1ull);
 }
 
@@ -818,7 +1002,6 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     const size_t a4 = (((size_t)(nc + 1) * 4) + 255) & ~(size_t)255;
     NODAL_HIP_TRY(h, H->rstart.reserve(2 * a4 + 256 + scan_tmp_bytes(nc + 1)));
     NODAL_HIP_TRY(h, H->keys.reserve((size_t)PW * n * 8 + 64));
-    NODAL_HIP_TRY(h, H->lists.reserve(2 * a4 + 64));
     char *rs = H->rstart.as<char>();
     uint32_t *rstart = reinterpret_cast<uint32_t *>(rs);
     uint32_t *cursor = reinterpret_cast<uint32_t *>(rs + a4);
@@ -830,16 +1013,8 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     NODAL_TRY(scan_exclusive_u32(h, rstart, rstart, nc + 1, nullptr, scan_tmp2));
     uint64_t *keys = H->keys.as<uint64_t>();
     r_fill<<<g, TB, 0, st>>>(n, ld, L->pcol.as<int32_t>(), rstart, cursor, keys);
-    int32_t *medium_list = H->lists.as<int32_t>();
-    int32_t *long_list = reinterpret_cast<int32_t *>(H->lists.as<char>() + a4);
-    grp::sort_rows_short<<<grid_for(nc), TB, 0, st>>>(rstart, keys, nc, medium_list, long_list, counts);
-    {
-        const unsigned gm = (unsigned)(nc < 1024 ? nc : 1024);
-        grp::sort_rows_medium<<<gm, TB, 0, st>>>(rstart, keys, medium_list, counts);
-        NODAL_HIP_TRY(h, h->work3.reserve((size_t)PW * n * 16 + 64));  // padded scratch of the long sort
-        grp::sort_rows_long<<<gm < 128 ? gm : 128, 1024, 0, st>>>(rstart, keys, h->work3.as<uint64_t>(), long_list,
-                                                                 counts);
-    }
+    r_sort_short<<<grid_for(nc), TB, 0, st>>>(rstart, keys, nc);
+    r_sort_medium<<<(unsigned)(nc < 8192 ? nc : 8192), 64, 0, st>>>(rstart, keys, nc);
     NODAL_HIP_TRY(h, hipGetLastError());
 
     SLevel *C = H->level(l + 1);
@@ -851,26 +1026,47 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     NODAL_HIP_TRY(h, L->rcol.reserve((size_t)RCAP * C->ld * 4 + 64));
     NODAL_HIP_TRY(h, L->rval.reserve((size_t)RCAP * C->ld * 8 + 64));
     NODAL_HIP_TRY(h, L->rlen.reserve((size_t)C->ld * 4 + 64));
-    r_to_ell<<<grid_for(nc), TB, 0, st>>>(nc, L->rld, rstart, keys, ld, L->pval.as<double>(),
-                                         L->rcol.as<int32_t>(), L->rval.as<double>(), L->rlen.as<int32_t>(),
-                                         dstats + (size_t)l * ST_COUNT);
+    {
+        const unsigned gr = grid_for(nc * 8);
+        r_to_ell<<<gr, TB, 0, st>>>(nc, L->rld, rstart, keys, ld, L->pval.as<double>(), L->rcol.as<int32_t>(),
+                                   L->rval.as<double>(), L->rlen.as<int32_t>(), dstats + (size_t)l * ST_COUNT,
+                                   H->bstat.as<uint32_t>());
+        reduce_bstat<<<1, 1024, 0, st>>>((int)gr, H->bstat.as<uint32_t>(), dstats + (size_t)l * ST_COUNT, ST_MAXR, -1);
+    }
     NODAL_HIP_TRY(h, C->acol.reserve((size_t)ACAP * C->ld * 4 + 64));
     NODAL_HIP_TRY(h, C->aval.reserve((size_t)ACAP * C->ld * 8 + 64));
     NODAL_HIP_TRY(h, C->alen.reserve((size_t)C->ld * 4 + 64));
     NODAL_HIP_TRY(h, C->dinv.reserve((size_t)C->ld * 8 + 64));
     {
-        // R entries per group: pairs (G x longest row of A) and products (4 x pairs) of a group live in LDS;
-        // small budget where there are many coarse rows (occupancy), larger where rows are few and long
-        const int paircap = nc > 50000 ? 192 : 512;
-        int G = paircap / (A.width > 0 ? A.width : 1);
-        G = (G < 8 ? 8 : (G > 64 ? 64 : G)) & ~1;  // even: the product list's capacity is a multiple of 8
-        const size_t lds = 1024 + (size_t)G * A.width * 64;
-        NODAL_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(galerkin),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds > 65536 ? lds : 65536)));
-        galerkin<<<(unsigned)(nc < 32768 ? nc : 32768), 64, lds, st>>>(
-            A, L->pcol.as<int32_t>(), L->pval.as<double>(), nc, L->rld, L->rcol.as<int32_t>(), L->rval.as<double>(),
-            L->rlen.as<int32_t>(), C->ld, C->acol.as<int32_t>(), C->aval.as<double>(), C->alen.as<int32_t>(),
-            C->dinv.as<double>(), dstats + (size_t)(l + 1) * ST_COUNT, G);
+        // AP = A P (one thread per fine row), then A_c = R (AP) (one wavefront per coarse row)
+        // (an AP row reaches the aggregates within two steps of the node: up to ~10 on a 5-point grid)
+        const int apw = A.width <= 6 ? 16 : 64;
+        NODAL_HIP_TRY(h, H->apcol.reserve((size_t)apw * ld * 4 + 64));
+        NODAL_HIP_TRY(h, H->apval.reserve((size_t)apw * ld * 8 + 64));
+        NODAL_HIP_TRY(h, H->aplen.reserve((size_t)ld * 4 + 64));
+        int32_t *apcol = H->apcol.as<int32_t>(), *aplen = H->aplen.as<int32_t>();
+        double *apval = H->apval.as<double>();
+        unsigned long long *lst = dstats + (size_t)l * ST_COUNT;
+        switch (apw) {
+        case 16: ap_rows<16><<<g, TB, 0, st>>>(A, L->pcol.as<int32_t>(), L->pval.as<double>(), apcol, apval, aplen, lst); break;
+        default: {
+            const unsigned gl = (unsigned)((n + 63) / 64 < 4096 ? (n + 63) / 64 : 4096);
+            ap_rows_lds<64><<<gl, 64, 0, st>>>(A, L->pcol.as<int32_t>(), L->pval.as<double>(), apcol, apval, aplen, lst);
+        } break;
+        }
+        NODAL_HIP_TRY(h, hipGetLastError());
+        // R entries per group: G * apw products (12 bytes each) in the LDS list
+        int G = 1024 / apw;
+        G = (G < 8 ? 8 : (G > 64 ? 64 : G));
+        const int pcap = G * apw + 8;
+        const size_t lds = 1024 + (size_t)pcap * 12;
+        const unsigned gg = (unsigned)(nc < BSTAT_MAX ? nc : BSTAT_MAX);
+        galerkin<<<gg, 64, lds, st>>>(
+            ld, apcol, apval, aplen, nc, L->rld, L->rcol.as<int32_t>(), L->rval.as<double>(), L->rlen.as<int32_t>(),
+            C->ld, C->acol.as<int32_t>(), C->aval.as<double>(), C->alen.as<int32_t>(), C->dinv.as<double>(),
+            dstats + (size_t)(l + 1) * ST_COUNT, H->bstat.as<uint32_t>(), G, pcap);
+        reduce_bstat<<<1, 1024, 0, st>>>((int)gg, H->bstat.as<uint32_t>(), dstats + (size_t)(l + 1) * ST_COUNT,
+                                         ST_MAXLEN, ST_NNZ);
     }
     NODAL_HIP_TRY(h, hipGetLastError());
     return NODAL_OK;
@@ -966,8 +1162,13 @@ int sagg_setup(nodal_ctx *h, bool *accepted, int32_t *floating) {
     unsigned long long *dstats = H->stats.as<unsigned long long>();
     unsigned long long *hs = reinterpret_cast<unsigned long long *>(H->host_stats);
     NODAL_HIP_TRY(h, hipMemsetAsync(dstats, 0, (size_t)MAX_LEVELS * ST_COUNT * 8, st));
-    row_stats<<<grid_for(n0), TB, 0, st>>>(n0, h->indptr.as<int32_t>(), h->indices.as<int32_t>(),
-                                          h->data.as<double>(), 0.9, 8.0, dstats);
+    NODAL_HIP_TRY(h, H->bstat.reserve((size_t)2 * BSTAT_MAX * 4 + 64));
+    {
+        const unsigned gr = grid_for(n0);
+        row_stats<<<gr, TB, 0, st>>>(n0, h->indptr.as<int32_t>(), h->indices.as<int32_t>(), h->data.as<double>(), 0.9,
+                                    8.0, dstats, H->bstat.as<uint32_t>());
+        reduce_bstat<<<1, 1024, 0, st>>>((int)gr, H->bstat.as<uint32_t>(), dstats, ST_MAXLEN, ST_GRADED);
+    }
     NODAL_HIP_TRY(h, hipGetLastError());
     NODAL_HIP_TRY(h, hipMemcpyAsync(hs, dstats, ST_COUNT * 8, hipMemcpyDeviceToHost, st));
     NODAL_HIP_TRY(h, hipStreamSynchronize(st));
@@ -1114,7 +1315,13 @@ int cycle(nodal_ctx *h, SHierarchy *H, int l, const double *b, const double *x0,
     double *r = L->v(V_R), *xp = L->v(V_XP);
     double *rc = C->v(V_RC), *c1 = C->v(V_C1), *c2 = C->v(V_C2);
     const unsigned g = sb ? (unsigned)sb->g0 : grid_for(n);
-    SAGG_DISPATCH_W(L->wfix, (k_smooth_residual<W><<<g, TB, 0, st>>>(A, b, x0, r)));
+    const int nu = H->nu[l < 2 ? l : 2];
+    if (nu >= 2) {  // second pre-smoothing sweep: x1 = x0 + w D^-1 (b - A x0)
+        double *x1 = L->v(V_X1);
+        SAGG_DISPATCH_W(L->wfix, (k_post<W, false><<<g, TB, 0, st>>>(A, dinv, b, x0, x1, nullptr, nullptr, nullptr)));
+        x = x1;
+    }
+    SAGG_DISPATCH_W(L->wfix, (k_smooth_residual<W><<<g, TB, 0, st>>>(A, b, x, r)));
     double *x0c = C->v(V_X);
     k_restrict<<<grid_for(nc * RL), TB, 0, st>>>(nc, L->rld, L->rcol.as<int32_t>(), L->rval.as<double>(),
                                                 L->rlen.as<int32_t>(), r, rc, C->dinv.as<double>(), x0c);
@@ -1149,11 +1356,17 @@ int cycle(nodal_ctx *h, SHierarchy *H, int l, const double *b, const double *x0,
     }
     k_prolong<<<grid_for(n), TB, 0, st>>>(n, L->ld, L->pcol.as<int32_t>(), L->pval.as<double>(), x, c1, c2, coef,
                                          xp);
+    const double *cur = xp;
+    if (nu >= 2) {  // first of two post-smoothing sweeps
+        double *mid = L->v(V_T);
+        SAGG_DISPATCH_W(L->wfix, (k_post<W, false><<<g, TB, 0, st>>>(A, dinv, b, cur, mid, nullptr, nullptr, nullptr)));
+        cur = mid;
+    }
     if (sb) {
-        SAGG_DISPATCH_W(L->wfix, (k_post<W, true><<<g, TB, 0, st>>>(A, dinv, b, xp, out, sb->Ap, sb->part_rz,
+        SAGG_DISPATCH_W(L->wfix, (k_post<W, true><<<g, TB, 0, st>>>(A, dinv, b, cur, out, sb->Ap, sb->part_rz,
                                                                     sb->part_zap)));
     } else {
-        SAGG_DISPATCH_W(L->wfix, (k_post<W, false><<<g, TB, 0, st>>>(A, dinv, b, xp, out, nullptr, nullptr, nullptr)));
+        SAGG_DISPATCH_W(L->wfix, (k_post<W, false><<<g, TB, 0, st>>>(A, dinv, b, cur, out, nullptr, nullptr, nullptr)));
     }
     NODAL_HIP_TRY(h, hipGetLastError());
     return NODAL_OK;
@@ -1192,6 +1405,9 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     h->amg_levels = H->nlev;
     static const int kc = getenv("NODAL_SA_KCYCLE") ? atoi(getenv("NODAL_SA_KCYCLE")) : 1;
     H->kcycle = kc != 0;
+    if (const char *e = getenv("NODAL_SA_NU")) {  // e.g. "212": sweeps at level 0, level 1, deeper levels
+        for (int k = 0; k < 3 && e[k] >= '1' && e[k] <= '2'; ++k) H->nu[k] = e[k] - '0';
+    }
 
     const size_t vec = align_up((size_t)n * 8);
     NODAL_HIP_TRY(h, h->solver.reserve(5 * vec + 4 * MAX_PARTIALS * 8 + F_COUNT * 8 + 256));

@@ -113,9 +113,19 @@ __global__ __launch_bounds__(TB) void k_restrict(int64_t nc, int64_t rld, const 
         double s = 0.0;
         if (I < nc) {
             const int32_t len = rlen[I];
-            for (int32_t q = 0; q * RL < len; ++q) {
-                const int64_t at = ((int64_t)q * rld + I) * RL + sub;
-                if (q * RL + sub < len) s = fma(rval[at], r[rcol[at]], s);
+            // (rows are zero-padded to whole blocks: no per-entry test) three blocks in flight
+            for (int32_t q0 = 0; q0 * RL < len; q0 += 3) {
+                int32_t c[3];
+                double v[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const bool ok = (q0 + u) * RL < len;
+                    const int64_t at = ((int64_t)(ok ? q0 + u : q0) * rld + I) * RL + sub;
+                    c[u] = rcol[at];
+                    v[u] = ok ? rval[at] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) s = fma(v[u], r[c[u]], s);
             }
         }
 #pragma unroll
