@@ -232,6 +232,12 @@ void sagg_destroy(nodal_ctx *h);
 // smoothed-aggregation FCG (sagg.hip): NODAL_OK, -1 breakdown, -2 structurally singular,
 // -3 declined (not this hierarchy's kind of network: use amg.hip)
 int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, int32_t *iters, double *resid);
+// the same hierarchy as a preconditioner for any device CSR matrix (general: a few off-diagonals
+// of either sign, not symmetric); sagg_apply: z ~= A^-1 r with one cycle
+int sagg_setup_csr(nodal_ctx *h, int64_t n, int64_t nnz, const int32_t *indptr, const int32_t *indices,
+                   const double *data, bool general, bool *accepted, int32_t *floating);
+int sagg_apply(nodal_ctx *h, const double *r, double *z);
+int sagg_levels(nodal_ctx *h);
 int amg_has_floating_component(nodal_ctx *h, const uint8_t *grounded0, int32_t *floating);
 int csr_has_floating_component(nodal_ctx *h, const uint8_t *grounded, int32_t *floating);
 

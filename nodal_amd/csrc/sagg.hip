@@ -177,7 +177,8 @@ __global__ __launch_bounds__(1024) void reduce_bstat(int nblocks, const uint32_t
 __global__ __launch_bounds__(TB) void row_stats(int64_t n, const int32_t *__restrict__ indptr,
                                                 const int32_t *__restrict__ indices,
                                                 const double *__restrict__ data, double share, double spread,
-                                                unsigned long long *__restrict__ stats, uint32_t *__restrict__ bstat) {
+                                                bool general, unsigned long long *__restrict__ stats,
+                                                uint32_t *__restrict__ bstat) {
     int32_t mlen = 0;
     uint32_t graded = 0, bad = 0;
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(TB) void row_stats(int64_t n, const int32_t *__rest
             else if (v != 0.0) {
                 mx = fmax(mx, fabs(v));
                 mn = fmin(mn, fabs(v));
-                if (v > 0.0) bad = 1;  // positive off-diagonal: not an M-matrix
+                if (v > 0.0 && !general) bad = 1;  // positive off-diagonal: not an M-matrix
             }
         }
         if (!(d > 0.0)) bad = 1;
@@ -1145,7 +1146,11 @@ void sagg_destroy(nodal_ctx *h) {
 // beyond the caps): nothing is kept, the caller uses amg.hip.  *floating: a connected
 // component without a resistor to ground (structurally singular; the reference's spsolve
 // returns NaNs).
-int sagg_setup(nodal_ctx *h, bool *accepted, int32_t *floating) {
+// general: the matrix is the node block of a system with transconductance stamps (a few
+// off-diagonals of either sign, not symmetric): the hierarchy serves as a preconditioner of
+// FGMRES; no structural-singularity verdict is asked for.
+int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr0, const int32_t *indices0,
+                   const double *data0, bool general, bool *accepted, int32_t *floating) {
     *accepted = false;
     *floating = 0;
     static const bool enabled = !(getenv("NODAL_SAGG") && atoi(getenv("NODAL_SAGG")) == 0);
@@ -1154,7 +1159,6 @@ int sagg_setup(nodal_ctx *h, bool *accepted, int32_t *floating) {
     SHierarchy *H = hierarchy_of(h);
     H->ready = false;
     hipStream_t st = h->stream;
-    const int64_t n0 = h->n;
     if (n0 >= (1ll << 30)) return NODAL_OK;
     NODAL_HIP_TRY(h, H->stats.reserve((size_t)MAX_LEVELS * ST_COUNT * 8 + 64));
     if (!H->host_stats)
@@ -1165,8 +1169,7 @@ int sagg_setup(nodal_ctx *h, bool *accepted, int32_t *floating) {
     NODAL_HIP_TRY(h, H->bstat.reserve((size_t)2 * BSTAT_MAX * 4 + 64));
     {
         const unsigned gr = grid_for(n0);
-        row_stats<<<gr, TB, 0, st>>>(n0, h->indptr.as<int32_t>(), h->indices.as<int32_t>(), h->data.as<double>(), 0.9,
-                                    8.0, dstats, H->bstat.as<uint32_t>());
+        row_stats<<<gr, TB, 0, st>>>(n0, indptr0, indices0, data0, 0.9, 8.0, general, dstats, H->bstat.as<uint32_t>());
         reduce_bstat<<<1, 1024, 0, st>>>((int)gr, H->bstat.as<uint32_t>(), dstats, ST_MAXLEN, ST_GRADED);
     }
     NODAL_HIP_TRY(h, hipGetLastError());
@@ -1184,15 +1187,15 @@ int sagg_setup(nodal_ctx *h, bool *accepted, int32_t *floating) {
     L0->n = n0;
     L0->ld = pad64(n0);
     L0->maxlen = (int32_t)hs[ST_MAXLEN];
-    L0->nnz = h->nnz;
-    L0->wfix = choose_wfix(L0->maxlen, n0, h->nnz, 8);
+    L0->nnz = nnz0;
+    L0->wfix = choose_wfix(L0->maxlen, n0, nnz0, 8);
     L0->width = L0->wfix ? L0->wfix : L0->maxlen;
     NODAL_HIP_TRY(h, L0->acol.reserve((size_t)L0->width * L0->ld * 4 + 64));
     NODAL_HIP_TRY(h, L0->aval.reserve((size_t)L0->width * L0->ld * 8 + 64));
     NODAL_HIP_TRY(h, L0->alen.reserve((size_t)L0->ld * 4 + 64));
     NODAL_HIP_TRY(h, L0->dinv.reserve((size_t)L0->ld * 8 + 64));
-    csr_to_ell<<<grid_for(n0), TB, 0, st>>>(n0, L0->ld, h->indptr.as<int32_t>(), h->indices.as<int32_t>(),
-                                           h->data.as<double>(), L0->acol.as<int32_t>(), L0->aval.as<double>(),
+    csr_to_ell<<<grid_for(n0), TB, 0, st>>>(n0, L0->ld, indptr0, indices0, data0, L0->acol.as<int32_t>(),
+                                           L0->aval.as<double>(),
                                            L0->alen.as<int32_t>(), L0->dinv.as<double>(), L0->wfix);
     NODAL_HIP_TRY(h, hipGetLastError());
 
@@ -1253,7 +1256,11 @@ int sagg_setup(nodal_ctx *h, bool *accepted, int32_t *floating) {
     NODAL_TRY(build_tail(h, H, hs));
 
     // structural singularity: OR the "touches ground" flags up, look at the last level
-    {
+    if (general) {
+        NODAL_HIP_TRY(h, hipMemcpyAsync(hs, dstats, (size_t)MAX_LEVELS * ST_COUNT * 8, hipMemcpyDeviceToHost, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        if (hs[(size_t)l * ST_COUNT + ST_BADDIAG] & 2ull) return NODAL_OK;  // coarsest pivot not positive
+    } else {
         NODAL_HIP_TRY(h, H->level(0)->gflag.reserve((size_t)n0 + 64));
         NODAL_TRY(grounded_flags(h, H->level(0)->gflag.as<uint8_t>()));
         for (int k = 0; k + 1 < H->nlev; ++k) {
@@ -1286,6 +1293,11 @@ int sagg_setup(nodal_ctx *h, bool *accepted, int32_t *floating) {
     H->ready = true;
     *accepted = true;
     return NODAL_OK;
+}
+
+int sagg_setup(nodal_ctx *h, bool *accepted, int32_t *floating) {
+    return sagg_setup_csr(h, h->n, h->nnz, h->indptr.as<int32_t>(), h->indices.as<int32_t>(), h->data.as<double>(),
+                          false, accepted, floating);
 }
 
 namespace {
@@ -1381,6 +1393,28 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
+// z ~= A^-1 r with one cycle of the hierarchy built by sagg_setup_csr (the preconditioner of the
+// general path's FGMRES, sparse_general.hip)
+__global__ __launch_bounds__(TB) void k_x0(int64_t n, const double *__restrict__ dinv, const double *__restrict__ r,
+                                           double *__restrict__ x0) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        x0[i] = OMEGA * dinv[i] * r[i];
+}
+bool sagg_ready(nodal_ctx *h, int64_t n) {
+    SHierarchy *H = static_cast<SHierarchy *>(h->sagg);
+    return H && H->ready && H->pool[0]->n == n;
+}
+int sagg_levels(nodal_ctx *h) { return h->sagg ? static_cast<SHierarchy *>(h->sagg)->nlev : 0; }
+int sagg_apply(nodal_ctx *h, const double *r, double *z) {
+    SHierarchy *H = static_cast<SHierarchy *>(h->sagg);
+    if (!H || !H->ready) return nodal_fail(h, NODAL_E_INVALID, "sagg_setup_csr not called");
+    SLevel *L0 = H->pool[0];
+    double *x0 = L0->v(V_X);
+    k_x0<<<grid_for(L0->n), TB, 0, h->stream>>>(L0->n, L0->dinv.as<double>(), r, x0);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return cycle(h, H, 0, r, x0, z, nullptr);
+}
+
 // Flexible CG preconditioned by the hierarchy.  Return: NODAL_OK (converged, *info = 0); -2 the
 // network is structurally singular (caller fills NaNs); -1 breakdown / no convergence (caller
 // falls back); SAGG_DECLINED (-3) the hierarchy does not take this matrix; > 0 a status.
@@ -1470,17 +1504,18 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
         else if (conv) status = 1;
         else if (enqueued >= maxit) status = 3;
         else {
-            // remaining iterations from the observed reduction per iteration, one less than the
-            // estimate: an iteration past convergence still runs its multigrid cycle (only the CG
-            // kernels return at once), a poll costs ~20 us
+            // remaining iterations from the observed reduction per iteration; three quarters of the
+            // estimate are enqueued (the rate of the first iterations is not the asymptotic one): an
+            // iteration past convergence still runs its multigrid cycle, ~250 us, a poll costs ~30 us
             int next = 2;
             const double target = tol * tol * hs[F_BB];
             const double rr_ref = rr_prev > 0.0 ? rr_prev : hs[F_BB];
             const int64_t it_ref = rr_prev > 0.0 ? it_prev : 0;
             if (hs[F_RR] > 0.0 && hs[F_RR] < rr_ref && enqueued > it_ref) {
                 const double rate = log(hs[F_RR] / rr_ref) / (double)(enqueued - it_ref);  // < 0
-                next = (int)floor(log(target / hs[F_RR]) / rate);
+                next = (int)floor(0.75 * log(target / hs[F_RR]) / rate);
             }
+            if (next > enqueued) next = (int)enqueued;  // (at most doubling: early rates are pessimistic)
             batch = next < 1 ? 1 : (next > 32 ? 32 : next);
             rr_prev = hs[F_RR];
             it_prev = enqueued;

@@ -365,10 +365,21 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
     NODAL_HIP_TRY(h, h->schur.reserve((size_t)(n - K) * 8 + 64));
     double *flag = h->schur.as<double>() + (n - K);  // spare word: multigrid's SPD flag (unused here)
     NODAL_HIP_TRY(h, hipMemsetAsync(flag, 0, 8, st));
-    NODAL_TRY(amg_setup_csr(h, K, gn_nnz, h->gn_indptr.as<int32_t>(), h->gn_indices.as<int32_t>(),
-                            h->gn_rowidx.as<int32_t>(), h->gn_data.as<double>(),
-                            h->gn_diag.as<int32_t>(), flag));
-    h->amg_levels = amg_num_levels(h);
+    // node block: smoothed aggregation where it takes the matrix (sagg.hip), else plain aggregation
+    bool use_sa = false;
+    {
+        int32_t floating = 0;
+        NODAL_TRY(sagg_setup_csr(h, K, gn_nnz, h->gn_indptr.as<int32_t>(), h->gn_indices.as<int32_t>(),
+                                 h->gn_data.as<double>(), true, &use_sa, &floating));
+    }
+    if (use_sa) {
+        h->amg_levels = sagg_levels(h);
+    } else {
+        NODAL_TRY(amg_setup_csr(h, K, gn_nnz, h->gn_indptr.as<int32_t>(), h->gn_indices.as<int32_t>(),
+                                h->gn_rowidx.as<int32_t>(), h->gn_data.as<double>(),
+                                h->gn_diag.as<int32_t>(), flag));
+        h->amg_levels = amg_num_levels(h);
+    }
     if (n > K) {
         schur_diag<<<grid_for(n - K), TB, 0, st>>>(indptr, indices, data, K, (int)n,
                                                   h->gn_data.as<double>(), h->gn_diag.as<int32_t>(),
@@ -428,7 +439,8 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
         for (; j < RESTART; ++j) {
             double *vj = V + (int64_t)j * ld, *zj = Z + (int64_t)j * ld;
             // z_j = M^-1 v_j
-            NODAL_TRY(amg_apply(h, vj, zj));
+            if (use_sa) NODAL_TRY(sagg_apply(h, vj, zj));
+            else NODAL_TRY(amg_apply(h, vj, zj));
             if (n > K) {
                 branch_solve<<<grid_for(n - K), TB, 0, st>>>(indptr, indices, data, K, (int)n,
                                                             h->schur.as<double>(), vj, zj);

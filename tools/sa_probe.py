@@ -14,9 +14,16 @@ def golden(name):
     return None
 
 def main():
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    what = sys.argv[1] if len(sys.argv) > 1 else "1000"
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-    table = gen.grid_table(N)
+    if what.startswith("cfg5"):
+        N = int(what[5:] or 1000) if ":" in what else 1000
+        table = gen.cfg5_table(N)
+        gname = f"cfg5({N})"
+    else:
+        N = int(what)
+        table = gen.grid_table(N)
+        gname = f"grid({N})"
     h = _ffi.Handle(0)
     h.upload(table)
     for r in range(reps):
@@ -29,7 +36,7 @@ def main():
               f"iterations {it}, levels {lv}, relres {rr:.2e}, kernel {h.kernel_stats()}")
     x = h.download_x()
     print("residual", h.residual(), "x0", x[0])
-    g = golden(f"grid({N})")
+    g = golden(gname)
     if g:
         idx = np.array(g["x_idx"]); ref = np.array(g["x_sparse_samples"])
         print("normwise error vs reference samples", np.abs(x[idx] - ref).max() / g["x_sparse_absmax"])
