@@ -235,7 +235,7 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
 // the same hierarchy as a preconditioner for any device CSR matrix (general: a few off-diagonals
 // of either sign, not symmetric); sagg_apply: z ~= A^-1 r with one cycle
 int sagg_setup_csr(nodal_ctx *h, int64_t n, int64_t nnz, const int32_t *indptr, const int32_t *indices,
-                   const double *data, bool general, bool *accepted, int32_t *floating);
+                   const double *data, bool general, bool check_floating, bool *accepted, int32_t *floating);
 int sagg_apply(nodal_ctx *h, const double *r, double *z);
 int sagg_levels(nodal_ctx *h);
 int amg_has_floating_component(nodal_ctx *h, const uint8_t *grounded0, int32_t *floating);

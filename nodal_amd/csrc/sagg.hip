@@ -1148,9 +1148,11 @@ void sagg_destroy(nodal_ctx *h) {
 // returns NaNs).
 // general: the matrix is the node block of a system with transconductance stamps (a few
 // off-diagonals of either sign, not symmetric): the hierarchy serves as a preconditioner of
-// FGMRES; no structural-singularity verdict is asked for.
+// FGMRES.  check_floating: the context's component table says which nodes a resistor joins to
+// ground (grounded_flags); a connected component of the matrix pattern without such a node is
+// reported in *floating.
 int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr0, const int32_t *indices0,
-                   const double *data0, bool general, bool *accepted, int32_t *floating) {
+                   const double *data0, bool general, bool check_floating, bool *accepted, int32_t *floating) {
     *accepted = false;
     *floating = 0;
     static const bool enabled = !(getenv("NODAL_SAGG") && atoi(getenv("NODAL_SAGG")) == 0);
@@ -1256,7 +1258,7 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
     NODAL_TRY(build_tail(h, H, hs));
 
     // structural singularity: OR the "touches ground" flags up, look at the last level
-    if (general) {
+    if (!check_floating) {
         NODAL_HIP_TRY(h, hipMemcpyAsync(hs, dstats, (size_t)MAX_LEVELS * ST_COUNT * 8, hipMemcpyDeviceToHost, st));
         NODAL_HIP_TRY(h, hipStreamSynchronize(st));
         if (hs[(size_t)l * ST_COUNT + ST_BADDIAG] & 2ull) return NODAL_OK;  // coarsest pivot not positive
@@ -1297,7 +1299,7 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
 
 int sagg_setup(nodal_ctx *h, bool *accepted, int32_t *floating) {
     return sagg_setup_csr(h, h->n, h->nnz, h->indptr.as<int32_t>(), h->indices.as<int32_t>(), h->data.as<double>(),
-                          false, accepted, floating);
+                          false, true, accepted, floating);
 }
 
 namespace {

@@ -724,6 +724,78 @@ int lowdeg_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const in
     return NODAL_OK;
 }
 
+// Structural verdict for a general system (branch equations present) from the host copy of the
+// component table, for the cases the iterative path cannot answer: the reference's spsolve
+// reports an exactly singular matrix with NaNs + MatrixRankWarning (reference nodal/nodal.py:
+// 323-336), it does not raise.
+//   (a) a node that no resistor or voltage-defined branch (E, VCVS, CCVS) ties -- directly or
+//       through other nodes -- to the ground node has an undetermined potential: the rows of
+//       its island sum to a row with no conductance to anything fixed;
+//   (b) a loop of independent voltage sources makes their branch equations linearly dependent
+//       whatever the values.
+// O(components) on the host; only called after the device solve has given up (or, (b) alone,
+// when the presolve has declined the pattern).
+namespace {
+struct UnionFind {
+    std::vector<int32_t> p;
+    explicit UnionFind(int64_t n) : p((size_t)n) {
+        for (int64_t i = 0; i < n; ++i) p[(size_t)i] = (int32_t)i;
+    }
+    int32_t find(int32_t x) {
+        while (p[(size_t)x] != x) {
+            p[(size_t)x] = p[(size_t)p[(size_t)x]];
+            x = p[(size_t)x];
+        }
+        return x;
+    }
+    bool unite(int32_t a, int32_t b) {  // false: already joined
+        a = find(a);
+        b = find(b);
+        if (a == b) return false;
+        p[(size_t)(a < b ? b : a)] = a < b ? a : b;
+        return true;
+    }
+};
+const double *host_values(const nodal_ctx *h) {
+    if (h->batch > 0 && !h->host.values_batch.empty())
+        return h->host.values_batch.data() + (size_t)h->member * h->ncomp;
+    return h->host.value.data();
+}
+}  // namespace
+
+bool general_source_loop(const nodal_ctx *h) {
+    const HostTable &t = h->host;
+    if (t.type.empty()) return false;
+    const int32_t K = h->K;
+    UnionFind uf((int64_t)K + 1);
+    for (int64_t i = 0; i < h->ncomp; ++i)
+        if (t.type[(size_t)i] == NODAL_T_E) {
+            const int32_t a = t.a[(size_t)i] < 0 ? K : t.a[(size_t)i], b = t.b[(size_t)i] < 0 ? K : t.b[(size_t)i];
+            if (!uf.unite(a, b)) return true;
+        }
+    return false;
+}
+
+bool general_floating_island(const nodal_ctx *h) {
+    const HostTable &t = h->host;
+    if (t.type.empty()) return false;
+    const double *value = host_values(h);
+    const int32_t K = h->K;
+    UnionFind uf((int64_t)K + 1);
+    for (int64_t i = 0; i < h->ncomp; ++i) {
+        const uint8_t ty = t.type[(size_t)i];
+        const bool ties = (ty == NODAL_T_R && value[i] != 0.0 && value[i] == value[i]) || ty == NODAL_T_E ||
+                          ty == NODAL_T_VCVS || ty == NODAL_T_CCVS;
+        if (!ties) continue;
+        const int32_t a = t.a[(size_t)i] < 0 ? K : t.a[(size_t)i], b = t.b[(size_t)i] < 0 ? K : t.b[(size_t)i];
+        uf.unite(a, b);
+    }
+    const int32_t g = uf.find(K);
+    for (int32_t i = 0; i < K; ++i)
+        if (uf.find(i) != g) return true;
+    return false;
+}
+
 int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, double *resid) {
     if (!h->have_numeric) return nodal_fail(h, NODAL_E_INVALID, "assemble_numeric not called");
     const int64_t n = h->n;
@@ -792,7 +864,14 @@ int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, do
         }
     } else if (method == NODAL_SPARSE_LU) {
         if (h->csr_only) return nodal_fail(h, NODAL_E_UNSUPPORTED, "matrix-only context: no general solver");
-        NODAL_TRY(sparse_general_solve(h, info, iters, resid));
+        const int s = sparse_general_solve(h, info, iters, resid);
+        if (s == NODAL_E_UNSUPPORTED && (general_floating_island(h) || general_source_loop(h))) {
+            // the iteration gave up on a matrix that is singular by construction: the reference's
+            // answer is NaNs + a warning (quirk 3), not an exception
+            *info = 1;
+        } else if (s != NODAL_OK) {
+            return s;
+        }
     } else {
         return nodal_fail(h, NODAL_E_INVALID, "unknown sparse method");
     }

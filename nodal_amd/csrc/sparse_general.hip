@@ -323,6 +323,8 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace
 
 int csr_spmv(nodal_ctx *h, const double *x, double *y);  // sparse.hip
+bool general_source_loop(const nodal_ctx *h);                // sparse.hip
+bool general_floating_island(const nodal_ctx *h);            // sparse.hip
 
 int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
     const int64_t n = h->n;
@@ -340,6 +342,17 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
         bool done = false;
         NODAL_TRY(presolve_solve(h, &done, info, iters, resid));
         if (done) return NODAL_OK;
+        // A loop of independent voltage sources (one of the patterns the presolve declines) makes
+        // the matrix exactly singular whatever the values; with consistent values a Krylov
+        // iteration would still hand back one of the infinitely many solutions, where the
+        // reference's spsolve reports the singular matrix (NaNs + MatrixRankWarning).
+        // The same for an island that nothing ties to the ground node: its equations are consistent
+        // (no net current can enter it), so the iteration would "converge" with arbitrary island
+        // potentials.  (The presolved system asks the multigrid hierarchy instead, below.)
+        if (general_source_loop(h) || general_floating_island(h)) {
+            *info = 1;
+            return NODAL_OK;
+        }
     }
 
     // ---- preconditioner setup: node block + multigrid + Schur diagonal ----
@@ -368,9 +381,16 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
     // node block: smoothed aggregation where it takes the matrix (sagg.hip), else plain aggregation
     bool use_sa = false;
     {
+        // a presolved system (no branch unknowns left, resistors / current sources / transconductances):
+        // its table says which nodes touch ground, so the hierarchy can tell a floating island
+        const bool check_floating = h->B == 0 && h->have_table && !h->csr_only && K == (int)n;
         int32_t floating = 0;
         NODAL_TRY(sagg_setup_csr(h, K, gn_nnz, h->gn_indptr.as<int32_t>(), h->gn_indices.as<int32_t>(),
-                                 h->gn_data.as<double>(), true, &use_sa, &floating));
+                                 h->gn_data.as<double>(), true, check_floating, &use_sa, &floating));
+        if (use_sa && floating) {  // singular: NaNs + warning, as the reference's spsolve (quirk 3)
+            *info = 1;
+            return NODAL_OK;
+        }
     }
     if (use_sa) {
         h->amg_levels = sagg_levels(h);
