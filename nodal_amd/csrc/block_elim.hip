@@ -1,6 +1,8 @@
 // Dense block elimination with explicitly inverted diagonal blocks: the passive (SPD) dense
 // path and the presolved systems of dense_lu.hip's dispatcher.
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "dense_common.h"
 
@@ -339,8 +341,9 @@ int invert_diag(nodal_ctx *h, hipStream_t sp, double *D, int64_t lda, int w, dou
     return NODAL_OK;
 }
 
+// bnd: block boundaries 0 = bnd[0] < bnd[1] < ... < bnd[nb] = n (widths <= BI_MAX, possibly mixed)
 int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncols, int32_t *dinfo,
-                    GemmTimer &tm, int64_t wb) {
+                    GemmTimer &tm, const std::vector<int64_t> &bnd) {
     // Three streams.  Per block k = [J0, J1), next block [J1, J2), once A12(k) <- Q(k) A12(k)
     // (called W(k) below) is done and the previous bulk update has retired:
     //   sp (high priority): diag   A[J1:J2, J1:J2] -= A[J1:J2, J0:J1] W(k)       (small)
@@ -356,44 +359,48 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
     hipStream_t s3 = full_mask ? h->stream2 : h->stream3;
     hipEvent_t ev_wfirst = h->ev_bi[0], ev_strip = h->ev_bi[1], ev_wrest = h->ev_bi[2],
                ev_start = h->ev_bi[3], ev_done = h->ev_bi[4], ev_q = h->ev_bi[5], ev_rest = nullptr;
-    const int64_t FIRST = 2 * wb;  // columns of W(k) that the next two diagonal blocks need
-    // scratch: Q[2] (wb x wb), the inverse's T1 / T2 per recursion level, S1 (wb x FIRST), S (wb x ncols)
-    const size_t qb = (size_t)wb * wb, tb = 2 * (size_t)(2 * GJ) * (2 * GJ) + 2 * (size_t)GJ * GJ;
-    NODAL_HIP_TRY(h, h->work.reserve((2 * qb + tb + (size_t)wb * FIRST + (size_t)wb * (size_t)ncols) * 8 + 256));
+    const int nb = (int)bnd.size() - 1;
+    int64_t wmax = 0;
+    for (int k = 0; k < nb; ++k) wmax = std::max(wmax, bnd[k + 1] - bnd[k]);
+    const int64_t FIRST = 2 * wmax;  // (capacity) columns of W(k) that the next two diagonal blocks need
+    // scratch: Q[2] (wmax x wmax), the inverse's T1 / T2 per recursion level, S1 (wmax x FIRST), S (wmax x ncols)
+    const size_t qb = (size_t)wmax * wmax, tb = 2 * (size_t)(2 * GJ) * (2 * GJ) + 2 * (size_t)GJ * GJ;
+    NODAL_HIP_TRY(h, h->work.reserve((2 * qb + tb + (size_t)wmax * FIRST + (size_t)wmax * (size_t)ncols) * 8 + 256));
     double *Q[2] = {h->work.as<double>(), h->work.as<double>() + qb};
-    double *T = Q[1] + qb, *S1 = T + tb, *S = S1 + (size_t)wb * FIRST;
+    double *T = Q[1] + qb, *S1 = T + tb, *S = S1 + (size_t)wmax * FIRST;
 
     // A12 <- Q A12 for the block [J0, J1): columns [c0, c1) on stream st through scratch buf
     auto scale_cols = [&](hipStream_t st, const double *Qk, double *buf, int64_t J0, int64_t J1, int64_t c0,
                           int64_t c1) -> int {
         if (c1 <= c0) return NODAL_OK;
         const int w = (int)(J1 - J0);
-        copy_block<<<blocks_for(c1 - c0, 4), 256, 0, st>>>(A + c0 * lda + J0, lda, buf, wb, w, c1 - c0);
+        copy_block<<<blocks_for(c1 - c0, 4), 256, 0, st>>>(A + c0 * lda + J0, lda, buf, wmax, w, c1 - c0);
         NODAL_HIP_TRY(h, hipGetLastError());
-        return gemm_f64(h, st, GEMM_SET, A + c0 * lda + J0, lda, Qk, wb, buf, wb, w, c1 - c0, w);
+        return gemm_f64(h, st, GEMM_SET, A + c0 * lda + J0, lda, Qk, wmax, buf, wmax, w, c1 - c0, w);
     };
-    auto first_end = [&](int64_t J1) { return J1 + FIRST < ncols ? J1 + FIRST : ncols; };
+    // W(k)'s first columns: those the next two diagonal blocks (k + 1, k + 2) read
+    auto first_end = [&](int k) {
+        const int64_t e = bnd[k + 3 < nb ? k + 3 : nb];
+        return e < ncols ? e : ncols;
+    };
 
     NODAL_HIP_TRY(h, hipEventRecord(ev_start, sp));  // the matrix was prepared on the main stream
     NODAL_HIP_TRY(h, hipStreamWaitEvent(sg, ev_start, 0));
     NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_start, 0));
     {
-        const int64_t J1 = n < wb ? n : wb;
-        NODAL_TRY(invert_diag(h, sp, A, lda, (int)J1, Q[0], wb, T, dinfo, 0));
+        const int64_t J1 = bnd[1];
+        NODAL_TRY(invert_diag(h, sp, A, lda, (int)J1, Q[0], wmax, T, dinfo, 0));
         NODAL_HIP_TRY(h, hipEventRecord(ev_q, sp));
-        NODAL_TRY(scale_cols(sp, Q[0], S1, 0, J1, J1, first_end(J1)));
+        NODAL_TRY(scale_cols(sp, Q[0], S1, 0, J1, J1, first_end(0)));
         NODAL_HIP_TRY(h, hipEventRecord(ev_wfirst, sp));
         NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_q, 0));
-        NODAL_TRY(scale_cols(s3, Q[0], S, 0, J1, first_end(J1), ncols));
+        NODAL_TRY(scale_cols(s3, Q[0], S, 0, J1, first_end(0), ncols));
         NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_wfirst, 0));  // ev_wrest then stands for ALL of W(k):
         NODAL_HIP_TRY(h, hipEventRecord(ev_wrest, s3));          // one barrier packet less in front of the bulk GEMM
     }
-    int blk = 0;
-    for (int64_t J0 = 0; J0 < n; J0 += wb, ++blk) {
-        const int64_t J1 = J0 + wb < n ? J0 + wb : n;
+    for (int blk = 0; blk + 1 < nb; ++blk) {
+        const int64_t J0 = bnd[blk], J1 = bnd[blk + 1], J2 = bnd[blk + 2];
         const int w = (int)(J1 - J0);
-        if (J1 >= n) break;
-        const int64_t J2 = J1 + wb < n ? J1 + wb : n;
         const double *L = A + J0 * lda, *U = A + J1 * lda + J0;  // A[:, J0:J1] and W(k)
         double *Qn = Q[(blk + 1) & 1];
         if (ev_rest) {  // block row k+1 was last written by the previous bulk update
@@ -403,7 +410,7 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
         NODAL_HIP_TRY(h, hipStreamWaitEvent(sg, ev_wrest, 0));  // all of W(k) (s3 waited for the first columns)
         // sp: diag + inverse chain
         NODAL_TRY(gemm_sub_f64(h, sp, A + J1 * lda + J1, lda, L + J1, lda, U, lda, J2 - J1, J2 - J1, w));
-        NODAL_TRY(invert_diag(h, sp, A + J1 * lda + J1, lda, (int)(J2 - J1), Qn, wb, T, dinfo, (int)J1));
+        NODAL_TRY(invert_diag(h, sp, A + J1 * lda + J1, lda, (int)(J2 - J1), Qn, wmax, T, dinfo, (int)J1));
         NODAL_HIP_TRY(h, hipEventRecord(ev_q, sp));
         // s3: strip
         NODAL_TRY(gemm_sub_f64(h, s3, A + J2 * lda + J1, lda, L + J1, lda, U + (J2 - J1) * lda, lda,
@@ -419,10 +426,10 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
         } else ev_rest = nullptr;
         // W(k+1): the first columns on the critical stream, the wide remainder beside it
         NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_strip, 0));
-        NODAL_TRY(scale_cols(sp, Qn, S1, J1, J2, J2, first_end(J2)));
+        NODAL_TRY(scale_cols(sp, Qn, S1, J1, J2, J2, first_end(blk + 1)));
         NODAL_HIP_TRY(h, hipEventRecord(ev_wfirst, sp));
         NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_q, 0));
-        NODAL_TRY(scale_cols(s3, Qn, S, J1, J2, first_end(J2), ncols));
+        NODAL_TRY(scale_cols(s3, Qn, S, J1, J2, first_end(blk + 1), ncols));
         NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_wfirst, 0));
         NODAL_HIP_TRY(h, hipEventRecord(ev_wrest, s3));
     }
@@ -441,20 +448,31 @@ int dense_block_elimination(nodal_ctx *h, double *A, int64_t n, int64_t lda, int
     const int64_t ncols = n + nrhs;
     hipStream_t st = h->stream;
     GemmTimer tm{h};  // (reset and collected by the caller, dense_factor_solve_multi)
-    // Block width 256.  (512 is implemented -- NODAL_BI_WIDTH=512 -- and was measured on
-    // config 2: the K = 512 bulk updates run at 43 instead of 38 TFLOP/s, 13.1 instead of
-    // 15.9 ms in total, but their 150-us tiles make every launch of the inverse chain wait
-    // longer for a free CU: 20.4 ms per solve against 20.5.)
-    int64_t wb = W;
-    if (const char *e = getenv("NODAL_BI_WIDTH")) wb = atoi(e) == 512 ? 512 : 256;
-    NODAL_TRY(factor_blockinv(h, A, n, lda, ncols, dinfo, tm, wb));
+    // Block widths.  While the bulk update of a block is long (many rows left) K = 512 updates run at
+    // 43 instead of 38 TFLOP/s (two K = 256 launches read and write C twice); narrow blocks keep
+    // the inverse chain short where it is the longer of the two.  NODAL_BI_WIDTH=256 / 512 forces
+    // one width; NODAL_BI_SWITCH the number of rows left at which the width drops to 256.
+    std::vector<int64_t> bnd;
+    {
+        int64_t sw = 5632;
+        if (const char *e = getenv("NODAL_BI_SWITCH")) sw = atoll(e);
+        int forced = 0;
+        if (const char *e = getenv("NODAL_BI_WIDTH")) forced = atoi(e) == 512 ? 512 : 256;
+        bnd.push_back(0);
+        for (int64_t j = 0; j < n;) {
+            const int64_t left = n - j;
+            const int64_t wb = forced ? forced : (left > sw + 512 ? 512 : W);
+            j = j + wb < n ? j + wb : n;
+            bnd.push_back(j);
+        }
+    }
+    NODAL_TRY(factor_blockinv(h, A, n, lda, ncols, dinfo, tm, bnd));
     double *y = A + n * lda;
-    for (int64_t j1 = n; j1 > 0;) {
-        const int64_t j0 = ((j1 - 1) / wb) * wb;
+    for (int k = (int)bnd.size() - 2; k >= 0; --k) {
+        const int64_t j0 = bnd[k], j1 = bnd[k + 1];
         dim3 grid(blocks_for(j0 > 0 ? j0 : 1, 64), (unsigned)nrhs);
         if (grid.x > 256 && nrhs > 1) grid.x = 256;  // many columns: fewer workgroups per column
         bs_block<<<grid, 256, 0, st>>>(A, lda, y, xout, ldx, (int)j0, (int)j1);
-        j1 = j0;
     }
     NODAL_HIP_TRY(h, hipGetLastError());
     return NODAL_OK;
