@@ -102,6 +102,7 @@ struct TailDesc {
     int nlev;  // tail levels; the last one is solved with its dense inverse / diagonal
     TailLevelDesc lv[TAIL_LEVELS];
     const double *inv;
+    int nu;           // Jacobi sweeps before / after each coarse correction inside the tail
     int image_bytes;  // matrices and transfer operators (packed once per setup)
     int lds_bytes;    // image + vectors
 };
@@ -112,6 +113,7 @@ struct SHierarchy {
     int tail = -1;          // first level inside the tail kernel
     bool ready = false;
     bool kcycle = true;          // two inner FCG steps at the first coarse level
+    int klevels = 1;             // ... at the first `klevels` coarse levels (NODAL_SA_KLEVELS)
     int nu[3] = {1, 1, 1};       // Jacobi sweeps before and after the coarse correction: level 0 / 1 / deeper
                                  // (NODAL_SA_NU=212: 28 instead of 32 iterations on the 1e6-node grid, but 16.9 instead of 14.9 ms)
     bool dense_coarsest = true;  // last level: dense inverse; false: nothing but isolated nodes (diagonal)
@@ -1082,6 +1084,8 @@ int build_tail(nodal_ctx *h, SHierarchy *H, const unsigned long long *hs) {
         TailDesc d;
         memset(&d, 0, sizeof d);
         d.nlev = last - t + 1;
+        d.nu = getenv("NODAL_SA_TAIL_NU") ? atoi(getenv("NODAL_SA_TAIL_NU")) : 3;
+        if (d.nu < 1) d.nu = 1;
         int off = 0;
         bool ok = true;
         for (int k = 0; k < d.nlev; ++k) {  // image part
@@ -1343,7 +1347,7 @@ int cycle(nodal_ctx *h, SHierarchy *H, int l, const double *b, const double *x0,
     int nparts = 0;
     // K-cycle (two flexible-CG steps on the coarse problem) at the first coarse level only, when
     // that level is large enough to be outside the tail; plain V hand-over everywhere else
-    const bool kcycle = l == 0 && H->kcycle && l + 1 != H->tail && l + 1 != H->nlev - 1;
+    const bool kcycle = l < H->klevels && H->kcycle && l + 1 != H->tail && l + 1 != H->nlev - 1;
     if (kcycle) {
         double *v1 = C->v(V_V1), *v2 = C->v(V_V2), *r2 = C->v(V_R2);
         double *part = C->part.as<double>();
@@ -1441,6 +1445,7 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     h->amg_levels = H->nlev;
     static const int kc = getenv("NODAL_SA_KCYCLE") ? atoi(getenv("NODAL_SA_KCYCLE")) : 1;
     H->kcycle = kc != 0;
+    H->klevels = getenv("NODAL_SA_KLEVELS") ? atoi(getenv("NODAL_SA_KLEVELS")) : 1;
     if (const char *e = getenv("NODAL_SA_NU")) {  // e.g. "212": sweeps at level 0, level 1, deeper levels
         for (int k = 0; k < 3 && e[k] >= '1' && e[k] <= '2'; ++k) H->nu[k] = e[k] - '0';
     }

@@ -286,10 +286,10 @@ __global__ __launch_bounds__(TB) void k_coarsest(int64_t n, const double *__rest
 // A level visit of separate launches costs 4-7 us per kernel whatever its size (two to three
 // dependent memory round trips + the launch); here the levels' matrices (f64 values, u16 columns,
 // rows padded to the level's longest), transfer operators and vectors are copied into LDS once
-// per launch and the V-cycle -- TAIL_NU Jacobi sweeps before and after each coarse correction,
+// per launch and the V-cycle -- d.nu Jacobi sweeps before and after each coarse correction,
 // cheap at LDS latency -- runs between workgroup barriers.  The last level is solved with its
 // dense inverse (or its diagonal: nothing but isolated nodes).
-constexpr int TAIL_NU = 2;
+
 
 // row i of an LDS-resident ELL matrix times x, by the `lpr` (power of two) adjacent lanes that
 // share the row: lane `sub` takes the slots sub, sub + lpr, ...; four slots in flight; every lane
@@ -355,6 +355,7 @@ __global__ __launch_bounds__(1024) void k_tail(TailDesc d, const char *__restric
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int last = d.nlev - 1;
+    const int TAIL_NU = d.nu;
     auto f64 = [&](int off) { return reinterpret_cast<double *>(smem + off); };
     auto u16 = [&](int off) { return reinterpret_cast<uint16_t *>(smem + off); };
     {   // image -> LDS: 16-byte pieces, eight in flight per lane (one round trip for ~128 KB)
