@@ -216,6 +216,9 @@ int nodal_upload_internal(nodal_ctx *h, int64_t ncomp, const uint8_t *type, cons
         t.drv.assign(drv, drv + ncomp);
         t.k.assign(k, k + ncomp);
         t.values_batch.clear();
+        t.branch_rows.clear();
+        for (int64_t i = 0; i < ncomp; ++i)
+            if (type[i] >= NODAL_T_E && type[i] <= NODAL_T_CCCS) t.branch_rows.push_back(i);
     } else {
         h->host = HostTable();
     }

@@ -97,6 +97,9 @@ void replicate_host(const nodal_ctx *h, nodal_ctx *c, int32_t first, int32_t cou
     t.a.resize(total); t.b.resize(total); t.c.resize(total); t.d.resize(total);
     t.drv.resize(total); t.k.resize(total);
     t.values_batch.clear();
+    t.branch_rows.clear();
+    for (int32_t m = 0; m < count; ++m)
+        for (const int64_t r : s.branch_rows) t.branch_rows.push_back((int64_t)m * nc + r);
     for (int32_t m = 0; m < count; ++m) {
         const double *vals = s.values_batch.data() + (size_t)(first + m) * nc;
         for (int64_t r = 0; r < nc; ++r) {

@@ -39,6 +39,8 @@ struct HostTable {
     std::vector<double> value;
     std::vector<int32_t> a, b, c, d, drv, k;
     std::vector<double> values_batch;
+    std::vector<int64_t> branch_rows;  // rows of the components that own a branch unknown (types E .. CCCS),
+                                       // in file order: what the presolve's planning pass looks at
 };
 
 struct nodal_ctx {

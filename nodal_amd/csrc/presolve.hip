@@ -218,7 +218,15 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
     struct Raw { int kk, a, b, c, d; double cst, gain; };
     std::vector<Raw> raws;
     const uint8_t *ty_arr = t.type.data();
-    for (int64_t i = 0; i < nc; ++i) {
+    // (the rows with a branch unknown were listed once at upload: 2e4 of the 2e6 rows of config 5)
+    std::vector<int64_t> scanned;
+    const std::vector<int64_t> *rows = &t.branch_rows;
+    if (rows->empty() && B > 0) {  // a table built on the device (batch.hip) has no list
+        for (int64_t i = 0; i < nc; ++i)
+            if (ty_arr[i] >= NODAL_T_E && ty_arr[i] <= NODAL_T_CCCS) scanned.push_back(i);
+        rows = &scanned;
+    }
+    for (const int64_t i : *rows) {
         const int ty = ty_arr[i];
         if (ty < NODAL_T_E || ty > NODAL_T_CCCS) continue;
         const int kk = t.k[i];
@@ -262,23 +270,38 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
     auto id_of = [&](int node) {
         return node < 0 ? 0 : (int)(std::lower_bound(ids.begin() + 1, ids.end(), node) - ids.begin());
     };
-    std::vector<std::vector<std::pair<int, int>>> adj(nn);  // (neighbour id, raw index)
+    // adjacency in CSR form (two flat arrays: a vector per node costs an allocation per node, 1 ms at
+    // 3e4 lead nodes): neighbours of id u are adj_nb / adj_raw [adj_start[u], adj_start[u + 1])
+    std::vector<int> adj_start(nn + 1, 0), adj_nb(2 * raws.size()), adj_raw(2 * raws.size()), lead_a(raws.size()),
+        lead_b(raws.size());
     for (int m = 0; m < (int)raws.size(); ++m) {
-        const int ia = id_of(raws[m].a), ib = id_of(raws[m].b);
-        adj[ia].push_back({ib, m});
-        adj[ib].push_back({ia, m});
+        lead_a[m] = id_of(raws[m].a);
+        lead_b[m] = id_of(raws[m].b);
+        ++adj_start[lead_a[m] + 1];
+        ++adj_start[lead_b[m] + 1];
+    }
+    for (int u = 0; u < nn; ++u) adj_start[u + 1] += adj_start[u];
+    {
+        std::vector<int> fill(adj_start.begin(), adj_start.end() - 1);
+        for (int m = 0; m < (int)raws.size(); ++m) {  // (in branch order, as the per-node lists were)
+            adj_nb[fill[lead_a[m]]] = lead_b[m];
+            adj_raw[fill[lead_a[m]]++] = m;
+            adj_nb[fill[lead_b[m]]] = lead_a[m];
+            adj_raw[fill[lead_b[m]]++] = m;
+        }
     }
     std::vector<int> parent(nn, -1), via(nn, -1), order;
     std::vector<char> visited(nn, 0);
     order.reserve(nn);
     for (int root = 0; root < nn; ++root) {  // id 0 = ground goes first
-        if (visited[root] || adj[root].empty()) continue;
+        if (visited[root] || adj_start[root] == adj_start[root + 1]) continue;
         visited[root] = 1;
         size_t head = order.size();
         order.push_back(root);
         while (head < order.size()) {
             const int u = order[head++];
-            for (const auto &[v, m] : adj[u]) {
+            for (int e = adj_start[u]; e < adj_start[u + 1]; ++e) {
+                const int v = adj_nb[e], m = adj_raw[e];
                 if (m == via[u]) continue;
                 if (visited[v]) return;  // a loop of voltage-defined branches
                 visited[v] = 1;
@@ -302,8 +325,10 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
         return (it != ids.end() && *it == node) ? (int)(it - ids.begin()) : -1;
     };
     // explicit stack instead of recursion (chains can be long)
+    std::vector<int> stack;
     auto resolve = [&](int start) {
-        std::vector<int> stack{start};
+        stack.clear();
+        stack.push_back(start);
         while (!stack.empty() && !failed) {
             const int v = stack.back();
             if (state[v] == 2) { stack.pop_back(); continue; }
