@@ -186,14 +186,21 @@ __global__ __launch_bounds__(TB) void k_prolong(int64_t n, int64_t ld, const int
     const bool two = coef != nullptr;
     const double s1 = two ? coef[0] : 1.0, s2 = two ? coef[1] : 0.0;
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        // all eight loads of the row at once (empty slots hold value 0: their column is clamped), then
+        // the gathers: two dependent stages instead of three
+        int32_t J[PW];
+        double w[PW];
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+            J[q] = pcol[(int64_t)q * ld + i];
+            w[q] = pval[(int64_t)q * ld + i];
+        }
         double s = x[i];
 #pragma unroll
         for (int q = 0; q < PW; ++q) {
-            const int32_t J = pcol[(int64_t)q * ld + i];
-            if (J >= 0) {
-                const double e = two ? s1 * c1[J] + s2 * c2[J] : c1[J];
-                s = fma(pval[(int64_t)q * ld + i], e, s);
-            }
+            const int32_t j = J[q] < 0 ? 0 : J[q];
+            const double e = two ? s1 * c1[j] + s2 * c2[j] : c1[j];
+            s = fma(J[q] < 0 ? 0.0 : w[q], e, s);
         }
         xp[i] = s;
     }
