@@ -921,7 +921,7 @@ SHierarchy *hierarchy_of(nodal_ctx *h) {
 }
 
 struct SolveBufs {
-    double *r, *z, *p, *p2, *Ap, *x0, *part_rz, *part_zap, *part_rr, *part_pap, *sc;
+    double *r, *z, *p, *Ap, *x0, *part_rz, *part_zap, *part_rr, *part_pap, *sc;
     int g0;  // grid of the level-0 kernels that produce / consume dot partials
 };
 
@@ -1451,7 +1451,7 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     }
 
     const size_t vec = align_up((size_t)n * 8);
-    NODAL_HIP_TRY(h, h->solver.reserve(6 * vec + 4 * MAX_PARTIALS * 8 + F_COUNT * 8 + 256));
+    NODAL_HIP_TRY(h, h->solver.reserve(5 * vec + 4 * MAX_PARTIALS * 8 + F_COUNT * 8 + 256));
     char *base = h->solver.as<char>();
     SolveBufs sb;
     sb.r = reinterpret_cast<double *>(base);
@@ -1459,8 +1459,7 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     sb.p = reinterpret_cast<double *>(base + 2 * vec);
     sb.Ap = reinterpret_cast<double *>(base + 3 * vec);
     sb.x0 = reinterpret_cast<double *>(base + 4 * vec);
-    sb.p2 = reinterpret_cast<double *>(base + 5 * vec);
-    sb.part_rz = reinterpret_cast<double *>(base + 6 * vec);
+    sb.part_rz = reinterpret_cast<double *>(base + 5 * vec);
     sb.part_zap = sb.part_rz + MAX_PARTIALS;
     sb.part_rr = sb.part_zap + MAX_PARTIALS;
     sb.part_pap = sb.part_rr + MAX_PARTIALS;
@@ -1490,14 +1489,12 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
         for (int c = 0; c < batch; ++c, ++enqueued) {
             const int it = (int)enqueued;
             NODAL_TRY(cycle(h, H, 0, sb.r, sb.x0, sb.z, &sb));
-            double *p_old = (it & 1) ? sb.p2 : sb.p, *p_new = (it & 1) ? sb.p : sb.p2;
+            f_direction<<<sb.g0, TB, 0, st>>>(sb.z, sb.p, sb.part_rz, sb.part_zap, sb.part_rr, sb.g0, sb.sc, it, n);
             const bool timed = c == 0;
             if (timed) NODAL_HIP_TRY(h, hipEventRecord(e0, st));
-            SAGG_DISPATCH_W(H->pool[0]->wfix, (f_spmv<W><<<sb.g0, TB, 0, st>>>(A0, sb.z, p_old, p_new, sb.Ap, sb.part_rz,
-                                                                               sb.part_zap, sb.part_rr, sb.g0,
-                                                                               sb.part_pap, sb.sc, it)));
+            SAGG_DISPATCH_W(H->pool[0]->wfix, (f_spmv<W><<<sb.g0, TB, 0, st>>>(A0, sb.p, sb.Ap, sb.part_pap, sb.sc, it)));
             if (timed) NODAL_HIP_TRY(h, hipEventRecord(e1, st));
-            f_update<<<sb.g0, TB, 0, st>>>(x, sb.r, p_new, sb.Ap, sb.part_pap, sb.g0, dinv0, sb.x0, sb.part_rr, sb.sc, it, n);
+            f_update<<<sb.g0, TB, 0, st>>>(x, sb.r, sb.p, sb.Ap, sb.part_pap, sb.g0, dinv0, sb.x0, sb.part_rr, sb.sc, it, n);
             NODAL_HIP_TRY(h, hipGetLastError());
         }
         NODAL_HIP_TRY(h, hipMemcpyAsync(hs, sb.sc, F_COUNT * 8, hipMemcpyDeviceToHost, st));
@@ -1535,9 +1532,7 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     *iters = (int32_t)its;
     *resid = hs[F_BB] > 0 ? sqrt(hs[F_RR] / hs[F_BB]) : 0.0;
     const SLevel *L0 = H->pool[0];
-    // algorithmic bytes of one f_spmv launch: the matrix once (12 B per entry), z and p_old read, p_new
-    // and Ap written (8 B each per row), row lengths (4 B; none when the rows are padded)
-    h->kern_alg = 12.0 * (double)L0->nnz + 32.0 * (double)n + (L0->wfix ? 0.0 : 4.0 * (double)n);
+    h->kern_alg = 12.0 * (double)L0->nnz + 4.0 * (double)n + 16.0 * (double)n;
     if (trace)
         fprintf(stderr, "[sagg] %d iterations (%lld enqueued, %d polls), relative residual %.2e, status %d\n", *iters,
                 (long long)enqueued, polls, *resid, status);

@@ -494,16 +494,12 @@ __global__ __launch_bounds__(TB) void f_init(const double *__restrict__ b, doubl
     if (threadIdx.x == 0) part_rr[blockIdx.x] = srr;
 }
 
-// Direction and SpMV in one pass: beta from the dots of the cycle's last kernel, convergence test on
-// |r|^2, then row by row  p_new = z + beta p_old,  Ap = A p_new  (p_new at the neighbours is formed
-// from z_j and p_old_j on the fly, so the direction vector is not written and read back through a
-// launch of its own; p ping-pongs between two buffers because neighbours read p_old).
-template <int W>
-__global__ __launch_bounds__(TB) void f_spmv(Ell A, const double *__restrict__ z, const double *__restrict__ p_old,
-                                             double *__restrict__ p_new, double *__restrict__ Ap,
-                                             const double *__restrict__ part_rz, const double *__restrict__ part_zap,
-                                             const double *__restrict__ part_rr, int nparts,
-                                             double *__restrict__ part_pap, double *__restrict__ sc, int iter) {
+// beta from the dots of the cycle's last kernel; p = z + beta p; convergence test on |r|^2
+__global__ __launch_bounds__(TB) void f_direction(const double *__restrict__ z, double *__restrict__ p,
+                                                  const double *__restrict__ part_rz,
+                                                  const double *__restrict__ part_zap,
+                                                  const double *__restrict__ part_rr, int nparts,
+                                                  double *__restrict__ sc, int iter, int64_t n) {
     const int cur = iter & 1, prev = cur ^ 1;
     if (iter > 0 && sc[F_CONV + prev] != 0.0) {  // converged earlier: hand the flag on
         if (blockIdx.x == 0 && threadIdx.x == 0) sc[F_CONV + cur] = 1.0;
@@ -526,13 +522,21 @@ __global__ __launch_bounds__(TB) void f_spmv(Ell A, const double *__restrict__ z
         if (converged) sc[F_ITERS] = (double)iter;
     }
     if (converged) return;  // uniform over the grid: every workgroup reduces the same partials
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        p[i] = iter > 0 ? fma(beta, p[i], z[i]) : z[i];
+}
+
+// Ap = A p, partials of p.Ap
+template <int W>
+__global__ __launch_bounds__(TB) void f_spmv(Ell A, const double *__restrict__ p, double *__restrict__ Ap,
+                                             double *__restrict__ part_pap, const double *__restrict__ sc,
+                                             int iter) {
+    if (sc[F_CONV + (iter & 1)] != 0.0) return;
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
-        const double s = ell_row_w<W>(A, i, [&](int32_t j) { return fma(beta, p_old[j], z[j]); });
-        const double pi = fma(beta, p_old[i], z[i]);
-        p_new[i] = pi;
+        const double s = ell_row_w<W>(A, i, [&](int32_t j) { return p[j]; });
         Ap[i] = s;
-        acc = fma(pi, s, acc);
+        acc = fma(p[i], s, acc);
     }
     acc = block_sum(acc);
     if (threadIdx.x == 0) part_pap[blockIdx.x] = acc;
