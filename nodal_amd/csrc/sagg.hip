@@ -27,6 +27,8 @@
 //      regenerates the products in (R entry, A slot, P slot) order, stages them in LDS and
 //      every lane sums the products of "its" column in that fixed order.
 // One host round trip per level (the number of aggregates sizes the next level).
+#include <hip/hip_ext.h>
+
 #include "group.h"
 
 int grounded_flags(nodal_ctx *h, uint8_t *flags_dev);  // lowdeg.hip
@@ -1490,10 +1492,16 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
             const int it = (int)enqueued;
             NODAL_TRY(cycle(h, H, 0, sb.r, sb.x0, sb.z, &sb));
             f_direction<<<sb.g0, TB, 0, st>>>(sb.z, sb.p, sb.part_rz, sb.part_zap, sb.part_rr, sb.g0, sb.sc, it, n);
-            const bool timed = c == 0;
-            if (timed) NODAL_HIP_TRY(h, hipEventRecord(e0, st));
-            SAGG_DISPATCH_W(H->pool[0]->wfix, (f_spmv<W><<<sb.g0, TB, 0, st>>>(A0, sb.p, sb.Ap, sb.part_pap, sb.sc, it)));
-            if (timed) NODAL_HIP_TRY(h, hipEventRecord(e1, st));
+            // one launch per poll batch is timed: start / stop events tied to the dispatch itself
+            // (hipExtLaunchKernelGGL), i.e. the kernel's own duration as rocprofv3 reports it -- a pair
+            // of hipEventRecord calls around a 14-us kernel also measures ~3.5 us of launch
+            if (c == 0) {
+                SAGG_DISPATCH_W(H->pool[0]->wfix, (hipExtLaunchKernelGGL((f_spmv<W>), dim3(sb.g0), dim3(TB), 0, st, e0, e1, 0,
+                                                                         A0, (const double *)sb.p, sb.Ap, sb.part_pap,
+                                                                         (const double *)sb.sc, it)));
+            } else {
+                SAGG_DISPATCH_W(H->pool[0]->wfix, (f_spmv<W><<<sb.g0, TB, 0, st>>>(A0, sb.p, sb.Ap, sb.part_pap, sb.sc, it)));
+            }
             f_update<<<sb.g0, TB, 0, st>>>(x, sb.r, sb.p, sb.Ap, sb.part_pap, sb.g0, dinv0, sb.x0, sb.part_rr, sb.sc, it, n);
             NODAL_HIP_TRY(h, hipGetLastError());
         }

@@ -7,7 +7,8 @@ Each DIR is the -d directory of one `rocprofv3 --pmc <COUNTER> --output-format c
 `python3 bench.py --workload WORKLOAD --no-cpu --no-also` (counters in separate passes, no
 trace domains, as MI355X_MICROARCH.md prescribes).  FETCH_SIZE / WRITE_SIZE are reported in KB
 per dispatch; on gfx950 FETCH_SIZE undercounts 8-byte-per-lane streaming reads by 2x
-(calibrated on fcg_update: 32.0 MB read -> 15.7 MB counted), so reads are doubled; writes are exact.
+(calibrated on f_update: x, r, p, Ap read = 32.0 MB per launch at 1e6 rows -> ~16 MB counted), so reads are
+doubled; writes are exact.
 """
 import collections
 import csv
@@ -19,9 +20,9 @@ import sys
 
 DOMINANT = {  # workload -> (kernel name regex, minimum grid size in threads)
     "cfg2": (r"gemm_sub_kernel<0>", 200000),
-    "cfg3": (r"pcg_spmv|spmv_kernel", 0),
-    "cfg4": (r"pcg_spmv|spmv_kernel", 0),
-    "cfg5": (r"spmv_kernel|pcg_spmv", 0),
+    "cfg3": (r"f_spmv<", 200000),
+    "cfg4": (r"f_spmv<", 200000),
+    "cfg5": (r"^spmv_kernel", 200000),
 }
 
 
