@@ -14,4 +14,11 @@ for w in cfg2 cfg3 cfg4 cfg5; do
   done
 done
 tail -1 $O/bench_default.log
+# summaries only travel back (gpurun merges at most 64 MiB): PMC passes -> one JSON, the per-dispatch
+# traces and counter files stay on the box
+python3 tools/pmc_summary.py $O/pmc_traffic.json cfg2:$O/pmc_cfg2_FETCH_SIZE:$O/pmc_cfg2_WRITE_SIZE \
+  cfg3:$O/pmc_cfg3_FETCH_SIZE:$O/pmc_cfg3_WRITE_SIZE cfg4:$O/pmc_cfg4_FETCH_SIZE:$O/pmc_cfg4_WRITE_SIZE \
+  cfg5:$O/pmc_cfg5_FETCH_SIZE:$O/pmc_cfg5_WRITE_SIZE > $O/pmc_summary.log 2>&1
+cp $O/default/default_kernel_stats.csv $O/bench_default_kernel_stats.csv
+rm -rf $O/default $O/pmc_cfg*_FETCH_SIZE $O/pmc_cfg*_WRITE_SIZE
 # (a plain `python bench.py > gpurun_out/bench_plain.log` gives profiles/<round>_bench_default.json)
