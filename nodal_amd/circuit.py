@@ -155,8 +155,12 @@ class Circuit:
 
         Raises numpy.linalg.LinAlgError when the dense system is singular and
         the circuit is connected, UnconnectedCircuitError when it is not.  The
-        sparse path never raises on a singular matrix: like the reference's
-        spsolve call it warns (MatrixRankWarning) and returns NaNs."""
+        sparse path does not raise on a matrix that is singular by construction
+        (floating sub-network, loop of voltage sources, exact zero pivot of a
+        small system): like the reference's spsolve call it warns
+        (MatrixRankWarning) and returns NaNs.  A large general system whose
+        iteration does not converge and that is not singular by construction
+        raises NodalHipError (never a wrong answer)."""
         h = self._handle
         if self.sparse:
             e, info, self.iterations, self.relative_residual = h.solve_sparse()
