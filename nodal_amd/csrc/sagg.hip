@@ -66,6 +66,7 @@ struct Ell {
     int32_t width = 0;
     const int32_t *col = nullptr;
     const double *val = nullptr;
+    const float *valf = nullptr;  // the same values rounded to f32: what the preconditioner's sweeps read
     const int32_t *len = nullptr;
 };
 
@@ -83,10 +84,12 @@ struct SLevel {
     DevBuf rcol, rval, rlen;
     int64_t rld = 0;
     DevBuf vec, part, gflag;
+    DevBuf avalf, pvalf, rvalf;  // f32 copies of A, P, R for the cycle kernels (levels outside the tail)
     Ell A() const {
         Ell e;
         e.n = n; e.ld = ld; e.width = width;
         e.col = acol.as<int32_t>(); e.val = aval.as<double>(); e.len = alen.as<int32_t>();
+        e.valf = avalf.as<float>();
         return e;
     }
     double *v(int which) const { return vec.as<double>() + (int64_t)which * ld; }
@@ -107,6 +110,8 @@ struct TailDesc {
     int nu;           // Jacobi sweeps before / after each coarse correction inside the tail
     int image_bytes;  // matrices and transfer operators (packed once per setup)
     int lds_bytes;    // image + vectors
+    int slots;        // register slots per lane the first level needs: ceil(width / lpr)
+    long long *stamps;  // development probe (NODAL_TAIL_PROBE): wall-clock ticks at the phase boundaries
 };
 
 struct SHierarchy {
@@ -119,7 +124,7 @@ struct SHierarchy {
     int nu[3] = {1, 1, 1};       // Jacobi sweeps before and after the coarse correction: level 0 / 1 / deeper
                                  // (NODAL_SA_NU=212: 28 instead of 32 iterations on the 1e6-node grid, but 16.9 instead of 14.9 ms)
     bool dense_coarsest = true;  // last level: dense inverse; false: nothing but isolated nodes (diagonal)
-    DevBuf tail_image, apcol, apval, aplen, bstat;
+    DevBuf tail_stamps, tail_image, apcol, apval, aplen, bstat;
     DevBuf stats, coarse_inv, mis_t, mis_m, mis_flag, mis_id, agg1, keys, rstart, cursor, lists;
     TailDesc td;
     uint64_t *host_stats = nullptr;  // pinned
@@ -130,11 +135,12 @@ struct SHierarchy {
     ~SHierarchy() {
         for (SLevel *l : pool) {
             DevBuf *b[] = {&l->acol, &l->aval, &l->alen, &l->dinv, &l->agg, &l->pcol, &l->pval, &l->rcol,
-                           &l->rval, &l->rlen, &l->vec, &l->part, &l->gflag};
+                           &l->rval, &l->rlen, &l->vec, &l->part, &l->gflag, &l->avalf, &l->pvalf, &l->rvalf};
             for (DevBuf *x : b) x->release();
             delete l;
         }
         tail_image.release();
+        tail_stamps.release();
         bstat.release();
         apcol.release();
         apval.release();
@@ -910,6 +916,10 @@ int width_class(int maxlen) {
     return 0;
 }
 // padded rows pay when the padding is small, or when the level is so small that latency is all
+__global__ __launch_bounds__(TB) void to_f32(const double *__restrict__ src, float *__restrict__ dst, int64_t count) {
+    for (int64_t e = (int64_t)blockIdx.x * TB + threadIdx.x; e < count; e += (int64_t)gridDim.x * TB) dst[e] = (float)src[e];
+}
+
 int choose_wfix(int maxlen, int64_t n, int64_t nnz, int pad_limit) {
     const int c = width_class(maxlen);
     if (c == 0 || c > pad_limit) return 0;
@@ -1077,6 +1087,13 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     return NODAL_OK;
 }
 
+// the tail kernel whose register slots cover ceil(width / lpr) of the first tail level
+const void *tail_kernel(int slots) {
+    return slots <= 8 ? reinterpret_cast<const void *>(k_tail<8>)
+                      : slots <= 16 ? reinterpret_cast<const void *>(k_tail<16>)
+                                    : reinterpret_cast<const void *>(k_tail<32>);
+}
+
 int build_tail(nodal_ctx *h, SHierarchy *H, const unsigned long long *hs) {
     H->tail = -1;
     const int last = H->nlev - 1;
@@ -1127,9 +1144,14 @@ int build_tail(nodal_ctx *h, SHierarchy *H, const unsigned long long *hs) {
         }
         d.inv = H->dense_coarsest ? H->coarse_inv.as<double>() : nullptr;
         d.lds_bytes = off;
+        if (getenv("NODAL_TAIL_PROBE")) {
+            NODAL_HIP_TRY(h, H->tail_stamps.reserve(64 * sizeof(long long)));
+            d.stamps = H->tail_stamps.as<long long>();
+        }
         if (!ok || off > TAIL_LDS_BUDGET) continue;
-        NODAL_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_tail),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, off));
+        d.slots = d.nlev > 1 ? (d.lv[0].width + d.lv[0].lpr - 1) / d.lv[0].lpr : 1;
+        if (d.slots > 32) continue;
+        NODAL_HIP_TRY(h, hipFuncSetAttribute(tail_kernel(d.slots), hipFuncAttributeMaxDynamicSharedMemorySize, off));
         NODAL_HIP_TRY(h, H->tail_image.reserve((size_t)d.image_bytes + 256));
         k_tail_pack<<<1, 1024, 0, h->stream>>>(d, H->tail_image.as<char>());
         NODAL_HIP_TRY(h, hipGetLastError());
@@ -1291,6 +1313,23 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
         }
         *floating = hs[(size_t)(MAX_LEVELS - 1) * ST_COUNT + ST_COUNT - 1] != 0 ? 1 : 0;
     }
+    // The cycle is a preconditioner: its matrices are read in f32 (a third less traffic per sweep;
+    // the iteration count does not move), the vectors, the outer SpMV and the residual stay f64.
+    {
+        const int visited = H->tail >= 0 ? H->tail : H->nlev - 1;  // levels whose sweeps are separate launches
+        for (int k = 0; k < visited; ++k) {
+            SLevel *L = H->pool[k];
+            const int64_t na = (int64_t)(L->wfix ? L->wfix : L->maxlen) * L->ld, np = (int64_t)PW * L->ld;
+            const int64_t nr = (int64_t)((hs[(size_t)k * ST_COUNT + ST_MAXR] + 7) / 8) * L->rld * RL;
+            NODAL_HIP_TRY(h, L->avalf.reserve((size_t)na * 4 + 64));
+            NODAL_HIP_TRY(h, L->pvalf.reserve((size_t)np * 4 + 64));
+            NODAL_HIP_TRY(h, L->rvalf.reserve((size_t)nr * 4 + 64));
+            to_f32<<<grid_for(na / 4 + 1), TB, 0, st>>>(L->aval.as<double>(), L->avalf.as<float>(), na);
+            to_f32<<<grid_for(np / 4 + 1), TB, 0, st>>>(L->pval.as<double>(), L->pvalf.as<float>(), np);
+            to_f32<<<grid_for(nr / 4 + 1), TB, 0, st>>>(L->rval.as<double>(), L->rvalf.as<float>(), nr);
+        }
+        NODAL_HIP_TRY(h, hipGetLastError());
+    }
     if (trace) {
         fprintf(stderr, "[sagg] levels (rows/entries/longest row/padded width):");
         for (int k = 0; k < H->nlev; ++k)
@@ -1317,7 +1356,9 @@ int cycle(nodal_ctx *h, SHierarchy *H, int l, const double *b, const double *x0,
     SLevel *L = H->pool[l];
     const int64_t n = L->n;
     if (l == H->tail) {
-        k_tail<<<1, 1024, (size_t)H->td.lds_bytes, st>>>(H->td, H->tail_image.as<char>(), b, out);
+        if (H->td.slots <= 8) k_tail<8><<<1, 1024, (size_t)H->td.lds_bytes, st>>>(H->td, H->tail_image.as<char>(), b, out);
+        else if (H->td.slots <= 16) k_tail<16><<<1, 1024, (size_t)H->td.lds_bytes, st>>>(H->td, H->tail_image.as<char>(), b, out);
+        else k_tail<32><<<1, 1024, (size_t)H->td.lds_bytes, st>>>(H->td, H->tail_image.as<char>(), b, out);
         NODAL_HIP_TRY(h, hipGetLastError());
         return NODAL_OK;
     }
@@ -1335,15 +1376,16 @@ int cycle(nodal_ctx *h, SHierarchy *H, int l, const double *b, const double *x0,
     double *r = L->v(V_R), *xp = L->v(V_XP);
     double *rc = C->v(V_RC), *c1 = C->v(V_C1), *c2 = C->v(V_C2);
     const unsigned g = sb ? (unsigned)sb->g0 : grid_for(n);
+    const unsigned tb = L->wfix ? TB : TB * LPR_RAGGED;  // (ragged rows: LPR_RAGGED lanes each, same rows per workgroup)
     const int nu = H->nu[l < 2 ? l : 2];
     if (nu >= 2) {  // second pre-smoothing sweep: x1 = x0 + w D^-1 (b - A x0)
         double *x1 = L->v(V_X1);
-        SAGG_DISPATCH_W(L->wfix, (k_post<W, false><<<g, TB, 0, st>>>(A, dinv, b, x0, x1, nullptr, nullptr, nullptr)));
+        SAGG_DISPATCH_W(L->wfix, (k_post<W, false><<<g, tb, 0, st>>>(A, dinv, b, x0, x1, nullptr, nullptr, nullptr)));
         x = x1;
     }
-    SAGG_DISPATCH_W(L->wfix, (k_smooth_residual<W><<<g, TB, 0, st>>>(A, b, x, r)));
+    SAGG_DISPATCH_W(L->wfix, (k_smooth_residual<W><<<g, tb, 0, st>>>(A, b, x, r)));
     double *x0c = C->v(V_X);
-    k_restrict<<<grid_for(nc * RL), TB, 0, st>>>(nc, L->rld, L->rcol.as<int32_t>(), L->rval.as<double>(),
+    k_restrict<<<grid_for(nc * RL), TB, 0, st>>>(nc, L->rld, L->rcol.as<int32_t>(), L->rvalf.as<float>(),
                                                 L->rlen.as<int32_t>(), r, rc, C->dinv.as<double>(), x0c);
     NODAL_HIP_TRY(h, hipGetLastError());
     int nparts = 0;
@@ -1355,14 +1397,15 @@ int cycle(nodal_ctx *h, SHierarchy *H, int l, const double *b, const double *x0,
         double *part = C->part.as<double>();
         const Ell Ac = C->A();
         const unsigned gd = grid_for(nc, DOT_BLOCKS);  // (grid-stride beyond DOT_BLOCKS x TB rows)
+        const unsigned tbc = C->wfix ? TB : TB * LPR_RAGGED;
         nparts = (int)gd;
         NODAL_TRY(cycle(h, H, l + 1, rc, x0c, c1, nullptr));
-        SAGG_DISPATCH_W(C->wfix, (k_spmv_dots<W><<<gd, TB, 0, st>>>(Ac, c1, v1, rc, nullptr, part + 0 * DOT_BLOCKS,
+        SAGG_DISPATCH_W(C->wfix, (k_spmv_dots<W><<<gd, tbc, 0, st>>>(Ac, c1, v1, rc, nullptr, part + 0 * DOT_BLOCKS,
                                                                     part + 1 * DOT_BLOCKS, nullptr)));
         k_second_residual<<<grid_for(nc), TB, 0, st>>>(nc, rc, v1, part, nparts, r2, C->dinv.as<double>(), x0c);
         NODAL_HIP_TRY(h, hipGetLastError());
         NODAL_TRY(cycle(h, H, l + 1, r2, x0c, c2, nullptr));
-        SAGG_DISPATCH_W(C->wfix, (k_spmv_dots<W><<<gd, TB, 0, st>>>(Ac, c2, v2, v1, r2, part + 3 * DOT_BLOCKS,
+        SAGG_DISPATCH_W(C->wfix, (k_spmv_dots<W><<<gd, tbc, 0, st>>>(Ac, c2, v2, v1, r2, part + 3 * DOT_BLOCKS,
                                                                     part + 2 * DOT_BLOCKS, part + 4 * DOT_BLOCKS)));
         NODAL_HIP_TRY(h, hipGetLastError());
     } else {
@@ -1374,19 +1417,19 @@ int cycle(nodal_ctx *h, SHierarchy *H, int l, const double *b, const double *x0,
         k_kcoef<<<1, 320, 0, st>>>(C->part.as<double>(), nparts, cf);
         coef = cf;
     }
-    k_prolong<<<grid_for(n), TB, 0, st>>>(n, L->ld, L->pcol.as<int32_t>(), L->pval.as<double>(), x, c1, c2, coef,
+    k_prolong<<<grid_for(n), TB, 0, st>>>(n, L->ld, L->pcol.as<int32_t>(), L->pvalf.as<float>(), x, c1, c2, coef,
                                          xp);
     const double *cur = xp;
     if (nu >= 2) {  // first of two post-smoothing sweeps
         double *mid = L->v(V_T);
-        SAGG_DISPATCH_W(L->wfix, (k_post<W, false><<<g, TB, 0, st>>>(A, dinv, b, cur, mid, nullptr, nullptr, nullptr)));
+        SAGG_DISPATCH_W(L->wfix, (k_post<W, false><<<g, tb, 0, st>>>(A, dinv, b, cur, mid, nullptr, nullptr, nullptr)));
         cur = mid;
     }
     if (sb) {
-        SAGG_DISPATCH_W(L->wfix, (k_post<W, true><<<g, TB, 0, st>>>(A, dinv, b, cur, out, sb->Ap, sb->part_rz,
+        SAGG_DISPATCH_W(L->wfix, (k_post<W, true><<<g, tb, 0, st>>>(A, dinv, b, cur, out, sb->Ap, sb->part_rz,
                                                                     sb->part_zap)));
     } else {
-        SAGG_DISPATCH_W(L->wfix, (k_post<W, false><<<g, TB, 0, st>>>(A, dinv, b, cur, out, nullptr, nullptr, nullptr)));
+        SAGG_DISPATCH_W(L->wfix, (k_post<W, false><<<g, tb, 0, st>>>(A, dinv, b, cur, out, nullptr, nullptr, nullptr)));
     }
     NODAL_HIP_TRY(h, hipGetLastError());
     return NODAL_OK;
@@ -1495,12 +1538,13 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
             // one launch per poll batch is timed: start / stop events tied to the dispatch itself
             // (hipExtLaunchKernelGGL), i.e. the kernel's own duration as rocprofv3 reports it -- a pair
             // of hipEventRecord calls around a 14-us kernel also measures ~3.5 us of launch
+            const unsigned tb0 = H->pool[0]->wfix ? TB : TB * LPR_RAGGED;
             if (c == 0) {
-                SAGG_DISPATCH_W(H->pool[0]->wfix, (hipExtLaunchKernelGGL((f_spmv<W>), dim3(sb.g0), dim3(TB), 0, st, e0, e1, 0,
+                SAGG_DISPATCH_W(H->pool[0]->wfix, (hipExtLaunchKernelGGL((f_spmv<W>), dim3(sb.g0), dim3(tb0), 0, st, e0, e1, 0,
                                                                          A0, (const double *)sb.p, sb.Ap, sb.part_pap,
                                                                          (const double *)sb.sc, it)));
             } else {
-                SAGG_DISPATCH_W(H->pool[0]->wfix, (f_spmv<W><<<sb.g0, TB, 0, st>>>(A0, sb.p, sb.Ap, sb.part_pap, sb.sc, it)));
+                SAGG_DISPATCH_W(H->pool[0]->wfix, (f_spmv<W><<<sb.g0, tb0, 0, st>>>(A0, sb.p, sb.Ap, sb.part_pap, sb.sc, it)));
             }
             f_update<<<sb.g0, TB, 0, st>>>(x, sb.r, sb.p, sb.Ap, sb.part_pap, sb.g0, dinv0, sb.x0, sb.part_rr, sb.sc, it, n);
             NODAL_HIP_TRY(h, hipGetLastError());
@@ -1544,6 +1588,18 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     if (trace)
         fprintf(stderr, "[sagg] %d iterations (%lld enqueued, %d polls), relative residual %.2e, status %d\n", *iters,
                 (long long)enqueued, polls, *resid, status);
+    if (trace && H->tail >= 0 && H->td.stamps) {
+        long long ts[64];
+        if (hipMemcpy(ts, H->td.stamps, sizeof ts, hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "[sagg] tail phases (us):");
+            for (int k = 1; k < (int)ts[63] && k < 63; ++k) fprintf(stderr, " %.2f", (double)(ts[k] - ts[k - 1]) * 0.01);
+            fprintf(stderr, "  total %.2f, image %d B, lds %d B\n", (double)(ts[ts[63] - 1] - ts[0]) * 0.01,
+                    H->td.image_bytes, H->td.lds_bytes);
+            for (int k = 0; k < H->td.nlev; ++k)
+                fprintf(stderr, "[sagg]   tail level %d: n %d width %d lpr %d nq %d\n", k, H->td.lv[k].n,
+                        H->td.lv[k].width, H->td.lv[k].lpr, H->td.lv[k].nq);
+        }
+    }
     if (status != 1) return -1;
     *info = 0;
     return NODAL_OK;

@@ -5,41 +5,54 @@
 namespace {
 
 // ---------------------------------------------------------------------------------
-// row kernels on ELL: one thread per row, four slots in flight
+// row kernels on ELL
 // ---------------------------------------------------------------------------------
-template <class XF>
-__device__ __forceinline__ double ell_row(const int32_t *__restrict__ col, const double *__restrict__ val,
-                                          int64_t ld, int32_t len, int64_t i, XF xf) {
+// Rows of uneven length (W == 0): LPR_RAGGED adjacent lanes share a row, lane `sub` takes the slots
+// sub, sub + LPR, ...; up to eight of them in flight, so a row of 32 entries costs three dependent
+// round trips (length, entries, gathers) where one thread walking it alone needed 2 x len / 4 + 1.
+// Every lane of the group returns the sum.
+constexpr int LPR_RAGGED = 1;
+template <int W> struct RowLanes { static constexpr int value = W == 0 ? LPR_RAGGED : 1; };
+
+template <class VT, class XF>
+__device__ __forceinline__ double ell_row_lanes(const Ell &A, const VT *__restrict__ val, int64_t i, int sub, XF xf) {
+    constexpr int Q = 8;
+    const int32_t len = A.len[i];
     double acc = 0.0;
-    for (int32_t s0 = 0; s0 < len; s0 += 4) {
-        int32_t c[4];
-        double v[4];
+    for (int32_t s0 = sub; s0 < len; s0 += LPR_RAGGED * Q) {
+        int32_t c[Q];
+        double v[Q];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool ok = s0 + q < len;
-            const int64_t at = (int64_t)(ok ? s0 + q : 0) * ld + i;  // slot 0 exists: len > 0 here
-            c[q] = col[at];
-            v[q] = ok ? val[at] : 0.0;
+        for (int q = 0; q < Q; ++q) {
+            const bool ok = s0 + q * LPR_RAGGED < len;  // (a slot past the end re-reads the lane's first one)
+            const int64_t at = (int64_t)(ok ? s0 + q * LPR_RAGGED : s0) * A.ld + i;
+            c[q] = A.col[at];
+            const VT loaded = val[at];  // (unconditional: `at` is always a slot of the row)
+            v[q] = ok ? (double)loaded : 0.0;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc = fma(v[q], xf(c[q]), acc);
+        for (int q = 0; q < Q; ++q) acc = fma(v[q], xf(c[q]), acc);
     }
+#pragma unroll
+    for (int off = LPR_RAGGED >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     return acc;
 }
 
 // W > 0: every row holds exactly W slots (zero-padded): all loads issued at once, no length load
-// in front of them; W == 0: per-row length.
-template <int W, class XF>
-__device__ __forceinline__ double ell_row_w(const Ell &A, int64_t i, XF xf) {
+// in front of them, one thread per row; W == 0: per-row length, LPR_RAGGED lanes per row.
+// `t` is the global thread number: row t / lanes, lane t % lanes of the row.
+// `val`: A.valf inside the cycle, A.val in the outer iteration's SpMV.
+template <int W, class VT, class XF>
+__device__ __forceinline__ double ell_row_w(const Ell &A, const VT *__restrict__ val, int64_t i, int sub, XF xf) {
     if constexpr (W == 0) {
-        return ell_row(A.col, A.val, A.ld, A.len[i], i, xf);
+        return ell_row_lanes(A, val, i, sub, xf);
     } else {
         int32_t c[W];
         double v[W];
 #pragma unroll
         for (int q = 0; q < W; ++q) {
             c[q] = A.col[(int64_t)q * A.ld + i];
-            v[q] = A.val[(int64_t)q * A.ld + i];
+            v[q] = (double)val[(int64_t)q * A.ld + i];
         }
         double acc = 0.0;
 #pragma unroll
@@ -67,15 +80,16 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
 }
-__device__ __forceinline__ double block_sum(double v) {  // TB threads; valid in every thread
-    __shared__ double ws[TB / 64];
+template <int NT = TB>
+__device__ __forceinline__ double block_sum(double v) {  // NT threads; valid in every thread
+    __shared__ double ws[NT / 64];
     __syncthreads();
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
     __syncthreads();
     double s = 0.0;
 #pragma unroll
-    for (int w = 0; w < TB / 64; ++w) s += ws[w];
+    for (int w = 0; w < NT / 64; ++w) s += ws[w];
     return s;
 }
 // every workgroup reduces the same partial array in the same order: deterministic, no atomics
@@ -89,11 +103,14 @@ __device__ __forceinline__ double reduce_partials(const double *__restrict__ par
 // whoever produced b (f_init / f_update, k_restrict, k_second_residual): the row sum then gathers
 // one vector, not D^-1 and b.
 template <int W>
-__global__ __launch_bounds__(TB) void k_smooth_residual(Ell A, const double *__restrict__ b,
+__global__ __launch_bounds__(TB * RowLanes<W>::value) void k_smooth_residual(Ell A, const double *__restrict__ b,
                                                         const double *__restrict__ x0, double *__restrict__ r) {
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
-        const double s = ell_row_w<W>(A, i, [&](int32_t j) { return x0[j]; });
-        r[i] = b[i] - s;
+    constexpr int LPR = RowLanes<W>::value, NT = TB * LPR;  // (the workgroup still covers TB rows)
+    const int sub = threadIdx.x & (LPR - 1);
+    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t / LPR < A.n; t += (int64_t)gridDim.x * NT) {
+        const int64_t i = t / LPR;
+        const double s = ell_row_w<W>(A, A.valf, i, sub, [&](int32_t j) { return x0[j]; });
+        if (sub == 0) r[i] = b[i] - s;
     }
 }
 
@@ -103,7 +120,7 @@ __global__ __launch_bounds__(TB) void k_smooth_residual(Ell A, const double *__r
 // 17-40 entries alone: 10-20 dependent round trips, 15-20 us whatever the level's size.)
 constexpr int RL = 8;
 __global__ __launch_bounds__(TB) void k_restrict(int64_t nc, int64_t rld, const int32_t *__restrict__ rcol,
-                                                 const double *__restrict__ rval, const int32_t *__restrict__ rlen,
+                                                 const float *__restrict__ rval, const int32_t *__restrict__ rlen,
                                                  const double *__restrict__ r, double *__restrict__ rc,
                                                  const double *__restrict__ cdinv, double *__restrict__ x0c) {
     const int sub = threadIdx.x & (RL - 1);
@@ -113,19 +130,21 @@ __global__ __launch_bounds__(TB) void k_restrict(int64_t nc, int64_t rld, const 
         double s = 0.0;
         if (I < nc) {
             const int32_t len = rlen[I];
-            // (rows are zero-padded to whole blocks: no per-entry test) three blocks in flight
-            for (int32_t q0 = 0; q0 * RL < len; q0 += 3) {
-                int32_t c[3];
-                double v[3];
+            // (rows are zero-padded to whole blocks: no per-entry test) RU blocks in flight
+            constexpr int RU = 6;
+            for (int32_t q0 = 0; q0 * RL < len; q0 += RU) {
+                int32_t c[RU];
+                double v[RU];
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
+                for (int u = 0; u < RU; ++u) {
                     const bool ok = (q0 + u) * RL < len;
                     const int64_t at = ((int64_t)(ok ? q0 + u : q0) * rld + I) * RL + sub;
                     c[u] = rcol[at];
-                    v[u] = ok ? rval[at] : 0.0;
+                    const float loaded = rval[at];  // (unconditional: a block of the row either way)
+                    v[u] = ok ? (double)loaded : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < 3; ++u) s = fma(v[u], r[c[u]], s);
+                for (int u = 0; u < RU; ++u) s = fma(v[u], r[c[u]], s);
             }
         }
 #pragma unroll
@@ -180,7 +199,7 @@ __global__ __launch_bounds__(320) void k_kcoef(const double *__restrict__ part, 
 
 // xp = x + P (s1 c1 + s2 c2)   (coef == nullptr: plain V hand-over, xp = x + P c1)
 __global__ __launch_bounds__(TB) void k_prolong(int64_t n, int64_t ld, const int32_t *__restrict__ pcol,
-                                                const double *__restrict__ pval, const double *__restrict__ x,
+                                                const float *__restrict__ pval, const double *__restrict__ x,
                                                 const double *__restrict__ c1, const double *__restrict__ c2,
                                                 const double *__restrict__ coef, double *__restrict__ xp) {
     const bool two = coef != nullptr;
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(TB) void k_prolong(int64_t n, int64_t ld, const int
 #pragma unroll
         for (int q = 0; q < PW; ++q) {
             J[q] = pcol[(int64_t)q * ld + i];
-            w[q] = pval[(int64_t)q * ld + i];
+            w[q] = (double)pval[(int64_t)q * ld + i];
         }
         double s = x[i];
 #pragma unroll
@@ -208,13 +227,17 @@ __global__ __launch_bounds__(TB) void k_prolong(int64_t n, int64_t ld, const int
 
 // out = xp + w D^-1 (b - A xp); DOTS: partial sums of out.b and out.u (the outer iteration's z.r, z.Ap)
 template <int W, bool DOTS>
-__global__ __launch_bounds__(TB) void k_post(Ell A, const double *__restrict__ dinv, const double *__restrict__ b,
+__global__ __launch_bounds__(TB * RowLanes<W>::value) void k_post(Ell A, const double *__restrict__ dinv, const double *__restrict__ b,
                                              const double *__restrict__ xp, double *__restrict__ out,
                                              const double *__restrict__ u, double *__restrict__ p_ob,
                                              double *__restrict__ p_ou) {
     double a0 = 0.0, a1 = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
-        const double s = ell_row_w<W>(A, i, [&](int32_t j) { return xp[j]; });
+    constexpr int LPR = RowLanes<W>::value, NT = TB * LPR;  // (the workgroup still covers TB rows)
+    const int sub = threadIdx.x & (LPR - 1);
+    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t / LPR < A.n; t += (int64_t)gridDim.x * NT) {
+        const int64_t i = t / LPR;
+        const double s = ell_row_w<W>(A, A.valf, i, sub, [&](int32_t j) { return xp[j]; });
+        if (sub != 0) continue;
         const double bi = b[i];
         const double o = fma(OMEGA * dinv[i], bi - s, xp[i]);
         out[i] = o;
@@ -224,8 +247,8 @@ __global__ __launch_bounds__(TB) void k_post(Ell A, const double *__restrict__ d
         }
     }
     if (DOTS) {
-        a0 = block_sum(a0);
-        a1 = block_sum(a1);
+        a0 = block_sum<NT>(a0);
+        a1 = block_sum<NT>(a1);
         if (threadIdx.x == 0) {
             p_ob[blockIdx.x] = a0;
             p_ou[blockIdx.x] = a1;
@@ -235,22 +258,26 @@ __global__ __launch_bounds__(TB) void k_post(Ell A, const double *__restrict__ d
 
 // v = A c and the partial dot products c.v, c.u1 (and c.u2 when given)
 template <int W>
-__global__ __launch_bounds__(TB) void k_spmv_dots(Ell A, const double *__restrict__ c, double *__restrict__ v,
+__global__ __launch_bounds__(TB * RowLanes<W>::value) void k_spmv_dots(Ell A, const double *__restrict__ c, double *__restrict__ v,
                                                   const double *__restrict__ u1, const double *__restrict__ u2,
                                                   double *__restrict__ p_cv, double *__restrict__ p_cu1,
                                                   double *__restrict__ p_cu2) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
-        const double s = ell_row_w<W>(A, i, [&](int32_t j) { return c[j]; });
+    constexpr int LPR = RowLanes<W>::value, NT = TB * LPR;  // (the workgroup still covers TB rows)
+    const int sub = threadIdx.x & (LPR - 1);
+    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t / LPR < A.n; t += (int64_t)gridDim.x * NT) {
+        const int64_t i = t / LPR;
+        const double s = ell_row_w<W>(A, A.valf, i, sub, [&](int32_t j) { return c[j]; });
+        if (sub != 0) continue;
         v[i] = s;
         const double ci = c[i];
         a0 = fma(ci, s, a0);
         a1 = fma(ci, u1[i], a1);
         if (u2) a2 = fma(ci, u2[i], a2);
     }
-    a0 = block_sum(a0);
-    a1 = block_sum(a1);
-    a2 = block_sum(a2);
+    a0 = block_sum<NT>(a0);
+    a1 = block_sum<NT>(a1);
+    a2 = block_sum<NT>(a2);
     if (threadIdx.x == 0) {
         p_cv[blockIdx.x] = a0;
         p_cu1[blockIdx.x] = a1;
@@ -357,6 +384,24 @@ __global__ __launch_bounds__(1024) void k_tail_pack(TailDesc d, char *__restrict
     else copy_f64(f64(L.o_aval), L.dinv, L.n, L.n, 1);
 }
 
+// row i of the tail's FIRST level, whose slots this lane keeps in registers for the whole launch
+// (slot j of the lane is slot sub + j * lpr of the row; padding slots hold value 0, column 0)
+template <int SLOTS>
+__device__ __forceinline__ double reg_row(const double (&v)[SLOTS], const uint32_t (&c)[SLOTS / 2], int lpr,
+                                          const double *x) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < SLOTS; j += 2) {
+        s0 = fma(v[j], x[c[j / 2] & 0xffffu], s0);
+        s1 = fma(v[j + 1], x[c[j / 2] >> 16], s1);
+    }
+    double s = s0 + s1;
+    for (int off = lpr >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    return s;
+}
+
+// SLOTS >= ceil(width / lpr) of the first tail level (8, 16 or 32)
+template <int SLOTS>
 __global__ __launch_bounds__(1024) void k_tail(TailDesc d, const char *__restrict__ image,
                                                const double *__restrict__ rc, double *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -365,21 +410,47 @@ __global__ __launch_bounds__(1024) void k_tail(TailDesc d, const char *__restric
     const int TAIL_NU = d.nu;
     auto f64 = [&](int off) { return reinterpret_cast<double *>(smem + off); };
     auto u16 = [&](int off) { return reinterpret_cast<uint16_t *>(smem + off); };
-    {   // image -> LDS: 16-byte pieces, eight in flight per lane (one round trip for ~128 KB)
+    int stamp_no = 0;
+    auto stamp = [&]() {
+        if (d.stamps && tid == 0) d.stamps[stamp_no] = wall_clock64();
+        ++stamp_no;
+    };
+    stamp();
+    {   // image -> LDS: 16-byte pieces, all of a lane's in flight at once (one round trip; the
+        // image never survives in L2 between two launches, the level-0 kernels stream past it)
+        constexpr int FLY = (TAIL_LDS_BUDGET / 16 + 1023) / 1024;
         const int4 *src = reinterpret_cast<const int4 *>(image);
         int4 *dst = reinterpret_cast<int4 *>(smem);
         const int pieces = d.image_bytes / 16;
-        for (int e0 = tid; e0 < pieces; e0 += 8 * 1024) {
-            int4 v[8];
+        int4 v[FLY];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[e0 + u * 1024 < pieces ? e0 + u * 1024 : 0];
+        for (int u = 0; u < FLY; ++u) v[u] = src[tid + u * 1024 < pieces ? tid + u * 1024 : 0];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (e0 + u * 1024 < pieces) dst[e0 + u * 1024] = v[u];
-        }
+        for (int u = 0; u < FLY; ++u)
+            if (tid + u * 1024 < pieces) dst[tid + u * 1024] = v[u];
     }
     for (int i = tid; i < d.lv[0].n; i += 1024) f64(d.lv[0].o_B)[i] = rc[i];
     __syncthreads();
+    // the first level's matrix: LDS -> registers (no LDS matrix traffic in the sweeps)
+    double v0[SLOTS];
+    uint32_t c0[SLOTS / 2];
+    {
+        const TailLevelDesc &L = d.lv[0];
+        const double *aval = f64(L.o_aval);
+        const uint16_t *acol = u16(L.o_acol);
+        const int lpr = L.lpr, sub = tid & (lpr - 1), i = tid / lpr, ii = i < L.n ? i : L.n - 1;
+        const bool row = last > 0 && i < L.n;
+#pragma unroll
+        for (int j = 0; j < SLOTS; j += 2) {
+            const int ta = sub + j * lpr, tb = ta + lpr;
+            const bool ha = row && ta < L.width, hb = row && tb < L.width;
+            v0[j] = ha ? aval[ta * L.n + ii] : 0.0;
+            v0[j + 1] = hb ? aval[tb * L.n + ii] : 0.0;
+            const uint32_t ca = ha ? acol[ta * L.n + ii] : 0u, cb = hb ? acol[tb * L.n + ii] : 0u;
+            c0[j / 2] = ca | (cb << 16);
+        }
+    }
+    stamp();
     // ---- down ----
     for (int k = 0; k < last; ++k) {
         const TailLevelDesc &L = d.lv[k];
@@ -390,9 +461,10 @@ __global__ __launch_bounds__(1024) void k_tail(TailDesc d, const char *__restric
         for (int i = tid; i < L.n; i += 1024) X[i] = OMEGA * dinv[i] * B[i];
         __syncthreads();
         for (int sweep = 1; sweep < TAIL_NU; ++sweep) {
-            for (int i0 = 0; i0 < L.n; i0 += rows) {
+            for (int i0 = 0; i0 < L.n; i0 += rows) {  // (one pass at the first level: n * lpr <= 1024)
                 const int i = i0 + tid / lpr, ii = i < L.n ? i : L.n - 1;
-                const double ax = lds_row(aval, acol, L.n, L.width, ii, sub, lpr, X);
+                const double ax = k == 0 ? reg_row<SLOTS>(v0, c0, lpr, X)
+                                         : lds_row(aval, acol, L.n, L.width, ii, sub, lpr, X);
                 if (i < L.n && sub == 0) Y[i] = fma(OMEGA * dinv[i], B[i] - ax, X[i]);
             }
             __syncthreads();
@@ -400,10 +472,12 @@ __global__ __launch_bounds__(1024) void k_tail(TailDesc d, const char *__restric
         }
         for (int i0 = 0; i0 < L.n; i0 += rows) {
             const int i = i0 + tid / lpr, ii = i < L.n ? i : L.n - 1;
-            const double ax = lds_row(aval, acol, L.n, L.width, ii, sub, lpr, X);
+            const double ax = k == 0 ? reg_row<SLOTS>(v0, c0, lpr, X)
+                                     : lds_row(aval, acol, L.n, L.width, ii, sub, lpr, X);
             if (i < L.n && sub == 0) R[i] = B[i] - ax;
         }
         __syncthreads();
+        stamp();
         // (X holds the smoothed iterate: remember which buffer via the parity of TAIL_NU below)
         const double *rval = f64(L.o_rval);
         const uint16_t *rcol = u16(L.o_rcol);
@@ -411,16 +485,28 @@ __global__ __launch_bounds__(1024) void k_tail(TailDesc d, const char *__restric
         for (int I0 = 0; I0 < L.nc; I0 += 1024 / RL) {  // eight lanes per coarse row
             const int I = I0 + tid / RL, r8 = tid & (RL - 1);
             double s = 0.0;
-            if (I < L.nc)
-                for (int q = 0; q < L.nq; ++q) {
-                    const int e = (q * L.nc + I) * RL + r8;
-                    s = fma(rval[e], R[rcol[e]], s);
+            if (I < L.nc) {
+                double s1 = 0.0;
+                const int e0 = I * RL + r8, step = L.nc * RL;
+                int q = 0;
+                for (; q + 3 < L.nq; q += 4) {  // (four blocks in flight)
+                    const int ea = e0 + q * step, eb = ea + step, ec = eb + step, ed = ec + step;
+                    const double va = rval[ea], vb = rval[eb], vc = rval[ec], vd = rval[ed];
+                    const int ca = rcol[ea], cb = rcol[eb], cc = rcol[ec], cd = rcol[ed];
+                    s = fma(va, R[ca], s);
+                    s1 = fma(vb, R[cb], s1);
+                    s = fma(vc, R[cc], s);
+                    s1 = fma(vd, R[cd], s1);
                 }
+                for (; q < L.nq; ++q) s = fma(rval[e0 + q * step], R[rcol[e0 + q * step]], s);
+                s += s1;
+            }
 #pragma unroll
             for (int off = RL >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
             if (I < L.nc && r8 == 0) Bc[I] = s;
         }
         __syncthreads();
+        stamp();
     }
     {
         const TailLevelDesc &L = d.lv[last];
@@ -428,13 +514,25 @@ __global__ __launch_bounds__(1024) void k_tail(TailDesc d, const char *__restric
         double *E = f64(L.o_X);
         for (int i = tid; i < L.n; i += 1024) {
             double s = 0.0;
-            if (d.inv)
-                for (int j = 0; j < L.n; ++j) s = fma(inv[i * L.n + j], B[j], s);
-            else
+            if (d.inv) {
+                double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                const double *row = inv + i * L.n;
+                int j = 0;
+                for (; j + 3 < L.n; j += 4) {
+                    s = fma(row[j], B[j], s);
+                    s1 = fma(row[j + 1], B[j + 1], s1);
+                    s2 = fma(row[j + 2], B[j + 2], s2);
+                    s3 = fma(row[j + 3], B[j + 3], s3);
+                }
+                for (; j < L.n; ++j) s = fma(row[j], B[j], s);
+                s = (s + s1) + (s2 + s3);
+            } else {
                 s = inv[i] * B[i];
+            }
             E[i] = s;
         }
         __syncthreads();
+        stamp();
     }
     // ---- up ----
     const double *Ec = f64(d.lv[last].o_X);
@@ -450,19 +548,24 @@ __global__ __launch_bounds__(1024) void k_tail(TailDesc d, const char *__restric
             Y[i] = s;
         }
         __syncthreads();
+        stamp();
         const int lpr = L.lpr, sub = tid & (lpr - 1), rows = 1024 / lpr;
         for (int sweep = 0; sweep < TAIL_NU; ++sweep) {
             for (int i0 = 0; i0 < L.n; i0 += rows) {
                 const int i = i0 + tid / lpr, ii = i < L.n ? i : L.n - 1;
-                const double ax = lds_row(aval, acol, L.n, L.width, ii, sub, lpr, Y);
+                const double ax = k == 0 ? reg_row<SLOTS>(v0, c0, lpr, Y)
+                                         : lds_row(aval, acol, L.n, L.width, ii, sub, lpr, Y);
                 if (i < L.n && sub == 0) X[i] = fma(OMEGA * dinv[i], B[i] - ax, Y[i]);
             }
             __syncthreads();
             double *t = X; X = Y; Y = t;
         }
         Ec = Y;  // the last sweep's result
+        stamp();
     }
     for (int i = tid; i < d.lv[0].n; i += 1024) out[i] = Ec[i];
+    stamp();
+    if (d.stamps && tid == 0) d.stamps[63] = stamp_no;
 }
 
 // ---------------------------------------------------------------------------------
@@ -528,17 +631,21 @@ __global__ __launch_bounds__(TB) void f_direction(const double *__restrict__ z, 
 
 // Ap = A p, partials of p.Ap
 template <int W>
-__global__ __launch_bounds__(TB) void f_spmv(Ell A, const double *__restrict__ p, double *__restrict__ Ap,
+__global__ __launch_bounds__(TB * RowLanes<W>::value) void f_spmv(Ell A, const double *__restrict__ p, double *__restrict__ Ap,
                                              double *__restrict__ part_pap, const double *__restrict__ sc,
                                              int iter) {
     if (sc[F_CONV + (iter & 1)] != 0.0) return;
     double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
-        const double s = ell_row_w<W>(A, i, [&](int32_t j) { return p[j]; });
+    constexpr int LPR = RowLanes<W>::value, NT = TB * LPR;  // (the workgroup still covers TB rows)
+    const int sub = threadIdx.x & (LPR - 1);
+    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t / LPR < A.n; t += (int64_t)gridDim.x * NT) {
+        const int64_t i = t / LPR;
+        const double s = ell_row_w<W>(A, A.val, i, sub, [&](int32_t j) { return p[j]; });
+        if (sub != 0) continue;
         Ap[i] = s;
         acc = fma(p[i], s, acc);
     }
-    acc = block_sum(acc);
+    acc = block_sum<NT>(acc);
     if (threadIdx.x == 0) part_pap[blockIdx.x] = acc;
 }
 
