@@ -26,6 +26,9 @@ constexpr int TB = 256;
 constexpr int RESTART = 40;
 constexpr int MAXV = RESTART + 1;
 constexpr int DOT_GRID = 1024;
+// the small least-squares problem's state on the device (see gs_finish)
+enum { G_H = 0, G_CS = G_H + MAXV * RESTART, G_SN = G_CS + RESTART, G_G = G_SN + RESTART,
+       G_INV_H = G_G + MAXV, G_EST, G_DONE, G_COUNT, G_INFO, G_TOLB, G_WORDS };
 
 inline unsigned grid_for(int64_t n, unsigned cap = 4096) {
     int64_t g = (n + TB - 1) / TB;
@@ -291,15 +294,97 @@ __global__ __launch_bounds__(TB) void scale_to(const double *__restrict__ src, d
 
 // x += sum_i y_i Z_i
 __global__ __launch_bounds__(TB) void add_combination(const double *__restrict__ Z, int64_t ld,
-                                                      int nv, const double *__restrict__ y,
-                                                      double *__restrict__ x, int64_t n) {
+                                                      int nv_max, const double *__restrict__ y,
+                                                      double *__restrict__ x, const double *__restrict__ gst,
+                                                      int64_t n) {
     __shared__ double ys[MAXV];
+    const int count = (int)gst[G_COUNT], nv = count < nv_max ? count : nv_max;  // (columns of this cycle)
     if (threadIdx.x < MAXV) ys[threadIdx.x] = (int)threadIdx.x < nv ? y[threadIdx.x] : 0.0;
     __syncthreads();
     for (int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x; r < n; r += (int64_t)gridDim.x * TB) {
         double xr = x[r];
         for (int i = 0; i < nv; ++i) xr = fma(ys[i], Z[(int64_t)i * ld + r], xr);
         x[r] = xr;
+    }
+}
+
+// ---- the small least-squares problem, on the device -----------------------------------
+// The Hessenberg column, the Givens rotations and the residual estimate of every iteration
+// live in one block of doubles, so the host never waits inside a restart cycle: it enqueues
+// iterations in batches and only polls G_DONE / G_EST (as the flexible CG of sagg.hip does).
+
+__global__ void gst_begin(double *__restrict__ gst, double rnorm, double tolb) {
+    for (int i = threadIdx.x; i < MAXV; i += blockDim.x) gst[G_G + i] = i == 0 ? rnorm : 0.0;
+    if (threadIdx.x == 0) {
+        gst[G_INV_H] = 0.0;
+        gst[G_EST] = rnorm;
+        gst[G_DONE] = 0.0;
+        gst[G_COUNT] = 0.0;
+        gst[G_INFO] = 0.0;
+        gst[G_TOLB] = tolb;
+    }
+}
+
+// Iteration j's last step: |w|^2 from the blocks' partial sums (fixed order), the new column
+// h = h1 + h2 of H, the rotations so far applied to it, the new rotation, g and the estimate.
+// Once G_DONE is raised (converged, happy breakdown or singular operator) later iterations'
+// calls leave the state alone.
+__global__ __launch_bounds__(TB) void gs_finish(const double *__restrict__ h1, const double *__restrict__ h2,
+                                                const double *__restrict__ partial2, int nblocks2, int j,
+                                                double *__restrict__ gst) {
+    if (gst[G_DONE] != 0.0) return;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks2; b += TB) s += partial2[b];
+    s = block_sum(s);
+    if (threadIdx.x != 0) return;
+    const int nv = j + 1;
+    double *H = gst + G_H, *cs = gst + G_CS, *sn = gst + G_SN, *g = gst + G_G;
+    const double hnext = sqrt(s);
+    for (int i = 0; i < nv; ++i) H[i * RESTART + j] = h1[i] + h2[i];
+    H[nv * RESTART + j] = hnext;
+    for (int i = 0; i < j; ++i) {
+        const double a = H[i * RESTART + j], b = H[(i + 1) * RESTART + j];
+        H[i * RESTART + j] = cs[i] * a + sn[i] * b;
+        H[(i + 1) * RESTART + j] = -sn[i] * a + cs[i] * b;
+    }
+    const double d = hypot(H[j * RESTART + j], H[(j + 1) * RESTART + j]);
+    if (!(d > 0.0) || d != d) {  // breakdown: singular operator
+        gst[G_INFO] = 1.0;
+        gst[G_DONE] = 1.0;
+        return;
+    }
+    cs[j] = H[j * RESTART + j] / d;
+    sn[j] = H[(j + 1) * RESTART + j] / d;
+    H[j * RESTART + j] = d;
+    H[(j + 1) * RESTART + j] = 0.0;
+    g[j + 1] = -sn[j] * g[j];
+    g[j] = cs[j] * g[j];
+    const double est = fabs(g[j + 1]);
+    gst[G_EST] = est;
+    gst[G_COUNT] = (double)(j + 1);
+    gst[G_INV_H] = hnext > 0.0 ? 1.0 / hnext : 0.0;
+    if (est <= gst[G_TOLB] || hnext == 0.0) gst[G_DONE] = 1.0;
+}
+
+// v_{j+1} = w / h_{j+1,j}
+__global__ __launch_bounds__(TB) void scale_by_device(const double *__restrict__ src, const double *__restrict__ gst,
+                                                      double *__restrict__ dst, int64_t n) {
+    if (gst[G_DONE] != 0.0) return;
+    const double scale = gst[G_INV_H];
+    for (int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x; r < n; r += (int64_t)gridDim.x * TB)
+        dst[r] = src[r] * scale;
+}
+
+// y = H^-1 g over the G_COUNT columns of the cycle (zero beyond)
+__global__ void gst_solve(const double *__restrict__ gst, double *__restrict__ y) {
+    if (threadIdx.x != 0) return;
+    const int m = (int)gst[G_COUNT];
+    const double *H = gst + G_H, *g = gst + G_G;
+    for (int i = m; i < MAXV; ++i) y[i] = 0.0;
+    for (int i = m - 1; i >= 0; --i) {
+        double s = g[i];
+        for (int k = i + 1; k < m; ++k) s -= H[i * RESTART + k] * y[k];
+        y[i] = s / H[i * RESTART + i];
     }
 }
 
@@ -410,7 +495,7 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
     // ---- Krylov storage: V (m+1), Z (m), w, r ----
     const int64_t ld = (int64_t)(align_up((size_t)n * 8) / 8);
     const size_t vecs = (size_t)(2 * RESTART + 3) * ld * 8;
-    const size_t scal = ((size_t)DOT_GRID * MAXV + DOT_GRID + 2 * (MAXV + 1) + MAXV) * 8;
+    const size_t scal = ((size_t)DOT_GRID * MAXV + DOT_GRID + 2 * (MAXV + 1) + MAXV + G_WORDS) * 8;
     NODAL_HIP_TRY(h, h->krylov.reserve(vecs + scal + 1024));
     double *V = h->krylov.as<double>();
     double *Z = V + (int64_t)(RESTART + 1) * ld;
@@ -421,6 +506,7 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
     double *hdev = partial2 + DOT_GRID;        // MAXV + 1
     double *hdev2 = hdev + (MAXV + 1);         // MAXV + 1
     double *ydev = hdev2 + (MAXV + 1);         // MAXV
+    double *gst = ydev + MAXV;                 // G_WORDS: the small least-squares problem
 
     const unsigned gd = grid_for(n, DOT_GRID), gv = grid_for(n);
     NODAL_HIP_TRY(h, hipMemsetAsync(x, 0, (size_t)n * 8, st));
@@ -446,76 +532,75 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
     double rnorm = bnorm;
     int total = 0;
     bool converged = false;
-    double H[MAXV][RESTART], cs[RESTART], sn[RESTART], g[MAXV], hcol[2 * (MAXV + 1)];
     h->kern_ms = 0;
     h->kern_launches = 0;
     hipEvent_t e0 = h->ev[2], e1 = h->ev[3];
+    double hst[6];  // G_INV_H .. G_TOLB, as polled
 
     for (int cyc = 0; cyc < max_cycles && !converged; ++cyc) {
         scale_to<<<gv, TB, 0, st>>>(r, 1.0 / rnorm, V, n);
-        for (int i = 0; i < MAXV; ++i) g[i] = 0.0;
-        g[0] = rnorm;
-        int j = 0;
-        for (; j < RESTART; ++j) {
-            double *vj = V + (int64_t)j * ld, *zj = Z + (int64_t)j * ld;
-            // z_j = M^-1 v_j
-            if (use_sa) NODAL_TRY(sagg_apply(h, vj, zj));
-            else NODAL_TRY(amg_apply(h, vj, zj));
-            if (n > K) {
-                branch_solve<<<grid_for(n - K), TB, 0, st>>>(indptr, indices, data, K, (int)n,
-                                                            h->schur.as<double>(), vj, zj);
+        gst_begin<<<1, 64, 0, st>>>(gst, rnorm, tol * bnorm);
+        // Iterations are enqueued in batches; between batches the host reads the estimate and
+        // sizes the next batch from the convergence rate seen so far (three quarters of what is
+        // still missing, at least two).  A batch that overshoots costs idle launches only: every
+        // kernel that touches the small problem returns once G_DONE is up.
+        int enq = 0, batch = 6;
+        double est_prev = rnorm;
+        int at_prev = 0;
+        bool done = false;
+        while (!done && enq < RESTART) {
+            if (batch > RESTART - enq) batch = RESTART - enq;
+            for (int c = 0; c < batch; ++c, ++enq) {
+                const int j = enq;
+                double *vj = V + (int64_t)j * ld, *zj = Z + (int64_t)j * ld;
+                // z_j = M^-1 v_j
+                if (use_sa) NODAL_TRY(sagg_apply(h, vj, zj));
+                else NODAL_TRY(amg_apply(h, vj, zj));
+                if (n > K) {
+                    branch_solve<<<grid_for(n - K), TB, 0, st>>>(indptr, indices, data, K, (int)n,
+                                                                h->schur.as<double>(), vj, zj);
+                    NODAL_HIP_TRY(h, hipGetLastError());
+                }
+                // w = A z_j   (one launch per batch is timed)
+                if (c == 0) NODAL_HIP_TRY(h, hipEventRecord(e0, st));
+                NODAL_TRY(csr_spmv(h, zj, w));
+                if (c == 0) NODAL_HIP_TRY(h, hipEventRecord(e1, st));
+                // classical Gram-Schmidt, twice
+                const int nv = j + 1;
+                DISPATCH_NV(nv, (gs_dots<NV><<<gd, TB, 0, st>>>(V, ld, nv, w, n, partial)));
+                gs_reduce<<<nv, TB, 0, st>>>(partial, (int)gd, nv, hdev, nullptr, 0);
+                DISPATCH_NV(nv, (gs_update_dots<NV><<<gd, TB, 0, st>>>(V, ld, nv, hdev, w, n, partial)));
+                gs_reduce<<<nv, TB, 0, st>>>(partial, (int)gd, nv, hdev2, nullptr, 0);
+                DISPATCH_NV(nv, (gs_update<NV><<<gd, TB, 0, st>>>(V, ld, nv, hdev2, w, n, partial2)));
+                gs_finish<<<1, TB, 0, st>>>(hdev, hdev2, partial2, (int)gd, j, gst);
+                scale_by_device<<<gv, TB, 0, st>>>(w, gst, V + (int64_t)(j + 1) * ld, n);
                 NODAL_HIP_TRY(h, hipGetLastError());
             }
-            // w = A z_j
-            NODAL_HIP_TRY(h, hipEventRecord(e0, st));
-            NODAL_TRY(csr_spmv(h, zj, w));
-            NODAL_HIP_TRY(h, hipEventRecord(e1, st));
-            // classical Gram-Schmidt, twice
-            const int nv = j + 1;
-            DISPATCH_NV(nv, (gs_dots<NV><<<gd, TB, 0, st>>>(V, ld, nv, w, n, partial)));
-            gs_reduce<<<nv, TB, 0, st>>>(partial, (int)gd, nv, hdev, nullptr, 0);
-            DISPATCH_NV(nv, (gs_update_dots<NV><<<gd, TB, 0, st>>>(V, ld, nv, hdev, w, n, partial)));
-            gs_reduce<<<nv, TB, 0, st>>>(partial, (int)gd, nv, hdev2, nullptr, 0);
-            DISPATCH_NV(nv, (gs_update<NV><<<gd, TB, 0, st>>>(V, ld, nv, hdev2, w, n, partial2)));
-            gs_reduce<<<1, TB, 0, st>>>(partial, 0, 0, hdev2, partial2, (int)gd);  // |w|^2 -> hdev2[MAXV]
-            NODAL_HIP_TRY(h, hipGetLastError());
-            NODAL_HIP_TRY(h, hipMemcpyAsync(hcol, hdev, 2 * (MAXV + 1) * 8, hipMemcpyDeviceToHost, st));
+            NODAL_HIP_TRY(h, hipMemcpyAsync(hst, gst + G_INV_H, sizeof hst, hipMemcpyDeviceToHost, st));
             NODAL_HIP_TRY(h, hipStreamSynchronize(st));
             float ms = 0;
             if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { h->kern_ms += ms; h->kern_launches += 1; }
-            const double hnext = std::sqrt(hcol[(MAXV + 1) + MAXV]);
-            for (int i = 0; i < nv; ++i) H[i][j] = hcol[i] + hcol[(MAXV + 1) + i];
-            H[nv][j] = hnext;
-            // Givens rotations
-            for (int i = 0; i < j; ++i) {
-                const double t = cs[i] * H[i][j] + sn[i] * H[i + 1][j];
-                H[i + 1][j] = -sn[i] * H[i][j] + cs[i] * H[i + 1][j];
-                H[i][j] = t;
+            const double est = hst[G_EST - G_INV_H];
+            done = hst[G_DONE - G_INV_H] != 0.0;
+            if (hst[G_INFO - G_INV_H] != 0.0) *info = 1;
+            if (done) break;
+            // contraction per iteration since the last poll -> iterations still missing
+            double need = RESTART;
+            if (est > 0.0 && est < est_prev && enq > at_prev) {
+                const double rate = std::log(est / est_prev) / (double)(enq - at_prev);
+                need = std::log(tol * bnorm / est) / rate;
             }
-            const double d = std::hypot(H[j][j], H[j + 1][j]);
-            if (!(d > 0.0) || d != d) { *info = 1; break; }  // breakdown: singular operator
-            cs[j] = H[j][j] / d;
-            sn[j] = H[j + 1][j] / d;
-            H[j][j] = d;
-            H[j + 1][j] = 0.0;
-            g[j + 1] = -sn[j] * g[j];
-            g[j] = cs[j] * g[j];
-            ++total;
-            const double est = std::fabs(g[j + 1]);
-            if (hnext > 0.0) scale_to<<<gv, TB, 0, st>>>(w, 1.0 / hnext, V + (int64_t)(j + 1) * ld, n);
-            if (est <= tol * bnorm || hnext == 0.0) { ++j; break; }
+            batch = (int)std::floor(0.75 * need);
+            if (batch < 2) batch = 2;
+            if (batch > enq) batch = enq;  // (at most doubling)
+            est_prev = est;
+            at_prev = enq;
         }
+        total += (int)hst[G_COUNT - G_INV_H];
         if (*info) break;
         // y = H^-1 g ; x += Z y
-        const int m = j > RESTART ? RESTART : j;
-        double y[MAXV];
-        for (int i = m - 1; i >= 0; --i) {
-            double s = g[i];
-            for (int k = i + 1; k < m; ++k) s -= H[i][k] * y[k];
-            y[i] = s / H[i][i];
-        }
-        NODAL_HIP_TRY(h, hipMemcpyAsync(ydev, y, (size_t)m * 8, hipMemcpyHostToDevice, st));
-        add_combination<<<gv, TB, 0, st>>>(Z, ld, m, ydev, x, n);
+        gst_solve<<<1, 64, 0, st>>>(gst, ydev);
+        add_combination<<<gv, TB, 0, st>>>(Z, ld, RESTART, ydev, x, gst, n);
         // true residual
         NODAL_TRY(csr_spmv(h, x, w));
         residual_of<<<gd, TB, 0, st>>>(b, w, r, n, partial2);
