@@ -67,6 +67,72 @@ __global__ __launch_bounds__(TB) void fill_nan_rows(double *__restrict__ out, in
         out[i] = __builtin_nan("");
 }
 
+
+// ---- the block system's symbolic phase, from one member's ------------------------------
+// Without branch unknowns member m's rows, entries and contributions are the topology's, shifted:
+// row r -> m n + r, entry e -> m nnz + e, contribution p -> m C + p, component i -> m ncomp + i.
+// Grouping the block table from scratch (stamp_symbolic on count x ncomp rows) finds exactly
+// this -- the per-row sort keys (column, component, slot) shift monotonically -- at count times
+// the cost.
+
+// dst[m * per + j] = src[j] + m * step   (src[j] < 0 stays negative when `keep_negative`)
+__global__ __launch_bounds__(TB) void shift_copies_i32(int64_t per, int32_t count, const int32_t *__restrict__ src,
+                                                       int64_t step, bool keep_negative,
+                                                       int32_t *__restrict__ dst) {
+    const int64_t total = per * count;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TB) {
+        const int64_t m = i / per, j = i - m * per;
+        const int32_t v = src[j];
+        dst[i] = (keep_negative && v < 0) ? v : (int32_t)(v + m * step);
+    }
+}
+__global__ void set_i32(int32_t *p, int32_t v) { *p = v; }
+
+int replicate_symbolic(nodal_ctx *h, nodal_ctx *c, int32_t count) {
+    hipStream_t st = h->stream;
+    const int64_t n = h->n, nnz = h->nnz, C = h->ncontrib, nr = h->nrhs, Cr = h->nrhs_contrib;
+    if (nnz * count >= (1ll << 31) - 2 || C * count >= (1ll << 31) - 2)
+        return nodal_fail(h, NODAL_E_UNSUPPORTED, "run_batch: shard too large for 32-bit indices; split it");
+    ++c->struct_epoch;
+    c->nnz = nnz * count;
+    c->ncontrib = C * count;
+    c->nrhs = nr * count;
+    c->nrhs_contrib = Cr * count;
+    NODAL_HIP_TRY(h, c->indices.reserve((size_t)c->nnz * 4 + 4));
+    NODAL_HIP_TRY(h, c->rowidx.reserve((size_t)c->nnz * 4 + 4));
+    NODAL_HIP_TRY(h, c->cptr.reserve((size_t)(c->nnz + 1) * 4));
+    NODAL_HIP_TRY(h, c->contrib.reserve((size_t)c->ncontrib * 4 + 4));
+    NODAL_HIP_TRY(h, c->indptr.reserve((size_t)(c->n + 1) * 4));
+    NODAL_HIP_TRY(h, c->diag_pos.reserve((size_t)c->n * 4 + 4));
+    NODAL_HIP_TRY(h, c->rhs_row.reserve((size_t)c->nrhs * 4 + 4));
+    NODAL_HIP_TRY(h, c->rhs_cptr.reserve((size_t)(c->nrhs + 1) * 4));
+    NODAL_HIP_TRY(h, c->rhs_contrib.reserve((size_t)c->nrhs_contrib * 4 + 4));
+    auto shift = [&](int64_t per, const DevBuf &src, int64_t step, bool keep_negative, DevBuf &dst) {
+        if (per > 0)
+            shift_copies_i32<<<grid_for(per * count), TB, 0, st>>>(per, count, src.as<int32_t>(), step, keep_negative,
+                                                                   dst.as<int32_t>());
+    };
+    shift(nnz, h->indices, n, false, c->indices);
+    shift(nnz, h->rowidx, n, false, c->rowidx);
+    shift(nnz, h->cptr, C, false, c->cptr);
+    set_i32<<<1, 1, 0, st>>>(c->cptr.as<int32_t>() + c->nnz, (int32_t)c->ncontrib);
+    shift(C, h->contrib, (int64_t)h->ncomp << 3, false, c->contrib);  // (u32 comp << 3 | slot)
+    shift(n, h->indptr, nnz, false, c->indptr);
+    set_i32<<<1, 1, 0, st>>>(c->indptr.as<int32_t>() + c->n, (int32_t)c->nnz);
+    shift(n, h->diag_pos, nnz, true, c->diag_pos);
+    shift(nr, h->rhs_row, n, false, c->rhs_row);
+    shift(nr, h->rhs_cptr, Cr, false, c->rhs_cptr);
+    set_i32<<<1, 1, 0, st>>>(c->rhs_cptr.as<int32_t>() + c->nrhs, (int32_t)c->nrhs_contrib);
+    shift(Cr, h->rhs_contrib, (int64_t)h->ncomp << 3, false, c->rhs_contrib);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    NODAL_HIP_TRY(h, c->data.reserve((size_t)c->nnz * 8 + 8));
+    NODAL_HIP_TRY(h, c->rhs.reserve((size_t)c->n * 8 + 8));
+    NODAL_HIP_TRY(h, c->x.reserve((size_t)c->n * 8 + 8));
+    NODAL_HIP_TRY(h, c->status.reserve(64));
+    c->have_symbolic = true;
+    return NODAL_OK;
+}
+
 nodal_ctx *block_child(nodal_ctx *h) {
     if (!h->blocksys) {
         nodal_ctx *c = new nodal_ctx();
@@ -220,7 +286,14 @@ int nodal_run_batch(nodal_handle h, int32_t first, int32_t count, int32_t reuse_
         c->keep_host_table = h->B > 0 && !h->host.type.empty() && !h->host.values_batch.empty();
         if (c->keep_host_table) replicate_host(h, c, first, count);
         else c->host = HostTable();
-        if (!c->have_symbolic) s = stamp_symbolic(c);
+        if (!c->have_symbolic) {
+            if (h->B == 0) {  // one member's grouping, shifted (the parent's symbolic phase is redone too unless kept)
+                if (!(reuse_symbolic && h->have_symbolic)) s = stamp_symbolic(h);
+                if (s == NODAL_OK) s = replicate_symbolic(h, c, count);
+            } else {
+                s = stamp_symbolic(c);
+            }
+        }
         NODAL_HIP_TRY(h, hipEventRecord(ev[1], st));
         int32_t inf = 0, it = 0;
         double rs = 0.0;
