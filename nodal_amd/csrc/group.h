@@ -30,11 +30,31 @@ inline unsigned grid_for(int64_t n) {
     return (unsigned)(g > MAX_GRID ? MAX_GRID : g);
 }
 
+// One atomic per DISTINCT row of an item, not per tuple: a resistor's four stamps fall in two rows,
+// so half the atomics (and none of them colliding inside the lane).  `s` is a compile-time
+// constant after the enumerator's unrolled loop is inlined: rows[] / cols[] stay in registers.
 template <class E>
 __global__ __launch_bounds__(TB) void count_rows(E en, uint32_t *__restrict__ rowcount) {
+    constexpr int S = E::SLOTS;
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < en.nitems;
-         i += (int64_t)gridDim.x * TB)
-        en.for_each(i, [&](int, int row, int) { atomicAdd(&rowcount[row], 1u); });
+         i += (int64_t)gridDim.x * TB) {
+        int rows[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) rows[s] = -1;
+        en.for_each(i, [&](int s, int row, int) { rows[s] = row; });
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (rows[s] < 0) continue;
+            bool leader = true;
+            unsigned cnt = 1;
+#pragma unroll
+            for (int t = 0; t < S; ++t) {
+                if (t < s && rows[t] == rows[s]) leader = false;
+                if (t > s && rows[t] == rows[s]) ++cnt;
+            }
+            if (leader) atomicAdd(&rowcount[rows[s]], cnt);
+        }
+    }
 }
 
 template <class E>
@@ -42,13 +62,37 @@ __global__ __launch_bounds__(TB) void emit_tuples(E en, const uint32_t *__restri
                                                   uint32_t *__restrict__ fill,
                                                   uint64_t *__restrict__ skey,
                                                   int32_t *__restrict__ srow) {
+    constexpr int S = E::SLOTS;
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < en.nitems;
-         i += (int64_t)gridDim.x * TB)
-        en.for_each(i, [&](int s, int row, int col) {
-            const uint32_t p = rowstart[row] + atomicAdd(&fill[row], 1u);
-            skey[p] = ((uint64_t)(uint32_t)col << 32) | ((uint64_t)i << 3) | (uint64_t)s;
-            srow[p] = row;
-        });
+         i += (int64_t)gridDim.x * TB) {
+        int rows[S], cols[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) rows[s] = -1;
+        en.for_each(i, [&](int s, int row, int col) { rows[s] = row; cols[s] = col; });
+        uint32_t at[S];  // position of tuple s inside its row's segment
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (rows[s] < 0) continue;
+            int first = s;
+            unsigned before = 0, cnt = 1;
+#pragma unroll
+            for (int t = S - 1; t >= 0; --t) {
+                if (t < s && rows[t] == rows[s]) { first = t; ++before; }
+                if (t > s && rows[t] == rows[s]) ++cnt;
+            }
+            at[s] = first == s ? atomicAdd(&fill[rows[s]], cnt) : 0u;
+#pragma unroll
+            for (int t = 0; t < S; ++t)
+                if (t == first && t < s) at[s] = at[t] + before;
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (rows[s] < 0) continue;
+            const uint32_t p = rowstart[rows[s]] + at[s];
+            skey[p] = ((uint64_t)(uint32_t)cols[s] << 32) | ((uint64_t)i << 3) | (uint64_t)s;
+            srow[p] = rows[s];
+        }
+    }
 }
 
 // ---- per-row sorts -------------------------------------------------------------
