@@ -38,7 +38,10 @@ namespace {
 using grp::TB;
 constexpr int PW = 4;            // prolongation entries per fine row
 constexpr int ACAP = 64;         // row cap of a coarse matrix: one lane per column in the Galerkin kernel
-constexpr int RCAP = 96;         // row cap of R
+constexpr int RCAP = 96;         // row cap of R on large levels
+constexpr int RCAP_SMALL = 256;  // ... on levels of at most RCAP_SMALL_ROWS coarse rows (aggregates of a few
+constexpr int RCAP_SMALL_ROWS = 16384;  // thousand-row level with 30-entry rows reach 100+ members)
+inline int rcap_for(int64_t nc) { return nc <= RCAP_SMALL_ROWS ? RCAP_SMALL : RCAP; }
 constexpr int W0_MAX = 32;       // level-0 rows longer than this (hubs): decline
 constexpr int COARSEST = 64;     // dense inverse below this
 constexpr int MAX_LEVELS = 12;
@@ -99,7 +102,7 @@ enum { V_X = 0, V_R = 1, V_XP = 2, V_RC = 3, V_C1 = 4, V_C2 = 5, V_V1 = 6, V_V2 
 
 struct TailLevelDesc {
     int n, nc, ld, rld, width, nq, lpr;  // width: longest row of A; nq: blocks of 8 per row of R; lpr: lanes per row
-    const int32_t *acol, *pcol, *rcol, *rlen;
+    const int32_t *acol, *pcol, *rcol, *rlen, *alen;
     const double *aval, *dinv, *pval, *rval;
     int o_aval, o_acol, o_dinv, o_pval, o_pcol, o_rval, o_rcol, o_B, o_X, o_Y, o_R;  // LDS offsets (bytes)
 };
@@ -109,7 +112,8 @@ struct TailDesc {
     const double *inv;
     int nu;           // Jacobi sweeps before / after each coarse correction inside the tail
     int image_bytes;  // matrices and transfer operators (packed once per setup)
-    int lds_bytes;    // image + vectors
+    int lds_bytes;    // image + vectors, less `skip`
+    int skip;         // leading bytes of the image that never go to LDS (the first level's matrix: registers)
     int slots;        // register slots per lane the first level needs: ceil(width / lpr)
     long long *stamps;  // development probe (NODAL_TAIL_PROBE): wall-clock ticks at the phase boundaries
 };
@@ -435,7 +439,8 @@ __global__ __launch_bounds__(TB) void r_to_ell(int64_t nc, int64_t rld, const ui
                                                const uint64_t *__restrict__ keys, int64_t ld,
                                                const double *__restrict__ pval, int32_t *__restrict__ rcol,
                                                double *__restrict__ rval, int32_t *__restrict__ rlen,
-                                               unsigned long long *__restrict__ stats, uint32_t *__restrict__ bstat) {
+                                               unsigned long long *__restrict__ stats, uint32_t *__restrict__ bstat,
+                                               uint32_t rcap) {
     uint32_t mlen = 0;
     const int sub = threadIdx.x & 7;
     const int64_t rows_per_pass = (int64_t)gridDim.x * (TB / 8);
@@ -443,10 +448,10 @@ __global__ __launch_bounds__(TB) void r_to_ell(int64_t nc, int64_t rld, const ui
         const uint32_t s0 = rstart[I];
         uint32_t l = rstart[I + 1] - s0;
         mlen = l > mlen ? l : mlen;
-        if (l > (uint32_t)RCAP) l = RCAP;
+        if (l > rcap) l = rcap;
         // zero padding: to the end of the last block of 8, and on small levels (the LDS tail copies
-        // whole rows without looking at their length) up to RCAP
-        const uint32_t upto = nc <= 4096 ? (uint32_t)RCAP : ((l + 7u) & ~7u);
+        // whole rows without looking at their length) up to the cap
+        const uint32_t upto = nc <= 4096 ? rcap : ((l + 7u) & ~7u);
         for (uint32_t t = sub; t < upto; t += 8) {
             const int64_t at = ((int64_t)(t >> 3) * rld + I) * 8 + (t & 7);
             if (t < l) {
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(TB) void r_to_ell(int64_t nc, int64_t rld, const ui
         }
         if (sub == 0) rlen[I] = (int32_t)l;
     }
-    if (mlen > (uint32_t)RCAP) atomicOr(&stats[ST_OVERFLOW], 2ull);  // (rare)
+    if (mlen > rcap) atomicOr(&stats[ST_OVERFLOW], 2ull);  // (rare)
     __shared__ unsigned int s_max;
     if (threadIdx.x == 0) s_max = 0;
     __syncthreads();
@@ -493,32 +498,33 @@ __global__ __launch_bounds__(TB) void r_sort_short(const uint32_t *__restrict__ 
         else if (len <= 32) grp::sort_short_row<32>(keys + s0, len);
     }
 }
-// 33..128 keys (the coarser levels): one wavefront per row, bitonic network in LDS.  Longer rows are
-// beyond RCAP: left as they are, the setup declines.  (No work lists: ten thousand rows appending
+// 33..256 keys (the coarser levels): one wavefront per row, bitonic network in LDS.  Longer rows are
+// beyond every cap: left as they are, the setup declines.  (No work lists: ten thousand rows appending
 // themselves to one list through one counter cost 100 us.)
 __global__ __launch_bounds__(64) void r_sort_medium(const uint32_t *__restrict__ rstart, uint64_t *__restrict__ keys,
                                                     int64_t nc) {
-    __shared__ uint64_t buf[128];
+    __shared__ uint64_t buf[RCAP_SMALL];
     const int lane = threadIdx.x;
     for (int64_t I = blockIdx.x; I < nc; I += gridDim.x) {
         const uint32_t s0 = rstart[I];
         const int len = (int)(rstart[I + 1] - s0);
-        if (len <= 32 || len > 128) continue;  // uniform over the wavefront
-        buf[lane] = lane < len ? keys[s0 + lane] : ~0ull;
-        buf[lane + 64] = lane + 64 < len ? keys[s0 + lane + 64] : ~0ull;
+        if (len <= 32 || len > RCAP_SMALL) continue;  // uniform over the wavefront
+        const int P = len <= 64 ? 64 : (len <= 128 ? 128 : 256);
+        for (int e = lane; e < P; e += 64) buf[e] = e < len ? keys[s0 + e] : ~0ull;
         __syncthreads();
-        for (int size = 2; size <= 128; size <<= 1)
+        for (int size = 2; size <= P; size <<= 1)
             for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                // 64 compare-exchanges per step: pair (i, i ^ stride) with i the lane's index with bit `stride` clear
-                const int i = ((lane & ~(stride - 1)) << 1) | (lane & (stride - 1));
-                const int j = i | stride;
-                const bool up = (i & size) == 0;
-                const uint64_t a = buf[i], b = buf[j];
-                if ((a > b) == up) { buf[i] = b; buf[j] = a; }
+                // P / 2 compare-exchanges per step: pair (i, i ^ stride), i = the pair number with bit `stride` opened
+                for (int p = lane; p < P / 2; p += 64) {
+                    const int i = ((p & ~(stride - 1)) << 1) | (p & (stride - 1));
+                    const int j = i | stride;
+                    const bool up = (i & size) == 0;
+                    const uint64_t a = buf[i], b = buf[j];
+                    if ((a > b) == up) { buf[i] = b; buf[j] = a; }
+                }
                 __syncthreads();
             }
-        if (lane < len) keys[s0 + lane] = buf[lane];
-        if (lane + 64 < len) keys[s0 + lane + 64] = buf[lane + 64];
+        for (int e = lane; e < len; e += 64) keys[s0 + e] = buf[e];
         __syncthreads();
     }
 }
@@ -1020,7 +1026,6 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     char *rs = H->rstart.as<char>();
     uint32_t *rstart = reinterpret_cast<uint32_t *>(rs);
     uint32_t *cursor = reinterpret_cast<uint32_t *>(rs + a4);
-    uint32_t *counts = reinterpret_cast<uint32_t *>(rs + 2 * a4);
     void *scan_tmp2 = rs + 2 * a4 + 256;
     NODAL_HIP_TRY(h, hipMemsetAsync(rs, 0, 2 * a4 + 256, st));
     r_count<<<g, TB, 0, st>>>(n, ld, L->pcol.as<int32_t>(), rstart);
@@ -1038,14 +1043,15 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     C->width = ACAP;
     C->nc = 0;
     L->rld = C->ld;
-    NODAL_HIP_TRY(h, L->rcol.reserve((size_t)RCAP * C->ld * 4 + 64));
-    NODAL_HIP_TRY(h, L->rval.reserve((size_t)RCAP * C->ld * 8 + 64));
+    const int rcap = rcap_for(nc);
+    NODAL_HIP_TRY(h, L->rcol.reserve((size_t)rcap * C->ld * 4 + 64));
+    NODAL_HIP_TRY(h, L->rval.reserve((size_t)rcap * C->ld * 8 + 64));
     NODAL_HIP_TRY(h, L->rlen.reserve((size_t)C->ld * 4 + 64));
     {
         const unsigned gr = grid_for(nc * 8);
         r_to_ell<<<gr, TB, 0, st>>>(nc, L->rld, rstart, keys, ld, L->pval.as<double>(), L->rcol.as<int32_t>(),
                                    L->rval.as<double>(), L->rlen.as<int32_t>(), dstats + (size_t)l * ST_COUNT,
-                                   H->bstat.as<uint32_t>());
+                                   H->bstat.as<uint32_t>(), (uint32_t)rcap);
         reduce_bstat<<<1, 1024, 0, st>>>((int)gr, H->bstat.as<uint32_t>(), dstats + (size_t)l * ST_COUNT, ST_MAXR, -1);
     }
     NODAL_HIP_TRY(h, C->acol.reserve((size_t)ACAP * C->ld * 4 + 64));
@@ -1106,21 +1112,19 @@ int build_tail(nodal_ctx *h, SHierarchy *H, const unsigned long long *hs) {
         d.nu = getenv("NODAL_SA_TAIL_NU") ? atoi(getenv("NODAL_SA_TAIL_NU")) : 3;
         if (d.nu < 1) d.nu = 1;
         int off = 0;
-        bool ok = true;
         for (int k = 0; k < d.nlev; ++k) {  // image part
             const SLevel *L = H->pool[t + k];
             TailLevelDesc &q = d.lv[k];
             q.n = (int)L->n; q.nc = (int)L->nc; q.ld = (int)L->ld; q.rld = (int)L->rld; q.width = L->maxlen;
             q.acol = L->acol.as<int32_t>(); q.aval = L->aval.as<double>();
-            q.dinv = L->dinv.as<double>();
+            q.dinv = L->dinv.as<double>(); q.alen = L->alen.as<int32_t>();
             q.pcol = L->pcol.as<int32_t>(); q.pval = L->pval.as<double>();
             q.rcol = L->rcol.as<int32_t>(); q.rval = L->rval.as<double>(); q.rlen = L->rlen.as<int32_t>();
             if (k == d.nlev - 1) {  // dense inverse (n^2) or diagonal (n)
                 q.o_aval = off; off = up16(off + (H->dense_coarsest ? q.n * q.n : q.n) * 8);
                 continue;
             }
-            // rows of A are zero-padded by the Galerkin kernel up to APAD slots only
-            if (q.width > APAD) ok = false;
+            // (slots past a row's end hold zeros up to APAD only: the pack kernel masks by the row length)
             const int maxr = (int)hs[(size_t)(t + k) * ST_COUNT + ST_MAXR];
             q.nq = (maxr + 7) / 8;
             q.lpr = 1;
@@ -1143,15 +1147,16 @@ int build_tail(nodal_ctx *h, SHierarchy *H, const unsigned long long *hs) {
             q.o_R = off; off = up16(off + q.n * 8);
         }
         d.inv = H->dense_coarsest ? H->coarse_inv.as<double>() : nullptr;
-        d.lds_bytes = off;
+        d.skip = d.nlev > 1 ? d.lv[0].o_dinv : 0;
+        d.lds_bytes = off - d.skip;
         if (getenv("NODAL_TAIL_PROBE")) {
             NODAL_HIP_TRY(h, H->tail_stamps.reserve(64 * sizeof(long long)));
             d.stamps = H->tail_stamps.as<long long>();
         }
-        if (!ok || off > TAIL_LDS_BUDGET) continue;
+        if (d.lds_bytes > TAIL_LDS_BUDGET) continue;
         d.slots = d.nlev > 1 ? (d.lv[0].width + d.lv[0].lpr - 1) / d.lv[0].lpr : 1;
         if (d.slots > 32) continue;
-        NODAL_HIP_TRY(h, hipFuncSetAttribute(tail_kernel(d.slots), hipFuncAttributeMaxDynamicSharedMemorySize, off));
+        NODAL_HIP_TRY(h, hipFuncSetAttribute(tail_kernel(d.slots), hipFuncAttributeMaxDynamicSharedMemorySize, d.lds_bytes));
         NODAL_HIP_TRY(h, H->tail_image.reserve((size_t)d.image_bytes + 256));
         k_tail_pack<<<1, 1024, 0, h->stream>>>(d, H->tail_image.as<char>());
         NODAL_HIP_TRY(h, hipGetLastError());
@@ -1242,8 +1247,12 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
         NODAL_TRY(build_level(h, H, l, hs, &declined, &stop));
         if (declined) {
             if (trace)
-                fprintf(stderr, "[sagg] declined at level %d (%lld rows): does not coarsen / over a cap / not positive\n",
-                        l, (long long)L->n);
+                fprintf(stderr, "[sagg] declined at level %d (%lld rows): does not coarsen / over a cap / not positive "
+                                "(this level: overflow %llx baddiag %llx; level above: overflow %llx unassigned %llu maxr %llu)\n",
+                        l, (long long)L->n, hs[(size_t)l * ST_COUNT + ST_OVERFLOW], hs[(size_t)l * ST_COUNT + ST_BADDIAG],
+                        l > 0 ? hs[(size_t)(l - 1) * ST_COUNT + ST_OVERFLOW] : 0ull,
+                        l > 0 ? hs[(size_t)(l - 1) * ST_COUNT + ST_UNASSIGNED] : 0ull,
+                        l > 0 ? hs[(size_t)(l - 1) * ST_COUNT + ST_MAXR] : 0ull);
             return NODAL_OK;
         }
         if (stop) {
@@ -1335,7 +1344,8 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
         for (int k = 0; k < H->nlev; ++k)
             fprintf(stderr, " %lld/%lld/%d/%d", (long long)H->pool[k]->n, (long long)H->pool[k]->nnz,
                     H->pool[k]->maxlen, H->pool[k]->wfix);
-        fprintf(stderr, "  tail %d  coarsest %s\n", H->tail, H->dense_coarsest ? "dense" : "diagonal");
+        fprintf(stderr, "  tail %d (%d register slots)  coarsest %s\n", H->tail, H->tail >= 0 ? H->td.slots : 0,
+                H->dense_coarsest ? "dense" : "diagonal");
     }
     H->ready = true;
     *accepted = true;

@@ -370,8 +370,14 @@ __global__ __launch_bounds__(1024) void k_tail_pack(TailDesc d, char *__restrict
     };
     for (int k = 0; k < last; ++k) {
         const TailLevelDesc &L = d.lv[k];
-        copy_f64(f64(L.o_aval), L.aval, L.n, L.ld, L.width);  // (rows are zero-padded by the Galerkin kernel)
-        copy_u16(u16(L.o_acol), L.acol, L.n, L.ld, L.width);
+        // A: slot t of row i, zero / column 0 past the row's end
+        for (int e = tid; e < L.n * L.width; e += 1024) {
+            const int t = e / L.n, i = e - t * L.n;
+            const bool in = t < L.alen[i];
+            f64(L.o_aval)[e] = in ? L.aval[(int64_t)t * L.ld + i] : 0.0;
+            const int32_t c = in ? L.acol[(int64_t)t * L.ld + i] : 0;
+            u16(L.o_acol)[e] = (uint16_t)(c < 0 ? 0 : c);
+        }
         copy_f64(f64(L.o_dinv), L.dinv, L.n, L.ld, 1);
         copy_f64(f64(L.o_pval), L.pval, L.n, L.ld, PW);       // (empty slots: value 0, column -1 -> 0)
         copy_u16(u16(L.o_pcol), L.pcol, L.n, L.ld, PW);
@@ -408,20 +414,43 @@ __global__ __launch_bounds__(1024) void k_tail(TailDesc d, const char *__restric
     const int tid = threadIdx.x;
     const int last = d.nlev - 1;
     const int TAIL_NU = d.nu;
-    auto f64 = [&](int off) { return reinterpret_cast<double *>(smem + off); };
-    auto u16 = [&](int off) { return reinterpret_cast<uint16_t *>(smem + off); };
+    // LDS holds the image from d.skip on (the first level's matrix, which leads the image, goes to
+    // registers straight from global memory): offsets in the descriptor are image offsets
+    auto f64 = [&](int off) { return reinterpret_cast<double *>(smem + (off - d.skip)); };
+    auto u16 = [&](int off) { return reinterpret_cast<uint16_t *>(smem + (off - d.skip)); };
     int stamp_no = 0;
     auto stamp = [&]() {
         if (d.stamps && tid == 0) d.stamps[stamp_no] = wall_clock64();
         ++stamp_no;
     };
     stamp();
-    {   // image -> LDS: 16-byte pieces, all of a lane's in flight at once (one round trip; the
-        // image never survives in L2 between two launches, the level-0 kernels stream past it)
+    // the first level's matrix: image -> registers (no LDS matrix traffic in the sweeps, no LDS space)
+    double v0[SLOTS];
+    uint32_t c0[SLOTS / 2];
+    {
+        const TailLevelDesc &L = d.lv[0];
+        const double *aval = reinterpret_cast<const double *>(image + L.o_aval);
+        const uint16_t *acol = reinterpret_cast<const uint16_t *>(image + L.o_acol);
+        const int lpr = L.lpr, sub = tid & (lpr - 1), i = tid / lpr, ii = i < L.n ? i : L.n - 1;
+        const bool row = last > 0 && i < L.n;
+#pragma unroll
+        for (int j = 0; j < SLOTS; j += 2) {
+            const int ta = sub + j * lpr, tb = ta + lpr;
+            const bool ha = row && ta < L.width, hb = row && tb < L.width;
+            const int ea = ha ? ta * L.n + ii : 0, eb = hb ? tb * L.n + ii : 0;  // (unconditional loads)
+            const double va = aval[ea], vb = aval[eb];
+            const uint32_t ca = acol[ea], cb = acol[eb];
+            v0[j] = ha ? va : 0.0;
+            v0[j + 1] = hb ? vb : 0.0;
+            c0[j / 2] = (ha ? ca : 0u) | ((hb ? cb : 0u) << 16);
+        }
+    }
+    {   // the rest of the image -> LDS: 16-byte pieces, all of a lane's in flight at once (one round
+        // trip; the image never survives in L2 between two launches, the level-0 kernels stream past it)
         constexpr int FLY = (TAIL_LDS_BUDGET / 16 + 1023) / 1024;
-        const int4 *src = reinterpret_cast<const int4 *>(image);
+        const int4 *src = reinterpret_cast<const int4 *>(image + d.skip);
         int4 *dst = reinterpret_cast<int4 *>(smem);
-        const int pieces = d.image_bytes / 16;
+        const int pieces = (d.image_bytes - d.skip) / 16;
         int4 v[FLY];
 #pragma unroll
         for (int u = 0; u < FLY; ++u) v[u] = src[tid + u * 1024 < pieces ? tid + u * 1024 : 0];
@@ -431,25 +460,6 @@ __global__ __launch_bounds__(1024) void k_tail(TailDesc d, const char *__restric
     }
     for (int i = tid; i < d.lv[0].n; i += 1024) f64(d.lv[0].o_B)[i] = rc[i];
     __syncthreads();
-    // the first level's matrix: LDS -> registers (no LDS matrix traffic in the sweeps)
-    double v0[SLOTS];
-    uint32_t c0[SLOTS / 2];
-    {
-        const TailLevelDesc &L = d.lv[0];
-        const double *aval = f64(L.o_aval);
-        const uint16_t *acol = u16(L.o_acol);
-        const int lpr = L.lpr, sub = tid & (lpr - 1), i = tid / lpr, ii = i < L.n ? i : L.n - 1;
-        const bool row = last > 0 && i < L.n;
-#pragma unroll
-        for (int j = 0; j < SLOTS; j += 2) {
-            const int ta = sub + j * lpr, tb = ta + lpr;
-            const bool ha = row && ta < L.width, hb = row && tb < L.width;
-            v0[j] = ha ? aval[ta * L.n + ii] : 0.0;
-            v0[j + 1] = hb ? aval[tb * L.n + ii] : 0.0;
-            const uint32_t ca = ha ? acol[ta * L.n + ii] : 0u, cb = hb ? acol[tb * L.n + ii] : 0u;
-            c0[j / 2] = ca | (cb << 16);
-        }
-    }
     stamp();
     // ---- down ----
     for (int k = 0; k < last; ++k) {

@@ -203,6 +203,28 @@ def test_cfg3_large_grid_sparse(name):
     h.close()
 
 
+@pytest.mark.parametrize("N,seed", [(66, 0), (80, 1), (97, 2), (128, 3), (181, 4), (230, 5)])
+def test_sparse_grids_of_many_sizes_against_superlu(N, seed):
+    """The multigrid path on grids whose hierarchies differ in depth, in the width class of every
+    level and in the shape of the single-workgroup tail (rows per lane, register slots): random
+    resistances within a factor 4, every unknown compared with the reference's SuperLU route."""
+    rng = np.random.default_rng(seed)
+    vals = rng.uniform(0.5, 2.0, gen.grid_resistor_count(N))
+    table = gen.grid_table(N, vals)
+    Go, Ao = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(Go.tocsr(), Ao, True)
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    x, info, iters, relres = h.solve_sparse()
+    assert info == 0 and 0 < iters <= 60
+    assert normwise(x, xo) <= TOL
+    assert h.residual() <= 1e-13
+    assert h.solve_info()[1] >= 3  # a multigrid hierarchy, not the dense fallback
+    h.close()
+
+
 def test_cfg5_full_size_general_sparse():
     """BASELINE.json config 5 at full size (1e6-node grid + 1% E + CCCS/VCVS,
     non-symmetric, zero diagonals): samples of the reference's own SuperLU solution."""
