@@ -39,7 +39,7 @@ using grp::TB;
 constexpr int PW = 4;            // prolongation entries per fine row
 constexpr int ACAP = 64;         // row cap of a coarse matrix: one lane per column in the Galerkin kernel
 constexpr int RCAP = 96;         // row cap of R on large levels
-constexpr int RCAP_SMALL = 256;  // ... on levels of at most RCAP_SMALL_ROWS coarse rows (aggregates of a few
+constexpr int RCAP_SMALL = 512;  // ... on levels of at most RCAP_SMALL_ROWS coarse rows (aggregates of a few
 constexpr int RCAP_SMALL_ROWS = 16384;  // thousand-row level with 30-entry rows reach 100+ members)
 inline int rcap_for(int64_t nc) { return nc <= RCAP_SMALL_ROWS ? RCAP_SMALL : RCAP; }
 constexpr int W0_MAX = 32;       // level-0 rows longer than this (hubs): decline
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(TB) void r_sort_short(const uint32_t *__restrict__ 
         else if (len <= 32) grp::sort_short_row<32>(keys + s0, len);
     }
 }
-// 33..256 keys (the coarser levels): one wavefront per row, bitonic network in LDS.  Longer rows are
+// 33..512 keys (the coarser levels): one wavefront per row, bitonic network in LDS.  Longer rows are
 // beyond every cap: left as they are, the setup declines.  (No work lists: ten thousand rows appending
 // themselves to one list through one counter cost 100 us.)
 __global__ __launch_bounds__(64) void r_sort_medium(const uint32_t *__restrict__ rstart, uint64_t *__restrict__ keys,
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64) void r_sort_medium(const uint32_t *__restrict__
         const uint32_t s0 = rstart[I];
         const int len = (int)(rstart[I + 1] - s0);
         if (len <= 32 || len > RCAP_SMALL) continue;  // uniform over the wavefront
-        const int P = len <= 64 ? 64 : (len <= 128 ? 128 : 256);
+        const int P = len <= 64 ? 64 : (len <= 128 ? 128 : (len <= 256 ? 256 : 512));
         for (int e = lane; e < P; e += 64) buf[e] = e < len ? keys[s0 + e] : ~0ull;
         __syncthreads();
         for (int size = 2; size <= P; size <<= 1)
