@@ -105,7 +105,7 @@ int nodal_create(int device_id, nodal_handle *out) {
             return NODAL_E_HIP;
         }
     if (const char *e = getenv("NODAL_DENSE_BLOCKINV")) h->dense_blockinv = atoi(e) != 0;
-    if (const char *e = getenv("NODAL_GJ_SCALAR")) h->gj_scalar = atoi(e) != 0;
+    if (const char *e = getenv("NODAL_GJ_SCALAR")) h->gj_scalar = atoi(e);
     *out = h;
     return NODAL_OK;
 }

@@ -252,6 +252,156 @@ __global__ __launch_bounds__(1024) void gj128_mfma(const double *__restrict__ sr
     }
 }
 
+// Two-level variant: RANK-16 outer steps (8 instead of 32 block steps, 2 barriers each instead of
+// 4 x 3).  Outer step q, pivots k0 = 16 q .. 16 q + 15 = the 16-row half `mip` of tile `tp`:
+//   1. the owners publish the 16 pivot rows (raw) and the 16 pivot columns, already negated and with
+//      zeros in the pivot rows (= the column panel Lp), and clear their copy of the pivot columns;
+//   2. row panel Rp = P^-1 [pivot rows] on the matrix cores (every wave eight columns), with P^-1
+//      itself in the pivot columns;
+//   3. every wave: acc += Lp Rp as four rank-4 MFMA sweeps; the row owners take Rp as their rows;
+//   4. the wave that owns the NEXT pivot block inverts it right after its own update, in registers:
+//      lane (r, g) holds P[r][4 j + g], sixteen Gauss-Jordan steps whose pivot row / column travel
+//      by wave shuffles -- no LDS traffic, no barrier, and hidden behind the other waves' updates
+//      (the sixteen dependent reciprocals are 2 us per outer step on the critical path otherwise).
+// The column panel is double-buffered (step q+1 publishes it while slower waves still read step q's).
+constexpr int GJ16_LDS = (16 * 128 + 16 * RP_S + 2 * 16 * CP_S + 16 * 17) * 8;
+
+// in-wave inverse of the 16 x 16 block held as a[j] = P[lane & 15][4 j + (lane >> 4)]
+__device__ __forceinline__ void gj16_in_wave(double (&a)[4], int lane, int32_t *__restrict__ dinfo, int first) {
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int kj = k >> 2, kl = k & 3;  // column k lives in register kj of lane group kl (compile-time)
+        const double pv = __shfl(a[kj], k + 16 * kl, 64);
+        if (lane == 0 && !(pv != 0.0 && pv == pv) && *dinfo == 0) *dinfo = first + k + 1;
+        const double ip = rcp_f64(pv);
+        const double f = __shfl(a[kj], r + 16 * kl, 64);  // my row's entry in column k
+        double rk[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) rk[t] = __shfl(a[t], k + 16 * g, 64) * ip;  // scaled pivot row, my columns
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool pc = g == kl && t == kj;  // my column 4 t + g is the pivot column
+            a[t] = r == k ? (pc ? ip : rk[t]) : (pc ? -f * ip : fma(-f, rk[t], a[t]));
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void gj128_mfma16(const double *__restrict__ src, int64_t lds_, int m,
+                                                      double *__restrict__ dst, int64_t ldd,
+                                                      int32_t *__restrict__ dinfo, int base) {
+    extern __shared__ __attribute__((aligned(16))) double gj16_smem[];
+    double (*rowraw)[128] = reinterpret_cast<double (*)[128]>(gj16_smem);
+    double (*rowpan)[RP_S] = reinterpret_cast<double (*)[RP_S]>(gj16_smem + 16 * 128);
+    double (*colpan2)[CP_S] = reinterpret_cast<double (*)[CP_S]>(gj16_smem + 16 * 128 + 16 * RP_S);
+    double (*pinv)[17] = reinterpret_cast<double (*)[17]>(gj16_smem + 16 * 128 + 16 * RP_S + 2 * 16 * CP_S);
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tr = wave & 3, tc = wave >> 2;
+    const int lr = lane & 15, lc = lane >> 4, lq = lane & 3;
+    double acc0[8], acc1[8];
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+        const int r0 = 32 * tr + lr, r1 = r0 + 16, c = 32 * tc + 4 * c8 + lc;
+        acc0[c8] = (r0 < m && c < m) ? src[(int64_t)c * lds_ + r0] : (r0 == c ? 1.0 : 0.0);
+        acc1[c8] = (r1 < m && c < m) ? src[(int64_t)c * lds_ + r1] : (r1 == c ? 1.0 : 0.0);
+    }
+    if (wave == 0) {  // the first pivot block
+        double a[4] = {acc0[0], acc0[1], acc0[2], acc0[3]};
+        gj16_in_wave(a, lane, dinfo, base);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pinv[lr][4 * j + lc] = a[j];
+    }
+    const int nouter = (m + 15) / 16;
+    for (int q = 0; q < nouter; ++q) {
+        const int k0 = 16 * q, tp = q >> 1, mip = q & 1;
+        double (*colpan)[CP_S] = colpan2 + 16 * (q & 1);
+        // ---- 1. publish ----
+        if (tr == tp) {
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) rowraw[lr][32 * tc + 4 * c8 + lc] = mip == 0 ? acc0[c8] : acc1[c8];
+        }
+        if (tc == tp) {  // uniform per wave; the pivot columns are c8 = 4 mip + j
+            // (two branches with static register indices: a select `mip ? acc0[4 + j] : acc0[j]` is
+            // turned into a dynamically indexed, scratch-resident array)
+            const bool p0 = tr == tp && mip == 0, p1 = tr == tp && mip == 1;  // my rows ARE the pivot rows
+            if (mip == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    colpan[4 * j + lc][32 * tr + lr] = p0 ? 0.0 : -acc0[j];
+                    colpan[4 * j + lc][32 * tr + 16 + lr] = p1 ? 0.0 : -acc1[j];
+                    acc0[j] = 0.0;
+                    acc1[j] = 0.0;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    colpan[4 * j + lc][32 * tr + lr] = p0 ? 0.0 : -acc0[4 + j];
+                    colpan[4 * j + lc][32 * tr + 16 + lr] = p1 ? 0.0 : -acc1[4 + j];
+                    acc0[4 + j] = 0.0;
+                    acc1[4 + j] = 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 2. row panel Rp = P^-1 [pivot rows]: wave w computes columns 8 w .. 8 w + 7 ----
+        {
+            double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double bf = pinv[lr][4 * ks + lc];
+                const double a0 = rowraw[4 * ks + lc][8 * wave + lq], a1 = rowraw[4 * ks + lc][8 * wave + 4 + lq];
+                d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, bf, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, bf, d1, 0, 0, 0);
+            }
+            const int x0 = 8 * wave + lc, x1 = x0 + 4;
+            rowpan[lr][x0] = (x0 >= k0 && x0 < k0 + 16) ? pinv[lr][x0 - k0] : d0;
+            rowpan[lr][x1] = (x1 >= k0 && x1 < k0 + 16) ? pinv[lr][x1 - k0] : d1;
+        }
+        __syncthreads();
+        // ---- 3. rank-16 update ----
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            double bf[2], af[8];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) bf[mi] = colpan[4 * ks + lc][32 * tr + 16 * mi + lr];
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) af[c8] = rowpan[4 * ks + lc][32 * tc + 4 * c8 + lq];
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                acc0[c8] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[c8], bf[0], acc0[c8], 0, 0, 0);
+                acc1[c8] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[c8], bf[1], acc1[c8], 0, 0, 0);
+            }
+        }
+        if (tr == tp) {
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                const double v = rowpan[lr][32 * tc + 4 * c8 + lc];
+                acc0[c8] = mip == 0 ? v : acc0[c8];
+                acc1[c8] = mip == 1 ? v : acc1[c8];
+            }
+        }
+        // ---- 4. the next pivot block's inverse, by its owner (its tile is up to date now) ----
+        if (q + 1 < nouter && tr == ((q + 1) >> 1) && tc == tr) {
+            double a[4];
+            if (((q + 1) & 1) == 0) { a[0] = acc0[0]; a[1] = acc0[1]; a[2] = acc0[2]; a[3] = acc0[3]; }
+            else { a[0] = acc1[4]; a[1] = acc1[5]; a[2] = acc1[6]; a[3] = acc1[7]; }
+            gj16_in_wave(a, lane, dinfo, base + k0 + 16);
+            // (pinv of this step was last read before the barrier above)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pinv[lr][4 * j + lc] = a[j];
+        }
+        // (the next publish writes rowraw and the OTHER column panel; rowpan is rewritten after a barrier
+        // that every wave reaches only after this step's reads of it)
+    }
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+        const int r0 = 32 * tr + lr, r1 = r0 + 16, c = 32 * tc + 4 * c8 + lc;
+        if (r0 < m && c < m) dst[(int64_t)c * ldd + r0] = acc0[c8];
+        if (r1 < m && c < m) dst[(int64_t)c * ldd + r1] = acc1[c8];
+    }
+}
+
 // dst (rows x cols, ldd) = src (rows x cols, lds_): four columns per workgroup pass,
 // whole lines moved
 __global__ __launch_bounds__(256) void copy_block(const double *__restrict__ src, int64_t lds_,
@@ -321,8 +471,16 @@ __global__ __launch_bounds__(256) void bs_block(const double *__restrict__ A, in
 int invert_diag(nodal_ctx *h, hipStream_t sp, double *D, int64_t lda, int w, double *Q, int64_t ldq,
                 double *scratch, int32_t *dinfo, int base) {
     if (w <= GJ) {
-        if (h->gj_scalar) gj128<<<1, 1024, 0, sp>>>(D, lda, w, Q, ldq, dinfo, base);
-        else gj128_mfma<<<1, 1024, 0, sp>>>(D, lda, w, Q, ldq, dinfo, base);
+        if (h->gj_scalar == 1) {
+            gj128<<<1, 1024, 0, sp>>>(D, lda, w, Q, ldq, dinfo, base);
+        } else if (h->gj_scalar == 2) {
+            gj128_mfma<<<1, 1024, 0, sp>>>(D, lda, w, Q, ldq, dinfo, base);
+        } else {
+            static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void *>(gj128_mfma16),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, GJ16_LDS) == hipSuccess;
+            if (!attr) return nodal_fail(h, NODAL_E_HIP, "hipFuncSetAttribute(gj128_mfma16) failed");
+            gj128_mfma16<<<1, 1024, GJ16_LDS, sp>>>(D, lda, w, Q, ldq, dinfo, base);
+        }
         NODAL_HIP_TRY(h, hipGetLastError());
         return NODAL_OK;
     }

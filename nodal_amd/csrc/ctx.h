@@ -53,7 +53,7 @@ struct nodal_ctx {
     size_t gt_used = 0;              // GemmTimer (dense_common.h): timed launches, their flops
     double gt_flops = 0.0;
     bool optimistic_nopivot = false; // dense: block elimination although not passive (caller verifies the answer)
-    bool gj_scalar = false;          // NODAL_GJ_SCALAR=1: scalar Gauss-Jordan instead of the rank-4 MFMA one
+    int gj_scalar = 0;               // NODAL_GJ_SCALAR=1: scalar Gauss-Jordan, 2: rank-4 MFMA steps; default rank-16
     bool dense_blockinv = true;      // passive dense systems: block elimination (NODAL_DENSE_BLOCKINV=0: LU)
     std::string err;
 
