@@ -266,23 +266,38 @@ __global__ __launch_bounds__(1024) void gj128_mfma(const double *__restrict__ sr
 // The column panel is double-buffered (step q+1 publishes it while slower waves still read step q's).
 constexpr int GJ16_LDS = (16 * 128 + 16 * RP_S + 2 * 16 * CP_S + 16 * 17) * 8;
 
-// in-wave inverse of the 16 x 16 block held as a[j] = P[lane & 15][4 j + (lane >> 4)]
+// In-wave inverse of the 16 x 16 block held as a[t] = P[lane & 15][4 t + (lane >> 4)]: block
+// Gauss-Jordan with 2 x 2 pivots (eight steps: the pivot block, its two rows and the lane's two
+// column entries travel by wave shuffles, one reciprocal -- of the 2 x 2 determinant -- per step).
+// With scalar pivots the sixteen dependent shuffle -> reciprocal -> update chains took 3.4 us, more
+// than everything else in an outer step together.
 __device__ __forceinline__ void gj16_in_wave(double (&a)[4], int lane, int32_t *__restrict__ dinfo, int first) {
     const int r = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int kj = k >> 2, kl = k & 3;  // column k lives in register kj of lane group kl (compile-time)
-        const double pv = __shfl(a[kj], k + 16 * kl, 64);
-        if (lane == 0 && !(pv != 0.0 && pv == pv) && *dinfo == 0) *dinfo = first + k + 1;
-        const double ip = rcp_f64(pv);
-        const double f = __shfl(a[kj], r + 16 * kl, 64);  // my row's entry in column k
-        double rk[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) rk[t] = __shfl(a[t], k + 16 * g, 64) * ip;  // scaled pivot row, my columns
+    for (int k = 0; k < 16; k += 2) {
+        const int kj = k >> 2, kl = k & 3;  // columns k, k + 1: register kj of lane groups kl, kl + 1 (compile-time)
+        const double p00 = __shfl(a[kj], k + 16 * kl, 64), p01 = __shfl(a[kj], k + 16 * (kl + 1), 64);
+        const double p10 = __shfl(a[kj], k + 1 + 16 * kl, 64), p11 = __shfl(a[kj], k + 1 + 16 * (kl + 1), 64);
+        const double f0 = __shfl(a[kj], r + 16 * kl, 64), f1 = __shfl(a[kj], r + 16 * (kl + 1), 64);
+        double r0[4], r1[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const bool pc = g == kl && t == kj;  // my column 4 t + g is the pivot column
-            a[t] = r == k ? (pc ? ip : rk[t]) : (pc ? -f * ip : fma(-f, rk[t], a[t]));
+            r0[t] = __shfl(a[t], k + 16 * g, 64);
+            r1[t] = __shfl(a[t], k + 1 + 16 * g, 64);
+        }
+        const double det = fma(p00, p11, -p01 * p10);
+        if (lane == 0 && !(det != 0.0 && det == det) && *dinfo == 0)
+            *dinfo = first + k + ((p00 != 0.0 && p00 == p00) ? 2 : 1);  // (the column a scalar elimination stops at)
+        const double id = rcp_f64(det);
+        const double i00 = p11 * id, i01 = -p01 * id, i10 = -p10 * id, i11 = p00 * id;
+        const double m0 = -fma(f0, i00, f1 * i10), m1 = -fma(f0, i01, f1 * i11);  // -[f0 f1] P2^-1
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool c0 = t == kj && g == kl, c1 = t == kj && g == kl + 1;  // my column is k / k + 1
+            const double n0 = fma(i00, r0[t], i01 * r1[t]), n1 = fma(i10, r0[t], i11 * r1[t]);
+            const double rowk = c0 ? i00 : (c1 ? i01 : n0), rowk1 = c0 ? i10 : (c1 ? i11 : n1);
+            const double other = c0 ? m0 : (c1 ? m1 : fma(m0, r0[t], fma(m1, r1[t], a[t])));
+            a[t] = r == k ? rowk : (r == k + 1 ? rowk1 : other);
         }
     }
 }
