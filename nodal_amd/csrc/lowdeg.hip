@@ -373,7 +373,11 @@ int lowdeg_solve(nodal_ctx *h, int min_share, bool *done, int32_t *info, int32_t
         // a third to a half of every wire); a network that keeps yielding a trickle of candidates is cut off
         slow = (int64_t)nelim * 32 < n;
         nk = n - (int64_t)nelim;
-        if ((int64_t)nelim * min_share < n || nk < 1 || h->ld_rounds >= 48 ||
+        // (the first round needs a real share of such nodes -- 1/64: the four corners of every member of
+        // a batch of small grids are 0.3 % and eliminating them only leaves graded links behind, which
+        // the smoothed-aggregation hierarchy then declines; later rounds go on at n / min_share)
+        const int bar = h->ld_rounds == 0 && min_share > 64 ? 64 : min_share;
+        if ((int64_t)nelim * bar < n || nk < 1 || h->ld_rounds >= 48 ||
             (slow && h->ld_slow_rounds >= 12)) {
             remember(1);
             return NODAL_OK;

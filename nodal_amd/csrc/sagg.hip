@@ -1006,7 +1006,9 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
         *stop = true;
         return NODAL_OK;
     }
-    if (nc * 2 > n || nc < 1) {  // coarsening too slow to pay: not this path's kind of graph
+    // coarsening too slow to pay: not this path's kind of graph.  (Small levels may shrink by less: the
+    // last steps of a batch of small circuits go from one or two nodes per member to one.)
+    if ((nc * 2 > n && n > 4096) || nc < 1) {
         *declined = true;
         return NODAL_OK;
     }

@@ -517,12 +517,14 @@ def test_value_sweep_batch_reuses_symbolic():
     h.close()
 
 
-def test_block_diagonal_batch_matches_per_member_oracle():
+@pytest.mark.parametrize("N,members", [(24, 12), (12, 300), (18, 64), (35, 40), (50, 9)])
+def test_block_diagonal_batch_matches_per_member_oracle(N, members):
     """BASELINE.json config 4: a shard's members are solved as one block-diagonal
     system built on the device (nodal_run_batch); every member must match its own
-    oracle solve."""
+    oracle solve.  Shapes: few large members, many tiny ones (their last multigrid levels
+    hold one or two nodes per member), sizes whose corners are a visible share of the nodes."""
     from nodal_amd import batch
-    N, members = 24, 12  # 12 x 575 nodes: above the multigrid threshold
+    # (all above the multigrid threshold: members x (N^2 - 1) > 4096 unknowns)
     table = gen.grid_table(N)
     vals = np.ones((members, table.ncomp))
     for b in range(members):
