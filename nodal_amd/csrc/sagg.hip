@@ -125,8 +125,12 @@ struct SHierarchy {
     bool ready = false;
     bool kcycle = true;          // two inner FCG steps at the first coarse level
     int klevels = 1;             // ... at the first `klevels` coarse levels (NODAL_SA_KLEVELS)
-    int nu[3] = {1, 1, 1};       // Jacobi sweeps before and after the coarse correction: level 0 / 1 / deeper
-                                 // (NODAL_SA_NU=212: 28 instead of 32 iterations on the 1e6-node grid, but 16.9 instead of 14.9 ms)
+    int nu[3] = {1, 1, 2};       // Jacobi sweeps before and after the coarse correction: level 0 / 1 / deeper.
+                                 // Two on the small levels outside the tail cost eight 4-us launches per iteration and
+                                 // make the count independent of where the level sizes fall: grid(1600) / grid(2000),
+                                 // whose 1050- / 1600-row level just misses the tail, 39 / 40 -> 31 iterations; grid(1000)
+                                 // 30 -> 28 at the same time; the 128-member batch 32 -> 29.  (NODAL_SA_NU=212: 28
+                                 // iterations on the 1e6-node grid too, but 16.9 instead of 14.9 ms.)
     bool dense_coarsest = true;  // last level: dense inverse; false: nothing but isolated nodes (diagonal)
     DevBuf tail_stamps, tail_image, apcol, apval, aplen, bstat;
     DevBuf stats, coarse_inv, mis_t, mis_m, mis_flag, mis_id, agg1, keys, rstart, cursor, lists;

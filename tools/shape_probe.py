@@ -37,14 +37,15 @@ def single(table, reps=3):
 
 def main():
     for spec in sys.argv[1:]:
-        kind, arg = spec.split(":")
+        kind, arg = spec.split(":", 1)
         if kind == "grid":
             out = single(gen.grid_table(int(arg)))
         elif kind == "rgrid":  # random resistances within a factor 4
             N = int(arg)
             out = single(gen.grid_table(N, np.random.default_rng(1).uniform(0.5, 2.0, gen.grid_resistor_count(N))))
-        elif kind == "cfg5":
-            out = single(gen.cfg5_table(int(arg)))
+        elif kind == "cfg5":  # cfg5:N or cfg5:N:seed
+            parts = [int(v) for v in arg.split(":")]
+            out = single(gen.cfg5_table(*parts))
         elif kind == "grid3":
             out = single(grid3_table(int(arg)))
         elif kind == "batch":
