@@ -973,7 +973,8 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     static const bool trace_mis = getenv("NODAL_TRACE") != nullptr;
     if (trace_mis) NODAL_HIP_TRY(h, hipMemsetAsync(cnt, 0, (MIS_ROUNDS + 2) * 8, st));
     mis_init<<<g, TB, 0, st>>>(n, T);
-    for (int r = 0; r < MIS_ROUNDS; ++r) {
+    static const int mis_rounds = getenv("NODAL_SA_MIS") ? std::min(MIS_ROUNDS, std::max(1, atoi(getenv("NODAL_SA_MIS")))) : MIS_ROUNDS;
+    for (int r = 0; r < mis_rounds; ++r) {
         mis_max<<<g, TB, 0, st>>>(A, T, M);
         mis_update<<<g, TB, 0, st>>>(A, T, M);
         if (trace_mis) mis_count<<<g, TB, 0, st>>>(n, T, cnt + r + 1);
