@@ -106,6 +106,7 @@ int nodal_create(int device_id, nodal_handle *out) {
         }
     if (const char *e = getenv("NODAL_DENSE_BLOCKINV")) h->dense_blockinv = atoi(e) != 0;
     if (const char *e = getenv("NODAL_GJ_SCALAR")) h->gj_scalar = atoi(e);
+    if (const char *e = getenv("NODAL_PRESOLVE")) h->use_presolve = atoi(e) != 0;  // 0: branch equations stay in the system
     *out = h;
     return NODAL_OK;
 }

@@ -672,6 +672,24 @@ def test_large_general_regular_system_still_solves():
     assert normwise(x, xo) <= TOL
 
 
+def test_fgmres_restart_cycles_without_presolve(monkeypatch):
+    """The full-system FGMRES (branch equations left in: NODAL_PRESOLVE=0) needs more than one
+    restart cycle of 40 on a config-5 circuit of 6.5e4 unknowns; the small least-squares problem
+    lives on the device across the batches of iterations the host enqueues.  SuperLU agrees."""
+    monkeypatch.setenv("NODAL_PRESOLVE", "0")
+    table = gen.cfg5_table(250)
+    Go, Ao = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(Go.tocsr(), Ao, True)
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    x, info, iters, relres = h.solve_sparse(method=_ffi.SPARSE_LU)
+    h.close()
+    assert info == 0 and iters > 40
+    assert normwise(x, xo) <= TOL
+
+
 def test_cli_scripts(tmp_path, capsys):
     from nodal_amd import solver
     case = next(c for c in CASES if c["name"] == "doc/1.6.1")
