@@ -1,5 +1,6 @@
 // Dense block elimination with explicitly inverted diagonal blocks: the passive (SPD) dense
 // path and the presolved systems of dense_lu.hip's dispatcher.
+#include <atomic>
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
@@ -491,9 +492,13 @@ int invert_diag(nodal_ctx *h, hipStream_t sp, double *D, int64_t lda, int w, dou
         } else if (h->gj_scalar == 2) {
             gj128_mfma<<<1, 1024, 0, sp>>>(D, lda, w, Q, ldq, dinfo, base);
         } else {
-            static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void *>(gj128_mfma16),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, GJ16_LDS) == hipSuccess;
-            if (!attr) return nodal_fail(h, NODAL_E_HIP, "hipFuncSetAttribute(gj128_mfma16) failed");
+            static std::atomic<bool> lds_allowed[64];  // per device: the attribute belongs to the device's code object
+            const int dev = h->device >= 0 && h->device < 64 ? h->device : 0;
+            if (!lds_allowed[dev].load(std::memory_order_acquire)) {
+                NODAL_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(gj128_mfma16),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, GJ16_LDS));
+                lds_allowed[dev].store(true, std::memory_order_release);
+            }
             gj128_mfma16<<<1, 1024, GJ16_LDS, sp>>>(D, lda, w, Q, ldq, dinfo, base);
         }
         NODAL_HIP_TRY(h, hipGetLastError());
