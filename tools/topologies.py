@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sparse passive path on topologies other than the benchmark grids: iterations, time and the
-distance from the CPU oracle (scipy SuperLU) for ladders, trees, grids with dangling wires,
+scaled residual for ladders, trees, grids with dangling wires,
 high-contrast grids.  Run on the GPU box:
 
     python tools/topologies.py [name ...]          # NODAL_LOWDEG=0 switches the elimination off
@@ -69,7 +69,7 @@ CASES = {
 }
 
 
-def run(name, oracle_check=True):
+def run(name):
     table = CASES[name]()
     h = _ffi.Handle(0)
     h.upload(table)
@@ -83,19 +83,13 @@ def run(name, oracle_check=True):
         x, info, iters, relres = h.solve_sparse()
         times.append((time.perf_counter() - t0) * 1e3)
     first, best = times[0], min(times[1:])
-    res = h.residual()
-    err = float("nan")
-    if oracle_check:
-        from oracle import nodal_oracle as oracle
-        G, A = oracle.assemble_fast(table)
-        xo, _ = oracle.solve(G.tocsr(), A, True)
-        err = float(np.abs(x - xo).max() / np.abs(xo).max())
-    print(f"{name:16s} n={len(x):8d} info={info} iters={iters:5d} first {first:7.2f} ms, then {best:7.2f} ms  residual {res:.1e}  "
-          f"vs SuperLU {err:.1e}", flush=True)
+    res = h.residual()  # (distances to SuperLU are the tests' business: tests/test_gpu_kernels.py)
+    print(f"{name:16s} n={len(x):8d} info={info} iters={iters:5d} first {first:7.2f} ms, then {best:7.2f} ms  residual {res:.1e}",
+          flush=True)
     h.close()
 
 
 if __name__ == "__main__":
     names = sys.argv[1:] or [c for c in CASES if c not in ("grid1000", "contrast300d8", "contrast300d10", "contrast300d12", "contrast1000d4", "contrast1000d6", "contrast3000d4", "general300d4", "general300d0")]
     for nm in names:
-        run(nm, oracle_check=os.environ.get("NODAL_TOPO_NO_ORACLE") is None)
+        run(nm)
