@@ -98,6 +98,35 @@ __device__ __forceinline__ double reduce_partials(const double *__restrict__ par
     for (int i = threadIdx.x; i < count; i += TB) s += part[i];
     return block_sum(s);
 }
+// two / three arrays at once: their loads in flight together, one pair of barriers
+__device__ __forceinline__ void reduce_partials3(const double *__restrict__ pa, const double *__restrict__ pb,
+                                                 const double *__restrict__ pc, int count, double &ra, double &rb,
+                                                 double &rc) {
+    __shared__ double ws[3][TB / 64];
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < count; i += TB) {
+        a += pa[i];
+        b += pb[i];
+        if (pc) c += pc[i];
+    }
+    __syncthreads();
+    a = wave_sum(a);
+    b = wave_sum(b);
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) {
+        ws[0][threadIdx.x >> 6] = a;
+        ws[1][threadIdx.x >> 6] = b;
+        ws[2][threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    ra = rb = rc = 0.0;
+#pragma unroll
+    for (int w = 0; w < TB / 64; ++w) {
+        ra += ws[0][w];
+        rb += ws[1][w];
+        rc += ws[2][w];
+    }
+}
 
 // r = b - A x0, where x0 = w D^-1 b is the pre-smoothed iterate from a zero guess.  x0 comes from
 // whoever produced b (f_init / f_update, k_restrict, k_second_residual): the row sum then gathers
@@ -291,8 +320,8 @@ __global__ __launch_bounds__(TB) void k_second_residual(int64_t n, const double 
                                                         const double *__restrict__ part, int nparts,
                                                         double *__restrict__ r2, const double *__restrict__ dinv,
                                                         double *__restrict__ x0) {
-    const double rho1 = reduce_partials(part + 0 * DOT_BLOCKS, nparts);
-    const double alpha1 = reduce_partials(part + 1 * DOT_BLOCKS, nparts);
+    double rho1, alpha1, unused;
+    reduce_partials3(part + 0 * DOT_BLOCKS, part + 1 * DOT_BLOCKS, nullptr, nparts, rho1, alpha1, unused);
     const double t = rho1 > 0.0 ? alpha1 / rho1 : 0.0;
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
     {
@@ -618,9 +647,8 @@ __global__ __launch_bounds__(TB) void f_direction(const double *__restrict__ z, 
         if (blockIdx.x == 0 && threadIdx.x == 0) sc[F_CONV + cur] = 1.0;
         return;
     }
-    const double rz_new = reduce_partials(part_rz, nparts);
-    const double zap = reduce_partials(part_zap, nparts);
-    const double rr = reduce_partials(part_rr, nparts);
+    double rz_new, zap, rr;
+    reduce_partials3(part_rz, part_zap, part_rr, nparts, rz_new, zap, rr);
     const double rz_old = iter > 0 ? sc[F_RZ + prev] : 1.0;
     const double beta = (iter > 0 && rz_old != 0.0) ? -sc[F_ALPHA + prev] * zap / rz_old : 0.0;
     const double bb = iter == 0 ? rr : sc[F_BB];
