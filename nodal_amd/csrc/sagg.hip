@@ -57,9 +57,10 @@ constexpr int DOT_BLOCKS = 1024;   // partial sums per dot product of the K-cycl
 constexpr double OMEGA = NODAL_SA_OMEGA;      // damped-Jacobi smoother
 constexpr double OMEGA_P = 2.0 / 3.0;         // prolongator smoothing (rho(D^-1 A) <= 2 for an M-matrix)
 
-inline unsigned grid_for(int64_t n, unsigned cap = 8192) {
+inline unsigned grid_for(int64_t n, unsigned cap = 8192) {  // (caps are multiples of 8: see xcd_block)
     int64_t g = (n + TB - 1) / TB;
     if (g < 1) g = 1;
+    if (g >= 64) g = (g + 7) & ~(int64_t)7;
     return (unsigned)(g > cap ? cap : g);
 }
 inline int64_t pad64(int64_t n) { return (n + 63) & ~(int64_t)63; }

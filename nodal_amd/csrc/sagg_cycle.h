@@ -75,6 +75,17 @@ __device__ __forceinline__ double ell_row_w(const Ell &A, const VT *__restrict__
     default: { constexpr int W = 0; CALL; } break;       \
     }
 
+// Workgroups are handed to the eight XCDs round-robin (workgroup b runs on XCD b % 8, each with its own
+// L2).  The row kernels walk virtual block numbers instead: XCD k gets the contiguous eighth
+// [k G/8, (k+1) G/8) of a grid of G blocks, so the vector lines a row block gathers (its neighbours'
+// entries, the fine entries under a coarse row) are mostly lines the same L2 already holds, and the
+// same rows stay on the same XCD from one kernel of the cycle to the next.  Grids are multiples of 8
+// (grid_for rounds up; surplus blocks find no rows).
+__device__ __forceinline__ unsigned xcd_block() {
+    const unsigned g = gridDim.x, b = blockIdx.x;
+    return (g & 7u) ? b : (b & 7u) * (g >> 3) + (b >> 3);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(TB * RowLanes<W>::value) void k_smooth_residual(Ell
                                                         const double *__restrict__ x0, double *__restrict__ r) {
     constexpr int LPR = RowLanes<W>::value, NT = TB * LPR;  // (the workgroup still covers TB rows)
     const int sub = threadIdx.x & (LPR - 1);
-    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t / LPR < A.n; t += (int64_t)gridDim.x * NT) {
+    for (int64_t t = (int64_t)xcd_block() * NT + threadIdx.x; t / LPR < A.n; t += (int64_t)gridDim.x * NT) {
         const int64_t i = t / LPR;
         const double s = ell_row_w<W>(A, A.valf, i, sub, [&](int32_t j) { return x0[j]; });
         if (sub == 0) r[i] = b[i] - s;
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(TB) void k_restrict(int64_t nc, int64_t rld, const 
                                                  const double *__restrict__ cdinv, double *__restrict__ x0c) {
     const int sub = threadIdx.x & (RL - 1);
     const int64_t rows_per_pass = (int64_t)gridDim.x * (TB / RL);
-    for (int64_t I0 = (int64_t)blockIdx.x * (TB / RL); I0 < nc; I0 += rows_per_pass) {
+    for (int64_t I0 = (int64_t)xcd_block() * (TB / RL); I0 < nc; I0 += rows_per_pass) {
         const int64_t I = I0 + threadIdx.x / RL;
         double s = 0.0;
         if (I < nc) {
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(TB) void k_prolong(int64_t n, int64_t ld, const int
                                                 const double *__restrict__ coef, double *__restrict__ xp) {
     const bool two = coef != nullptr;
     const double s1 = two ? coef[0] : 1.0, s2 = two ? coef[1] : 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
         // all eight loads of the row at once (empty slots hold value 0: their column is clamped), then
         // the gathers: two dependent stages instead of three
         int32_t J[PW];
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(TB * RowLanes<W>::value) void k_post(Ell A, const d
     double a0 = 0.0, a1 = 0.0;
     constexpr int LPR = RowLanes<W>::value, NT = TB * LPR;  // (the workgroup still covers TB rows)
     const int sub = threadIdx.x & (LPR - 1);
-    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t / LPR < A.n; t += (int64_t)gridDim.x * NT) {
+    for (int64_t t = (int64_t)xcd_block() * NT + threadIdx.x; t / LPR < A.n; t += (int64_t)gridDim.x * NT) {
         const int64_t i = t / LPR;
         const double s = ell_row_w<W>(A, A.valf, i, sub, [&](int32_t j) { return xp[j]; });
         if (sub != 0) continue;
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(TB * RowLanes<W>::value) void k_spmv_dots(Ell A, co
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     constexpr int LPR = RowLanes<W>::value, NT = TB * LPR;  // (the workgroup still covers TB rows)
     const int sub = threadIdx.x & (LPR - 1);
-    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t / LPR < A.n; t += (int64_t)gridDim.x * NT) {
+    for (int64_t t = (int64_t)xcd_block() * NT + threadIdx.x; t / LPR < A.n; t += (int64_t)gridDim.x * NT) {
         const int64_t i = t / LPR;
         const double s = ell_row_w<W>(A, A.valf, i, sub, [&](int32_t j) { return c[j]; });
         if (sub != 0) continue;
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(TB) void k_second_residual(int64_t n, const double 
     double rho1, alpha1, unused;
     reduce_partials3(part + 0 * DOT_BLOCKS, part + 1 * DOT_BLOCKS, nullptr, nparts, rho1, alpha1, unused);
     const double t = rho1 > 0.0 ? alpha1 / rho1 : 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
     {
         const double v = fma(-t, v1[i], rc[i]);
         r2[i] = v;
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(TB) void k_second_residual(int64_t n, const double 
 __global__ __launch_bounds__(TB) void k_coarsest(int64_t n, const double *__restrict__ inv,
                                                  const double *__restrict__ dinv, const double *__restrict__ b,
                                                  double *__restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
         double s = 0.0;
         if (inv)
             for (int64_t j = 0; j < n; ++j) s = fma(inv[i * n + j], b[j], s);
@@ -624,7 +635,7 @@ __global__ __launch_bounds__(TB) void f_init(const double *__restrict__ b, doubl
                                              const double *__restrict__ dinv, double *__restrict__ x0,
                                              double *__restrict__ part_rr, int64_t n) {
     double srr = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
         const double ri = b[i];
         x[i] = 0.0;
         r[i] = ri;
@@ -663,7 +674,7 @@ __global__ __launch_bounds__(TB) void f_direction(const double *__restrict__ z, 
         if (converged) sc[F_ITERS] = (double)iter;
     }
     if (converged) return;  // uniform over the grid: every workgroup reduces the same partials
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
         p[i] = iter > 0 ? fma(beta, p[i], z[i]) : z[i];
 }
 
@@ -676,7 +687,7 @@ __global__ __launch_bounds__(TB * RowLanes<W>::value) void f_spmv(Ell A, const d
     double acc = 0.0;
     constexpr int LPR = RowLanes<W>::value, NT = TB * LPR;  // (the workgroup still covers TB rows)
     const int sub = threadIdx.x & (LPR - 1);
-    for (int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x; t / LPR < A.n; t += (int64_t)gridDim.x * NT) {
+    for (int64_t t = (int64_t)xcd_block() * NT + threadIdx.x; t / LPR < A.n; t += (int64_t)gridDim.x * NT) {
         const int64_t i = t / LPR;
         const double s = ell_row_w<W>(A, A.val, i, sub, [&](int32_t j) { return p[j]; });
         if (sub != 0) continue;
@@ -705,7 +716,7 @@ __global__ __launch_bounds__(TB) void f_update(double *__restrict__ x, double *_
         if (bad) sc[F_FLAG] = 1.0;
     }
     double srr = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
         x[i] = fma(alpha, p[i], x[i]);
         const double ri = fma(-alpha, Ap[i], r[i]);
         r[i] = ri;
