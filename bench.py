@@ -347,7 +347,7 @@ DOMINANT_SPARSE_KERNEL = {
     # the two smoother passes (k_smooth_residual<5>, k_post<5, true>) that read the same ELL arrays.
     "cfg3": "f_spmv<5>: fp64 ELL SpMV of the flexible CG on the 1e6-node level (sagg_cycle.h)",
     "cfg4": "f_spmv<5>: fp64 ELL SpMV of the flexible CG on the block-diagonal fine level (sagg_cycle.h)",
-    "cfg5": "spmv_kernel: CSR-stream SpMV of FGMRES on the full system (sparse.hip)",
+    "cfg5": "k_ell_spmv<W>: fp64 ELL SpMV of FGMRES on the presolved system (sagg_cycle.h)",
 }
 
 

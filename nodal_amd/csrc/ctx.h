@@ -240,6 +240,7 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n, int64_t nnz, const int32_t *indptr, 
                    const double *data, bool general, bool check_floating, bool *accepted, int32_t *floating);
 int sagg_apply(nodal_ctx *h, const double *r, double *z);
 int sagg_levels(nodal_ctx *h);
+int sagg_spmv(nodal_ctx *h, const double *x, double *y, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);  // y = A x on the hierarchy's own (level-0, ELL) matrix
 int amg_has_floating_component(nodal_ctx *h, const uint8_t *grounded0, int32_t *floating);
 int csr_has_floating_component(nodal_ctx *h, const uint8_t *grounded, int32_t *floating);
 

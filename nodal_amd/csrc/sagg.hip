@@ -1491,6 +1491,24 @@ int sagg_apply(nodal_ctx *h, const double *r, double *z) {
     return cycle(h, H, 0, r, x0, z, nullptr);
 }
 
+// y = A x with the level-0 ELL copy of the matrix the hierarchy was built on
+// (start / stop: optional events bound to the dispatch itself, as in sagg_fcg_solve)
+int sagg_spmv(nodal_ctx *h, const double *x, double *y, hipEvent_t start, hipEvent_t stop) {
+    SHierarchy *H = static_cast<SHierarchy *>(h->sagg);
+    if (!H || !H->ready) return nodal_fail(h, NODAL_E_INVALID, "sagg_setup_csr not called");
+    const SLevel *L0 = H->pool[0];
+    const Ell A0 = L0->A();
+    const unsigned tb0 = L0->wfix ? TB : TB * LPR_RAGGED;
+    if (start && stop) {
+        SAGG_DISPATCH_W(L0->wfix, (hipExtLaunchKernelGGL((k_ell_spmv<W>), dim3(grid_for(L0->n)), dim3(tb0), 0, h->stream,
+                                                         start, stop, 0, A0, x, y)));
+    } else {
+        SAGG_DISPATCH_W(L0->wfix, (k_ell_spmv<W><<<grid_for(L0->n), tb0, 0, h->stream>>>(A0, x, y)));
+    }
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
+}
+
 // Flexible CG preconditioned by the hierarchy.  Return: NODAL_OK (converged, *info = 0); -2 the
 // network is structurally singular (caller fills NaNs); -1 breakdown / no convergence (caller
 // falls back); SAGG_DECLINED (-3) the hierarchy does not take this matrix; > 0 a status.

@@ -678,6 +678,20 @@ __global__ __launch_bounds__(TB) void f_direction(const double *__restrict__ z, 
         p[i] = iter > 0 ? fma(beta, p[i], z[i]) : z[i];
 }
 
+// y = A x on the level-0 matrix (fp64 values): the Krylov SpMV of the general path when the hierarchy's
+// matrix IS the system's (sagg_spmv)
+template <int W>
+__global__ __launch_bounds__(TB * RowLanes<W>::value) void k_ell_spmv(Ell A, const double *__restrict__ x,
+                                                                      double *__restrict__ y) {
+    constexpr int LPR = RowLanes<W>::value, NT = TB * LPR;
+    const int sub = threadIdx.x & (LPR - 1);
+    for (int64_t t = (int64_t)xcd_block() * NT + threadIdx.x; t / LPR < A.n; t += (int64_t)gridDim.x * NT) {
+        const int64_t i = t / LPR;
+        const double s = ell_row_w<W>(A, A.val, i, sub, [&](int32_t j) { return x[j]; });
+        if (sub == 0) y[i] = s;
+    }
+}
+
 // Ap = A p, partials of p.Ap
 template <int W>
 __global__ __launch_bounds__(TB * RowLanes<W>::value) void f_spmv(Ell A, const double *__restrict__ p, double *__restrict__ Ap,

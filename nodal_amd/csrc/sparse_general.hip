@@ -477,6 +477,12 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
             return NODAL_OK;
         }
     }
+    // the hierarchy's level-0 matrix is the system itself (a presolved network: no branch rows, no
+    // diagonal had to be added): its ELL copy serves the Krylov SpMV too (13 instead of 22 us at 1e6 rows)
+    const bool ell_spmv = use_sa && K == (int)n && gn_nnz == (uint32_t)h->nnz;
+    auto system_spmv = [&](const double *in, double *out) -> int {
+        return ell_spmv ? sagg_spmv(h, in, out) : csr_spmv(h, in, out);
+    };
     if (use_sa) {
         h->amg_levels = sagg_levels(h);
     } else {
@@ -562,9 +568,13 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
                     NODAL_HIP_TRY(h, hipGetLastError());
                 }
                 // w = A z_j   (one launch per batch is timed)
-                if (c == 0) NODAL_HIP_TRY(h, hipEventRecord(e0, st));
-                NODAL_TRY(csr_spmv(h, zj, w));
-                if (c == 0) NODAL_HIP_TRY(h, hipEventRecord(e1, st));
+                if (ell_spmv) {
+                    NODAL_TRY(sagg_spmv(h, zj, w, c == 0 ? e0 : nullptr, c == 0 ? e1 : nullptr));
+                } else {
+                    if (c == 0) NODAL_HIP_TRY(h, hipEventRecord(e0, st));
+                    NODAL_TRY(csr_spmv(h, zj, w));
+                    if (c == 0) NODAL_HIP_TRY(h, hipEventRecord(e1, st));
+                }
                 // classical Gram-Schmidt, twice
                 const int nv = j + 1;
                 DISPATCH_NV(nv, (gs_dots<NV><<<gd, TB, 0, st>>>(V, ld, nv, w, n, partial)));
@@ -602,7 +612,7 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
         gst_solve<<<1, 64, 0, st>>>(gst, ydev);
         add_combination<<<gv, TB, 0, st>>>(Z, ld, RESTART, ydev, x, gst, n);
         // true residual
-        NODAL_TRY(csr_spmv(h, x, w));
+        NODAL_TRY(system_spmv(x, w));
         residual_of<<<gd, TB, 0, st>>>(b, w, r, n, partial2);
         NODAL_TRY(device_norm(&rnorm));
         if (!(rnorm == rnorm)) { *info = 1; break; }

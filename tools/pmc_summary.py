@@ -22,7 +22,7 @@ DOMINANT = {  # workload -> (kernel name regex, minimum grid size in threads)
     "cfg2": (r"gemm_sub_kernel<0>", 200000),
     "cfg3": (r"f_spmv<", 200000),
     "cfg4": (r"f_spmv<", 200000),
-    "cfg5": (r"^spmv_kernel", 200000),
+    "cfg5": (r"k_ell_spmv<", 200000),
 }
 
 
