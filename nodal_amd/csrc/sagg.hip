@@ -65,6 +65,18 @@ inline unsigned grid_for(int64_t n, unsigned cap = 8192) {  // (caps are multipl
 }
 inline int64_t pad64(int64_t n) { return (n + 63) & ~(int64_t)63; }
 
+// Workgroups are handed to the eight XCDs round-robin (workgroup b runs on XCD b % 8, each with its own
+// L2).  The row kernels walk virtual block numbers instead: XCD k gets the contiguous eighth
+// [k G/8, (k+1) G/8) of a grid of G blocks, so the vector lines a row block gathers (its neighbours'
+// entries, the fine entries under a coarse row) are mostly lines the same L2 already holds, and the
+// same rows stay on the same XCD from one kernel of the cycle to the next.  Grids are multiples of 8
+// (grid_for rounds up; surplus blocks find no rows).
+__device__ __forceinline__ unsigned xcd_block() {
+    const unsigned g = gridDim.x, b = blockIdx.x;
+    return (g & 7u) ? b : (b & 7u) * (g >> 3) + (b >> 3);
+}
+
+
 struct Ell {
     int64_t n = 0, ld = 0;
     int32_t width = 0;
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(TB) void row_stats(int64_t n, const int32_t *__rest
                                                 uint32_t *__restrict__ bstat) {
     int32_t mlen = 0;
     uint32_t graded = 0, bad = 0;
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
         const int32_t e0 = indptr[i], e1 = indptr[i + 1];
         mlen = max(mlen, e1 - e0);
         double d = 0.0, mx = 0.0, mn = 1e300;
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(TB) void csr_to_ell(int64_t n, int64_t ld, const in
                                                  const double *__restrict__ data, int32_t *__restrict__ col,
                                                  double *__restrict__ val, int32_t *__restrict__ len,
                                                  double *__restrict__ dinv, int32_t wpad) {
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
         const int32_t e0 = indptr[i], e1 = indptr[i + 1];
         double d = 1.0;
         for (int32_t e = e0; e < e1; ++e) {
@@ -271,13 +283,13 @@ __device__ __forceinline__ uint32_t hash30(uint32_t x) {
 }
 
 __global__ __launch_bounds__(TB) void mis_init(int64_t n, uint32_t *__restrict__ T) {
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
         T[i] = (1u << 30) | hash30((uint32_t)i);
 }
 
 // m[i] = max of v over the closed neighbourhood of i
 __global__ __launch_bounds__(TB) void mis_max(Ell A, const uint32_t *__restrict__ v, uint32_t *__restrict__ m) {
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
         uint32_t best = v[i];
         const int32_t l = A.len[i];
         for (int32_t s = 0; s < l; ++s) {
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(TB) void mis_max(Ell A, const uint32_t *__restrict_
 // neighbourhood becomes a root; one that sees a root there drops out.  (No count of the nodes left
 // undecided: 15 000 wavefronts adding to one word cost 150 us, ten times the kernel.)
 __global__ __launch_bounds__(TB) void mis_update(Ell A, uint32_t *__restrict__ T, const uint32_t *__restrict__ m1) {
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
         const uint32_t own = T[i];
         if ((own >> 30) != 1) continue;
         uint32_t best = m1[i];
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(TB) void mis_update(Ell A, uint32_t *__restrict__ T
 __global__ __launch_bounds__(TB) void mis_count(int64_t n, const uint32_t *__restrict__ T,
                                                 unsigned long long *__restrict__ out) {
     uint32_t left = 0;
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
         left += (T[i] >> 30) == 1 ? 1u : 0u;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) left += __shfl_down(left, off, 64);
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(TB) void mis_count(int64_t n, const uint32_t *__res
 // roots, plus the nodes still undecided after the last round that have no root next to them
 __global__ __launch_bounds__(TB) void mis_flag_roots(Ell A, const uint32_t *__restrict__ T,
                                                      uint32_t *__restrict__ flag) {
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i <= A.n; i += (int64_t)gridDim.x * TB) {
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i <= A.n; i += (int64_t)gridDim.x * TB) {
         uint32_t f = 0;
         if (i < A.n) {
             const uint32_t own = T[i];
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(TB) void mis_flag_roots(Ell A, const uint32_t *__re
 __global__ __launch_bounds__(TB) void assign_near(Ell A, const uint32_t *__restrict__ T,
                                                   const uint32_t *__restrict__ flag,
                                                   const uint32_t *__restrict__ id, int32_t *__restrict__ agg1) {
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
         int32_t a = -1;
         if (flag[i]) a = (int32_t)id[i];
         else {
@@ -360,7 +372,7 @@ __global__ __launch_bounds__(TB) void assign_near(Ell A, const uint32_t *__restr
 // the rest joins the aggregate of its strongest assigned neighbour
 __global__ __launch_bounds__(TB) void assign_far(Ell A, const int32_t *__restrict__ agg1, int32_t *__restrict__ agg,
                                                  unsigned long long *__restrict__ stats) {
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
         int32_t a = agg1[i];
         if (a < 0) {
             double bw = -1.0;
@@ -384,7 +396,7 @@ __global__ __launch_bounds__(TB) void assign_far(Ell A, const int32_t *__restric
 __global__ __launch_bounds__(TB) void build_P(Ell A, const double *__restrict__ dinv,
                                               const int32_t *__restrict__ agg, int32_t *__restrict__ pcol,
                                               double *__restrict__ pval) {
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
         int32_t c[PW];
         double v[PW];
 #pragma unroll
@@ -419,7 +431,7 @@ __global__ __launch_bounds__(TB) void build_P(Ell A, const double *__restrict__ 
 // ---- R = P^T by coarse row: count, scan, fill, sort each row's (node << 2 | slot) keys ----
 __global__ __launch_bounds__(TB) void r_count(int64_t n, int64_t ld, const int32_t *__restrict__ pcol,
                                               uint32_t *__restrict__ cnt) {
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
 #pragma unroll
         for (int k = 0; k < PW; ++k) {
             const int32_t J = pcol[(int64_t)k * ld + i];
@@ -430,7 +442,7 @@ __global__ __launch_bounds__(TB) void r_count(int64_t n, int64_t ld, const int32
 __global__ __launch_bounds__(TB) void r_fill(int64_t n, int64_t ld, const int32_t *__restrict__ pcol,
                                              const uint32_t *__restrict__ rstart, uint32_t *__restrict__ cursor,
                                              uint64_t *__restrict__ keys) {
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
 #pragma unroll
         for (int k = 0; k < PW; ++k) {
             const int32_t J = pcol[(int64_t)k * ld + i];
@@ -449,7 +461,7 @@ __global__ __launch_bounds__(TB) void r_to_ell(int64_t nc, int64_t rld, const ui
     uint32_t mlen = 0;
     const int sub = threadIdx.x & 7;
     const int64_t rows_per_pass = (int64_t)gridDim.x * (TB / 8);
-    for (int64_t I = (int64_t)blockIdx.x * (TB / 8) + threadIdx.x / 8; I < nc; I += rows_per_pass) {
+    for (int64_t I = (int64_t)xcd_block() * (TB / 8) + threadIdx.x / 8; I < nc; I += rows_per_pass) {
         const uint32_t s0 = rstart[I];
         uint32_t l = rstart[I + 1] - s0;
         mlen = l > mlen ? l : mlen;
@@ -493,7 +505,7 @@ __global__ __launch_bounds__(TB) void r_to_ell(int64_t nc, int64_t rld, const ui
 // workgroup-per-row LDS sort for the rest cost 80 us per 1e5 rows).
 __global__ __launch_bounds__(TB) void r_sort_short(const uint32_t *__restrict__ rstart, uint64_t *__restrict__ keys,
                                                    int64_t nc) {
-    for (int64_t I = (int64_t)blockIdx.x * TB + threadIdx.x; I < nc; I += (int64_t)gridDim.x * TB) {
+    for (int64_t I = (int64_t)xcd_block() * TB + threadIdx.x; I < nc; I += (int64_t)gridDim.x * TB) {
         const uint32_t s0 = rstart[I];
         const int len = (int)(rstart[I + 1] - s0);
         if (len < 2) continue;
@@ -558,7 +570,7 @@ __global__ __launch_bounds__(TB) void ap_rows(Ell A, const int32_t *__restrict__
                                               int32_t *__restrict__ apcol, double *__restrict__ apval,
                                               int32_t *__restrict__ aplen, unsigned long long *__restrict__ stats) {
     bool overflow = false;
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
         int32_t c[APW];
         double v[APW];
 #pragma unroll
@@ -613,7 +625,7 @@ __global__ __launch_bounds__(64) void ap_rows_lds(Ell A, const int32_t *__restri
     __shared__ double tv[APW * 64];
     const int lane = threadIdx.x;
     bool overflow = false;
-    for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < A.n; i0 += (int64_t)gridDim.x * 64) {
+    for (int64_t i0 = (int64_t)xcd_block() * 64; i0 < A.n; i0 += (int64_t)gridDim.x * 64) {
         const int64_t i = i0 + lane;
 #pragma unroll 8
         for (int q = 0; q < APW; ++q) tc[q * 64 + lane] = -1;
@@ -865,7 +877,7 @@ __global__ __launch_bounds__(256) void coarsest_inverse(Ell A, double *__restric
 //      last level by label propagation in one workgroup ------------------------------------
 __global__ __launch_bounds__(TB) void flags_up(int64_t n, const int32_t *__restrict__ agg,
                                                const uint8_t *__restrict__ fine, uint8_t *__restrict__ coarse) {
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
         if (fine[i]) coarse[agg[i]] = 1;  // benign race: every writer stores 1
 }
 __global__ __launch_bounds__(64) void last_level_floating(Ell A, const uint8_t *__restrict__ grounded,
@@ -904,7 +916,7 @@ __global__ __launch_bounds__(64) void last_level_floating(Ell A, const uint8_t *
 // diagonal last level: every node is a component of its own
 __global__ __launch_bounds__(TB) void any_unflagged(int64_t n, const uint8_t *__restrict__ grounded,
                                                     uint32_t *__restrict__ floating) {
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
         if (!grounded[i]) *floating = 1;  // benign race
 }
 
@@ -928,7 +940,7 @@ int width_class(int maxlen) {
 }
 // padded rows pay when the padding is small, or when the level is so small that latency is all
 __global__ __launch_bounds__(TB) void to_f32(const double *__restrict__ src, float *__restrict__ dst, int64_t count) {
-    for (int64_t e = (int64_t)blockIdx.x * TB + threadIdx.x; e < count; e += (int64_t)gridDim.x * TB) dst[e] = (float)src[e];
+    for (int64_t e = (int64_t)xcd_block() * TB + threadIdx.x; e < count; e += (int64_t)gridDim.x * TB) dst[e] = (float)src[e];
 }
 
 int choose_wfix(int maxlen, int64_t n, int64_t nnz, int pad_limit) {
@@ -1473,7 +1485,7 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 // general path's FGMRES, sparse_general.hip)
 __global__ __launch_bounds__(TB) void k_x0(int64_t n, const double *__restrict__ dinv, const double *__restrict__ r,
                                            double *__restrict__ x0) {
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
         x0[i] = OMEGA * dinv[i] * r[i];
 }
 bool sagg_ready(nodal_ctx *h, int64_t n) {

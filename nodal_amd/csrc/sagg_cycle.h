@@ -75,17 +75,6 @@ __device__ __forceinline__ double ell_row_w(const Ell &A, const VT *__restrict__
     default: { constexpr int W = 0; CALL; } break;       \
     }
 
-// Workgroups are handed to the eight XCDs round-robin (workgroup b runs on XCD b % 8, each with its own
-// L2).  The row kernels walk virtual block numbers instead: XCD k gets the contiguous eighth
-// [k G/8, (k+1) G/8) of a grid of G blocks, so the vector lines a row block gathers (its neighbours'
-// entries, the fine entries under a coarse row) are mostly lines the same L2 already holds, and the
-// same rows stay on the same XCD from one kernel of the cycle to the next.  Grids are multiples of 8
-// (grid_for rounds up; surplus blocks find no rows).
-__device__ __forceinline__ unsigned xcd_block() {
-    const unsigned g = gridDim.x, b = blockIdx.x;
-    return (g & 7u) ? b : (b & 7u) * (g >> 3) + (b >> 3);
-}
-
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
