@@ -24,10 +24,19 @@ constexpr int TB = 256;           // threads = rows per block
 constexpr int STREAM_CAP = 3072;  // staged entries per row block (24 KB of LDS)
 constexpr int LONG_PART = 96;     // longer parts of a row inside a chunk are summed by the whole workgroup
 
-inline unsigned grid_for_rows(int64_t n, unsigned cap = 8192) {
+inline unsigned grid_for_rows(int64_t n, unsigned cap = 8192) {  // (a multiple of 8 from 64 blocks on: below)
     int64_t g = (n + TB - 1) / TB;
     if (g < 1) g = 1;
+    if (g >= 64) g = (g + 7) & ~(int64_t)7;
     return (unsigned)(g > cap ? cap : g);
+}
+
+// Workgroup b runs on XCD b % 8 (one L2 each): row blocks are walked under a virtual block number
+// that gives XCD k the contiguous eighth [k G/8, (k+1) G/8) of the grid, so the vector entries a
+// row block gathers from its neighbours are mostly lines its own L2 already holds.
+__device__ __forceinline__ unsigned xcd_block() {
+    const unsigned g = gridDim.x, b = blockIdx.x;
+    return (g & 7u) ? b : (b & 7u) * (g >> 3) + (b >> 3);
 }
 
 template <class EntryF, class RowF>
@@ -37,7 +46,7 @@ __device__ __forceinline__ void for_rows(const int32_t *__restrict__ indptr,
                                          EntryF entry, RowF row) {
     __shared__ double staged[STREAM_CAP];
     const int64_t nblocks = (n + TB - 1) / TB;
-    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    for (int64_t blk = xcd_block(); blk < nblocks; blk += gridDim.x) {
         const int64_t r0 = blk * TB;
         const int64_t r1 = r0 + TB < n ? r0 + TB : n;
         const int32_t e0 = indptr[r0], e1 = indptr[r1];
