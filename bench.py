@@ -423,18 +423,35 @@ def launch_ranks(n, argv):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    import tempfile
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    code = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        code = code or p.returncode
-    sys.stdout.write(out.decode())
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    # a rank that dies leaves the others waiting in a collective: stop them (by their own PIDs) and
+    # report its exit code instead of hanging until the process-group timeout
+    code = 0
+    while any(p.poll() is None for p in procs):
+        failed = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+        if failed:
+            code = failed[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    for p in procs:
+        code = code or (p.returncode or 0)
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
     sys.exit(code)
 
