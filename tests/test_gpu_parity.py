@@ -225,6 +225,27 @@ def test_sparse_grids_of_many_sizes_against_superlu(N, seed):
     h.close()
 
 
+@pytest.mark.parametrize("N", [900, 1200])
+def test_grid_sizes_whose_small_levels_have_long_restriction_rows(N):
+    """grid(900) / grid(1200): a few-thousand-row level with 30-entry rows gives aggregates of 98-104
+    members, beyond the restriction-row cap that is right for the large levels.  The smoothed
+    aggregation must keep these sizes (round 1's hierarchy needs 60 / 108 iterations for them);
+    checked by size-independent properties (no SuperLU run at 1.4e6 unknowns)."""
+    table = gen.grid_table(N)
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    x, info, iters, relres = h.solve_sparse()
+    assert info == 0 and iters <= 40
+    assert h.residual() <= 1e-13
+    assert x.min() > 0 and x.argmax() == 0  # potentials between ground and the driven corner
+    # the driven corner sees two unit resistors in parallel towards the rest: 0.5 < R_eq, and the
+    # grid's corner-to-corner resistance grows like log N (8.87 at N = 1000)
+    assert 8.0 < x[0] < 10.0
+    h.close()
+
+
 def test_cfg5_full_size_general_sparse():
     """BASELINE.json config 5 at full size (1e6-node grid + 1% E + CCCS/VCVS,
     non-symmetric, zero diagonals): samples of the reference's own SuperLU solution."""
