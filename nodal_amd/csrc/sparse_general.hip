@@ -410,6 +410,7 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 int csr_spmv(nodal_ctx *h, const double *x, double *y);  // sparse.hip
 bool general_source_loop(const nodal_ctx *h);                // sparse.hip
 bool general_floating_island(const nodal_ctx *h);            // sparse.hip
+int grounded_flags(nodal_ctx *h, uint8_t *flags_dev);         // lowdeg.hip
 
 int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
     const int64_t n = h->n;
@@ -472,7 +473,12 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
         int32_t floating = 0;
         NODAL_TRY(sagg_setup_csr(h, K, gn_nnz, h->gn_indptr.as<int32_t>(), h->gn_indices.as<int32_t>(),
                                  h->gn_data.as<double>(), true, check_floating, &use_sa, &floating));
-        if (use_sa && floating) {  // singular: NaNs + warning, as the reference's spsolve (quirk 3)
+        if (!use_sa && check_floating) {  // the hierarchy declined the matrix: the same verdict on the CSR pattern
+            NODAL_HIP_TRY(h, h->work3.reserve((size_t)n + 256));
+            NODAL_TRY(grounded_flags(h, h->work3.as<uint8_t>()));
+            NODAL_TRY(csr_has_floating_component(h, h->work3.as<uint8_t>(), &floating));
+        }
+        if (floating) {  // singular: NaNs + warning, as the reference's spsolve (quirk 3)
             *info = 1;
             return NODAL_OK;
         }

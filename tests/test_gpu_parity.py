@@ -685,6 +685,28 @@ def test_large_general_singular_systems_give_nans_like_spsolve(kind):
     assert any(issubclass(i.category, MatrixRankWarning) for i in w)
 
 
+def test_large_general_floating_island_in_a_graded_network():
+    """The same verdict when the presolved network is one the smoothed-aggregation hierarchy
+    declines (resistances over three decades): the island is then found on the CSR pattern."""
+    rng = np.random.default_rng(8)
+    N = 80
+    vals = 10.0 ** rng.uniform(-1.5, 1.5, gen.grid_resistor_count(N))
+    rows = list(gen.grid_rows(N, vals))[:-1]
+    rows += [["e1", "E", "5", "1", "g"], ["rv", "R", "3", "v1", "2"], ["d1", "VCVS", "0.5", "v1", "g", "3", "4"]]
+    regular = n.Netlist.from_rows(rows)
+    Go, Ao, _ = oracle.build_model(regular, True)
+    xo, _ = oracle.solve(Go, Ao, True)
+    assert normwise(n.Circuit(regular, sparse=True).solve().result, xo) <= TOL  # the graded network itself solves
+    nl = n.Netlist.from_rows(rows + [["ri1", "R", "2", "isl_a", "isl_b"], ["ri2", "R", "1", "isl_b", "isl_c"]])
+    assert nl.nums["kcl"] + nl.nums["be"] > 4096
+    circ = n.Circuit(nl, sparse=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        x = circ.solve().result
+    assert np.isnan(x).all()
+    assert any(issubclass(i.category, MatrixRankWarning) for i in w)
+
+
 def test_large_general_regular_system_still_solves():
     nl = n.Netlist.from_rows(_large_general_rows())
     Go, Ao, _ = oracle.build_model(nl, True)
