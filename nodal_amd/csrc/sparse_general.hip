@@ -424,10 +424,12 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
     *info = 0;
 
     // branch equations present: first try to eliminate them exactly (presolve.hip)
-    if (h->B > 0 && h->use_presolve) {
-        bool done = false;
-        NODAL_TRY(presolve_solve(h, &done, info, iters, resid));
-        if (done) return NODAL_OK;
+    if (h->B > 0) {
+        if (h->use_presolve) {
+            bool done = false;
+            NODAL_TRY(presolve_solve(h, &done, info, iters, resid));
+            if (done) return NODAL_OK;
+        }
         // A loop of independent voltage sources (one of the patterns the presolve declines) makes
         // the matrix exactly singular whatever the values; with consistent values a Krylov
         // iteration would still hand back one of the infinitely many solutions, where the
