@@ -384,6 +384,46 @@ def test_floating_island_sparse_returns_nan_like_reference():
     assert normwise(x2, oracle.solve(G2, A2, True)[0]) <= TOL
 
 
+@pytest.mark.parametrize("island", ["grid", "chain"])
+def test_floating_island_next_to_a_large_grid(island):
+    """The same on the multigrid path (7e3 unknowns): an island that is itself a 25 x 25 grid --
+    the hierarchy carries the touches-ground flags up its aggregates -- or a chain of 300
+    resistors, which the exact elimination of low-degree nodes meets first."""
+    rows = [r for r in gen.grid_rows(80)]
+    if island == "grid":
+        M = 25
+        lab = lambda r, c: f"y{r}_{c}"  # noqa: E731
+        for r in range(M):
+            for c in range(M):
+                if c + 1 < M:
+                    rows.append([f"ih{r}_{c}", "R", "1", lab(r, c), lab(r, c + 1)])
+                if r + 1 < M:
+                    rows.append([f"iv{r}_{c}", "R", "2", lab(r, c), lab(r + 1, c)])
+        rows.append(["ia", "A", "1", lab(0, 0), lab(M - 1, M - 1)])
+        tie = ["tie", "R", "5", lab(3, 4), "g"]
+    else:
+        rows += [[f"f{i}", "R", "1", f"x{i}", f"x{i + 1}"] for i in range(300)]
+        rows.append(["fa", "A", "1", "x3", "x77"])
+        tie = ["tie", "R", "5", "x0", "g"]
+    nl = n.Netlist.from_rows(rows)
+    assert nl.nums["kcl"] > 4096
+    if island == "chain":
+        # (SuperLU meets an exact zero pivot on the chain and returns NaNs; on the 1 / 2 ohm grid island
+        # rounding leaves a tiny pivot and it returns arbitrary finite potentials for the island without a
+        # warning -- the HIP path reports every structurally singular network the same way)
+        Go, Ao, _ = oracle.build_model(nl, True)
+        xo, warns = oracle.solve(Go, Ao, True)
+        assert np.isnan(xo).all() and warns == ["MatrixRankWarning"]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        x = n.Circuit(nl, sparse=True).solve().result
+    assert np.isnan(x).all()
+    assert any(issubclass(i.category, MatrixRankWarning) for i in w)
+    nl2 = n.Netlist.from_rows(rows + [tie])
+    G2, A2, _ = oracle.build_model(nl2, True)
+    assert normwise(n.Circuit(nl2, sparse=True).solve().result, oracle.solve(G2, A2, True)[0]) <= TOL
+
+
 def test_equivalent_resistance_golden():
     for case in EQUIV:
         if "gen" in case:
