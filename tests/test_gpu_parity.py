@@ -246,6 +246,27 @@ def test_grid_sizes_whose_small_levels_have_long_restriction_rows(N):
     h.close()
 
 
+def test_one_context_through_changing_sizes_and_paths():
+    """One device context, tables of different sizes and kinds one after the other: uniform grids
+    (smoothed aggregation), a graded grid (contrast mode of the older hierarchy), a grid with sources
+    (presolve + FGMRES), a ladder (exact elimination), larger and smaller again -- buffers only grow
+    and every cached decision must be tied to the table it was made for."""
+    rng = np.random.default_rng(21)
+    graded = 10.0 ** rng.uniform(-1.5, 1.5, gen.grid_resistor_count(90))
+    tables = [gen.grid_table(90), gen.grid_table(130), gen.grid_table(90, graded), gen.cfg5_table(80),
+              gen.ladder_table(9000), gen.grid_table(70), gen.cfg5_table(110), gen.grid_table(130)]
+    h = _ffi.Handle(0)
+    for t in tables:
+        Go, Ao = oracle.assemble_fast(t)
+        xo, _ = oracle.solve(Go.tocsr(), Ao, True)
+        h.upload(t)
+        for _ in range(2):  # (the second run reuses whatever the first one cached)
+            assert h.run(False) == 0
+            assert normwise(h.download_x(), xo) <= TOL
+        assert h.residual() <= 1e-12
+    h.close()
+
+
 def test_cfg5_full_size_general_sparse():
     """BASELINE.json config 5 at full size (1e6-node grid + 1% E + CCCS/VCVS,
     non-symmetric, zero diagonals): samples of the reference's own SuperLU solution."""
