@@ -267,6 +267,39 @@ def test_one_context_through_changing_sizes_and_paths():
     h.close()
 
 
+def test_concurrent_contexts_on_different_paths():
+    """Four host threads, one device context each, different kinds of circuits at the same time
+    (multigrid CG, presolve + FGMRES, dense block elimination, exact elimination): the solvers share
+    nothing but the device, every answer must still be its own oracle's."""
+    import threading
+    jobs = [(gen.grid_table(150), False), (gen.cfg5_table(100), False), (gen.grid_table(40), True),
+            (gen.ladder_table(8000), False)]
+    want = []
+    for t, dense in jobs:
+        Go, Ao = oracle.assemble_fast(t)
+        want.append(oracle.solve(Go.toarray() if dense else Go.tocsr(), Ao, not dense)[0])
+    errors = [None] * len(jobs)
+
+    def work(k):
+        try:
+            t, dense = jobs[k]
+            h = _ffi.Handle(0)
+            h.upload(t)
+            for _ in range(4):
+                assert h.run(dense) == 0
+                assert normwise(h.download_x(), want[k]) <= TOL
+            h.close()
+        except BaseException as e:  # noqa: BLE001 -- reported in the main thread
+            errors[k] = e
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert errors == [None] * len(jobs), errors
+
+
 def test_cfg5_full_size_general_sparse():
     """BASELINE.json config 5 at full size (1e6-node grid + 1% E + CCCS/VCVS,
     non-symmetric, zero diagonals): samples of the reference's own SuperLU solution."""
