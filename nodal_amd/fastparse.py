@@ -362,10 +362,16 @@ def lower_fast(netlist):
     """Vectorised equivalent of lowering.lower for a netlist read by `read_fast`."""
     from .lowering import ComponentTable, lower
     nl = netlist
-    kinds = nl._type.astype(str)
-    codes = np.array([c.TYPE_CODE[k] for k in np.unique(kinds)])
-    _, inv = np.unique(kinds, return_inverse=True)
-    tcode = codes[inv].astype(np.uint8)
+    tidx = getattr(nl, "_tidx", None)
+    if tidx is not None and len(tidx) == len(nl._type):
+        # the native reader's type indices (no component was added since): a table lookup instead of
+        # two sorts of 2e6 strings (0.3 s of the 0.5 s this function took at 1e6 nodes)
+        tcode = np.array([c.TYPE_CODE[k] for k in _TYPE_NAMES.tolist()], dtype=np.uint8)[tidx]
+    else:
+        kinds = nl._type.astype(str)
+        codes = np.array([c.TYPE_CODE[k] for k in np.unique(kinds)])
+        _, inv = np.unique(kinds, return_inverse=True)
+        tcode = codes[inv].astype(np.uint8)
     table = ComponentTable(len(tcode), nl.nums["kcl"], nl.nums["be"])
     if int(nl._is_anom.sum()) != nl.nums["be"]:
         raise Irregular("branch added after numbering")
