@@ -112,9 +112,11 @@ struct StringIds {
             slots[i] = (int32_t)e + 1;
         }
     }
-    // id of s, inserting it if new (*inserted tells which)
-    int32_t get(std::string_view s, bool *inserted) {
-        const uint64_t h = hash(s);
+    // (the table of a 2e6-row file is 50 MB: every probe of a new name is a cache miss unless the slot
+    // was requested a few rows ahead -- see the two-phase loop of nodal_csv_parse)
+    void prefetch(uint64_t h) const { __builtin_prefetch(&slots[h & mask]); }
+    // id of s (hash h), inserting it if new (*inserted tells which)
+    int32_t get(std::string_view s, uint64_t h, bool *inserted) {
         uint64_t i = h & mask;
         while (slots[i]) {
             const int32_t e = slots[i] - 1;
@@ -190,6 +192,32 @@ int nodal_csv_parse(const char *buf, int64_t len, nodal_csv_result *out) {
         return status;
     };
 
+    // Two phases per block of rows: tokenize BLOCK rows, hashing their name and lead labels and
+    // requesting the table slots; then run the table operations in file order (first-appearance ids,
+    // first duplicate reported).  Errors found while tokenizing a later row of the block are only
+    // returned after the earlier rows' table operations, so the FIRST irregular line is reported.
+    constexpr int BLOCK = 16;
+    struct Staged { std::string_view name, a, b; uint64_t hn, ha, hb; int64_t line; };
+    Staged block[BLOCK];
+    int staged = 0;
+    auto flush = [&]() -> int {
+        for (int q = 0; q < staged; ++q) {
+            const Staged &st = block[q];
+            bool fresh = false;
+            name_ids.get(st.name, st.hn, &fresh);
+            if (!fresh) return fail(CSV_DUPLICATE_NAME, st.line);
+            acode.push_back(node_ids.get(st.a, st.ha, &fresh));  // first-appearance ids
+            bcode.push_back(node_ids.get(st.b, st.hb, &fresh));
+        }
+        staged = 0;
+        return CSV_OK;
+    };
+    // (an irregular row stops the file: the rows staged before it are checked for duplicates first)
+    auto fail_after_flush = [&](int status, int64_t line) {
+        const int st_ = flush();
+        return st_ != CSV_OK ? st_ : fail(status, line);
+    };
+
     int64_t pos = 0, lineno = 0;
     char numbuf[64];
     while (pos < len) {
@@ -204,11 +232,11 @@ int nodal_csv_parse(const char *buf, int64_t len, nodal_csv_result *out) {
         bool blank = true;
         for (int64_t i = start; i < end; ++i) {
             const char ch = buf[i];
-            if (ch == '"') return fail(CSV_QUOTES, this_line);
-            if (ch == '\r') return fail(CSV_NEWLINE_IN_FIELD, this_line);
+            if (ch == '"') return fail_after_flush(CSV_QUOTES, this_line);
+            if (ch == '\r') return fail_after_flush(CSV_NEWLINE_IN_FIELD, this_line);
             if (ch != ' ' && ch != '\t') blank = false;
         }
-        if (blank) return fail(CSV_BLANK_WITH_SPACES, this_line);  // the reference raises IndexError there
+        if (blank) return fail_after_flush(CSV_BLANK_WITH_SPACES, this_line);  // the reference raises IndexError there
         // split (skipinitialspace: blanks right after a delimiter / at the start are dropped)
         std::string_view f[9];
         int nf = 0;
@@ -226,24 +254,24 @@ int nodal_csv_parse(const char *buf, int64_t len, nodal_csv_result *out) {
                 break;
             }
         }
-        if (f[0].empty()) return fail(CSV_EMPTY_FIRST_FIELD, this_line);
+        if (f[0].empty()) return fail_after_flush(CSV_EMPTY_FIRST_FIELD, this_line);
         if (f[0][0] == '#') continue;  // comment row
-        if (nf > 8) return fail(CSV_TOO_MANY_FIELDS, this_line);
-        if (nf < 2) return fail(CSV_FIELD_COUNT, this_line);
+        if (nf > 8) return fail_after_flush(CSV_TOO_MANY_FIELDS, this_line);
+        if (nf < 2) return fail_after_flush(CSV_FIELD_COUNT, this_line);
         const int ti = type_index(f[1]);
-        if (ti < 0) return fail(CSV_UNKNOWN_TYPE, this_line);
-        if (nf != TYPE_FIELDS[ti]) return fail(CSV_FIELD_COUNT, this_line);
+        if (ti < 0) return fail_after_flush(CSV_UNKNOWN_TYPE, this_line);
+        if (nf != TYPE_FIELDS[ti]) return fail_after_flush(CSV_FIELD_COUNT, this_line);
         // value: plain decimal spellings only; everything float() accepts beyond that
         // ("1_0", " 1 ", "nan", "inf") goes to the exact parser
         const std::string_view v = f[2];
-        if (v.empty() || v.size() >= sizeof numbuf) return fail(CSV_BAD_VALUE, this_line);
+        if (v.empty() || v.size() >= sizeof numbuf) return fail_after_flush(CSV_BAD_VALUE, this_line);
         bool digit = false;
         for (char ch : v) {
             if (ch >= '0' && ch <= '9') digit = true;
             else if (ch != '+' && ch != '-' && ch != '.' && ch != 'e' && ch != 'E')
-                return fail(CSV_BAD_VALUE, this_line);
+                return fail_after_flush(CSV_BAD_VALUE, this_line);
         }
-        if (!digit) return fail(CSV_BAD_VALUE, this_line);
+        if (!digit) return fail_after_flush(CSV_BAD_VALUE, this_line);
         double val;
         if (!parse_plain_decimal(v, &val)) {  // exponent forms, long mantissas: strtod (correctly rounded too)
             memcpy(numbuf, v.data(), v.size());
@@ -251,20 +279,28 @@ int nodal_csv_parse(const char *buf, int64_t len, nodal_csv_result *out) {
             char *endp = nullptr;
             errno = 0;
             val = strtod(numbuf, &endp);
-            if (endp != numbuf + v.size()) return fail(CSV_BAD_VALUE, this_line);
+            if (endp != numbuf + v.size()) return fail_after_flush(CSV_BAD_VALUE, this_line);
         }
-        bool fresh = false;
-        name_ids.get(f[0], &fresh);
-        if (!fresh) return fail(CSV_DUPLICATE_NAME, this_line);
-        int32_t codes[2];
-        for (int s = 0; s < 2; ++s) codes[s] = node_ids.get(f[3 + s], &fresh);  // first-appearance ids
+        Staged &st = block[staged++];
+        st.name = f[0]; st.a = f[3]; st.b = f[4];
+        st.hn = StringIds::hash(f[0]); st.ha = StringIds::hash(f[3]); st.hb = StringIds::hash(f[4]);
+        st.line = this_line;
+        name_ids.prefetch(st.hn);
+        node_ids.prefetch(st.ha);
+        node_ids.prefetch(st.hb);
         line_off.push_back(start);
         line_len.push_back((int32_t)(end - start));
         type_idx.push_back((uint8_t)ti);
         nfields.push_back((uint8_t)nf);
         value.push_back(val);
-        acode.push_back(codes[0]);
-        bcode.push_back(codes[1]);
+        if (staged == BLOCK) {
+            const int st_ = flush();
+            if (st_ != CSV_OK) return st_;
+        }
+    }
+    {
+        const int st_ = flush();
+        if (st_ != CSV_OK) return st_;
     }
     const std::vector<std::string_view> &names = name_ids.items, &labels = node_ids.items;
     if (names.empty()) return fail(CSV_NO_COMPONENTS, 0);
