@@ -144,84 +144,74 @@ class SingleCircuits:
 
 class BatchShard:
     """cfg4: this rank's 128 members of the value sweep as one block-diagonal system
-    (nodal_run_batch), results gathered from device memory over RCCL when world > 1."""
+    (nodal_run_batch), results gathered from device memory over RCCL when world > 1 (or with
+    --force-collective: the gather of a single rank, the RCCL path on a one-GPU box).  The
+    step itself is nodal_amd.batch.ShardedBatch -- the entry solve_batch_distributed and the
+    tests use; this class only adds the timers."""
 
-    def __init__(self, rank, world, per_gpu, device, dist):
+    def __init__(self, rank, world, per_gpu, device, dist, force_collective=False):
         import numpy as np
-        import torch
         from nodal_amd import generators as gen
-        from nodal_amd.batch import BatchSolver
+        from nodal_amd.batch import ShardedBatch
         self.name, self.per_step, self.dist, self.world = "cfg4", per_gpu, dist, world
         self.dense = False
         self.table = gen.grid_table(100)
+        self.shard = ShardedBatch(self.table, per_gpu * world, dist, device, force_collective=force_collective)
+        collective = self.shard.gathered is not None
         self.desc = (f"batch of {per_gpu * world} grid(100) value sweeps, {per_gpu} per GPU as one "
-                     "block-diagonal system, sparse path" + (", all_gather over RCCL" if world > 1 else ""))
+                     "block-diagonal system, sparse path" + (", all_gather over RCCL" if collective else ""))
         vals = np.ones((per_gpu, self.table.ncomp))
         for i in range(per_gpu):
             vals[i, :-1] = gen.cfg4_values(rank * per_gpu + i, 100)
-        self.solver = BatchSolver(self.table, device)
-        self.solver.h.assemble_symbolic()  # per-member n, nnz for the byte counts (untimed)
-        self.n, self.nnz = self.solver.h.n, self.solver.h.nnz
+        h = self.shard.session.h
+        h.assemble_symbolic()  # per-member n, nnz for the byte counts (untimed)
+        self.n, self.nnz = h.n, h.nnz
         t0 = time.perf_counter()
-        self.solver.upload_values(vals)
+        self.shard.upload(vals)
         self.h2d_ms = (time.perf_counter() - t0) * 1e3
         self.h2d_bytes = int(vals.nbytes)
-        dev = torch.device("cuda", device)
-        self.block = torch.empty((per_gpu, self.table.n), dtype=torch.float64, device=dev)
-        self.gathered = (torch.empty((world * per_gpu, self.table.n), dtype=torch.float64, device=dev)
-                         if world > 1 else None)
         self.phase = np.zeros(3)
         self.kern_ms = self.kern_n = 0
         self.kern_alg = 0.0
-        self.gather_ms = 0.0
         self.circuits_done = 0
 
+    @property
+    def gather_ms(self):
+        return self.shard.gather_ms
+
     def step(self):
-        import torch
-        s = self.solver
-        s.run(sparse=True, reuse_symbolic=False, download=False)
-        s.copy_to_device(self.block)
-        if self.gathered is not None:
-            t0 = time.perf_counter()
-            if self.dist.get_backend() == "nccl":
-                self.dist.all_gather_into_tensor(self.gathered, self.block)
-            else:  # rehearsal over gloo: through host memory
-                g = torch.empty(self.gathered.shape, dtype=torch.float64)
-                self.dist.all_gather_into_tensor(g, self.block.cpu())
-                self.gathered.copy_(g)
-            torch.cuda.synchronize()
-            self.gather_ms += (time.perf_counter() - t0) * 1e3
-        ms, launches, alg = s.h.kernel_stats()
+        self.shard.step(reuse_symbolic=False)
+        h = self.shard.session.h
+        ms, launches, alg = h.kernel_stats()
         self.kern_ms += ms
         self.kern_n += launches
         self.kern_alg = alg
-        self.phase += s.h.timings()
+        self.phase += h.timings()
         self.circuits_done += self.per_step
 
     def reset_stats(self):
         self.phase[:] = 0
         self.kern_ms = self.kern_n = 0
-        self.gather_ms = 0.0
+        self.shard.gather_ms = 0.0
         self.circuits_done = 0
 
     def finish(self):
         import numpy as np
-        h = self.solver.h
+        h = self.shard.session.h
         t0 = time.perf_counter()
-        x = self.block.cpu().numpy()
+        x = self.shard.own_block()
         d2h_ms = (time.perf_counter() - t0) * 1e3
         iterations, levels, _ = h.solve_info()
         # every rank must hold every member after the gather
         gathered_ok = None
-        if self.gathered is not None:
-            g = self.gathered.cpu().numpy()
-            rank = self.dist.get_rank()
-            gathered_ok = bool(np.array_equal(g[rank * self.per_step:(rank + 1) * self.per_step], x)
-                               and np.isfinite(g).all())
+        if self.shard.gathered is not None:
+            g = self.shard.result()
+            lo, hi = self.shard.lo, self.shard.hi
+            gathered_ok = bool(np.array_equal(g[lo:hi], x) and np.isfinite(g).all())
         out = dict(resid=h.residual(), x0=float(x[0, 0]), n=self.n, nnz=self.nnz,
                    iterations=iterations, amg_levels=levels, d2h_ms=d2h_ms, h2d_ms=self.h2d_ms,
                    h2d_bytes=self.h2d_bytes, d2h_bytes=int(x.nbytes), gathered_ok=gathered_ok)
-        self.solver.close()
+        self.shard.close()
         return out
 
 
@@ -263,15 +253,15 @@ def concurrent_throughput(name, device, streams, per_stream):
             "ms_per_circuit": elapsed / n * 1e3, "ms_latency_per_solve": elapsed / per_stream * 1e3}
 
 
-def make_workload(name, rank, world, device, dist, per_step):
+def make_workload(name, rank, world, device, dist, per_step, force_collective=False):
     if name == "cfg4":
-        return BatchShard(rank, world, per_step, device, dist)
+        return BatchShard(rank, world, per_step, device, dist, force_collective)
     return SingleCircuits(name, rank, per_step, device)
 
 
-def time_workload(name, rank, world, device, dist, steps, warmup, per_step):
+def time_workload(name, rank, world, device, dist, steps, warmup, per_step, force_collective=False):
     import torch
-    wl = make_workload(name, rank, world, device, dist if world > 1 else None, per_step)
+    wl = make_workload(name, rank, world, device, dist, per_step, force_collective)
     for _ in range(max(warmup, 1)):  # at least one untimed pass: buffers grow to their final size
         wl.step()
     wl.reset_stats()
@@ -465,11 +455,14 @@ def main():
     ap.add_argument("--per-step", type=int, default=0, help="circuits per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="cfg4 with the process group initialised and the all_gather run even at N = 1 "
+                         "(backend nccl = RCCL, world_size 1: the collective path on a one-GPU box)")
     ap.add_argument("--concurrent", type=int, default=4,
                     help="streams of the extra concurrent-throughput figure (0: skip it)")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.force_collective) and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus, sys.argv[1:])
 
     import torch
@@ -488,7 +481,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
@@ -497,9 +490,9 @@ def main():
             dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local))
         dist = dist_mod
 
-    name = args.workload or ("cfg3" if world == 1 else "cfg4")
+    name = args.workload or ("cfg3" if world == 1 and not args.force_collective else "cfg4")
     per_step = args.per_step or CIRCUITS_PER_STEP[name]
-    st = time_workload(name, rank, world, local, dist, args.steps, args.warmup, per_step)
+    st = time_workload(name, rank, world, local, dist, args.steps, args.warmup, per_step, args.force_collective)
     head = summary(st, world, with_cpu=(rank == 0 and world == 1 and not args.no_cpu))
     out = {
         "metric": "circuits_per_sec",
@@ -520,7 +513,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": head["workload"], "circuits_per_gpu_per_step": st["circuits_per_step"],
                    "n": st["n"], "nnz": st["nnz"],
-                   "parallelism": ("batch members sharded over ranks, all_gather of x" if name == "cfg4" and world > 1
+                   "parallelism": ("batch members sharded over ranks, all_gather of x"
+                                   if name == "cfg4" and (world > 1 or args.force_collective)
                                    else f"independent circuits x{world}")},
     }
     for key in ("phase_ms", "h2d_ms", "d2h_ms", "h2d_bytes", "d2h_bytes", "scaled_residual", "solver",
@@ -529,7 +523,7 @@ def main():
             out[key] = head[key]
     if rank == 0 and world == 1 and name != "cfg4" and args.concurrent > 1:
         out["concurrent"] = concurrent_throughput(name, local, args.concurrent, 16 if name != "cfg2" else 8)
-    if rank == 0 and world == 1 and not args.no_also:
+    if rank == 0 and world == 1 and not args.no_also and not args.force_collective:
         also = {}
         for other in ("cfg4", "cfg5", "cfg2"):
             if other == name:

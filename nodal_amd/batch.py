@@ -157,44 +157,115 @@ def solve_members(table, values, sparse=True, device=0, solver=None, session=Non
         return s.solve(values, sparse)
 
 
+class ShardedBatch:
+    """This rank's shard of a value sweep, kept across steps: the one entry the benchmark
+    (`bench.py` config 4), `solve_batch_distributed` and the tests share.
+
+    `total` members of one topology are split into contiguous shards (`shard_range`); a step
+    solves this rank's members as one block-diagonal system on its GPU (`nodal_run_batch`),
+    copies the [members][n] results device-to-device into `block` (`nodal_batch_x_device`)
+    and gathers every rank's block with `all_gather_into_tensor` -- RCCL over xGMI with
+    backend "nccl", straight from device memory; gloo (CPU tests, rehearsals) goes through
+    host memory.  `solver` replaces the HIP path by a stand-in (the CPU tests pass a reference
+    solver: there is no GPU in the build container).  `force_collective` runs the gather even with a
+    single rank (the RCCL path on a one-GPU box)."""
+
+    def __init__(self, table, total, dist=None, device=None, solver=None, force_collective=False):
+        import torch
+        self.table, self.total, self.dist, self.solver = table, total, dist, solver
+        grouped = dist is not None and dist.is_initialized()
+        self.rank = dist.get_rank() if grouped else 0
+        self.world = dist.get_world_size() if grouped else 1
+        self.backend = dist.get_backend() if grouped else None
+        self.lo, self.hi = shard_range(total, self.rank, self.world)
+        self.width = -(-total // self.world) if total else 0  # all_gather needs equal blocks
+        on_gpu = solver is None
+        dev_index = device if device is not None else (self.rank if self.backend == "nccl" else 0)
+        self.dev = torch.device("cuda", dev_index) if (on_gpu or self.backend == "nccl") else torch.device("cpu")
+        self.session = BatchSolver(table, dev_index) if on_gpu else None
+        # short shards are padded with NaN rows (written once: a step only rewrites the members)
+        self.block = torch.full((self.width, table.n), float("nan"), dtype=torch.float64, device=self.dev)
+        collective = grouped and (self.world > 1 or force_collective)
+        self.gathered = (torch.empty((self.world * self.width, table.n), dtype=torch.float64, device=self.dev)
+                         if collective else None)
+        self._sync_torch()
+        self.values = None
+        self.gather_ms = 0.0
+
+    def _sync_torch(self):
+        # `block` is written on the library's own stream and read by the collective on torch's:
+        # neither may start before the other side's previous use of the buffer has finished
+        if self.dev.type == "cuda":
+            import torch
+            torch.cuda.current_stream(self.dev).synchronize()
+
+    def close(self):
+        if self.session is not None:
+            self.session.close()
+            self.session = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def upload(self, values):
+        """`values`: this rank's [hi - lo, ncomp] slice of the sweep."""
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        assert values.shape[0] == self.hi - self.lo
+        self.values = values
+        if self.session is not None and values.shape[0]:
+            self.session.upload_values(values)
+
+    def step(self, reuse_symbolic=False):
+        import time
+        import torch
+        if self.hi > self.lo:
+            if self.session is not None:
+                self.session.run(sparse=True, reuse_symbolic=reuse_symbolic, download=False)
+                self._sync_torch()
+                self.session.copy_to_device(self.block)  # returns once the copy has finished
+            else:
+                mine = self.solver(self.table, self.values, True)
+                self.block[: self.hi - self.lo] = torch.from_numpy(np.ascontiguousarray(mine)).to(self.dev)
+        if self.gathered is not None:
+            t0 = time.perf_counter()
+            if self.backend == "nccl" or self.dev.type == "cpu":
+                self.dist.all_gather_into_tensor(self.gathered, self.block)
+            else:  # rehearsal: GPU results gathered over gloo through host memory
+                g = torch.empty(self.gathered.shape, dtype=torch.float64)
+                self.dist.all_gather_into_tensor(g, self.block.cpu())
+                self.gathered.copy_(g)
+            self._sync_torch()
+            self.gather_ms += (time.perf_counter() - t0) * 1e3
+
+    def own_block(self):
+        """[hi - lo, n] results of this rank's members (host copy)."""
+        return self.block[: self.hi - self.lo].cpu().numpy()
+
+    def result(self):
+        """[total, n]: every member, on every rank (after a step with the gather)."""
+        if self.gathered is None:
+            return self.own_block()
+        flat = self.gathered.cpu().numpy()
+        out = np.empty((self.total, self.table.n))
+        for r in range(self.world):
+            rlo, rhi = shard_range(self.total, r, self.world)
+            out[rlo:rhi] = flat[r * self.width: r * self.width + (rhi - rlo)]
+        return out
+
+
 def solve_batch_distributed(table, values, sparse=True, device=None, solver=None, dist=None,
                             session=None):
     """Every rank passes the same `table` and the full `values`; each solves its
     shard and all ranks return the gathered [members, n] array."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1 or not sparse:
         return solve_members(table, values, sparse, device or 0, solver, session)
-    import torch
-    rank, world = dist.get_rank(), dist.get_world_size()
-    total = values.shape[0]
-    lo, hi = shard_range(total, rank, world)
-    use_cuda = dist.get_backend() == "nccl"
-    dev_index = device if device is not None else rank
-    dev = torch.device("cuda", dev_index) if use_cuda else torch.device("cpu")
-    # all_gather needs equal block sizes: short shards are padded with NaN rows
-    width = -(-total // world)
-    block = torch.full((width, table.n), float("nan"), dtype=torch.float64, device=dev)
-    on_device = use_cuda and solver is None and sparse and hi > lo
-    if on_device:
-        # shard solved on this rank's GPU, results handed to RCCL without touching the host
-        own = session if session is not None else BatchSolver(table, dev_index)
-        try:
-            own.upload_values(np.ascontiguousarray(values[lo:hi], dtype=np.float64))
-            own.run(sparse=True, download=False)
-            own.copy_to_device(block)
-        finally:
-            if session is None:
-                own.close()
-    elif hi > lo:
-        mine = solve_members(table, values[lo:hi], sparse, dev_index, solver, session)
-        block[: hi - lo] = torch.from_numpy(np.ascontiguousarray(mine)).to(dev)
-    gathered = torch.empty((world * width, table.n), dtype=torch.float64, device=dev)
-    dist.all_gather_into_tensor(gathered, block)
-    flat = gathered.cpu().numpy()
-    out = np.empty((total, table.n))
-    for r in range(world):
-        rlo, rhi = shard_range(total, r, world)
-        out[rlo:rhi] = flat[r * width: r * width + (rhi - rlo)]
-    return out
+    with ShardedBatch(table, values.shape[0], dist, device, solver) as shard:
+        shard.upload(values[shard.lo:shard.hi])
+        shard.step()
+        return shard.result()
 
 
 def broadcast_table(table, dist, src=0):

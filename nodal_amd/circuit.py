@@ -138,6 +138,11 @@ class Circuit:
                 indptr, indices, data, rhs = h.export_csr()
                 import scipy.sparse as spsp
                 self._G = spsp.csr_matrix((data, indices, indptr), shape=(h.n, h.n))
+                # The reference stamps into a dok_matrix, which never stores an exact zero (a +g / -g
+                # pair, a zero gain): its `G.tocsr()` has no such entries (reference nodal/nodal.py:
+                # 396-397).  The device keeps them -- the pattern is the topology's, whatever the
+                # values -- so they are dropped from the exported copy only.
+                self._G.eliminate_zeros()
                 self._A = rhs
             else:
                 self._G, self._A = h.export_dense()

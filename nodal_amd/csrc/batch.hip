@@ -51,15 +51,58 @@ __global__ __launch_bounds__(TB) void replicate_rows(
     }
 }
 
-// block-diagonal unknown vector -> [count][K + B]
+// block-diagonal unknown vector -> [count][K + B], member m's part times its right-hand-side scale
 __global__ __launch_bounds__(TB) void split_members(int32_t count, int32_t K, int32_t B,
                                                     const double *__restrict__ x,
+                                                    const double *__restrict__ scale,
                                                     double *__restrict__ out) {
     const int64_t n = (int64_t)K + B, total = n * count;
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TB) {
         const int64_t m = i / n, j = i - m * n;
-        out[i] = j < K ? x[m * K + j] : x[(int64_t)count * K + m * B + (j - K)];
+        out[i] = scale[m] * (j < K ? x[m * K + j] : x[(int64_t)count * K + m * B + (j - K)]);
     }
+}
+
+// ---- per-member equilibration of the right-hand side -------------------------------------
+// The block system is solved by ONE Krylov iteration with ONE stopping test (|r| <= tol |b| over
+// the whole shard).  A member whose sources are orders of magnitude weaker than the others' would
+// be left far less converged than a solve of its own -- the reference's loop of per-circuit direct
+// solves treats every member alike -- so every member's right-hand side is scaled to [1, 2) by a
+// power of two (exact in floating point; the systems are linear and independent: x_m = s_m x~_m)
+// before the joint solve.  Then the one test bounds every member's relative residual.
+__device__ __forceinline__ int64_t member_of_row(int64_t i, int32_t count, int32_t K, int32_t B) {
+    const int64_t nodes = (int64_t)count * K;
+    return i < nodes ? i / K : (i - nodes) / B;
+}
+// absmax[m] = max |rhs_i| over member m's rows (non-negative doubles order like their bit patterns:
+// an integer atomicMax is exact and order-independent)
+__global__ __launch_bounds__(TB) void member_absmax(int64_t n, int32_t count, int32_t K, int32_t B,
+                                                    const double *__restrict__ rhs,
+                                                    unsigned long long *__restrict__ absmax) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        const double v = fabs(rhs[i]);
+        if (v > 0.0 && v == v) atomicMax(&absmax[member_of_row(i, count, K, B)], (unsigned long long)__double_as_longlong(v));
+    }
+}
+// absmax[m] (bit pattern) -> scale[m] = 2^floor(log2 absmax) (1 for an all-zero or non-finite member)
+__global__ __launch_bounds__(TB) void member_scales(int32_t count, const unsigned long long *__restrict__ absmax,
+                                                    double *__restrict__ scale) {
+    for (int32_t m = blockIdx.x * TB + threadIdx.x; m < count; m += gridDim.x * TB) {
+        const double v = __longlong_as_double((long long)absmax[m]);
+        int e = 0;
+        double s = 1.0;
+        if (v > 0.0 && v < 1.0 / 0.0) {
+            (void)frexp(v, &e);          // v = f 2^e, f in [0.5, 1)
+            s = ldexp(1.0, e - 1);       // 2^(e-1) <= v < 2^e
+            if (!(s > 0.0)) s = 1.0;     // (denormal range: leave it)
+        }
+        scale[m] = s;
+    }
+}
+__global__ __launch_bounds__(TB) void member_scale_rhs(int64_t n, int32_t count, int32_t K, int32_t B,
+                                                       const double *__restrict__ scale, double *__restrict__ rhs) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+        rhs[i] /= scale[member_of_row(i, count, K, B)];  // (a power of two: exact)
 }
 
 __global__ __launch_bounds__(TB) void fill_nan_rows(double *__restrict__ out, int64_t n) {
@@ -299,6 +342,17 @@ int nodal_run_batch(nodal_handle h, int32_t first, int32_t count, int32_t reuse_
         double rs = 0.0;
         int64_t bad = -1;
         if (s == NODAL_OK) s = stamp_numeric(c, 0, &bad);
+        double *scale = nullptr;
+        if (s == NODAL_OK) {  // every member's right-hand side to [1, 2): one stopping test serves them all
+            NODAL_HIP_TRY(h, h->batch_scale.reserve((size_t)count * 16 + 64));
+            unsigned long long *absmax = h->batch_scale.as<unsigned long long>();
+            scale = reinterpret_cast<double *>(absmax + count);
+            NODAL_HIP_TRY(h, hipMemsetAsync(absmax, 0, (size_t)count * 8, st));
+            member_absmax<<<grid_for(c->n), TB, 0, st>>>(c->n, count, h->K, h->B, c->rhs.as<double>(), absmax);
+            member_scales<<<grid_for(count), TB, 0, st>>>(count, absmax, scale);
+            member_scale_rhs<<<grid_for(c->n), TB, 0, st>>>(c->n, count, h->K, h->B, scale, c->rhs.as<double>());
+            NODAL_HIP_TRY(h, hipGetLastError());
+        }
         NODAL_HIP_TRY(h, hipEventRecord(ev[2], st));
         if (s == NODAL_OK) {
             c->amg_levels = 0;
@@ -306,7 +360,7 @@ int nodal_run_batch(nodal_handle h, int32_t first, int32_t count, int32_t reuse_
         }
         NODAL_HIP_TRY(h, hipEventRecord(ev[3], st));
         if (s == NODAL_OK && inf == 0) {
-            split_members<<<grid_for(n * count), TB, 0, st>>>(count, h->K, h->B, c->x.as<double>(), out);
+            split_members<<<grid_for(n * count), TB, 0, st>>>(count, h->K, h->B, c->x.as<double>(), scale, out);
             NODAL_HIP_TRY(h, hipGetLastError());
             if (info_out)
                 for (int32_t m = 0; m < count; ++m) info_out[m] = 0;

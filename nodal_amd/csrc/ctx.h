@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -23,6 +24,16 @@ struct DevBuf {
         size_t want = bytes + (bytes >> 3) + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
+        // A buffer that grows starts from zeros, whatever the allocator hands back (memory this
+        // process freed a moment ago holds old indices, NaN-filled solutions ...): a kernel that reads
+        // a slot nobody has written yet -- padding it multiplies by zero, a row it masks afterwards --
+        // then behaves the same in every run.  Only on growth: the steady state never allocates.
+        // NODAL_POISON=1 (debugging) fills with 0xFF bytes instead -- NaNs as doubles, -1 as integers --
+        // to make such reads show (expect out-of-bounds faults: run single cases, not the suite).
+        static const bool poison = getenv("NODAL_POISON") != nullptr;
+        if (e == hipSuccess) e = hipMemset(p, poison ? 0xFF : 0, want);
+        // (the fill runs on the null stream; the contexts' streams do not wait for that one by themselves)
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
         return e;
     }
     void release() {
@@ -70,6 +81,7 @@ struct nodal_ctx {
     nodal_ctx *blocksys = nullptr;
     uint64_t block_epoch = 0;      // (child) table_epoch of the parent its table was replicated from
     DevBuf batch_x;
+    DevBuf batch_scale;            // per-member right-hand-side scales of the last block solve (batch.hip)
     int32_t batch_count = 0;
     bool last_batch_block = false;  // the last solve was a block-diagonal batch (nodal_residual looks at it)
     hipEvent_t ev_batch[4] = {nullptr, nullptr, nullptr, nullptr};  // phase timing of nodal_run_batch
@@ -234,6 +246,7 @@ void sagg_destroy(nodal_ctx *h);
 // smoothed-aggregation FCG (sagg.hip): NODAL_OK, -1 breakdown, -2 structurally singular,
 // -3 declined (not this hierarchy's kind of network: use amg.hip)
 int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, int32_t *iters, double *resid);
+void sagg_invalidate(nodal_ctx *h);  // the hierarchy is not to be used again until the next setup
 // the same hierarchy as a preconditioner for any device CSR matrix (general: a few off-diagonals
 // of either sign, not symmetric); sagg_apply: z ~= A^-1 r with one cycle
 int sagg_setup_csr(nodal_ctx *h, int64_t n, int64_t nnz, const int32_t *indptr, const int32_t *indices,

@@ -29,6 +29,8 @@
 // One host round trip per level (the number of aggregates sizes the next level).
 #include <hip/hip_ext.h>
 
+#include <atomic>
+
 #include "group.h"
 
 int grounded_flags(nodal_ctx *h, uint8_t *flags_dev);  // lowdeg.hip
@@ -1176,7 +1178,18 @@ int build_tail(nodal_ctx *h, SHierarchy *H, const unsigned long long *hs) {
         if (d.lds_bytes > TAIL_LDS_BUDGET) continue;
         d.slots = d.nlev > 1 ? (d.lv[0].width + d.lv[0].lpr - 1) / d.lv[0].lpr : 1;
         if (d.slots > 32) continue;
-        NODAL_HIP_TRY(h, hipFuncSetAttribute(tail_kernel(d.slots), hipFuncAttributeMaxDynamicSharedMemorySize, d.lds_bytes));
+        {   // the attribute belongs to the device's code object, not to this handle: raised ONCE per device
+            // to the budget (a per-setup value could be lowered by another handle's smaller tail between
+            // this setup and this hierarchy's launches)
+            static std::atomic<bool> lds_allowed[64][3];
+            const int dev = h->device >= 0 && h->device < 64 ? h->device : 0;
+            const int which = d.slots <= 8 ? 0 : (d.slots <= 16 ? 1 : 2);
+            if (!lds_allowed[dev][which].load(std::memory_order_acquire)) {
+                NODAL_HIP_TRY(h, hipFuncSetAttribute(tail_kernel(d.slots), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     TAIL_LDS_BUDGET));
+                lds_allowed[dev][which].store(true, std::memory_order_release);
+            }
+        }
         NODAL_HIP_TRY(h, H->tail_image.reserve((size_t)d.image_bytes + 256));
         k_tail_pack<<<1, 1024, 0, h->stream>>>(d, H->tail_image.as<char>());
         NODAL_HIP_TRY(h, hipGetLastError());
@@ -1491,6 +1504,9 @@ __global__ __launch_bounds__(TB) void k_x0(int64_t n, const double *__restrict__
 bool sagg_ready(nodal_ctx *h, int64_t n) {
     SHierarchy *H = static_cast<SHierarchy *>(h->sagg);
     return H && H->ready && H->pool[0]->n == n;
+}
+void sagg_invalidate(nodal_ctx *h) {
+    if (h->sagg) static_cast<SHierarchy *>(h->sagg)->ready = false;
 }
 int sagg_levels(nodal_ctx *h) { return h->sagg ? static_cast<SHierarchy *>(h->sagg)->nlev : 0; }
 int sagg_apply(nodal_ctx *h, const double *r, double *z) {

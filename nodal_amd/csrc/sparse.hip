@@ -476,7 +476,15 @@ int amg_fcg_solve_ex(nodal_ctx *h, const double *b, bool do_setup, int32_t *info
                      double *resid) {
     {   // networks without graded links / hubs: smoothed aggregation (sagg.hip); it declines the rest
         const int s = sagg_fcg_solve(h, b, do_setup, info, iters, resid);
-        if (s != -3) return s;
+        if (s == -1) {
+            // the smoothed hierarchy took the matrix but the iteration broke down or hit its cap
+            // (slowly converging chain-like / graded networks): the plain-aggregation hierarchy below,
+            // with its contrast mode and its higher cap, gets its turn before Jacobi-CG does
+            sagg_invalidate(h);
+            do_setup = true;
+        } else if (s != -3) {
+            return s;
+        }
     }
     const int64_t n = h->n;
     hipStream_t st = h->stream;
@@ -786,6 +794,13 @@ bool general_floating_island(const nodal_ctx *h) {
         const uint8_t ty = t.type[(size_t)i];
         const bool ties = (ty == NODAL_T_R && value[i] != 0.0 && value[i] == value[i]) || ty == NODAL_T_E ||
                           ty == NODAL_T_VCVS || ty == NODAL_T_CCVS;
+        // (Control terminals never tie an island: the KCL rows of a set of nodes that no resistor or
+        // voltage-defined branch joins to the ground node sum to zero whatever the control terms say --
+        // what leaves one of its nodes enters another -- so such a system is singular even when a
+        // branch equation like e_a - e_b = gain (e_c - 0) seems to fix the island's level.  With the
+        // reference's stamps (VCCS rows are stamped as VCVS, reference nodal/nodal.py:377-378) there is
+        // no transconductance to ground; tests/test_gpu_parity.py::test_island_with_a_grounded_control_
+        // terminal_is_still_singular and ::test_island_grounded_through_a_vccs_row.)
         if (!ties) continue;
         const int32_t a = t.a[(size_t)i] < 0 ? K : t.a[(size_t)i], b = t.b[(size_t)i] < 0 ? K : t.b[(size_t)i];
         uf.unite(a, b);

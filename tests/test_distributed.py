@@ -70,3 +70,80 @@ def test_two_rank_gloo_batch(members):
     want = oracle_solver(table, vals, True)
     for rank in (0, 1):
         assert np.array_equal(results[rank], want)  # every rank holds the whole batch
+
+
+def _sharded_worker(rank, world, port, members, q):
+    """The same ShardedBatch entry bench.py's config 4 runs per rank (oracle stand-in: no GPU here)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    table = gen.grid_table(6)
+    vals = np.ones((members, table.ncomp))
+    for b in range(members):
+        vals[b, :-1] = gen.cfg4_values(b, 6)
+    with batch.ShardedBatch(table, members, dist, solver=oracle_solver) as shard:
+        shard.upload(vals[shard.lo:shard.hi])
+        shard.step()
+        first = shard.result()
+        shard.step()  # buffers are reused from step to step
+        q.put((rank, first, shard.result(), shard.own_block(), (shard.lo, shard.hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("members", [5, 8])
+def test_two_rank_sharded_batch_steps(members):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, members, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    table = gen.grid_table(6)
+    vals = np.ones((members, table.ncomp))
+    for b in range(members):
+        vals[b, :-1] = gen.cfg4_values(b, 6)
+    want = oracle_solver(table, vals, True)
+    for rank, first, second, own, (lo, hi) in got:
+        assert np.array_equal(first, want) and np.array_equal(second, want)
+        assert np.array_equal(own, want[lo:hi])
+
+
+def test_single_process_sharded_batch_without_group():
+    """No process group: one shard holding everything, no collective."""
+    table = gen.grid_table(5)
+    vals = np.ones((3, table.ncomp))
+    with batch.ShardedBatch(table, 3, None, solver=oracle_solver) as shard:
+        assert (shard.lo, shard.hi, shard.world) == (0, 3, 1) and shard.gathered is None
+        shard.upload(vals)
+        shard.step()
+        assert np.array_equal(shard.result(), oracle_solver(table, vals, True))
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_gather():
+    """Backend "nccl" (= RCCL) with world_size 1 on the one GPU of the box: config 4's per-GPU
+    shard through ShardedBatch in a FRESH child process (RCCL initialised before any other
+    GPU call there), all_gather_into_tensor on the device tensor nodal_batch_x_device filled;
+    the gathered block must equal the rank's own and member 3 the reference's golden samples."""
+    import json
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_child.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, child, str(port)], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    assert out["backend"] == "nccl" and out["world_size"] == 1
+    assert out["tensors_on_device"] and out["gathered_equals_block"] and out["finite"]
+    assert out["member3_normwise_error"] <= 1e-9
