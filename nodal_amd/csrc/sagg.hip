@@ -151,6 +151,16 @@ struct SHierarchy {
     DevBuf stats, coarse_inv, mis_t, mis_m, mis_flag, mis_id, agg1, keys, rstart, cursor, lists;
     TailDesc td;
     uint64_t *host_stats = nullptr;  // pinned
+    // The symbolic part of the setup -- aggregates, the patterns of P, R and of every coarse matrix, the
+    // tail's layout, the structural-singularity verdict -- depends on the PATTERN of the level-0 matrix
+    // only.  It is kept while the context's struct_epoch stands (a value sweep on one topology, a
+    // repeated solve, the members of a batch): a later setup recomputes values only (sagg_refresh).
+    bool sym_valid = false;
+    uint64_t sym_epoch = 0;
+    int64_t sym_n = 0, sym_nnz = 0;
+    bool sym_general = false, sym_check = false;
+    int32_t sym_floating = 0;
+    unsigned long long sym_stats[MAX_LEVELS * ST_COUNT] = {0};
     SLevel *level(int l) {
         while ((int)pool.size() <= l) pool.push_back(new SLevel());
         return pool[l];
@@ -244,11 +254,12 @@ __global__ __launch_bounds__(TB) void row_stats(int64_t n, const int32_t *__rest
     }
 }
 
+// (valf: the f32 copy of the values the cycle's sweeps read, written by the producer of the f64 ones)
 __global__ __launch_bounds__(TB) void csr_to_ell(int64_t n, int64_t ld, const int32_t *__restrict__ indptr,
                                                  const int32_t *__restrict__ indices,
                                                  const double *__restrict__ data, int32_t *__restrict__ col,
-                                                 double *__restrict__ val, int32_t *__restrict__ len,
-                                                 double *__restrict__ dinv, int32_t wpad) {
+                                                 double *__restrict__ val, float *__restrict__ valf,
+                                                 int32_t *__restrict__ len, double *__restrict__ dinv, int32_t wpad) {
     for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
         const int32_t e0 = indptr[i], e1 = indptr[i + 1];
         double d = 1.0;
@@ -257,11 +268,13 @@ __global__ __launch_bounds__(TB) void csr_to_ell(int64_t n, int64_t ld, const in
             const double v = data[e];
             col[(int64_t)(e - e0) * ld + i] = c;
             val[(int64_t)(e - e0) * ld + i] = v;
+            valf[(int64_t)(e - e0) * ld + i] = (float)v;
             if (c == (int32_t)i) d = v;
         }
         for (int32_t s = e1 - e0; s < wpad; ++s) {  // zero padding up to the fixed width
             col[(int64_t)s * ld + i] = (int32_t)i;
             val[(int64_t)s * ld + i] = 0.0;
+            valf[(int64_t)s * ld + i] = 0.0f;
         }
         len[i] = e1 - e0;
         dinv[i] = 1.0 / d;
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(TB) void assign_far(Ell A, const int32_t *__restric
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(TB) void build_P(Ell A, const double *__restrict__ dinv,
                                               const int32_t *__restrict__ agg, int32_t *__restrict__ pcol,
-                                              double *__restrict__ pval) {
+                                              double *__restrict__ pval, float *__restrict__ pvalf) {
     for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
         int32_t c[PW];
         double v[PW];
@@ -426,6 +439,7 @@ __global__ __launch_bounds__(TB) void build_P(Ell A, const double *__restrict__ 
         for (int k = 0; k < PW; ++k) {
             pcol[(int64_t)k * A.ld + i] = c[k];
             pval[(int64_t)k * A.ld + i] = v[k];
+            pvalf[(int64_t)k * A.ld + i] = (float)v[k];
         }
     }
 }
@@ -457,7 +471,8 @@ __global__ __launch_bounds__(TB) void r_fill(int64_t n, int64_t ld, const int32_
 __global__ __launch_bounds__(TB) void r_to_ell(int64_t nc, int64_t rld, const uint32_t *__restrict__ rstart,
                                                const uint64_t *__restrict__ keys, int64_t ld,
                                                const double *__restrict__ pval, int32_t *__restrict__ rcol,
-                                               double *__restrict__ rval, int32_t *__restrict__ rlen,
+                                               double *__restrict__ rval, float *__restrict__ rvalf,
+                                               int32_t *__restrict__ rlen,
                                                unsigned long long *__restrict__ stats, uint32_t *__restrict__ bstat,
                                                uint32_t rcap) {
     uint32_t mlen = 0;
@@ -476,11 +491,14 @@ __global__ __launch_bounds__(TB) void r_to_ell(int64_t nc, int64_t rld, const ui
             if (t < l) {
                 const uint64_t key = keys[s0 + t];
                 const int64_t i = (int64_t)(key >> 2);
+                const double v = pval[(int64_t)(key & 3) * ld + i];
                 rcol[at] = (int32_t)i;
-                rval[at] = pval[(int64_t)(key & 3) * ld + i];
+                rval[at] = v;
+                rvalf[at] = (float)v;
             } else {
                 rcol[at] = 0;
                 rval[at] = 0.0;
+                rvalf[at] = 0.0f;
             }
         }
         if (sub == 0) rlen[I] = (int32_t)l;
@@ -499,6 +517,32 @@ __global__ __launch_bounds__(TB) void r_to_ell(int64_t nc, int64_t rld, const ui
     if (threadIdx.x == 0) {
         bstat[blockIdx.x] = s_max;
         bstat[BSTAT_MAX + blockIdx.x] = 0;
+    }
+}
+
+// The values of R again for a matrix of the SAME pattern (a value sweep, a repeated solve: the
+// hierarchy's symbolic part -- aggregates, patterns of P, R and the coarse matrices -- is kept):
+// entry t of coarse row I names fine row i; its value is the entry of P's row i whose column is I.
+__global__ __launch_bounds__(TB) void r_refresh(int64_t nc, int64_t rld, const int32_t *__restrict__ rlen,
+                                                const int32_t *__restrict__ rcol, int64_t ld,
+                                                const int32_t *__restrict__ pcol, const double *__restrict__ pval,
+                                                double *__restrict__ rval, float *__restrict__ rvalf) {
+    const int sub = threadIdx.x & 7;
+    const int64_t rows_per_pass = (int64_t)gridDim.x * (TB / 8);
+    for (int64_t I = (int64_t)xcd_block() * (TB / 8) + threadIdx.x / 8; I < nc; I += rows_per_pass) {
+        const int32_t l = rlen[I];
+        for (int32_t t = sub; t < l; t += 8) {
+            const int64_t at = ((int64_t)(t >> 3) * rld + I) * 8 + (t & 7);
+            const int64_t i = rcol[at];
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < PW; ++k) {
+                const double pv = pval[(int64_t)k * ld + i];
+                v = pcol[(int64_t)k * ld + i] == (int32_t)I ? pv : v;
+            }
+            rval[at] = v;
+            rvalf[at] = (float)v;
+        }
     }
 }
 
@@ -727,11 +771,15 @@ __device__ __forceinline__ int galerkin_products(int64_t ld, const int32_t *__re
 }
 
 // G: R entries per group (G * APW products fit in the LDS list)
+// NUMERIC: the row's sorted column set is already in ccol / clen (same pattern as at the symbolic
+// setup): no hash set, no sort -- every lane takes its column and sums its products.
+template <bool NUMERIC>
 __global__ __launch_bounds__(64) void galerkin(int64_t ld, const int32_t *__restrict__ apcol,
                                                const double *__restrict__ apval, const int32_t *__restrict__ aplen,
                                                int64_t nc, int64_t rld, const int32_t *__restrict__ rcol,
                                                const double *__restrict__ rval, const int32_t *__restrict__ rlen,
                                                int64_t cld, int32_t *__restrict__ ccol, double *__restrict__ cval,
+                                               float *__restrict__ cvalf,
                                                int32_t *__restrict__ clen, double *__restrict__ cdinv,
                                                unsigned long long *__restrict__ stats, uint32_t *__restrict__ bstat,
                                                int G, int pcap) {
@@ -742,12 +790,18 @@ __global__ __launch_bounds__(64) void galerkin(int64_t ld, const int32_t *__rest
     const int lane = threadIdx.x;
     uint32_t my_max = 0, my_nnz = 0, my_flags = 0;
     for (int64_t I = blockIdx.x; I < nc; I += gridDim.x) {
-        for (int k = lane; k < 256; k += 64) set[k] = -1;
-        __syncthreads();
         const int rl = rlen[I];
         const int ngroups = (rl + G - 1) / G;
-        // pass 1: the set of columns
         int np = 0;
+        int total = 0;
+        int32_t myJ = 0x7fffffff;
+        if constexpr (NUMERIC) {
+            total = clen[I];
+            if (lane < total) myJ = ccol[(int64_t)lane * cld + I];
+        } else {
+        for (int k = lane; k < 256; k += 64) set[k] = -1;
+        __syncthreads();
+        // pass 1: the set of columns
         for (int g = 0; g < ngroups; ++g) {
             np = galerkin_products(ld, apcol, apval, aplen, rld, rcol, rval, I, g * G, min(G, rl - g * G), lJ, lV);
             for (int p = lane; p < np; p += 64) {
@@ -770,7 +824,6 @@ __global__ __launch_bounds__(64) void galerkin(int64_t ld, const int32_t *__rest
             mine[q] = set[lane * 4 + q];
             cnt += mine[q] >= 0 ? 1 : 0;
         }
-        int total = 0;
         int off = wave_excl_scan(cnt, &total);
         __syncthreads();
         // (the compacted columns go through `set` itself: every lane has read its slots)
@@ -782,7 +835,7 @@ __global__ __launch_bounds__(64) void galerkin(int64_t ld, const int32_t *__rest
             my_flags |= 1u;
             total = ACAP;
         }
-        int32_t myJ = lane < total ? set[lane] : 0x7fffffff;
+        myJ = lane < total ? set[lane] : 0x7fffffff;
         __syncthreads();
 #pragma unroll
         for (int k = 2; k <= 64; k <<= 1) {
@@ -794,11 +847,12 @@ __global__ __launch_bounds__(64) void galerkin(int64_t ld, const int32_t *__rest
                 myJ = (lower == up) ? lo : hi;
             }
         }
+        }  // !NUMERIC
         // pass 2: eight products per step, loaded unconditionally (a compare-then-load loop pays the
         // LDS latency twice per product); + 0.0 for the others leaves the sum, and its order, unchanged
         double acc = 0.0;
         for (int g = 0; g < ngroups; ++g) {
-            if (ngroups > 1)
+            if (ngroups > 1 || NUMERIC)
                 np = galerkin_products(ld, apcol, apval, aplen, rld, rcol, rval, I, g * G, min(G, rl - g * G), lJ, lV);
             for (int p = 0; p < np; p += 8) {
                 int32_t j8[8];
@@ -816,10 +870,12 @@ __global__ __launch_bounds__(64) void galerkin(int64_t ld, const int32_t *__rest
         if (lane >= total && lane < APAD) {  // zero padding: fixed-trip-count row loops (tail, unrolled kernels)
             ccol[(int64_t)lane * cld + I] = (int32_t)I;
             cval[(int64_t)lane * cld + I] = 0.0;
+            cvalf[(int64_t)lane * cld + I] = 0.0f;
         }
         if (lane < total) {
             ccol[(int64_t)lane * cld + I] = myJ;
             cval[(int64_t)lane * cld + I] = acc;
+            cvalf[(int64_t)lane * cld + I] = (float)acc;
             if (myJ == (int32_t)I) {
                 if (!(acc > 0.0)) my_flags |= 4u;
                 cdinv[I] = acc > 0.0 ? 1.0 / acc : 1.0;
@@ -941,10 +997,6 @@ int width_class(int maxlen) {
     return 0;
 }
 // padded rows pay when the padding is small, or when the level is so small that latency is all
-__global__ __launch_bounds__(TB) void to_f32(const double *__restrict__ src, float *__restrict__ dst, int64_t count) {
-    for (int64_t e = (int64_t)xcd_block() * TB + threadIdx.x; e < count; e += (int64_t)gridDim.x * TB) dst[e] = (float)src[e];
-}
-
 int choose_wfix(int maxlen, int64_t n, int64_t nnz, int pad_limit) {
     const int c = width_class(maxlen);
     if (c == 0 || c > pad_limit) return 0;
@@ -961,6 +1013,50 @@ struct SolveBufs {
     double *r, *z, *p, *Ap, *x0, *part_rz, *part_zap, *part_rr, *part_pap, *sc;
     int g0;  // grid of the level-0 kernels that produce / consume dot partials
 };
+
+// A_c = R (A P) of level l into level l + 1: AP = A P (one thread per fine row), then one
+// wavefront per coarse row.  NUMERIC: the pattern of A_c is already there (see SHierarchy::sym_valid).
+template <bool NUMERIC>
+int galerkin_product(nodal_ctx *h, SHierarchy *H, int l) {
+    hipStream_t st = h->stream;
+    SLevel *L = H->level(l), *C = H->level(l + 1);
+    const int64_t n = L->n, ld = L->ld, nc = C->n;
+    Ell A = L->A();
+    A.width = L->maxlen;
+    unsigned long long *dstats = H->stats.as<unsigned long long>();
+    // (an AP row reaches the aggregates within two steps of the node: up to ~10 on a 5-point grid)
+    const int apw = A.width <= 6 ? 16 : 64;
+    NODAL_HIP_TRY(h, H->apcol.reserve((size_t)apw * ld * 4 + 64));
+    NODAL_HIP_TRY(h, H->apval.reserve((size_t)apw * ld * 8 + 64));
+    NODAL_HIP_TRY(h, H->aplen.reserve((size_t)ld * 4 + 64));
+    int32_t *apcol = H->apcol.as<int32_t>(), *aplen = H->aplen.as<int32_t>();
+    double *apval = H->apval.as<double>();
+    unsigned long long *lst = dstats + (size_t)l * ST_COUNT;
+    const unsigned g = grid_for(n);
+    switch (apw) {
+    case 16: ap_rows<16><<<g, TB, 0, st>>>(A, L->pcol.as<int32_t>(), L->pval.as<double>(), apcol, apval, aplen, lst); break;
+    default: {
+        const unsigned gl = (unsigned)((n + 63) / 64 < 4096 ? (n + 63) / 64 : 4096);
+        ap_rows_lds<64><<<gl, 64, 0, st>>>(A, L->pcol.as<int32_t>(), L->pval.as<double>(), apcol, apval, aplen, lst);
+    } break;
+    }
+    NODAL_HIP_TRY(h, hipGetLastError());
+    // R entries per group: G * apw products (12 bytes each) in the LDS list
+    int G = 1024 / apw;
+    G = (G < 8 ? 8 : (G > 64 ? 64 : G));
+    const int pcap = G * apw + 8;
+    const size_t lds = 1024 + (size_t)pcap * 12;
+    const unsigned gg = (unsigned)(nc < BSTAT_MAX ? nc : BSTAT_MAX);
+    galerkin<NUMERIC><<<gg, 64, lds, st>>>(
+        ld, apcol, apval, aplen, nc, L->rld, L->rcol.as<int32_t>(), L->rval.as<double>(), L->rlen.as<int32_t>(),
+        C->ld, C->acol.as<int32_t>(), C->aval.as<double>(), C->avalf.as<float>(), C->alen.as<int32_t>(),
+        C->dinv.as<double>(), dstats + (size_t)(l + 1) * ST_COUNT, H->bstat.as<uint32_t>(), G, pcap);
+    if (!NUMERIC)
+        reduce_bstat<<<1, 1024, 0, st>>>((int)gg, H->bstat.as<uint32_t>(), dstats + (size_t)(l + 1) * ST_COUNT,
+                                         ST_MAXLEN, ST_NNZ);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
+}
 
 // one aggregation + transfer operators + Galerkin product: level l -> l + 1.
 // *stop: the level cannot be coarsened (every node is its own aggregate).
@@ -1037,8 +1133,9 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     assign_far<<<g, TB, 0, st>>>(A, H->agg1.as<int32_t>(), L->agg.as<int32_t>(), dstats + (size_t)l * ST_COUNT);
     NODAL_HIP_TRY(h, L->pcol.reserve((size_t)PW * ld * 4 + 64));
     NODAL_HIP_TRY(h, L->pval.reserve((size_t)PW * ld * 8 + 64));
+    NODAL_HIP_TRY(h, L->pvalf.reserve((size_t)PW * ld * 4 + 64));
     build_P<<<g, TB, 0, st>>>(A, L->dinv.as<double>(), L->agg.as<int32_t>(), L->pcol.as<int32_t>(),
-                             L->pval.as<double>());
+                             L->pval.as<double>(), L->pvalf.as<float>());
     NODAL_HIP_TRY(h, hipGetLastError());
 
     // R = P^T by coarse row
@@ -1068,50 +1165,21 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     const int rcap = rcap_for(nc);
     NODAL_HIP_TRY(h, L->rcol.reserve((size_t)rcap * C->ld * 4 + 64));
     NODAL_HIP_TRY(h, L->rval.reserve((size_t)rcap * C->ld * 8 + 64));
+    NODAL_HIP_TRY(h, L->rvalf.reserve((size_t)rcap * C->ld * 4 + 64));
     NODAL_HIP_TRY(h, L->rlen.reserve((size_t)C->ld * 4 + 64));
     {
         const unsigned gr = grid_for(nc * 8);
         r_to_ell<<<gr, TB, 0, st>>>(nc, L->rld, rstart, keys, ld, L->pval.as<double>(), L->rcol.as<int32_t>(),
-                                   L->rval.as<double>(), L->rlen.as<int32_t>(), dstats + (size_t)l * ST_COUNT,
-                                   H->bstat.as<uint32_t>(), (uint32_t)rcap);
+                                   L->rval.as<double>(), L->rvalf.as<float>(), L->rlen.as<int32_t>(),
+                                   dstats + (size_t)l * ST_COUNT, H->bstat.as<uint32_t>(), (uint32_t)rcap);
         reduce_bstat<<<1, 1024, 0, st>>>((int)gr, H->bstat.as<uint32_t>(), dstats + (size_t)l * ST_COUNT, ST_MAXR, -1);
     }
     NODAL_HIP_TRY(h, C->acol.reserve((size_t)ACAP * C->ld * 4 + 64));
     NODAL_HIP_TRY(h, C->aval.reserve((size_t)ACAP * C->ld * 8 + 64));
+    NODAL_HIP_TRY(h, C->avalf.reserve((size_t)ACAP * C->ld * 4 + 64));
     NODAL_HIP_TRY(h, C->alen.reserve((size_t)C->ld * 4 + 64));
     NODAL_HIP_TRY(h, C->dinv.reserve((size_t)C->ld * 8 + 64));
-    {
-        // AP = A P (one thread per fine row), then A_c = R (AP) (one wavefront per coarse row)
-        // (an AP row reaches the aggregates within two steps of the node: up to ~10 on a 5-point grid)
-        const int apw = A.width <= 6 ? 16 : 64;
-        NODAL_HIP_TRY(h, H->apcol.reserve((size_t)apw * ld * 4 + 64));
-        NODAL_HIP_TRY(h, H->apval.reserve((size_t)apw * ld * 8 + 64));
-        NODAL_HIP_TRY(h, H->aplen.reserve((size_t)ld * 4 + 64));
-        int32_t *apcol = H->apcol.as<int32_t>(), *aplen = H->aplen.as<int32_t>();
-        double *apval = H->apval.as<double>();
-        unsigned long long *lst = dstats + (size_t)l * ST_COUNT;
-        switch (apw) {
-        case 16: ap_rows<16><<<g, TB, 0, st>>>(A, L->pcol.as<int32_t>(), L->pval.as<double>(), apcol, apval, aplen, lst); break;
-        default: {
-            const unsigned gl = (unsigned)((n + 63) / 64 < 4096 ? (n + 63) / 64 : 4096);
-            ap_rows_lds<64><<<gl, 64, 0, st>>>(A, L->pcol.as<int32_t>(), L->pval.as<double>(), apcol, apval, aplen, lst);
-        } break;
-        }
-        NODAL_HIP_TRY(h, hipGetLastError());
-        // R entries per group: G * apw products (12 bytes each) in the LDS list
-        int G = 1024 / apw;
-        G = (G < 8 ? 8 : (G > 64 ? 64 : G));
-        const int pcap = G * apw + 8;
-        const size_t lds = 1024 + (size_t)pcap * 12;
-        const unsigned gg = (unsigned)(nc < BSTAT_MAX ? nc : BSTAT_MAX);
-        galerkin<<<gg, 64, lds, st>>>(
-            ld, apcol, apval, aplen, nc, L->rld, L->rcol.as<int32_t>(), L->rval.as<double>(), L->rlen.as<int32_t>(),
-            C->ld, C->acol.as<int32_t>(), C->aval.as<double>(), C->alen.as<int32_t>(), C->dinv.as<double>(),
-            dstats + (size_t)(l + 1) * ST_COUNT, H->bstat.as<uint32_t>(), G, pcap);
-        reduce_bstat<<<1, 1024, 0, st>>>((int)gg, H->bstat.as<uint32_t>(), dstats + (size_t)(l + 1) * ST_COUNT,
-                                         ST_MAXLEN, ST_NNZ);
-    }
-    NODAL_HIP_TRY(h, hipGetLastError());
+    NODAL_TRY(galerkin_product<false>(h, H, l));
     return NODAL_OK;
 }
 
@@ -1200,6 +1268,59 @@ int build_tail(nodal_ctx *h, SHierarchy *H, const unsigned long long *hs) {
     return NODAL_OK;
 }
 
+// Values of every level again for a level-0 matrix of the pattern the symbolic part was built for
+// (SHierarchy::sym_valid): level-0 ELL values, then per level P (same aggregates), R (same entries),
+// A P and the Galerkin sums into the known coarse patterns, the coarsest inverse, the tail's image.
+// No aggregation, no sorting, no sizes to wait for: one read-back at the end for the value-dependent
+// verdicts (graded links, a non-positive pivot).  *ok = false: those verdicts say the full setup has
+// to look at this matrix (it will most likely decline it).
+int sagg_refresh(nodal_ctx *h, SHierarchy *H, const int32_t *indptr0, const int32_t *indices0, const double *data0,
+                 bool general, bool *ok) {
+    *ok = false;
+    hipStream_t st = h->stream;
+    unsigned long long *dstats = H->stats.as<unsigned long long>();
+    unsigned long long *hs = reinterpret_cast<unsigned long long *>(H->host_stats);
+    NODAL_HIP_TRY(h, hipMemsetAsync(dstats, 0, (size_t)MAX_LEVELS * ST_COUNT * 8, st));
+    SLevel *L0 = H->pool[0];
+    const int64_t n0 = L0->n;
+    {
+        const unsigned gr = grid_for(n0);
+        static const double spread = getenv("NODAL_SA_SPREAD") ? atof(getenv("NODAL_SA_SPREAD")) : 16.0;
+        static const double share = getenv("NODAL_SA_SHARE") ? atof(getenv("NODAL_SA_SHARE")) : 0.9;
+        row_stats<<<gr, TB, 0, st>>>(n0, indptr0, indices0, data0, share, spread, general, dstats, H->bstat.as<uint32_t>());
+        reduce_bstat<<<1, 1024, 0, st>>>((int)gr, H->bstat.as<uint32_t>(), dstats, ST_MAXLEN, ST_GRADED);
+    }
+    csr_to_ell<<<grid_for(n0), TB, 0, st>>>(n0, L0->ld, indptr0, indices0, data0, L0->acol.as<int32_t>(),
+                                           L0->aval.as<double>(), L0->avalf.as<float>(),
+                                           L0->alen.as<int32_t>(), L0->dinv.as<double>(), L0->wfix);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    for (int l = 0; l + 1 < H->nlev; ++l) {
+        SLevel *L = H->pool[l], *C = H->pool[l + 1];
+        Ell A = L->A();
+        A.width = L->maxlen;
+        build_P<<<grid_for(L->n), TB, 0, st>>>(A, L->dinv.as<double>(), L->agg.as<int32_t>(), L->pcol.as<int32_t>(),
+                                              L->pval.as<double>(), L->pvalf.as<float>());
+        r_refresh<<<grid_for(C->n * 8), TB, 0, st>>>(C->n, L->rld, L->rlen.as<int32_t>(), L->rcol.as<int32_t>(), L->ld,
+                                                    L->pcol.as<int32_t>(), L->pval.as<double>(), L->rval.as<double>(),
+                                                    L->rvalf.as<float>());
+        NODAL_HIP_TRY(h, hipGetLastError());
+        NODAL_TRY(galerkin_product<true>(h, H, l));
+    }
+    const int last = H->nlev - 1;
+    if (H->dense_coarsest)
+        coarsest_inverse<<<1, 256, 0, st>>>(H->pool[last]->A(), H->coarse_inv.as<double>(), dstats + (size_t)last * ST_COUNT);
+    if (H->tail >= 0) k_tail_pack<<<1, 1024, 0, st>>>(H->td, H->tail_image.as<char>());
+    NODAL_HIP_TRY(h, hipGetLastError());
+    NODAL_HIP_TRY(h, hipMemcpyAsync(hs, dstats, (size_t)MAX_LEVELS * ST_COUNT * 8, hipMemcpyDeviceToHost, st));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    const int64_t bar = n0 / 100 < 32 ? (n0 / 100 > 0 ? n0 / 100 : 1) : 32;
+    if (hs[ST_BADDIAG] || (int64_t)hs[ST_GRADED] >= bar) return NODAL_OK;
+    for (int k = 1; k < H->nlev; ++k)
+        if (hs[(size_t)k * ST_COUNT + ST_BADDIAG] || hs[(size_t)k * ST_COUNT + ST_OVERFLOW]) return NODAL_OK;
+    *ok = true;
+    return NODAL_OK;
+}
+
 }  // namespace
 
 void sagg_destroy(nodal_ctx *h) {
@@ -1228,6 +1349,23 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
     H->ready = false;
     hipStream_t st = h->stream;
     if (n0 >= (1ll << 30)) return NODAL_OK;
+    static const bool reuse = !(getenv("NODAL_SA_REUSE") && atoi(getenv("NODAL_SA_REUSE")) == 0);
+    if (reuse && H->sym_valid && H->sym_epoch == h->struct_epoch && H->sym_n == n0 && H->sym_nnz == nnz0 &&
+        H->sym_general == general && H->sym_check == check_floating) {
+        // same pattern as the matrix the hierarchy's symbolic part was built for: values only
+        bool ok = false;
+        NODAL_TRY(sagg_refresh(h, H, indptr0, indices0, data0, general, &ok));
+        if (ok) {
+            *floating = H->sym_floating;
+            H->ready = true;
+            *accepted = true;
+            if (trace) fprintf(stderr, "[sagg] symbolic setup kept (struct epoch %llu): values refreshed\n",
+                               (unsigned long long)h->struct_epoch);
+            return NODAL_OK;
+        }
+        if (trace) fprintf(stderr, "[sagg] the kept hierarchy does not take the new values: full setup\n");
+    }
+    H->sym_valid = false;
     NODAL_HIP_TRY(h, H->stats.reserve((size_t)MAX_LEVELS * ST_COUNT * 8 + 64));
     if (!H->host_stats)
         NODAL_HIP_TRY(h, hipHostMalloc(reinterpret_cast<void **>(&H->host_stats), (size_t)MAX_LEVELS * ST_COUNT * 8 + 64));
@@ -1267,10 +1405,11 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
     L0->width = L0->wfix ? L0->wfix : L0->maxlen;
     NODAL_HIP_TRY(h, L0->acol.reserve((size_t)L0->width * L0->ld * 4 + 64));
     NODAL_HIP_TRY(h, L0->aval.reserve((size_t)L0->width * L0->ld * 8 + 64));
+    NODAL_HIP_TRY(h, L0->avalf.reserve((size_t)L0->width * L0->ld * 4 + 64));
     NODAL_HIP_TRY(h, L0->alen.reserve((size_t)L0->ld * 4 + 64));
     NODAL_HIP_TRY(h, L0->dinv.reserve((size_t)L0->ld * 8 + 64));
     csr_to_ell<<<grid_for(n0), TB, 0, st>>>(n0, L0->ld, indptr0, indices0, data0, L0->acol.as<int32_t>(),
-                                           L0->aval.as<double>(),
+                                           L0->aval.as<double>(), L0->avalf.as<float>(),
                                            L0->alen.as<int32_t>(), L0->dinv.as<double>(), L0->wfix);
     NODAL_HIP_TRY(h, hipGetLastError());
 
@@ -1362,23 +1501,9 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
         }
         *floating = hs[(size_t)(MAX_LEVELS - 1) * ST_COUNT + ST_COUNT - 1] != 0 ? 1 : 0;
     }
-    // The cycle is a preconditioner: its matrices are read in f32 (a third less traffic per sweep;
-    // the iteration count does not move), the vectors, the outer SpMV and the residual stay f64.
-    {
-        const int visited = H->tail >= 0 ? H->tail : H->nlev - 1;  // levels whose sweeps are separate launches
-        for (int k = 0; k < visited; ++k) {
-            SLevel *L = H->pool[k];
-            const int64_t na = (int64_t)(L->wfix ? L->wfix : L->maxlen) * L->ld, np = (int64_t)PW * L->ld;
-            const int64_t nr = (int64_t)((hs[(size_t)k * ST_COUNT + ST_MAXR] + 7) / 8) * L->rld * RL;
-            NODAL_HIP_TRY(h, L->avalf.reserve((size_t)na * 4 + 64));
-            NODAL_HIP_TRY(h, L->pvalf.reserve((size_t)np * 4 + 64));
-            NODAL_HIP_TRY(h, L->rvalf.reserve((size_t)nr * 4 + 64));
-            to_f32<<<grid_for(na / 4 + 1), TB, 0, st>>>(L->aval.as<double>(), L->avalf.as<float>(), na);
-            to_f32<<<grid_for(np / 4 + 1), TB, 0, st>>>(L->pval.as<double>(), L->pvalf.as<float>(), np);
-            to_f32<<<grid_for(nr / 4 + 1), TB, 0, st>>>(L->rval.as<double>(), L->rvalf.as<float>(), nr);
-        }
-        NODAL_HIP_TRY(h, hipGetLastError());
-    }
+    // (The cycle is a preconditioner: its sweeps read f32 copies of A, P, R -- a third less traffic, the
+    // iteration count does not move -- which csr_to_ell, build_P, r_to_ell and the Galerkin kernel wrote
+    // beside the f64 values; the vectors, the outer SpMV and the residual stay f64.)
     if (trace) {
         fprintf(stderr, "[sagg] levels (rows/entries/longest row/padded width):");
         for (int k = 0; k < H->nlev; ++k)
@@ -1389,6 +1514,14 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
     }
     H->ready = true;
     *accepted = true;
+    H->sym_valid = true;
+    H->sym_epoch = h->struct_epoch;
+    H->sym_n = n0;
+    H->sym_nnz = nnz0;
+    H->sym_general = general;
+    H->sym_check = check_floating;
+    H->sym_floating = *floating;
+    memcpy(H->sym_stats, hs, sizeof H->sym_stats);
     return NODAL_OK;
 }
 

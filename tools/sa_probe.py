@@ -16,6 +16,7 @@ def golden(name):
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "1000"
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    reuse = len(sys.argv) > 3 and sys.argv[3] == "reuse"  # symbolic phases kept from the first run on
     if what.startswith("cfg5"):
         N = int(what[5:] or 1000) if ":" in what else 1000
         table = gen.cfg5_table(N)
@@ -28,7 +29,7 @@ def main():
     h.upload(table)
     for r in range(reps):
         t0 = time.perf_counter()
-        info = h.run(False)
+        info = h.run(False, 0, reuse and r > 0)
         h.synchronize()
         dt = (time.perf_counter() - t0) * 1e3
         it, lv, rr = h.solve_info()
