@@ -215,7 +215,7 @@ class BatchShard:
         return out
 
 
-def concurrent_throughput(name, device, streams, per_stream):
+def concurrent_throughput(name, device, streams, per_stream, reuse=False):
     """Throughput with `streams` independent solves in flight (one handle, HIP stream and host thread
     each): a solve alternates bandwidth-bound passes over the fine level with latency-bound
     launches on the coarse levels, so independent circuits overlap well.  Reported beside the
@@ -236,7 +236,7 @@ def concurrent_throughput(name, device, streams, per_stream):
 
     def work(h):
         for _ in range(per_stream):
-            if h.run(dense) != 0:
+            if h.run(dense, 0, reuse) != 0:
                 raise RuntimeError("solver reported a singular system")
 
     threads = [threading.Thread(target=work, args=(h,)) for h in handles]
@@ -249,7 +249,7 @@ def concurrent_throughput(name, device, streams, per_stream):
     for h in handles:
         h.close()
     n = streams * per_stream
-    return {"streams": streams, "circuits": n, "circuits_per_sec": n / elapsed,
+    return {"streams": streams, "circuits": n, "symbolic_phases_kept": bool(reuse), "circuits_per_sec": n / elapsed,
             "ms_per_circuit": elapsed / n * 1e3, "ms_latency_per_solve": elapsed / per_stream * 1e3}
 
 

@@ -31,9 +31,10 @@ struct DevBuf {
         // NODAL_POISON=1 (debugging) fills with 0xFF bytes instead -- NaNs as doubles, -1 as integers --
         // to make such reads show (expect out-of-bounds faults: run single cases, not the suite).
         static const bool poison = getenv("NODAL_POISON") != nullptr;
-        if (e == hipSuccess) e = hipMemset(p, poison ? 0xFF : 0, want);
+        static const bool nofill = getenv("NODAL_NOFILL") != nullptr;
+        if (e == hipSuccess && !nofill) e = hipMemset(p, poison ? 0xFF : 0, want);
         // (the fill runs on the null stream; the contexts' streams do not wait for that one by themselves)
-        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e == hipSuccess && !nofill) e = hipStreamSynchronize(nullptr);
         return e;
     }
     void release() {
@@ -123,6 +124,7 @@ struct nodal_ctx {
     DevBuf rhs_row;         // i32[nrhs]
     DevBuf rhs_cptr;        // i32[nrhs+1]
     DevBuf rhs_contrib;     // u32[nrhs_contrib]
+    DevBuf rhs_none;        // scratch: the (unused) column list of the rhs grouping
     DevBuf diag_pos;        // i32[n] position of (i,i) in CSR or -1
 
     // ---- numeric assembly results ----

@@ -160,6 +160,8 @@ struct SHierarchy {
     int64_t sym_n = 0, sym_nnz = 0;
     bool sym_general = false, sym_check = false;
     int32_t sym_floating = 0;
+    bool refreshed = false;      // the last setup was a values-only refresh
+    int last_iters = 0;          // iterations of the last converged solve on this hierarchy (0: none yet)
     unsigned long long sym_stats[MAX_LEVELS * ST_COUNT] = {0};
     SLevel *level(int l) {
         while ((int)pool.size() <= l) pool.push_back(new SLevel());
@@ -1044,6 +1046,11 @@ int galerkin_product(nodal_ctx *h, SHierarchy *H, int l) {
     // R entries per group: G * apw products (12 bytes each) in the LDS list
     int G = 1024 / apw;
     G = (G < 8 ? 8 : (G > 64 ? 64 : G));
+    // (level 0: 40 instead of 64 R entries per group -- 8.2 instead of 13.4 KB of LDS per wavefront, 19
+    // instead of 11 wavefronts per CU; the few rows of R beyond 40 entries take a second group:
+    // 8.80 -> 8.66 ms per fresh solve of the 1e6-node grid, 7.45 -> 7.22 ms with the patterns kept)
+    static const int g_env = getenv("NODAL_SA_GG") ? atoi(getenv("NODAL_SA_GG")) : 40;
+    if (g_env >= 8 && g_env <= 64 && apw == 16) G = g_env & ~7;
     const int pcap = G * apw + 8;
     const size_t lds = 1024 + (size_t)pcap * 12;
     const unsigned gg = (unsigned)(nc < BSTAT_MAX ? nc : BSTAT_MAX);
@@ -1357,6 +1364,7 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
         NODAL_TRY(sagg_refresh(h, H, indptr0, indices0, data0, general, &ok));
         if (ok) {
             *floating = H->sym_floating;
+            H->refreshed = true;
             H->ready = true;
             *accepted = true;
             if (trace) fprintf(stderr, "[sagg] symbolic setup kept (struct epoch %llu): values refreshed\n",
@@ -1366,6 +1374,8 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
         if (trace) fprintf(stderr, "[sagg] the kept hierarchy does not take the new values: full setup\n");
     }
     H->sym_valid = false;
+    H->refreshed = false;
+    H->last_iters = 0;
     NODAL_HIP_TRY(h, H->stats.reserve((size_t)MAX_LEVELS * ST_COUNT * 8 + 64));
     if (!H->host_stats)
         NODAL_HIP_TRY(h, hipHostMalloc(reinterpret_cast<void **>(&H->host_stats), (size_t)MAX_LEVELS * ST_COUNT * 8 + 64));
@@ -1730,6 +1740,10 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     double hs[F_COUNT];
     int64_t enqueued = 0;
     int batch = 6;   // iterations enqueued before the first look at the residual
+    // Same hierarchy as the last solve (values refreshed on the same pattern, or another right-hand side):
+    // the iteration count will be about the same, so the first look comes when that many have run --
+    // one or two polls instead of six or seven (each drains the queue: ~40 us).
+    if (H->last_iters > 6 && (H->refreshed || !do_setup)) batch = H->last_iters + 1 > 32 ? 32 : H->last_iters + 1;
     int status = 0;  // 0 running, 1 converged, 2 breakdown, 3 maxit
     double rr_prev = -1.0;
     int64_t it_prev = 0;
@@ -1804,7 +1818,11 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
                         H->td.lv[k].width, H->td.lv[k].lpr, H->td.lv[k].nq);
         }
     }
-    if (status != 1) return -1;
+    if (status != 1) {
+        H->last_iters = 0;
+        return -1;
+    }
+    H->last_iters = (int)its;
     *info = 0;
     return NODAL_OK;
 }

@@ -266,10 +266,10 @@ int stamp_symbolic(nodal_ctx *h) {
     const Table tb = table_of(h);
     NODAL_TRY(grp::build_lists(h, MatrixStamps{tb, tb.ncomp}, n, &h->nnz, &h->ncontrib, h->indices,
                                h->rowidx, h->cptr, h->contrib, &h->indptr, &h->diag_pos));
-    DevBuf none;  // rhs entries have no column index
-    NODAL_TRY(grp::build_lists(h, RhsStamps{tb, tb.ncomp}, n, &h->nrhs, &h->nrhs_contrib, none,
+    // (rhs entries have no column index: the column list lands in a scratch buffer the context keeps --
+    // a local one meant a hipMalloc and a hipFree, which waits for the whole device, per symbolic phase)
+    NODAL_TRY(grp::build_lists(h, RhsStamps{tb, tb.ncomp}, n, &h->nrhs, &h->nrhs_contrib, h->rhs_none,
                                h->rhs_row, h->rhs_cptr, h->rhs_contrib, nullptr, nullptr));
-    none.release();
     NODAL_HIP_TRY(h, h->data.reserve((size_t)h->nnz * 8 + 8));
     NODAL_HIP_TRY(h, h->rhs.reserve((size_t)n * 8 + 8));
     NODAL_HIP_TRY(h, h->x.reserve((size_t)n * 8 + 8));
