@@ -48,20 +48,32 @@ FP64_MFMA_INSTR_TF = 36.2   # v_mfma_f64_16x16x4_f64, 138 cycles/instruction/wav
 FP64_VALU_FMA_TF = 59.3     # v_fma_f64
 
 CIRCUITS_PER_STEP = {"cfg3": 32, "cfg5": 16, "cfg2": 8, "cfg4": 128}
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def pmc_traffic(workload):
     """HBM bytes per launch of the workload's dominant kernel from the committed rocprofv3
     PMC summary (FETCH_SIZE x2 + WRITE_SIZE, separate passes; profiles/<round>_pmc_traffic.json).
     None if that workload was not profiled."""
-    for rnd in (PROFILE_ROUND, "r01"):
+    for rnd in (PROFILE_ROUND, "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")) as f:
                 return json.load(f)["dominant"][workload]["hbm_bytes_per_launch"]
         except Exception:
             continue
     return None
+
+
+def profile_classes(workload):
+    """Where the GPU time of one solve goes, by class of kernel, from the committed rocprofv3 kernel
+    trace of this bench (profiles/<round>_classes.json, made by tools/prof_classes.py): level-0 passes
+    with their algorithmic bytes and rate, coarse levels, hierarchy setup, stamping, and the top kernel
+    BY TIME.  None if that workload was not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_classes.json")) as f:
+            return json.load(f).get(workload)
+    except Exception:
+        return None
 
 
 def alg_bytes(table, n, nnz):
@@ -102,7 +114,12 @@ class SingleCircuits:
         t0 = time.perf_counter()
         self.h.upload(self.table)
         self.h.synchronize()
+        self.h2d_first_ms = (time.perf_counter() - t0) * 1e3  # (device buffers allocated and zero-filled here)
+        t0 = time.perf_counter()
+        self.h.upload(self.table)
+        self.h.synchronize()
         self.h2d_ms = (time.perf_counter() - t0) * 1e3
+        self.reuse = False  # True: the symbolic phases (stamping lists, multigrid patterns) of the last circuit are kept
         self.phase = np.zeros(3)
         self.kern_ms = self.kern_n = 0
         self.kern_alg = 0.0
@@ -111,7 +128,7 @@ class SingleCircuits:
     def step(self):
         h = self.h
         for _ in range(self.per_step):
-            info = h.run(self.dense, member=0, reuse_symbolic=False)
+            info = h.run(self.dense, member=0, reuse_symbolic=self.reuse)
             if info != 0:
                 raise RuntimeError(f"solver reported info={info}")
             ms, launches, alg = h.kernel_stats()
@@ -134,9 +151,10 @@ class SingleCircuits:
         d2h_ms = (time.perf_counter() - t0) * 1e3
         iterations, levels, _ = h.solve_info()
         out = dict(resid=h.residual(), x0=float(x[0]), n=h.n, nnz=h.nnz, iterations=iterations,
-                   amg_levels=levels, d2h_ms=d2h_ms, h2d_ms=self.h2d_ms,
+                   amg_levels=levels, d2h_ms=d2h_ms, h2d_ms=self.h2d_ms, h2d_first_ms=self.h2d_first_ms,
                    h2d_bytes=int(sum(np.asarray(getattr(self.table, f)).nbytes for f in
-                                     ("type", "value", "a", "b", "c", "d", "drv", "k"))),
+                                     (("type", "value", "a", "b") if self.table.B == 0 else
+                                      ("type", "value", "a", "b", "c", "d", "drv", "k")))),
                    d2h_bytes=int(x.nbytes))
         h.close()
         return out
@@ -164,6 +182,7 @@ class BatchShard:
         for i in range(per_gpu):
             vals[i, :-1] = gen.cfg4_values(rank * per_gpu + i, 100)
         h = self.shard.session.h
+        self.h2d_first_ms = None
         h.assemble_symbolic()  # per-member n, nnz for the byte counts (untimed)
         self.n, self.nnz = h.n, h.nnz
         t0 = time.perf_counter()
@@ -253,15 +272,33 @@ def concurrent_throughput(name, device, streams, per_stream, reuse=False):
             "ms_per_circuit": elapsed / n * 1e3, "ms_latency_per_solve": elapsed / per_stream * 1e3}
 
 
+def print_solution_seconds(device):
+    """str(Solution) of the 1e6-node grid (sorted() over 1e6 string names,
+    shortest-repr formatting of 1e6 doubles) -- the reference's output contract at scale."""
+    import numpy as np
+    from nodal_amd import generators as gen
+    from nodal_amd.circuit import Solution
+    from nodal_amd.netlist import Netlist
+    nl = Netlist.from_rows(gen.grid_rows(1000))
+    sol = Solution(np.linspace(0.0, 1.0, nl.nums["kcl"]), nl, [])
+    t0 = time.perf_counter()
+    text = str(sol)
+    dt = time.perf_counter() - t0
+    assert text.count("\n") == nl.nums["kcl"]
+    return dt
+
+
 def make_workload(name, rank, world, device, dist, per_step, force_collective=False):
     if name == "cfg4":
         return BatchShard(rank, world, per_step, device, dist, force_collective)
     return SingleCircuits(name, rank, per_step, device)
 
 
-def time_workload(name, rank, world, device, dist, steps, warmup, per_step, force_collective=False):
+def time_workload(name, rank, world, device, dist, steps, warmup, per_step, force_collective=False, reuse=False):
     import torch
     wl = make_workload(name, rank, world, device, dist, per_step, force_collective)
+    if reuse:
+        wl.reuse = True
     for _ in range(max(warmup, 1)):  # at least one untimed pass: buffers grow to their final size
         wl.step()
     wl.reset_stats()
@@ -319,6 +356,11 @@ def roofline_of(st, circuits_per_sec_per_gpu):
         out = {"bound": "mfma" if st["dense"] else "hbm", "kernel": None, "achieved": None,
                "peak": FP64_MFMA_PEAK_TF if st["dense"] else HBM_PEAK_GBS,
                "unit": "TFLOP/s" if st["dense"] else "GB/s", "frac": None, "traffic": None}
+    if not st["dense"]:
+        classes = profile_classes(st["name"])
+        if classes:
+            out["top_kernel_by_time"] = classes.get("top_kernel_by_time")
+            out["by_class"] = classes.get("by_class")
     if st["dense"]:
         flops = 2.0 / 3.0 * st["n"] ** 3 + 2.0 * st["n"] ** 2
         out["end_to_end"] = {"what": "circuits/s x (2/3 n^3 + 2 n^2) / fp64 matrix peak",
@@ -391,6 +433,18 @@ def summary(st, world, with_cpu):
            "d2h_bytes": st["d2h_bytes"], "scaled_residual": st["resid"],
            "solver": {"iterations": st["iterations"], "amg_levels": st["amg_levels"]},
            "roofline": roofline_of(st, value / world)}
+    if not st["dense"] and st["name"] != "cfg4":
+        b_asm, _ = alg_bytes(st["table"], st["n"], st["nnz"])
+        asm_ms = st["phase_ms"][0] + st["phase_ms"][1]
+        if asm_ms > 0:
+            out["assembly"] = {"what": "B_asm / (symbolic + numeric), SURVEY.md 8d", "B_asm": b_asm, "ms": asm_ms,
+                               "GB_per_s": b_asm / asm_ms / 1e6, "frac_of_hbm_peak": b_asm / asm_ms / 1e6 / HBM_PEAK_GBS}
+    if st["name"] != "cfg4" and st.get("h2d_ms") is not None:
+        # table up (pinned host memory -> HBM by DMA) and x down for EVERY circuit: what `value` leaves out
+        per = st["elapsed"] / st["circuits"] * 1e3 + st["h2d_ms"] + st["d2h_ms"]
+        out["pcie_inclusive"] = {"circuits_per_sec": world * 1e3 / per, "ms_per_circuit": per,
+                                 "h2d_GB_per_s": st["h2d_bytes"] / st["h2d_ms"] / 1e6 if st["h2d_ms"] > 0 else None,
+                                 "h2d_first_ms": st.get("h2d_first_ms")}
     if st["name"] == "cfg4":
         out["gather_ms_per_step"] = st["gather_ms"]
         out["gathered_ok"] = st["gathered_ok"]
@@ -518,11 +572,29 @@ def main():
                                    else f"independent circuits x{world}")},
     }
     for key in ("phase_ms", "h2d_ms", "d2h_ms", "h2d_bytes", "d2h_bytes", "scaled_residual", "solver",
-                "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "gather_ms_per_step", "gathered_ok"):
+                "roofline", "assembly", "pcie_inclusive", "cpu_baseline", "speedup_vs_cpu_baseline",
+                "gather_ms_per_step", "gathered_ok"):
         if key in head:
             out[key] = head[key]
+    if rank == 0 and world == 1 and name in ("cfg3", "cfg5") and not args.no_also:
+        # the same circuits with the symbolic phases of the previous one kept (nodal_run(reuse_symbolic = 1):
+        # stamping lists and, keyed on the same struct_epoch, the multigrid hierarchy's aggregates and
+        # patterns; values, Galerkin sums and the solve are redone) -- a value sweep on one topology
+        s3 = time_workload(name, 0, 1, local, None, max(2, args.steps // 4), 1, per_step, reuse=True)
+        r3 = summary(s3, 1, with_cpu=False)
+        out["reuse_symbolic"] = {k: r3[k] for k in ("circuits_per_sec", "ms_per_solve", "phase_ms", "solver",
+                                                    "scaled_residual")}
     if rank == 0 and world == 1 and name != "cfg4" and args.concurrent > 1:
-        out["concurrent"] = concurrent_throughput(name, local, args.concurrent, 16 if name != "cfg2" else 8)
+        per_stream = 12 if name != "cfg2" else 8
+        conc = [concurrent_throughput(name, local, args.concurrent, per_stream)]
+        if name in ("cfg3", "cfg5"):
+            for streams in sorted({2, 3, args.concurrent}):
+                conc.append(concurrent_throughput(name, local, streams, per_stream, reuse=True))
+        out["concurrent"] = max(conc, key=lambda c: c["circuits_per_sec"])
+        out["concurrent"]["all"] = [{k: c[k] for k in ("streams", "symbolic_phases_kept", "circuits_per_sec")}
+                                    for c in conc]
+    if rank == 0 and world == 1 and name == "cfg3" and not args.no_also:
+        out["print_1e6_s"] = print_solution_seconds(local)
     if rank == 0 and world == 1 and not args.no_also and not args.force_collective:
         also = {}
         for other in ("cfg4", "cfg5", "cfg2"):

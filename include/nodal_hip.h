@@ -19,6 +19,7 @@
 #ifndef NODAL_HIP_H
 #define NODAL_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -64,13 +65,24 @@ const char *nodal_version(void);
 
 /* ---- component table (replaces the per-component Python objects read by
  *      Circuit.build_model, reference nodal/nodal.py:338-368) --------------
- * Copies the structure-of-arrays table to HBM.  K = nums["kcl"], B = nums["be"]. */
+ * Copies the structure-of-arrays table to HBM.  K = nums["kcl"], B = nums["be"].
+ * The range check of the rows (nodes < K, drivers < ncomp, branch types <=> k >= 0)
+ * runs on the device behind the copies; NODAL_E_INVALID as before for a bad row.
+ * c, d, drv, k may be NULL -- all four together -- when B == 0 (resistors and current
+ * sources read none of them): the columns then hold -1 on the device.
+ * Columns that live in pinned memory (nodal_host_alloc) are copied by DMA at link
+ * rate; pageable memory goes through the runtime's staging copies. */
 int nodal_upload_components(nodal_handle h, int64_t ncomp,
                             const uint8_t *type, const double *value,
                             const int32_t *a, const int32_t *b,
                             const int32_t *c, const int32_t *d,
                             const int32_t *drv, const int32_t *k,
                             int32_t K, int32_t B);
+/* Page-locked host memory for the table's columns (what the lowering of a large netlist
+ * writes into: reference nodal/nodal.py:338-368 builds Python objects there).  Needs a
+ * HIP device; NODAL_E_HIP otherwise (callers fall back to ordinary memory). */
+int nodal_host_alloc(size_t bytes, void **out);
+int nodal_host_free(void *p);
 
 /* Replace the value column only (same topology): `batch` members, row-major
  * [batch][ncomp].  Used for value sweeps (BASELINE.json config 4). */

@@ -31,6 +31,8 @@ SIGNATURES = {
     "nodal_last_error": (C.c_char_p, [C.c_void_p]),
     "nodal_upload_components": (C.c_int, [C.c_void_p, C.c_int64, _u8p, _f64p, _i32p, _i32p,
                                           _i32p, _i32p, _i32p, _i32p, C.c_int32, C.c_int32]),
+    "nodal_host_alloc": (C.c_int, [C.c_size_t, _p(C.c_void_p)]),
+    "nodal_host_free": (C.c_int, [C.c_void_p]),
     "nodal_upload_values": (C.c_int, [C.c_void_p, C.c_int32, _f64p]),
     "nodal_assemble_symbolic": (C.c_int, [C.c_void_p]),
     "nodal_assemble_numeric": (C.c_int, [C.c_void_p, C.c_int32, _i64p]),
@@ -59,6 +61,7 @@ _live = weakref.WeakSet()  # handles still open; closed before the HIP runtime u
 
 @atexit.register
 def _close_all():
+    _closing[0] = True
     for h in list(_live):
         h.close()
 
@@ -89,6 +92,59 @@ def load():
 
 def _ptr(arr, ctype):
     return arr.ctypes.data_as(_p(ctype))
+
+
+# ---- pinned host arrays for large component tables ---------------------------------
+# A table column allocated here is page-locked: nodal_upload_components then copies it by
+# DMA at link rate instead of through the runtime's staging buffers.  Blocks are recycled
+# (hipHostMalloc of tens of MB costs milliseconds); without a HIP device the arrays are
+# ordinary numpy memory.
+PINNED_MIN_BYTES = 1 << 20
+_PINNED_POOL = {}          # bytes -> [address, ...] of free blocks
+_PINNED_POOL_BYTES = [0]
+_PINNED_POOL_MAX = 1 << 30
+_pinned_ok = [None]
+_closing = [False]
+
+
+def _pinned_release(addr, nbytes):
+    if _lib is None or _closing[0]:
+        return  # (interpreter shutdown: the runtime frees what is left)
+    if _PINNED_POOL_BYTES[0] + nbytes <= _PINNED_POOL_MAX:
+        _PINNED_POOL.setdefault(nbytes, []).append(addr)
+        _PINNED_POOL_BYTES[0] += nbytes
+    else:
+        _lib.nodal_host_free(C.c_void_p(addr))
+
+
+def host_empty(count, dtype):
+    """1-D numpy array of `count` items, in pinned host memory when it is large and a HIP
+    device is there, ordinary memory otherwise."""
+    dtype = np.dtype(dtype)
+    nbytes = int(count) * dtype.itemsize
+    if nbytes < PINNED_MIN_BYTES or _pinned_ok[0] is False:
+        return np.empty(count, dtype=dtype)
+    try:
+        lib = load()
+    except OSError:
+        _pinned_ok[0] = False
+        return np.empty(count, dtype=dtype)
+    size = (nbytes + 4095) & ~4095
+    free = _PINNED_POOL.get(size)
+    if free:
+        addr = free.pop()
+        _PINNED_POOL_BYTES[0] -= size
+    else:
+        out = C.c_void_p()
+        if lib.nodal_host_alloc(size, C.byref(out)) != OK or not out.value:
+            _pinned_ok[0] = False
+            return np.empty(count, dtype=dtype)
+        _pinned_ok[0] = True
+        addr = out.value
+    buf = (C.c_char * size).from_address(addr)
+    # every array (and view) made from `buf` keeps it alive; the block goes back to the pool with it
+    weakref.finalize(buf, _pinned_release, addr, size)
+    return np.frombuffer(buf, dtype=dtype, count=count)
 
 
 class Handle:
@@ -123,15 +179,16 @@ class Handle:
 
     # -- table ------------------------------------------------------------
     def upload(self, table):
-        cols = [np.ascontiguousarray(getattr(table, n)) for n in
-                ("type", "value", "a", "b", "c", "d", "drv", "k")]
+        # B == 0: resistors and current sources only -- the four columns they never read stay home
+        names = ("type", "value", "a", "b") if table.B == 0 else ("type", "value", "a", "b", "c", "d", "drv", "k")
+        cols = [np.ascontiguousarray(getattr(table, n)) for n in names]
         self._keep = cols
-        t, v, a, b, c, d, drv, k = cols
+        t, v, a, b = cols[:4]
+        rest = [_ptr(x, C.c_int32) for x in cols[4:]] or [None] * 4
         self.n_members = table.K + table.B
         self._check(self.lib.nodal_upload_components(
             self._h, table.ncomp, _ptr(t, C.c_uint8), _ptr(v, C.c_double),
-            _ptr(a, C.c_int32), _ptr(b, C.c_int32), _ptr(c, C.c_int32), _ptr(d, C.c_int32),
-            _ptr(drv, C.c_int32), _ptr(k, C.c_int32), table.K, table.B))
+            _ptr(a, C.c_int32), _ptr(b, C.c_int32), *rest, table.K, table.B))
 
     def upload_values(self, values):
         values = np.ascontiguousarray(values, dtype=np.float64)

@@ -36,6 +36,24 @@ int upload(nodal_ctx *h, DevBuf &buf, const T *src, int64_t count) {
     return NODAL_OK;
 }
 
+// Range check of the uploaded table ON THE DEVICE (a kernel must never see an out-of-range node; the
+// host loop that did this walked 2e6 rows x 8 columns on one thread: half of the upload time of the
+// 1e6-node grid).  *bad = first offending row (~0 if none).
+__global__ __launch_bounds__(256) void validate_table(int64_t ncomp, int32_t K, int32_t B,
+                                                      const uint8_t *__restrict__ type, const int32_t *__restrict__ a,
+                                                      const int32_t *__restrict__ b, const int32_t *__restrict__ c,
+                                                      const int32_t *__restrict__ d, const int32_t *__restrict__ drv,
+                                                      const int32_t *__restrict__ k, unsigned long long *__restrict__ bad) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ncomp; i += (int64_t)gridDim.x * 256) {
+        const uint8_t t = type[i];
+        const bool branch = t >= NODAL_T_E && t <= NODAL_T_CCCS;
+        const int32_t ci = c ? c[i] : -1, di = d ? d[i] : -1, ri = drv ? drv[i] : -1, ki = k ? k[i] : -1;
+        const bool ok = t <= NODAL_T_GM && a[i] >= -1 && a[i] < K && b[i] >= -1 && b[i] < K && ci >= -1 && ci < K &&
+                        di >= -1 && di < K && ri >= -1 && ri < ncomp && ki >= -1 && ki < B && (branch == (ki >= 0));
+        if (!ok) atomicMin(bad, (unsigned long long)i);
+    }
+}
+
 double elapsed(nodal_ctx *h, int a, int b) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, h->ev[a], h->ev[b]) != hipSuccess) return 0.0;
@@ -176,19 +194,13 @@ int nodal_upload_internal(nodal_ctx *h, int64_t ncomp, const uint8_t *type, cons
                           const int32_t *a, const int32_t *b, const int32_t *c, const int32_t *d,
                           const int32_t *drv, const int32_t *k, int32_t K, int32_t B) {
     if (!h || ncomp < 0 || K < 0 || B < 0) return NODAL_E_INVALID;
-    if (ncomp > 0 && (!type || !value || !a || !b || !c || !d || !drv || !k))
+    // c, d, drv, k may be null TOGETHER when the table holds no dependent source and no branch (B == 0:
+    // resistors and current sources read none of them): 16 of the 33 bytes per row stay on the host
+    const bool plain = !c && !d && !drv && !k;
+    if (ncomp > 0 && (!type || !value || !a || !b || (!plain && (!c || !d || !drv || !k)) || (plain && B != 0)))
         return nodal_fail(h, NODAL_E_INVALID, "null component column");
     DeviceGuard g(h);
-    // validate indices on the host: a kernel must never see an out-of-range node
     const int64_t n = (int64_t)K + B;
-    for (int64_t i = 0; i < ncomp; ++i) {
-        const bool branch = type[i] >= NODAL_T_E && type[i] <= NODAL_T_CCCS;
-        const bool ok = type[i] <= NODAL_T_GM && a[i] >= -1 && a[i] < K && b[i] >= -1 &&
-                        b[i] < K && c[i] >= -1 && c[i] < K && d[i] >= -1 && d[i] < K &&
-                        drv[i] >= -1 && drv[i] < ncomp && k[i] >= -1 && k[i] < B &&
-                        (branch == (k[i] >= 0));
-        if (!ok) return nodal_fail(h, NODAL_E_INVALID, "component table row out of range");
-    }
     h->have_table = h->have_symbolic = h->have_numeric = h->have_x = false;
     ++h->table_epoch;
     h->batch_count = 0;
@@ -201,11 +213,37 @@ int nodal_upload_internal(nodal_ctx *h, int64_t ncomp, const uint8_t *type, cons
     NODAL_TRY(upload(h, h->value, value, ncomp));
     NODAL_TRY(upload(h, h->a, a, ncomp));
     NODAL_TRY(upload(h, h->b, b, ncomp));
-    NODAL_TRY(upload(h, h->c, c, ncomp));
-    NODAL_TRY(upload(h, h->d, d, ncomp));
-    NODAL_TRY(upload(h, h->drv, drv, ncomp));
-    NODAL_TRY(upload(h, h->k, k, ncomp));
+    if (plain) {
+        DevBuf *cols[] = {&h->c, &h->d, &h->drv, &h->k};
+        for (DevBuf *col : cols) {
+            NODAL_HIP_TRY(h, col->reserve((size_t)ncomp * 4 + 16));
+            if (ncomp > 0) NODAL_HIP_TRY(h, hipMemsetAsync(col->p, 0xFF, (size_t)ncomp * 4, h->stream));  // -1
+        }
+    } else {
+        NODAL_TRY(upload(h, h->c, c, ncomp));
+        NODAL_TRY(upload(h, h->d, d, ncomp));
+        NODAL_TRY(upload(h, h->drv, drv, ncomp));
+        NODAL_TRY(upload(h, h->k, k, ncomp));
+    }
+    // the range check runs on the device, behind the copies; its verdict is the one word that comes back
+    NODAL_HIP_TRY(h, h->status.reserve(64));
+    unsigned long long *bad_dev = h->status.as<unsigned long long>() + 4;
+    unsigned long long bad = ~0ull;
+    NODAL_HIP_TRY(h, hipMemsetAsync(bad_dev, 0xFF, 8, h->stream));
+    if (ncomp > 0) {
+        const int64_t blocks = (ncomp + 255) / 256;
+        validate_table<<<(unsigned)(blocks > 4096 ? 4096 : blocks), 256, 0, h->stream>>>(
+            ncomp, K, B, h->type.as<uint8_t>(), h->a.as<int32_t>(), h->b.as<int32_t>(),
+            plain ? nullptr : h->c.as<int32_t>(), plain ? nullptr : h->d.as<int32_t>(),
+            plain ? nullptr : h->drv.as<int32_t>(), plain ? nullptr : h->k.as<int32_t>(), bad_dev);
+        NODAL_HIP_TRY(h, hipGetLastError());
+    }
+    NODAL_HIP_TRY(h, hipMemcpyAsync(&bad, bad_dev, 8, hipMemcpyDeviceToHost, h->stream));
     NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (bad != ~0ull) {
+        h->ncomp = 0;  // (nothing may run on this table)
+        return nodal_fail(h, NODAL_E_INVALID, "component table row out of range");
+    }
     if (h->keep_host_table && B > 0) {  // only systems with branch equations are presolved
         HostTable &t = h->host;
         t.type.assign(type, type + ncomp);
@@ -529,6 +567,32 @@ int nodal_synchronize(nodal_handle h) {
     if (!h) return NODAL_E_INVALID;
     DeviceGuard g(h);
     NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return NODAL_OK;
+}
+
+}  // extern "C"
+
+// ---- pinned host memory for the component table (include/nodal_hip.h) ----
+extern "C" {
+
+int nodal_host_alloc(size_t bytes, void **out) {
+    if (!out) return NODAL_E_INVALID;
+    *out = nullptr;
+    if (bytes == 0) return NODAL_OK;
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return e == hipErrorOutOfMemory ? NODAL_E_NOMEM : NODAL_E_HIP;
+    }
+    return NODAL_OK;
+}
+
+int nodal_host_free(void *p) {
+    if (p && hipHostFree(p) != hipSuccess) {
+        (void)hipGetLastError();
+        return NODAL_E_HIP;
+    }
     return NODAL_OK;
 }
 

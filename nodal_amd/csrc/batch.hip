@@ -322,6 +322,7 @@ int nodal_run_batch(nodal_handle h, int32_t first, int32_t count, int32_t reuse_
         c->B = (int32_t)((int64_t)count * h->B);
         c->n = (int64_t)c->K + c->B;
         c->batch = 0;
+        if (!same_shape) ++c->table_epoch;  // (another topology or member count: nothing cached about the block table holds)
         c->have_table = true;
         c->have_numeric = c->have_x = false;
         if (!(reuse_symbolic && same_shape && c->have_symbolic)) c->have_symbolic = false;

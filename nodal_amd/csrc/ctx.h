@@ -112,6 +112,8 @@ struct nodal_ctx {
 
     // ---- symbolic assembly results ----
     bool have_symbolic = false;
+    uint64_t sym_sizes_epoch = 0;  // table_epoch the sizes below were read back for (stamp_symbolic)
+    int64_t sym_sizes[4] = {0, 0, 0, 0};  // nnz, ncontrib, nrhs, nrhs_contrib
     int64_t nnz = 0;        // matrix entries
     int64_t ncontrib = 0;   // matrix contributions
     int64_t nrhs = 0;       // rhs entries (rows with at least one contribution)

@@ -285,12 +285,12 @@ struct emits_exactly<E, std::void_t<decltype(E::EXACT)>> : std::bool_constant<E:
 // Group one family of stamps (matrix or rhs) into entries.  On return:
 //   *nent entries, *ncon contributions; rowidx / cptr / contrib filled;
 //   indices, indptr, diag_pos filled when non-null.
-// `known_nent` >= 0: the caller knows the number of entries (e.g. one per aggregate): no
-// round trip for it either.
+// `known_nent` / `known_C` >= 0: the caller knows the number of entries / contributions (one entry per
+// aggregate; the same table grouped before): no round trip for them.
 template <class E>
 int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int64_t *ncon_out,
                 DevBuf &indices, DevBuf &rowidx, DevBuf &cptr, DevBuf &contrib, DevBuf *indptr,
-                DevBuf *diag_pos, int64_t known_nent = -1) {
+                DevBuf *diag_pos, int64_t known_nent = -1, int64_t known_C = -1) {
     hipStream_t st = h->stream;
     if (en.nitems >= (1ll << 29) || nrows >= (1ll << 31) - 2)
         return nodal_fail(h, NODAL_E_UNSUPPORTED, "too many items for 32-bit grouping keys");
@@ -312,7 +312,9 @@ int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int
     NODAL_HIP_TRY(h, hipGetLastError());
     NODAL_TRY(scan_exclusive_u32(h, rowstart, rowstart, nrows + 1, &counts[2], w + off_scan));
     int64_t C;
-    if constexpr (emits_exactly<E>::value) {
+    if (known_C >= 0) {  // (the caller grouped the very same items before: stamp_symbolic, same table_epoch)
+        C = known_C;
+    } else if constexpr (emits_exactly<E>::value) {
         C = en.nitems * E::SLOTS;
     } else {
         uint32_t C32 = 0;

@@ -559,6 +559,7 @@ static int presolve_build_reduced(nodal_ctx *h, nodal_ctx *r, const double *valu
     r->B = 0;
     r->n = plan.Kr;
     r->batch = 0;
+    ++r->table_epoch;  // (the reduced netlist is rewritten per solve: its list sizes are read back every time)
     r->have_table = true;
     r->have_symbolic = r->have_numeric = r->have_x = false;
     *ok = true;

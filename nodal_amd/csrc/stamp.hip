@@ -264,12 +264,23 @@ int stamp_symbolic(nodal_ctx *h) {
     ++h->struct_epoch;
     const int64_t n = h->n;
     const Table tb = table_of(h);
+    // The sizes of the lists (entries, contributions) depend on the topology only: known from the last
+    // symbolic phase of the SAME uploaded table (table_epoch), they spare the four size read-backs --
+    // each one drains the stream -- of a repeated assembly.
+    const bool known = h->sym_sizes_epoch == h->table_epoch;
     NODAL_TRY(grp::build_lists(h, MatrixStamps{tb, tb.ncomp}, n, &h->nnz, &h->ncontrib, h->indices,
-                               h->rowidx, h->cptr, h->contrib, &h->indptr, &h->diag_pos));
+                               h->rowidx, h->cptr, h->contrib, &h->indptr, &h->diag_pos,
+                               known ? h->sym_sizes[0] : -1, known ? h->sym_sizes[1] : -1));
     // (rhs entries have no column index: the column list lands in a scratch buffer the context keeps --
     // a local one meant a hipMalloc and a hipFree, which waits for the whole device, per symbolic phase)
     NODAL_TRY(grp::build_lists(h, RhsStamps{tb, tb.ncomp}, n, &h->nrhs, &h->nrhs_contrib, h->rhs_none,
-                               h->rhs_row, h->rhs_cptr, h->rhs_contrib, nullptr, nullptr));
+                               h->rhs_row, h->rhs_cptr, h->rhs_contrib, nullptr, nullptr,
+                               known ? h->sym_sizes[2] : -1, known ? h->sym_sizes[3] : -1));
+    h->sym_sizes[0] = h->nnz;
+    h->sym_sizes[1] = h->ncontrib;
+    h->sym_sizes[2] = h->nrhs;
+    h->sym_sizes[3] = h->nrhs_contrib;
+    h->sym_sizes_epoch = h->table_epoch;
     NODAL_HIP_TRY(h, h->data.reserve((size_t)h->nnz * 8 + 8));
     NODAL_HIP_TRY(h, h->rhs.reserve((size_t)n * 8 + 8));
     NODAL_HIP_TRY(h, h->x.reserve((size_t)n * 8 + 8));

@@ -33,10 +33,17 @@ class ComponentTable:
 
     def __init__(self, ncomp, K, B):
         self.ncomp, self.K, self.B = ncomp, K, B
-        self.type = np.zeros(ncomp, dtype=np.uint8)
-        self.value = np.zeros(ncomp, dtype=np.float64)
+        # large columns live in pinned host memory (copied to the GPU by DMA at link rate);
+        # ordinary numpy arrays when small or when no HIP device is there
+        from ._ffi import host_empty
+        self.type = host_empty(ncomp, np.uint8)
+        self.type[:] = 0
+        self.value = host_empty(ncomp, np.float64)
+        self.value[:] = 0.0
         for name in ("a", "b", "c", "d", "drv", "k"):
-            setattr(self, name, np.full(ncomp, -1, dtype=np.int32))
+            col = host_empty(ncomp, np.int32)
+            col[:] = -1
+            setattr(self, name, col)
         # (row index, exception instance, probe) of the first host-detected
         # stamping error, or None.  Rows after that index are not valid; the
         # row itself is a valid "probe" row (control entries stripped) iff

@@ -1,0 +1,99 @@
+"""Where the GPU time of a solve goes, by class of kernel (profiles/<round>_classes.json, read by
+bench.py for `roofline.by_class` / `top_kernel_by_time`).
+
+    rocprofv3 --kernel-trace -d DIR -- python3 bench.py --workload cfg3 --steps 2 --warmup 1 --no-cpu --no-also --concurrent 0
+    python tools/prof_classes.py DIR cfg3 1000000 4995995 > profiles/r03_classes_cfg3.json
+
+Dispatches are told apart by kernel name AND grid size: the level-0 launches of the cycle kernels
+(k_restrict, k_prolong, ...) are the ones whose grid covers the 1e6 rows; the row kernels of level 0
+run on a grid capped at 1024 workgroups and are recognised by their width class (<5, ...>).  Algorithmic bytes of the
+level-0 passes: rows x bytes per row of what the kernel reads and writes.
+"""
+import glob, json, sqlite3, sys
+
+
+def main():
+    path, workload, n, nnz = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    dbs = glob.glob(path + "/**/*.db", recursive=True) if not path.endswith(".db") else [path]
+    c = sqlite3.connect(dbs[0])
+    tables = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
+    kt = "kernels" if "kernels" in tables else [t for t in tables if "kernel" in t.lower()][0]
+    cols = [r[1] for r in c.execute(f"pragma table_info({kt})")]
+    if "--columns" in sys.argv:
+        print(kt, cols, file=sys.stderr)
+    gcol = next((x for x in ("grid_size_x", "grid_x", "grid_size") if x in cols), None)
+    wcol = next((x for x in ("workgroup_size_x", "workgroup_x", "workgroup_size") if x in cols), None)
+    q = f"select name, start, end, {gcol or 0}, {wcol or 1} from {kt} order by start"
+    rows = list(c.execute(q))
+    W = 5  # padded ELL width of the grid's level 0
+    f32row = W * 8          # col i32 + val f32 per slot
+    f64row = W * 12
+    # bytes per level-0 row of each pass (reads + writes, vectors f64)
+    level0_bytes = {
+        "k_smooth_residual": f32row + 8 + 8 + 8,            # A, x0 gather, b, r
+        "k_restrict": 4 * 8 + 8 + 8 / 7.0,                  # R entries (col + f32 val) of the 4 P slots per fine row, r, rc
+        "k_prolong": 4 * 8 + 8 + 8 + 8 / 7.0,               # P (col + f32 val) x 4, x, xp, coarse gathers
+        "k_post": f32row + 8 + 8 + 8 + 8 + 8 + 8,           # A, xp gather + own, b, dinv, out, u
+        "f_spmv": f64row + 8 + 8 + 8,                       # A (f64), p gather + own, Ap
+        "f_direction": 8 + 8 + 8,                           # z, p, p
+        "f_update": 8 * 4 + 8 * 3 + 8,                      # x r p Ap in, x r x0 out, dinv
+        "f_init": 8 * 2 + 8 * 4,
+    }
+    setup_names = ("mis_", "assign_", "build_P", "r_count", "r_fill", "r_sort", "r_to_ell", "r_refresh", "ap_rows",
+                   "galerkin", "coarsest_inverse", "flags_up", "last_level", "any_unflagged", "k_tail_pack", "row_stats",
+                   "csr_to_ell", "reduce_bstat", "scan_", "grounded_flags", "select_nodes")
+    stamp_names = ("grp::", "fold_matrix", "fold_rhs", "set_tail")
+    classes = {}
+    per_kernel = {}
+    total = 0
+
+    def short(name):
+        nm = name.replace("(anonymous namespace)::", "").replace("void ", "")
+        return nm.split("(")[0]
+
+    def add(cls, dur, nbytes=0.0):
+        a = classes.setdefault(cls, {"us": 0.0, "launches": 0, "alg_bytes": 0.0})
+        a["us"] += dur / 1e3
+        a["launches"] += 1
+        a["alg_bytes"] += nbytes
+
+    big = n / 256 * 0.9  # a grid that covers the level-0 rows (one thread per row, 256 per workgroup)
+    for name, start, end, grid, wg in rows:
+        nm = short(name)
+        dur = end - start
+        total += dur
+        pk = per_kernel.setdefault(nm, [0, 0])
+        pk[0] += 1
+        pk[1] += dur
+        wgs = (grid / wg) if (gcol and wcol and wg) else 0
+        base = nm.split("<")[0]
+        if any(base.startswith(p) or p in nm for p in stamp_names):
+            add("stamping", dur)
+        elif any(base.startswith(p) for p in setup_names):
+            add("hierarchy_setup", dur)
+        elif base in level0_bytes and (wgs >= big or nm.startswith(base + "<%d" % W) or
+                                       base in ("f_spmv", "f_direction", "f_update", "f_init")):
+            add("level0_passes", dur, level0_bytes[base] * n)
+        elif base.startswith("k_") or base.startswith("f_"):
+            add("coarse_levels", dur)
+        else:
+            add("other", dur)
+    out_classes = {}
+    for cls, a in classes.items():
+        e = {"share_of_gpu_time": a["us"] * 1e3 / total, "us": a["us"], "launches": a["launches"]}
+        if a["alg_bytes"]:
+            e["alg_bytes"] = a["alg_bytes"]
+            e["GB_per_s"] = a["alg_bytes"] / (a["us"] * 1e-6) / 1e9
+            e["frac_of_hbm_peak"] = e["GB_per_s"] / 8000.0
+        out_classes[cls] = e
+    top = max(per_kernel.items(), key=lambda kv: kv[1][1])
+    res = {workload: {"top_kernel_by_time": {"kernel": top[0], "launches": top[1][0],
+                                             "share_of_gpu_time": top[1][1] / total,
+                                             "avg_us": top[1][1] / top[1][0] / 1e3},
+                      "by_class": out_classes, "total_kernel_ms": total / 1e6,
+                      "source": "rocprofv3 --kernel-trace of bench.py --workload %s" % workload}}
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,7 @@
 """Timeline of one solve from a rocprofv3 results.db (rocpd sqlite): per-kernel durations, the
 gaps between consecutive kernels, and the share of wall time the GPU sat idle between them.
 
-    python tools/prof_timeline.py <dir-or-db> [first_kernel_substring] [occurrence]
+    python tools/prof_timeline.py <dir-or-db> [first_kernel_substring] [occurrence] [end_kernel_substring]
 """
 import glob, sqlite3, sys
 
@@ -23,7 +23,10 @@ def main():
         return
     i0 = starts[occ]
     # the solve: from the marker to the next marker (or the end)
-    nxt = [i for i in starts if i > i0]
+    if len(sys.argv) > 4:  # up to (not including) the first later kernel that matches the end marker
+        nxt = [i for i in range(i0 + 1, len(rows)) if sys.argv[4] in rows[i][0]]
+    else:
+        nxt = [i for i in starts if i > i0]
     i1 = nxt[0] if nxt else len(rows)
     seg = rows[i0:i1]
     busy = sum(r[2] - r[1] for r in seg)
