@@ -88,40 +88,6 @@ int nodal_create(int device_id, nodal_handle *out) {
             delete h;
             return NODAL_E_HIP;
         }
-    // second stream for the dense LU's trailing updates (lookahead).  It is confined to
-    // 224 of the 256 CUs: the panel chain on the main stream is a sequence of small
-    // latency-bound kernels and must always find idle CUs, otherwise every one of its
-    // ~1300 launches queues behind 58-us GEMM workgroups.  (If the CU mask is refused,
-    // fall back to a low-priority stream.)
-    {
-        uint32_t mask[8];
-        int reserve = 32;  // CUs kept free for the main stream (NODAL_PANEL_CUS to tune)
-        if (const char *e = getenv("NODAL_PANEL_CUS")) reserve = atoi(e);
-        if (reserve < 0) reserve = 0;
-        if (reserve > 224) reserve = 224;
-        for (int i = 0; i < 8; ++i) mask[i] = 0xFFFFFFFFu;
-        for (int cu = 0; cu < reserve; ++cu) mask[cu / 32] &= ~(1u << (cu % 32));
-        if (hipExtStreamCreateWithCUMask(&h->stream2, 8, mask) != hipSuccess) {
-            h->stream2 = nullptr;
-            (void)hipGetLastError();
-        }
-    }
-    if ((!h->stream2 &&
-         hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, lo) != hipSuccess) ||
-        hipEventCreateWithFlags(&h->ev_la[0], hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_la[1], hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) {
-        delete h;
-        return NODAL_E_HIP;
-    }
-    if (hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, lo) != hipSuccess) {
-        delete h;
-        return NODAL_E_HIP;
-    }
-    for (auto &e : h->ev_bi)
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) {
-            delete h;
-            return NODAL_E_HIP;
-        }
     if (const char *e = getenv("NODAL_DENSE_BLOCKINV")) h->dense_blockinv = atoi(e) != 0;
     if (const char *e = getenv("NODAL_GJ_SCALAR")) h->gj_scalar = atoi(e);
     if (const char *e = getenv("NODAL_PRESOLVE")) h->use_presolve = atoi(e) != 0;  // 0: branch equations stay in the system
@@ -130,6 +96,55 @@ int nodal_create(int device_id, nodal_handle *out) {
 }
 
 }  // extern "C"
+
+
+int nodal_ensure_aux_streams(nodal_ctx *ctx) {
+    nodal_ctx *h = ctx->stream_owner ? ctx->stream_owner : ctx;
+    if (!h->stream2 || !h->stream3) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(h->device);
+        int lo = 0, hi = 0;  // least / greatest priority
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        int status = NODAL_OK;
+        // second stream for the dense LU's trailing updates (lookahead).  It is confined to
+        // 224 of the 256 CUs: the panel chain on the main stream is a sequence of small
+        // latency-bound kernels and must always find idle CUs, otherwise every one of its
+        // ~1300 launches queues behind 58-us GEMM workgroups.  (If the CU mask is refused,
+        // fall back to a low-priority stream.)
+        if (!h->stream2) {
+            uint32_t mask[8];
+            int reserve = 32;  // CUs kept free for the main stream (NODAL_PANEL_CUS to tune)
+            if (const char *e = getenv("NODAL_PANEL_CUS")) reserve = atoi(e);
+            if (reserve < 0) reserve = 0;
+            if (reserve > 224) reserve = 224;
+            for (int i = 0; i < 8; ++i) mask[i] = 0xFFFFFFFFu;
+            for (int cu = 0; cu < reserve; ++cu) mask[cu / 32] &= ~(1u << (cu % 32));
+            if (hipExtStreamCreateWithCUMask(&h->stream2, 8, mask) != hipSuccess) {
+                h->stream2 = nullptr;
+                (void)hipGetLastError();
+            }
+            if (!h->stream2 && hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, lo) != hipSuccess) status = NODAL_E_HIP;
+        }
+        if (status == NODAL_OK && !h->stream3 &&
+            hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, lo) != hipSuccess) status = NODAL_E_HIP;
+        for (auto &e : h->ev_la)
+            if (status == NODAL_OK && !e &&
+                hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) status = NODAL_E_HIP;
+        for (auto &e : h->ev_bi)
+            if (status == NODAL_OK && !e &&
+                hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) status = NODAL_E_HIP;
+        if (prev >= 0) (void)hipSetDevice(prev);
+        if (status != NODAL_OK) return nodal_fail(ctx, status, "could not create the dense paths' streams");
+    }
+    if (ctx != h) {
+        ctx->stream2 = h->stream2;
+        ctx->stream3 = h->stream3;
+        for (int i = 0; i < 2; ++i) ctx->ev_la[i] = h->ev_la[i];
+        for (int i = 0; i < 6; ++i) ctx->ev_bi[i] = h->ev_bi[i];
+    }
+    return NODAL_OK;
+}
 
 void nodal_free_buffers(nodal_ctx *h) {
     amg_destroy(h);
@@ -504,6 +519,7 @@ int nodal_run(nodal_handle h, int32_t dense, int32_t member, int32_t reuse_symbo
     if (!h || !info) return NODAL_E_INVALID;
     DeviceGuard g(h);
     if (!(reuse_symbolic && h->have_symbolic)) NODAL_TRY(nodal_assemble_symbolic(h));
+    else h->ms[0] = 0.0;  // (kept: nothing ran)
     NODAL_TRY(nodal_assemble_numeric(h, member, nullptr));
     if (dense) return nodal_solve_dense(h, nullptr, info);
     return nodal_solve_sparse(h, NODAL_SPARSE_AUTO, nullptr, info, nullptr, nullptr);

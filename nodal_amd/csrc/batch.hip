@@ -187,6 +187,7 @@ nodal_ctx *block_child(nodal_ctx *h) {
         for (int i = 0; i < 2; ++i) c->ev_la[i] = h->ev_la[i];
         for (int i = 0; i < 6; ++i) c->ev_bi[i] = h->ev_bi[i];
         c->owns_streams = false;
+        c->stream_owner = h->stream_owner ? h->stream_owner : h;
         h->blocksys = c;
     }
     nodal_ctx *c = h->blocksys;

@@ -623,6 +623,7 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
 // columns, leading dimension lda); the solutions go to xout (column c at xout + c * ldx).
 int dense_block_elimination(nodal_ctx *h, double *A, int64_t n, int64_t lda, int32_t nrhs, double *xout,
                             int64_t ldx, int32_t *dinfo) {
+    NODAL_TRY(nodal_ensure_aux_streams(h));
     const int64_t ncols = n + nrhs;
     hipStream_t st = h->stream;
     GemmTimer tm{h};  // (reset and collected by the caller, dense_factor_solve_multi)

@@ -91,6 +91,7 @@ struct nodal_ctx {
     int32_t member = 0;            // batch member of the last numeric assembly
     nodal_ctx *reduced = nullptr;  // presolved (branch-free) system, see presolve.hip
     bool owns_streams = true;
+    nodal_ctx *stream_owner = nullptr;  // (child contexts) the context whose streams and events this one borrows
     bool use_presolve = true;
     bool use_graphs = false;       // hipGraph replay of the FCG iteration: measured no gain (kernels are not host-bound)
     DevBuf ps_buf, ps_newidx, ps_hits;
@@ -278,4 +279,8 @@ int sparse_residual(nodal_ctx *h, double *scaled);
 int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, double *resid,
                    bool dense_child = false);
 void nodal_free_buffers(nodal_ctx *h);  // api.hip
+// The dense paths' two extra streams (one CU-masked) and their events, created on first use: a handle
+// that only ever solves sparse systems holds ONE hardware queue, so that four of them in flight still
+// get a queue each (the runtime multiplexes streams beyond its hardware queues: erratic throughput).
+int nodal_ensure_aux_streams(nodal_ctx *h);  // api.hip
 void nodal_free_block_child(nodal_ctx *h);  // batch.hip

@@ -715,6 +715,7 @@ int dense_fill_nan(nodal_ctx *h, double *x, int64_t n) {
 }
 
 int dense_factor_solve(nodal_ctx *h, int32_t *info) {
+    NODAL_TRY(nodal_ensure_aux_streams(h));
     NODAL_TRY(dense_factor_solve_multi(h, 1, h->x.as<double>(), h->n, info));
     // Passive systems are eliminated without pivoting.  A floating sub-network makes G exactly
     // singular, but rounding can hide the zero pivot; a solution that does not satisfy the
@@ -743,6 +744,7 @@ int dense_factor_solve(nodal_ctx *h, int32_t *info) {
 // columns) and leave the solutions in xout (column c at xout + c * ldx).  *info as
 // LAPACK dgesv.
 int dense_factor_solve_multi(nodal_ctx *h, int32_t nrhs, double *xout, int64_t ldx, int32_t *info) {
+    NODAL_TRY(nodal_ensure_aux_streams(h));
     const int64_t n = h->n, lda = dense_lda(n), ncols = n + nrhs;
     hipStream_t st = h->stream;
     double *A = h->dense.as<double>();

@@ -399,6 +399,7 @@ int lowdeg_solve(nodal_ctx *h, int min_share, bool *done, int32_t *info, int32_t
         for (int i = 0; i < 2; ++i) c->ev_la[i] = h->ev_la[i];
         for (int i = 0; i < 6; ++i) c->ev_bi[i] = h->ev_bi[i];
         c->owns_streams = false;
+        c->stream_owner = h->stream_owner ? h->stream_owner : h;
         c->keep_host_table = false;
         c->csr_only = true;
         c->passive_network = true;

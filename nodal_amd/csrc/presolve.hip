@@ -648,6 +648,7 @@ int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, doub
         h->reduced->dense_blockinv = h->dense_blockinv;
         h->reduced->gj_scalar = h->gj_scalar;
         h->reduced->owns_streams = false;
+        h->reduced->stream_owner = h->stream_owner ? h->stream_owner : h;
         h->reduced->keep_host_table = false;
     }
     nodal_ctx *r = h->reduced;

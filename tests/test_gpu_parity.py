@@ -24,7 +24,8 @@ SYNTH = load_golden("synth.json")
 LARGE = load_golden("synth_large.json")
 EQUIV = load_golden("equiv.json")
 TOL = 1e-9  # north_star: 1e-9 rel-tol fp64, norm-wise
-PRINT_1E6_BOUND_S = 6.0  # print(solution) of 1e6 nodes: twice what bench.py measured on the GPU box (set below)
+PRINT_1E6_BOUND_S = 2.0  # print(solution) of 1e6 nodes: bench.py's `print_1e6_s` reads 0.5 s on the GPU box
+                         # (profiles/r03_bench_default.json); four times that, for a slower host
 EXC = {"ValueError": ValueError, "KeyError": KeyError, "AssertionError": AssertionError,
        "AttributeError": AttributeError, "NotImplementedError": NotImplementedError,
        "LinAlgError": np.linalg.LinAlgError, "ZeroDivisionError": ZeroDivisionError,
@@ -123,8 +124,8 @@ def test_print_solution_of_a_million_nodes():
     names = sorted(nl.nodenum)
     for k in (0, 1, 17, 500000, 999998):
         assert lines[1 + k] == f"e({names[k]}) \t= {np.float64(sol.result[nl.nodenum[names[k]]])}"
-    # measured on the GPU box: see `print_1e6_s` in bench.py's line (profiles/r03_bench_default.json);
-    # twice that is the bar.  (The reference's f-string loop over numpy scalars takes as long as its solve.)
+    # measured on the GPU box: `print_1e6_s` in bench.py's line (profiles/r03_bench_default.json).
+    # (The reference's f-string loop over numpy scalars takes as long as its solve.)
     assert dt < PRINT_1E6_BOUND_S, dt
     print(f"print(solution) at 1e6 nodes: {dt:.2f} s")
 

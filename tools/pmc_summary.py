@@ -26,6 +26,9 @@ DOMINANT = {  # workload -> (kernel name regex, minimum grid size in threads)
 }
 
 
+CIRCUITS_PER_STEP = {"cfg3": 32, "cfg5": 16, "cfg2": 8, "cfg4": 128}  # bench.py's
+
+
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     return re.split(r"\(", name)[0]
@@ -43,7 +46,7 @@ def read_pass(directory, counter):
 
 def main():
     out = sys.argv[1]
-    result = {"note": __doc__.strip().split("\n\n")[-1].replace("\n", " "), "kernels": {}, "dominant": {}}
+    result = {"note": __doc__.strip().split("\n\n")[-1].replace("\n", " "), "kernels": {}, "dominant": {}, "totals": {}}
     for spec in sys.argv[2:]:
         workload, fdir, wdir = spec.split(":")
         fetch, write = read_pass(fdir, "FETCH_SIZE"), read_pass(wdir, "WRITE_SIZE")
@@ -65,6 +68,11 @@ def main():
         for (name, grid), (n, rd, wr) in top:
             result["kernels"][f"{workload}:{name}:{grid}"] = {
                 "launches": n, "read_bytes_corrected": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
+        # everything the workload moved, and per circuit (bench.py --steps 1 --warmup 1: two steps)
+        total_bytes = sum(n * (rd + wr) for (n, rd, wr) in per_kernel.values())
+        circuits = 2 * CIRCUITS_PER_STEP.get(workload, 1)
+        result["totals"][workload] = {"hbm_bytes": total_bytes, "dispatches_counted": sum(n for n, _, _ in per_kernel.values()),
+                                      "circuits": circuits, "hbm_bytes_per_circuit": total_bytes / circuits}
         pat, min_grid = DOMINANT.get(workload, (None, 0))
         if pat:
             sel = [(n, rd, wr) for (name, grid), (n, rd, wr) in per_kernel.items()
