@@ -246,6 +246,12 @@ def concurrent_throughput(name, device, streams, per_stream, reuse=False):
              "cfg2": lambda: gen.grid_table(100)}[name]()
     dense = name == "cfg2"
     handles = []
+    # four and more solves in flight: main streams of default priority (a context's main stream is of the
+    # highest priority, which serves one or two solves best -- 9.1 instead of 9.7 ms for one -- but the
+    # device has few high-priority queues: 102 instead of 149 circuits/s with four)
+    prio = os.environ.get("NODAL_STREAM_PRIORITY")
+    if streams >= 4 and prio is None:
+        os.environ["NODAL_STREAM_PRIORITY"] = "normal"
     for _ in range(streams):
         h = _ffi.Handle(device)
         h.upload(table)
@@ -258,6 +264,8 @@ def concurrent_throughput(name, device, streams, per_stream, reuse=False):
             if h.run(dense, 0, reuse) != 0:
                 raise RuntimeError("solver reported a singular system")
 
+    if streams >= 4 and prio is None:
+        del os.environ["NODAL_STREAM_PRIORITY"]
     threads = [threading.Thread(target=work, args=(h,)) for h in handles]
     t0 = time.perf_counter()
     for t in threads:

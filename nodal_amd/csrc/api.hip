@@ -78,6 +78,8 @@ int nodal_create(int device_id, nodal_handle *out) {
     // factorisation, multigrid cycles)
     int lo = 0, hi = 0;  // least / greatest priority
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (const char *e = getenv("NODAL_STREAM_PRIORITY"))  // "normal": the default priority instead of the highest
+        if (e[0] == 'n') hi = 0;
     if (hipSetDevice(device_id) != hipSuccess ||
         hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, hi) != hipSuccess) {
         delete h;

@@ -160,6 +160,11 @@ struct SHierarchy {
     int64_t sym_n = 0, sym_nnz = 0;
     bool sym_general = false, sym_check = false;
     int32_t sym_floating = 0;
+    // A pair of outer iterations (parities 0 and 1: ~66 launches with fixed arguments) captured as a
+    // hipGraph and replayed while the hierarchy is kept: one API call instead of 66 (NODAL_SA_GRAPH=1).
+    hipGraph_t it_graph = nullptr;
+    hipGraphExec_t it_exec = nullptr;
+    uint64_t it_key = 0;         // hash of every pointer and size the captured launches carry
     bool refreshed = false;      // the last setup was a values-only refresh
     int last_iters = 0;          // iterations of the last converged solve on this hierarchy (0: none yet)
     unsigned long long sym_stats[MAX_LEVELS * ST_COUNT] = {0};
@@ -167,7 +172,15 @@ struct SHierarchy {
         while ((int)pool.size() <= l) pool.push_back(new SLevel());
         return pool[l];
     }
+    void drop_graph() {
+        if (it_exec) (void)hipGraphExecDestroy(it_exec);
+        if (it_graph) (void)hipGraphDestroy(it_graph);
+        it_exec = nullptr;
+        it_graph = nullptr;
+        it_key = 0;
+    }
     ~SHierarchy() {
+        drop_graph();
         for (SLevel *l : pool) {
             DevBuf *b[] = {&l->acol, &l->aval, &l->alen, &l->dinv, &l->agg, &l->pcol, &l->pval, &l->rcol,
                            &l->rval, &l->rlen, &l->vec, &l->part, &l->gflag, &l->avalf, &l->pvalf, &l->rvalf};
@@ -1376,6 +1389,7 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
     H->sym_valid = false;
     H->refreshed = false;
     H->last_iters = 0;
+    H->drop_graph();
     NODAL_HIP_TRY(h, H->stats.reserve((size_t)MAX_LEVELS * ST_COUNT * 8 + 64));
     if (!H->host_stats)
         NODAL_HIP_TRY(h, hipHostMalloc(reinterpret_cast<void **>(&H->host_stats), (size_t)MAX_LEVELS * ST_COUNT * 8 + 64));
@@ -1748,24 +1762,79 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     double rr_prev = -1.0;
     int64_t it_prev = 0;
     int polls = 0;
-    while (status == 0) {
-        for (int c = 0; c < batch; ++c, ++enqueued) {
-            const int it = (int)enqueued;
-            NODAL_TRY(cycle(h, H, 0, sb.r, sb.x0, sb.z, &sb));
-            f_direction<<<sb.g0, TB, 0, st>>>(sb.z, sb.p, sb.part_rz, sb.part_zap, sb.part_rr, sb.g0, sb.sc, it, n);
-            // one launch per poll batch is timed: start / stop events tied to the dispatch itself
-            // (hipExtLaunchKernelGGL), i.e. the kernel's own duration as rocprofv3 reports it -- a pair
-            // of hipEventRecord calls around a 14-us kernel also measures ~3.5 us of launch
-            const unsigned tb0 = H->pool[0]->wfix ? TB : TB * LPR_RAGGED;
-            if (c == 0) {
-                SAGG_DISPATCH_W(H->pool[0]->wfix, (hipExtLaunchKernelGGL((f_spmv<W>), dim3(sb.g0), dim3(tb0), 0, st, e0, e1, 0,
-                                                                         A0, (const double *)sb.p, sb.Ap, sb.part_pap,
-                                                                         (const double *)sb.sc, it)));
+    // one outer iteration (the kernels take its parity only: see f_direction)
+    auto iteration = [&](int it, bool timed) -> int {
+        NODAL_TRY(cycle(h, H, 0, sb.r, sb.x0, sb.z, &sb));
+        f_direction<<<sb.g0, TB, 0, st>>>(sb.z, sb.p, sb.part_rz, sb.part_zap, sb.part_rr, sb.g0, sb.sc, it & 1, n);
+        // one launch per poll batch is timed: start / stop events tied to the dispatch itself
+        // (hipExtLaunchKernelGGL), i.e. the kernel's own duration as rocprofv3 reports it -- a pair
+        // of hipEventRecord calls around a 14-us kernel also measures ~3.5 us of launch
+        const unsigned tb0 = H->pool[0]->wfix ? TB : TB * LPR_RAGGED;
+        if (timed) {
+            SAGG_DISPATCH_W(H->pool[0]->wfix, (hipExtLaunchKernelGGL((f_spmv<W>), dim3(sb.g0), dim3(tb0), 0, st, e0, e1, 0,
+                                                                     A0, (const double *)sb.p, sb.Ap, sb.part_pap,
+                                                                     (const double *)sb.sc, it & 1)));
+        } else {
+            SAGG_DISPATCH_W(H->pool[0]->wfix, (f_spmv<W><<<sb.g0, tb0, 0, st>>>(A0, sb.p, sb.Ap, sb.part_pap, sb.sc, it & 1)));
+        }
+        f_update<<<sb.g0, TB, 0, st>>>(x, sb.r, sb.p, sb.Ap, sb.part_pap, sb.g0, dinv0, sb.x0, sb.part_rr, sb.sc, it & 1, n);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        return NODAL_OK;
+    };
+    // kept hierarchy (values refreshed on the same pattern, another right-hand side): replay a captured
+    // pair of iterations.  The key covers every pointer and size the captured launches carry.
+    // (NODAL_SA_GRAPH=1; off by default: measured without gain -- 7.53 instead of 7.28 ms for one stream,
+    // and the same 180 / 211 / 182 / 210 circuits/s with 2 / 3 / 4 / 6 solves in flight: what bounds several
+    // streams is not the host's launch rate)
+    static const bool graphs = getenv("NODAL_SA_GRAPH") && atoi(getenv("NODAL_SA_GRAPH")) != 0;
+    if (graphs && (H->refreshed || !do_setup)) {
+        uint64_t key = 1469598103934665603ull;
+        auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
+        mix((uint64_t)(uintptr_t)base); mix((uint64_t)(uintptr_t)x); mix((uint64_t)n); mix((uint64_t)sb.g0);
+        mix((uint64_t)H->nlev); mix((uint64_t)(H->tail + 1)); mix((uint64_t)H->kcycle); mix((uint64_t)H->klevels);
+        mix((uint64_t)(H->nu[0] * 100 + H->nu[1] * 10 + H->nu[2])); mix((uint64_t)H->td.lds_bytes);
+        mix((uint64_t)(uintptr_t)H->tail_image.p); mix((uint64_t)(uintptr_t)H->coarse_inv.p);
+        for (int k = 0; k < H->nlev; ++k) {
+            const SLevel *L = H->pool[k];
+            const void *ps[] = {L->acol.p, L->aval.p, L->avalf.p, L->alen.p, L->dinv.p, L->pcol.p, L->pvalf.p,
+                                L->rcol.p, L->rvalf.p, L->rlen.p, L->vec.p, L->part.p};
+            for (const void *q : ps) mix((uint64_t)(uintptr_t)q);
+            mix((uint64_t)L->n); mix((uint64_t)L->ld); mix((uint64_t)L->wfix); mix((uint64_t)L->rld);
+        }
+        if (H->it_exec && H->it_key != key) H->drop_graph();
+        if (!H->it_exec) {
+            hipGraph_t g = nullptr;
+            hipGraphExec_t ex = nullptr;
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                int cs = iteration(0, false);
+                if (cs == NODAL_OK) cs = iteration(1, false);
+                const hipError_t ce = hipStreamEndCapture(st, &g);
+                if (cs == NODAL_OK && ce == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
+                    H->it_graph = g;
+                    H->it_exec = ex;
+                    H->it_key = key;
+                } else {
+                    if (g) (void)hipGraphDestroy(g);
+                    (void)hipGetLastError();
+                }
             } else {
-                SAGG_DISPATCH_W(H->pool[0]->wfix, (f_spmv<W><<<sb.g0, tb0, 0, st>>>(A0, sb.p, sb.Ap, sb.part_pap, sb.sc, it)));
+                (void)hipGetLastError();
             }
-            f_update<<<sb.g0, TB, 0, st>>>(x, sb.r, sb.p, sb.Ap, sb.part_pap, sb.g0, dinv0, sb.x0, sb.part_rr, sb.sc, it, n);
-            NODAL_HIP_TRY(h, hipGetLastError());
+        }
+    } else if (H->it_exec && do_setup) {
+        H->drop_graph();
+    }
+    while (status == 0) {
+        for (int c = 0; c < batch;) {
+            if (H->it_exec && c > 0 && c + 1 < batch && (enqueued & 1) == 0) {
+                NODAL_HIP_TRY(h, hipGraphLaunch(H->it_exec, st));
+                c += 2;
+                enqueued += 2;
+            } else {
+                NODAL_TRY(iteration((int)enqueued, c == 0));
+                ++c;
+                ++enqueued;
+            }
         }
         NODAL_HIP_TRY(h, hipMemcpyAsync(hs, sb.sc, F_COUNT * 8, hipMemcpyDeviceToHost, st));
         NODAL_HIP_TRY(h, hipStreamSynchronize(st));

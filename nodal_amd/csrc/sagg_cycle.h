@@ -616,7 +616,9 @@ __global__ __launch_bounds__(1024) void k_tail(TailDesc d, const char *__restric
 //   RZ[it&1], CONV[it&1]  written by f_direction(it);  ALPHA[it&1] by f_update(it).
 // Once an iteration has converged, CONV stays raised (f_direction hands it on) and the CG
 // kernels of every later iteration return at once.
-enum { F_RZ = 0, F_ALPHA = 2, F_CONV = 4, F_RR = 6, F_BB = 7, F_FLAG = 8, F_ITERS = 9, F_TOL2 = 10, F_COUNT = 16 };
+enum { F_RZ = 0, F_ALPHA = 2, F_CONV = 4, F_RR = 6, F_BB = 7, F_FLAG = 8, F_ITERS = 9, F_TOL2 = 10,
+       F_ITNO = 12,  // [parity]: iterations started before the NEXT one, written by f_direction (see there)
+       F_COUNT = 16 };
 constexpr int MAX_PARTIALS = 1024;
 
 __global__ __launch_bounds__(TB) void f_init(const double *__restrict__ b, double *__restrict__ x,
@@ -637,12 +639,18 @@ __global__ __launch_bounds__(TB) void f_init(const double *__restrict__ b, doubl
 }
 
 // beta from the dots of the cycle's last kernel; p = z + beta p; convergence test on |r|^2
+// The kernels of an iteration take its PARITY only; the iteration number itself lives on the device:
+// f_direction(parity cur) reads ITNO[prev] -- written by the previous iteration's f_direction, so no
+// workgroup of this launch can see it change -- and leaves ITNO[cur] = that + 1.  A pair of iterations
+// (parities 0, 1) therefore has fixed kernel arguments and can be replayed as a hipGraph.
 __global__ __launch_bounds__(TB) void f_direction(const double *__restrict__ z, double *__restrict__ p,
                                                   const double *__restrict__ part_rz,
                                                   const double *__restrict__ part_zap,
                                                   const double *__restrict__ part_rr, int nparts,
-                                                  double *__restrict__ sc, int iter, int64_t n) {
-    const int cur = iter & 1, prev = cur ^ 1;
+                                                  double *__restrict__ sc, int parity, int64_t n) {
+    const int cur = parity & 1, prev = cur ^ 1;
+    const int iter = (int)sc[F_ITNO + prev];
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc[F_ITNO + cur] = (double)(iter + 1);
     if (iter > 0 && sc[F_CONV + prev] != 0.0) {  // converged earlier: hand the flag on
         if (blockIdx.x == 0 && threadIdx.x == 0) sc[F_CONV + cur] = 1.0;
         return;
