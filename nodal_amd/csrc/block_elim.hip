@@ -434,6 +434,40 @@ __global__ __launch_bounds__(256) void copy_block(const double *__restrict__ src
         }
 }
 
+// dst (cols x rows, ldd) = src (rows x cols, lds_)^T, both at most BI_MAX wide: 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_block(const double *__restrict__ src, int64_t lds_,
+                                                       double *__restrict__ dst, int64_t ldd, int rows, int cols) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + tx, c = c0 + ty + 8 * k;
+        tile[ty + 8 * k][tx] = (r < rows && c < cols) ? src[(int64_t)c * lds_ + r] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + tx, r = r0 + ty + 8 * k;  // dst row index = src column
+        if (c < cols && r < rows) dst[(int64_t)r * ldd + c] = tile[tx][ty + 8 * k];
+    }
+}
+
+// max |A_ij - A_ji| and max |A_ij| over the n x n leading block (NODAL_TRACE: is the matrix the symmetric
+// elimination is about to take really symmetric?)
+__global__ __launch_bounds__(256) void asymmetry(const double *__restrict__ A, int64_t lda, int64_t n,
+                                                 unsigned long long *__restrict__ out) {
+    double d = 0.0, m = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n * n; e += (int64_t)gridDim.x * 256) {
+        const int64_t i = e % n, j = e / n;
+        const double a = A[j * lda + i], b = A[i * lda + j];
+        d = fmax(d, fabs(a - b));
+        m = fmax(m, fabs(a));
+    }
+    atomicMax(&out[0], (unsigned long long)__double_as_longlong(d));
+    atomicMax(&out[1], (unsigned long long)__double_as_longlong(m));
+}
+
 // Back substitution for the block-inverse form: x[j0:j1] = y[j0:j1] is final; the rows
 // above lose A[0:j0, j0:j1] x[j0:j1].  A workgroup owns 64 rows (one per lane); its four
 // waves split the block's columns, 16 independent loads in flight each, and meet in
@@ -520,8 +554,13 @@ int invert_diag(nodal_ctx *h, hipStream_t sp, double *D, int64_t lda, int w, dou
 }
 
 // bnd: block boundaries 0 = bnd[0] < bnd[1] < ... < bnd[nb] = n (widths <= BI_MAX, possibly mixed)
+// sym: the matrix is symmetric (a passive network) -- only its upper block triangle is updated.  The
+// block column below the diagonal block k is the transpose of the block row V(k) = A12(k) right of it
+// (as it stood before A12 <- Q A12), which is kept in a scratch panel: the bulk update
+// A22 -= V^T W touches the upper tiles only (half the flops, both operands read along k), the small
+// products of the chain take the 256 x 256 head of V^T from an explicit transpose.
 int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncols, int32_t *dinfo,
-                    GemmTimer &tm, const std::vector<int64_t> &bnd) {
+                    GemmTimer &tm, const std::vector<int64_t> &bnd, bool sym) {
     // Three streams.  Per block k = [J0, J1), next block [J1, J2), once A12(k) <- Q(k) A12(k)
     // (called W(k) below) is done and the previous bulk update has retired:
     //   sp (high priority): diag   A[J1:J2, J1:J2] -= A[J1:J2, J0:J1] W(k)       (small)
@@ -541,20 +580,36 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
     int64_t wmax = 0;
     for (int k = 0; k < nb; ++k) wmax = std::max(wmax, bnd[k + 1] - bnd[k]);
     const int64_t FIRST = 2 * wmax;  // (capacity) columns of W(k) that the next two diagonal blocks need
-    // scratch: Q[2] (wmax x wmax), the inverse's T1 / T2 per recursion level, S1 (wmax x FIRST), S (wmax x ncols)
+    // scratch: Q[2] (wmax x wmax), the inverse's T1 / T2 per recursion level, S1 (wmax x FIRST), S (wmax x ncols);
+    // sym: two panels V[2] (wmax x ncols: block k's bulk update reads V(k) while the chain fills V(k + 1))
+    // and two transposed heads Lt[2] (wmax x wmax) instead of S1 / S
     const size_t qb = (size_t)wmax * wmax, tb = 2 * (size_t)(2 * GJ) * (2 * GJ) + 2 * (size_t)GJ * GJ;
-    NODAL_HIP_TRY(h, h->work.reserve((2 * qb + tb + (size_t)wmax * FIRST + (size_t)wmax * (size_t)ncols) * 8 + 256));
+    const size_t panel = (size_t)wmax * (size_t)ncols;
+    NODAL_HIP_TRY(h, h->work.reserve((2 * qb + tb + (sym ? 2 * panel + 2 * qb : (size_t)wmax * FIRST + panel)) * 8 + 256));
     double *Q[2] = {h->work.as<double>(), h->work.as<double>() + qb};
     double *T = Q[1] + qb, *S1 = T + tb, *S = S1 + (size_t)wmax * FIRST;
+    double *V[2] = {T + tb, T + tb + panel};
+    double *Lt[2] = {V[1] + panel, V[1] + panel + qb};
 
     // A12 <- Q A12 for the block [J0, J1): columns [c0, c1) on stream st through scratch buf
+    // (sym: buf is the block's panel V, column j of it <-> global column J1 + j, and it is kept)
     auto scale_cols = [&](hipStream_t st, const double *Qk, double *buf, int64_t J0, int64_t J1, int64_t c0,
                           int64_t c1) -> int {
         if (c1 <= c0) return NODAL_OK;
         const int w = (int)(J1 - J0);
+        if (sym) buf += (c0 - J1) * wmax;
         copy_block<<<blocks_for(c1 - c0, 4), 256, 0, st>>>(A + c0 * lda + J0, lda, buf, wmax, w, c1 - c0);
         NODAL_HIP_TRY(h, hipGetLastError());
         return gemm_f64(h, st, GEMM_SET, A + c0 * lda + J0, lda, Qk, wmax, buf, wmax, w, c1 - c0, w);
+    };
+    // sym: Lt(k) = (first w_next columns of V(k))^T, the rows J1:J2 of the never-formed block column k
+    auto head_transpose = [&](hipStream_t st, int k) -> int {
+        if (!sym || k + 2 > nb) return NODAL_OK;
+        const int w = (int)(bnd[k + 1] - bnd[k]), wn = (int)(bnd[k + 2] - bnd[k + 1]);
+        transpose_block<<<dim3((unsigned)((w + 31) / 32), (unsigned)((wn + 31) / 32)), 256, 0, st>>>(
+            V[k & 1], wmax, Lt[k & 1], wmax, w, wn);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        return NODAL_OK;
     };
     // W(k)'s first columns: those the next two diagonal blocks (k + 1, k + 2) read
     auto first_end = [&](int k) {
@@ -569,10 +624,11 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
         const int64_t J1 = bnd[1];
         NODAL_TRY(invert_diag(h, sp, A, lda, (int)J1, Q[0], wmax, T, dinfo, 0));
         NODAL_HIP_TRY(h, hipEventRecord(ev_q, sp));
-        NODAL_TRY(scale_cols(sp, Q[0], S1, 0, J1, J1, first_end(0)));
+        NODAL_TRY(scale_cols(sp, Q[0], sym ? V[0] : S1, 0, J1, J1, first_end(0)));
+        NODAL_TRY(head_transpose(sp, 0));
         NODAL_HIP_TRY(h, hipEventRecord(ev_wfirst, sp));
         NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_q, 0));
-        NODAL_TRY(scale_cols(s3, Q[0], S, 0, J1, first_end(0), ncols));
+        NODAL_TRY(scale_cols(s3, Q[0], sym ? V[0] : S, 0, J1, first_end(0), ncols));
         NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_wfirst, 0));  // ev_wrest then stands for ALL of W(k):
         NODAL_HIP_TRY(h, hipEventRecord(ev_wrest, s3));          // one barrier packet less in front of the bulk GEMM
     }
@@ -580,6 +636,9 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
         const int64_t J0 = bnd[blk], J1 = bnd[blk + 1], J2 = bnd[blk + 2];
         const int w = (int)(J1 - J0);
         const double *L = A + J0 * lda, *U = A + J1 * lda + J0;  // A[:, J0:J1] and W(k)
+        // rows J1:J2 of the block column: in place, or (sym) the transposed head of V(k)
+        const double *Lhead = sym ? Lt[blk & 1] : L + J1;
+        const int64_t ldh = sym ? wmax : lda;
         double *Qn = Q[(blk + 1) & 1];
         if (ev_rest) {  // block row k+1 was last written by the previous bulk update
             NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_rest, 0));
@@ -587,27 +646,40 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
         }
         NODAL_HIP_TRY(h, hipStreamWaitEvent(sg, ev_wrest, 0));  // all of W(k) (s3 waited for the first columns)
         // sp: diag + inverse chain
-        NODAL_TRY(gemm_sub_f64(h, sp, A + J1 * lda + J1, lda, L + J1, lda, U, lda, J2 - J1, J2 - J1, w));
+        NODAL_TRY(gemm_sub_f64(h, sp, A + J1 * lda + J1, lda, Lhead, ldh, U, lda, J2 - J1, J2 - J1, w));
         NODAL_TRY(invert_diag(h, sp, A + J1 * lda + J1, lda, (int)(J2 - J1), Qn, wmax, T, dinfo, (int)J1));
         NODAL_HIP_TRY(h, hipEventRecord(ev_q, sp));
         // s3: strip
-        NODAL_TRY(gemm_sub_f64(h, s3, A + J2 * lda + J1, lda, L + J1, lda, U + (J2 - J1) * lda, lda,
+        NODAL_TRY(gemm_sub_f64(h, s3, A + J2 * lda + J1, lda, Lhead, ldh, U + (J2 - J1) * lda, lda,
                                J2 - J1, ncols - J2, w));
         NODAL_HIP_TRY(h, hipEventRecord(ev_strip, s3));
         // sg: rest
         if (J2 < n) {
             NODAL_TRY(tm.begin(sg));
-            NODAL_TRY(gemm_sub_f64(h, sg, A + J1 * lda + J2, lda, L + J2, lda, U, lda, n - J2, ncols - J1, w));
-            NODAL_TRY(tm.end(sg, 2.0 * (double)w * (double)(n - J2) * (double)(ncols - J1)));
+            if (sym) {  // upper tiles of A[J2:, J2:] -= V(k)[:, J2:]^T W(k)[:, J2:]
+                // the later diagonal blocks must come out whole: they start at multiples of the widest
+                // remaining block width from J2 (512-wide blocks come first, then 256-wide ones)
+                int64_t band = 128;
+                for (int q = blk + 2; q < nb; ++q) band = std::max(band, (bnd[q + 1] - bnd[q] + 127) / 128 * 128);
+                NODAL_TRY(gemm_sub_tn_upper_f64(h, sg, A + J2 * lda + J2, lda, V[blk & 1] + (J2 - J1) * wmax, wmax,
+                                                U + (J2 - J1) * lda, lda, n - J2, ncols - J2, w, (int)band));
+                // (the diagonal blocks are computed whole)
+                const double m = (double)(n - J2);
+                NODAL_TRY(tm.end(sg, 2.0 * (double)w * (m * (double)(ncols - J2) - 0.5 * m * std::max(0.0, m - (double)band))));
+            } else {
+                NODAL_TRY(gemm_sub_f64(h, sg, A + J1 * lda + J2, lda, L + J2, lda, U, lda, n - J2, ncols - J1, w));
+                NODAL_TRY(tm.end(sg, 2.0 * (double)w * (double)(n - J2) * (double)(ncols - J1)));
+            }
             ev_rest = tm.last_end();  // the timing event doubles as the dependency (one packet less;
                                       // dropping the timing events altogether was measured: no change)
         } else ev_rest = nullptr;
         // W(k+1): the first columns on the critical stream, the wide remainder beside it
         NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_strip, 0));
-        NODAL_TRY(scale_cols(sp, Qn, S1, J1, J2, J2, first_end(blk + 1)));
+        NODAL_TRY(scale_cols(sp, Qn, sym ? V[(blk + 1) & 1] : S1, J1, J2, J2, first_end(blk + 1)));
+        NODAL_TRY(head_transpose(sp, blk + 1));
         NODAL_HIP_TRY(h, hipEventRecord(ev_wfirst, sp));
         NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_q, 0));
-        NODAL_TRY(scale_cols(s3, Qn, S, J1, J2, first_end(blk + 1), ncols));
+        NODAL_TRY(scale_cols(s3, Qn, sym ? V[(blk + 1) & 1] : S, J1, J2, first_end(blk + 1), ncols));
         NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_wfirst, 0));
         NODAL_HIP_TRY(h, hipEventRecord(ev_wrest, s3));
     }
@@ -645,7 +717,22 @@ int dense_block_elimination(nodal_ctx *h, double *A, int64_t n, int64_t lda, int
             bnd.push_back(j);
         }
     }
-    NODAL_TRY(factor_blockinv(h, A, n, lda, ncols, dinfo, tm, bnd));
+    // a passive network's matrix is symmetric bit for bit (every off-diagonal pair is the same sum of the
+    // same -1/R terms in the same order); a presolved system with transconductance stamps is not
+    static const bool sym_env = !(getenv("NODAL_BI_SYM") && atoi(getenv("NODAL_BI_SYM")) == 0);
+    const bool sym = sym_env && h->passive_network && !h->optimistic_nopivot;
+    if (sym && getenv("NODAL_TRACE")) {
+        NODAL_HIP_TRY(h, h->work3.reserve(256));
+        unsigned long long *o = h->work3.as<unsigned long long>();
+        NODAL_HIP_TRY(h, hipMemsetAsync(o, 0, 16, st));
+        asymmetry<<<1024, 256, 0, st>>>(A, lda, n, o);
+        double host[2];
+        NODAL_HIP_TRY(h, hipMemcpyAsync(host, o, 16, hipMemcpyDeviceToHost, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        fprintf(stderr, "[dense] symmetric block elimination, n %lld: max |a_ij - a_ji| = %.3e, max |a_ij| = %.3e\n",
+                (long long)n, host[0], host[1]);
+    }
+    NODAL_TRY(factor_blockinv(h, A, n, lda, ncols, dinfo, tm, bnd, sym));
     double *y = A + n * lda;
     for (int k = (int)bnd.size() - 2; k >= 0; --k) {
         const int64_t j0 = bnd[k], j1 = bnd[k + 1];

@@ -215,6 +215,9 @@ struct GemmProblem {
 int gemm_pair_f64(nodal_ctx *h, hipStream_t stream, int mode, const GemmProblem &p0, const GemmProblem &p1);
 int gemm_sub_f64(nodal_ctx *h, hipStream_t stream, double *C, int64_t ldc, const double *A,
                  int64_t lda, const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K);
+// C -= At^T B for the upper triangle of a square-leading C (At: K x M panel, B: K x N, column-major)
+int gemm_sub_tn_upper_f64(nodal_ctx *h, hipStream_t stream, double *C, int64_t ldc, const double *At,
+                          int64_t ldat, const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K, int band);
 
 // ---- dense LU (dense_lu.hip) ----
 // leading dimension of the column-major dense panel: padded so that 32-row tiles

@@ -37,12 +37,19 @@ constexpr int NT = 256;  // threads per workgroup of the big kernel
 constexpr int LDA_S = 144;  // A image row stride (doubles)
 constexpr int LDB_S = 145;  // B image row stride: odd/2 -> conflict-free transposing writes
 
-template <int MODE>
+// TA: the A operand is given TRANSPOSED -- `A` points to a K x M column-major panel (leading dimension
+// lda) and the product is C -= A^T B: both operands are then read along k, the contiguous direction.
+// This is the bulk update of the SYMMETRIC block elimination (block_elim.hip), where the block column
+// below the diagonal is the transpose of the block row right of it and is never formed.
+// UPPER: C is square-leading (row i <-> column i) and only its upper block triangle is wanted: tiles
+// entirely below the diagonal blocks of `band` rows return at once.
+template <int MODE, bool TA = false, bool UPPER = false>
 __global__ __launch_bounds__(NT, 2) void gemm_sub_kernel(double *__restrict__ C, int64_t ldc,
                                                          const double *__restrict__ A, int64_t lda,
                                                          const double *__restrict__ B, int64_t ldb,
-                                                         int M, int N, int K) {
-    __shared__ double As[2][BK][LDA_S];
+                                                         int M, int N, int K, int band = BM) {
+    constexpr int LA = TA ? LDB_S : LDA_S;  // (transposing writes of the A image want the odd stride too)
+    __shared__ double As[2][BK][LA];
     __shared__ double Bs[2][BK][LDB_S];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;  // 2 x 2 waves, 64 x 64 each
@@ -52,6 +59,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_sub_kernel(double *__restrict__ C,
     const int tiles_m = (M + BM - 1) / BM;
     const int tm = (int)(blockIdx.x % (unsigned)tiles_m), tn = (int)(blockIdx.x / (unsigned)tiles_m);
     const int row0 = tm * BM, col0 = tn * BN;
+    // (uniform) strictly below the diagonal BLOCK the tile's rows belong to: the diagonal blocks (`band`
+    // rows and columns each, aligned with the origin of C) are wanted whole
+    if (UPPER && col0 + BN <= (row0 / band) * band) return;
     const int li = lane & 15, lk = lane >> 4, lq = lane & 3;
 
     double acc[4][4][4];
@@ -70,11 +80,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_sub_kernel(double *__restrict__ C,
     double ra[8], rb[8];
     const int ai = tid & 127, ak = tid >> 7;  // A image [k][i]: i contiguous in memory; k = ak + 2 r
     const int bk = tid & 15, bj = tid >> 4;   // B: 16 contiguous k of one column; j = bj + 16 r
-    const char *Abase = reinterpret_cast<const char *>(A + row0);
+    const char *Abase = reinterpret_cast<const char *>(TA ? A + (int64_t)row0 * lda : A + row0);
     const char *Bbase = reinterpret_cast<const char *>(B + (int64_t)col0 * ldb);
     const int64_t lda8 = lda * 8, ldb8 = ldb * 8;
     const uint32_t aoff = (uint32_t)((row0 + ai < M ? ai : M - 1 - row0) * 8);
     const int jlast = N - 1 - col0;  // uniform
+    const int ilast = M - 1 - row0;  // uniform (TA)
     auto load_chunk = [&](int k0) {
         const int gkb = k0 + bk;
         const uint32_t kb8 = (uint32_t)(gkb < K ? gkb : K - 1) * 8u;
@@ -82,8 +93,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_sub_kernel(double *__restrict__ C,
         const int klast = K - 1 - k0;                 // uniform
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const int kk = ak + 2 * r < klast ? ak + 2 * r : klast;
-            ra[r] = *reinterpret_cast<const double *>(Ak + ((uint32_t)kk * (uint32_t)lda8 + aoff));
+            if (TA) {  // like B: 16 contiguous k of one column i of the K x M panel; i = bj + 16 r
+                const int ii = bj + 16 * r < ilast ? bj + 16 * r : ilast;
+                ra[r] = *reinterpret_cast<const double *>(Abase + ((uint32_t)ii * (uint32_t)lda8 + kb8));
+            } else {
+                const int kk = ak + 2 * r < klast ? ak + 2 * r : klast;
+                ra[r] = *reinterpret_cast<const double *>(Ak + ((uint32_t)kk * (uint32_t)lda8 + aoff));
+            }
             const int jj = bj + 16 * r < jlast ? bj + 16 * r : jlast;
             rb[r] = *reinterpret_cast<const double *>(Bbase + ((uint32_t)jj * (uint32_t)ldb8 + kb8));
         }
@@ -94,7 +110,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_sub_kernel(double *__restrict__ C,
         const double mb = k0 + bk < K ? 1.0 : 0.0;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            As[buf][ak + 2 * r][ai] = ra[r] * (k0 + ak + 2 * r < K ? 1.0 : 0.0);
+            if (TA) As[buf][bk][bj + 16 * r] = ra[r] * mb;
+            else As[buf][ak + 2 * r][ai] = ra[r] * (k0 + ak + 2 * r < K ? 1.0 : 0.0);
             Bs[buf][bk][bj + 16 * r] = rb[r] * mb;
         }
     };
@@ -301,6 +318,18 @@ int gemm_f64(nodal_ctx *h, hipStream_t stream, int mode, double *C, int64_t ldc,
         gemm_sub_kernel<GEMM_SET><<<grid, NT, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
     else
         gemm_sub_kernel<GEMM_SETNEG><<<grid, NT, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
+}
+
+// C -= At^T B, upper block triangle of the square-leading C only (At: K x M, B: K x N, N >= M): the
+// diagonal blocks of `band` rows (a multiple of 128, aligned with C's origin) are updated whole.
+int gemm_sub_tn_upper_f64(nodal_ctx *h, hipStream_t stream, double *C, int64_t ldc, const double *At,
+                          int64_t ldat, const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K, int band) {
+    if (M <= 0 || N <= 0 || K <= 0) return NODAL_OK;
+    if (band < BM || band % BM) return nodal_fail(h, NODAL_E_INVALID, "gemm_sub_tn_upper: band must be a multiple of 128");
+    dim3 grid((unsigned)(((M + BM - 1) / BM) * ((N + BN - 1) / BN)));
+    gemm_sub_kernel<GEMM_SUB, true, true><<<grid, NT, 0, stream>>>(C, ldc, At, ldat, B, ldb, (int)M, (int)N, (int)K, band);
     NODAL_HIP_TRY(h, hipGetLastError());
     return NODAL_OK;
 }
