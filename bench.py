@@ -345,7 +345,8 @@ def roofline_of(st, circuits_per_sec_per_gpu):
         avg_s = st["kern_ms"] / st["kern_n"] * 1e-3
         if st["dense"]:
             achieved = st["kern_alg"] / avg_s / 1e12
-            out = {"bound": "mfma", "kernel": "gemm_sub_kernel (K=256 bulk update of the block elimination)",
+            out = {"bound": "mfma", "kernel": "gemm_sub_kernel<SUB, TA, UPPER>: bulk update A22 -= V^T W of the symmetric "
+                                              "block elimination, K = 256 / 512 (gemm_f64.hip)",
                    "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                    "frac": achieved / FP64_MFMA_PEAK_TF, "traffic": pmc_traffic(st["name"]),
                    "avg_launch_us": avg_s * 1e6, "launches_timed": st["kern_n"],

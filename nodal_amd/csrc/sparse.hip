@@ -823,6 +823,7 @@ int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, do
         return NODAL_OK;
     }
     const int64_t densify_max = 4096;
+    const int64_t dense_rescue_max = 32768;  // a general system the iteration gives up on is decided by the dense LU up to here
     const int64_t lowdeg_min = 1024;  // below this a direct solve costs less than an elimination round
     bool auto_passive = false;
     if (method == NODAL_SPARSE_AUTO) {
@@ -884,6 +885,24 @@ int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, do
             // the iteration gave up on a matrix that is singular by construction: the reference's
             // answer is NaNs + a warning (quirk 3), not an exception
             *info = 1;
+        } else if (s == NODAL_E_UNSUPPORTED && n <= dense_rescue_max) {
+            // The iteration did not converge and nothing in the STRUCTURE says why: singular for its
+            // particular values (a gain of exactly 1 around a loop), or too ill-conditioned for the
+            // iterative path.  The reference's spsolve decides by pivoting (reference nodal/nodal.py:325:
+            // an exact zero pivot -> NaNs + MatrixRankWarning, else the LU's answer); up to
+            // dense_rescue_max unknowns (8.6 GB as a dense panel, ~1.5 s) the pivoted dense LU here does
+            // the same.  Larger ones keep the loud error.
+            const std::string why = h->err;
+            const bool forced = h->force_pivoting;
+            h->force_pivoting = true;  // (the tournament LU's exact-zero-pivot test, not the pivot-free paths)
+            int d = dense_prepare(h);
+            if (d == NODAL_OK) d = dense_factor_solve(h, info);
+            h->force_pivoting = forced;
+            if (d != NODAL_OK) return d;
+            *iters = 0;
+            *resid = 0.0;
+            static const bool trace = getenv("NODAL_TRACE") != nullptr;
+            if (trace) fprintf(stderr, "[general] %s -- decided by the pivoted dense LU: info %d\n", why.c_str(), *info);
         } else if (s != NODAL_OK) {
             return s;
         }

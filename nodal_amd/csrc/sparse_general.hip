@@ -412,6 +412,20 @@ bool general_source_loop(const nodal_ctx *h);                // sparse.hip
 bool general_floating_island(const nodal_ctx *h);            // sparse.hip
 int grounded_flags(nodal_ctx *h, uint8_t *flags_dev);         // lowdeg.hip
 
+// A row whose stored entries are all exactly zero (a VCVS from a node to ground sensing that very node
+// with gain 1: its branch row reads (1 - 1) e = 0, reference nodal/models.py:53-78): G is exactly
+// singular, the reference's SuperLU meets the zero pivot whatever the rounding (NaNs +
+// MatrixRankWarning) -- but the system is consistent, so a Krylov iteration "converges" to one of its
+// solutions.  Looked for before anything is solved.
+__global__ __launch_bounds__(TB) void find_zero_row(const int32_t *__restrict__ indptr, const double *__restrict__ data,
+                                                    int64_t n, uint32_t *__restrict__ flag) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        bool any = false;
+        for (int32_t e = indptr[i]; e < indptr[i + 1]; ++e) any = any || data[e] != 0.0;
+        if (!any) *flag = 1u;  // benign race
+    }
+}
+
 int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
     const int64_t n = h->n;
     const int K = h->K;
@@ -423,6 +437,20 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
     double *x = h->x.as<double>();
     *info = 0;
 
+    if (h->B > 0) {  // (branch rows are the ones that can vanish; a node row of an all-resistor network cannot)
+        NODAL_HIP_TRY(h, h->status.reserve(64));
+        uint32_t *zr = reinterpret_cast<uint32_t *>(h->status.as<char>() + 48);
+        NODAL_HIP_TRY(h, hipMemsetAsync(zr, 0, 4, st));
+        find_zero_row<<<grid_for(n), TB, 0, st>>>(indptr, data, n, zr);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        uint32_t zero_row = 0;
+        NODAL_HIP_TRY(h, hipMemcpyAsync(&zero_row, zr, 4, hipMemcpyDeviceToHost, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        if (zero_row) {
+            *info = 1;
+            return NODAL_OK;
+        }
+    }
     // branch equations present: first try to eliminate them exactly (presolve.hip)
     if (h->B > 0) {
         if (h->use_presolve) {

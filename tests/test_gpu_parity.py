@@ -1008,3 +1008,31 @@ def test_batch_members_with_sources_over_eight_decades():
         Go, Ao = oracle.assemble_fast(t)
         xo, _ = oracle.solve(Go.tocsr(), Ao, True)
         assert normwise(out[b], xo) <= TOL, (b, amp[b])  # norm-wise per MEMBER, not over the shard
+
+
+@pytest.mark.parametrize("gain", ["1", "0.75"])
+def test_value_singular_large_general_system(gain):
+    """A large general system that is singular for its VALUES only: a VCVS from a node to ground
+    controlled by that same node with gain exactly 1 (reference nodal/models.py:53-78: its branch
+    row reads (1 - gain) e = 0, a zero row).  Nothing in the structure says so, the presolve declines
+    the self-controlled branch and the Krylov iteration cannot converge; the reference's spsolve hits
+    the zero pivot: NaNs + MatrixRankWarning (reference nodal/nodal.py:323-336).  Up to 32 768
+    unknowns the pivoted dense LU decides the same way here; with gain 0.75 the same netlist is
+    regular and must agree with the oracle."""
+    rows = list(gen.grid_rows(72))[:-1]
+    rows.append(["e0", "E", "1", "1", "g"])
+    rows.append(["a1", "A", "1", "17", "g"])
+    rows.append(["dq", "VCVS", gain, "40", "g", "40", "g"])
+    nl = n.Netlist.from_rows(rows)
+    Go, Ao, _ = oracle.build_model(nl, True)
+    xo, oracle_warnings = oracle.solve(Go, Ao, True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        sol = n.Circuit(nl, sparse=True).solve()
+    if gain == "1":
+        assert np.isnan(xo).all() and "MatrixRankWarning" in oracle_warnings
+        assert np.isnan(sol.result).all()
+        assert any(issubclass(i.category, MatrixRankWarning) for i in w)
+    else:
+        assert np.isfinite(xo).all() and not oracle_warnings and not w
+        assert normwise(sol.result, xo) <= TOL
