@@ -612,6 +612,12 @@ def main():
             s2 = time_workload(other, 0, 1, local, None, {"cfg4": 6, "cfg5": 2, "cfg2": 1}[other], 1,
                                {"cfg4": 128, "cfg5": 4, "cfg2": 4}[other])
             also[other] = summary(s2, 1, with_cpu=not args.no_cpu)
+            if other == "cfg5":  # the general path with the symbolic phases kept (stamping lists, the presolved
+                # netlist's lists, the hierarchy's patterns); the presolve's plan and rewrite are redone: they read values
+                s3 = time_workload(other, 0, 1, local, None, 2, 1, 4, reuse=True)
+                r3 = summary(s3, 1, with_cpu=False)
+                also[other]["reuse_symbolic"] = {k: r3[k] for k in ("circuits_per_sec", "ms_per_solve", "phase_ms", "solver",
+                                                                     "scaled_residual")}
         out["also"] = also
     if rank == 0:
         print(json.dumps(out))

@@ -90,6 +90,7 @@ struct nodal_ctx {
     bool keep_host_table = true;
     int32_t member = 0;            // batch member of the last numeric assembly
     nodal_ctx *reduced = nullptr;  // presolved (branch-free) system, see presolve.hip
+    uint64_t reduced_key = 0;      // (on the reduced context) fingerprint of the topology its symbolic lists belong to
     bool owns_streams = true;
     nodal_ctx *stream_owner = nullptr;  // (child contexts) the context whose streams and events this one borrows
     bool use_presolve = true;

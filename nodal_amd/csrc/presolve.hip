@@ -554,14 +554,33 @@ static int presolve_build_reduced(nodal_ctx *h, nodal_ctx *r, const double *valu
         NODAL_HIP_TRY(h, hipMemcpyAsync(o.k + nkeep, minus.data(), (size_t)nx * 4, hipMemcpyHostToDevice, st));
         NODAL_HIP_TRY(h, hipStreamSynchronize(st));
     }
+    // Fingerprint of the reduced netlist's TOPOLOGY: the parent's (struct_epoch: a value sweep on an
+    // assembled topology keeps it, a fresh symbolic assembly does not), the pivots, and the integer columns
+    // of the rewritten rows (which rows get emitted depends on values: a zero constant emits no source).
+    // Unchanged => the reduced system's stamping lists stand, and with them (same struct_epoch of the
+    // reduced context) the symbolic part of its multigrid hierarchy: only values are redone.
+    uint64_t key = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
+    mix(h->table_epoch); mix(h->struct_epoch); mix((uint64_t)np); mix((uint64_t)nkeep); mix((uint64_t)nx); mix((uint64_t)plan.Kr);
+    for (int32_t pv : plan.pivots) mix((uint64_t)(uint32_t)pv);
+    for (int64_t i = 0; i < nx; ++i) {
+        mix(x.type[(size_t)i]);
+        mix((uint64_t)(uint32_t)x.a[(size_t)i] << 32 | (uint32_t)x.b[(size_t)i]);
+        mix((uint64_t)(uint32_t)x.c[(size_t)i] << 32 | (uint32_t)x.d[(size_t)i]);
+    }
+    const bool same_topology = r->have_symbolic && r->reduced_key == key && r->ncomp == nkeep + nx && r->K == plan.Kr;
     r->ncomp = nkeep + nx;
     r->K = plan.Kr;
     r->B = 0;
     r->n = plan.Kr;
     r->batch = 0;
-    ++r->table_epoch;  // (the reduced netlist is rewritten per solve: its list sizes are read back every time)
     r->have_table = true;
-    r->have_symbolic = r->have_numeric = r->have_x = false;
+    r->have_numeric = r->have_x = false;
+    if (!same_topology) {
+        ++r->table_epoch;
+        r->have_symbolic = false;
+        r->reduced_key = key;
+    }
     *ok = true;
     return NODAL_OK;
 }
@@ -658,7 +677,7 @@ int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, doub
     NODAL_TRY(presolve_build_reduced(h, r, value, value_dev, plan, &built));
     if (!built) return NODAL_OK;
     const auto t2 = now();
-    int s = stamp_symbolic(r);
+    int s = r->have_symbolic ? NODAL_OK : stamp_symbolic(r);  // (kept: same topology as the last solve's)
     if (s == NODAL_OK) s = stamp_numeric(r, 0, nullptr);
     if (s != NODAL_OK) { h->err = r->err; return s; }
     const auto t3 = now();

@@ -1036,3 +1036,68 @@ def test_value_singular_large_general_system(gain):
     else:
         assert np.isfinite(xo).all() and not oracle_warnings and not w
         assert normwise(sol.result, xo) <= TOL
+
+
+def test_value_sweep_on_a_general_topology_keeps_the_symbolic_phases():
+    """A value sweep on config 5's topology (E sources, CCCS, VCVS: the large general path with the
+    presolve): member after member through nodal_run(reuse_symbolic = 1).  Kept from the first member
+    on: the stamping lists, the reduced (presolved) netlist's lists -- its topology fingerprint does
+    not change with the values -- and the symbolic part of the multigrid hierarchy; redone: every
+    value, the Galerkin sums, the solve.  Every member against the oracle's spsolve
+    (reference nodal/nodal.py:306-336: a loop of Circuit(...).solve())."""
+    table = gen.cfg5_table(100)
+    assert table.n > 4096 and table.B > 0
+    rng = np.random.default_rng(11)
+    members = 4
+    vals = np.tile(table.value, (members, 1))
+    is_r = table.type == 0
+    for m in range(1, members):
+        vals[m, is_r] *= rng.uniform(0.5, 2.0, int(is_r.sum()))       # every resistor
+        vals[m, ~is_r] *= rng.uniform(0.8, 1.25, int((~is_r).sum()))  # sources and gains
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.upload_values(vals)
+    iters = []
+    for m in range(members):
+        info = h.run(False, member=m, reuse_symbolic=m > 0)
+        assert info == 0
+        x = h.download_x()
+        iters.append(h.solve_info()[0])
+        t = table.truncated(table.ncomp)
+        t.value[:] = vals[m]
+        Go, Ao = oracle.assemble_fast(t)
+        xo, _ = oracle.solve(Go.tocsr(), Ao, True)
+        assert normwise(x, xo) <= TOL, m
+        assert h.residual() <= 1e-12
+    # and the same members again, fresh: same answers
+    info = h.run(False, member=2, reuse_symbolic=False)
+    t = table.truncated(table.ncomp)
+    t.value[:] = vals[2]
+    Go, Ao = oracle.assemble_fast(t)
+    xo, _ = oracle.solve(Go.tocsr(), Ao, True)
+    assert info == 0 and normwise(h.download_x(), xo) <= TOL
+    h.close()
+
+
+def test_value_sweep_on_the_grid_keeps_the_hierarchy():
+    """The same for a passive network (config 3's topology at 300 x 300): the multigrid's symbolic
+    setup is kept across members whose resistances differ by up to a factor 4 (values-only refresh,
+    csrc/sagg.hip: sagg_refresh), each member against the oracle."""
+    N = 300
+    table = gen.grid_table(N)
+    rng = np.random.default_rng(5)
+    members = 3
+    vals = np.ones((members, table.ncomp))
+    for m in range(1, members):
+        vals[m, :-1] = rng.uniform(0.5, 2.0, table.ncomp - 1)
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.upload_values(vals)
+    for m in range(members):
+        assert h.run(False, member=m, reuse_symbolic=m > 0) == 0
+        x = h.download_x()
+        Go, Ao = oracle.assemble_fast(gen.grid_table(N, vals[m, :-1]))
+        xo, _ = oracle.solve(Go.tocsr(), Ao, True)
+        assert normwise(x, xo) <= TOL, m
+        assert h.residual() <= 1e-13
+    h.close()
