@@ -378,6 +378,55 @@ __global__ __launch_bounds__(TB) void mis_flag_roots(Ell A, const uint32_t *__re
     }
 }
 
+// The whole independent-set computation of a SMALL level (init, every round's two neighbour-max passes,
+// the root flags) in one workgroup: fourteen launches of 4.5 us each become one of ~20 us.
+constexpr int64_t MIS_SMALL_MAX = 1024;  // (one row per thread; at 8.9 k rows nine rows per thread in sequence lose: 250 instead of 63 us)
+__global__ __launch_bounds__(1024) void mis_small(Ell A, uint32_t *__restrict__ T, uint32_t *__restrict__ M,
+                                                  uint32_t *__restrict__ flag, int rounds) {
+    const int64_t n = A.n;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) T[i] = (1u << 30) | hash30((uint32_t)i);
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+        for (int64_t i = threadIdx.x; i < n; i += 1024) {  // (mis_max)
+            uint32_t best = T[i];
+            const int32_t l = A.len[i];
+            for (int32_t s = 0; s < l; ++s) {
+                const uint32_t t = T[A.col[(int64_t)s * A.ld + i]];
+                best = t > best ? t : best;
+            }
+            M[i] = best;
+        }
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < n; i += 1024) {  // (mis_update)
+            const uint32_t own = T[i];
+            if ((own >> 30) != 1) continue;
+            uint32_t best = M[i];
+            const int32_t l = A.len[i];
+            for (int32_t s = 0; s < l; ++s) {
+                const uint32_t t = M[A.col[(int64_t)s * A.ld + i]];
+                best = t > best ? t : best;
+            }
+            if (best == own) T[i] = own | (2u << 30);
+            else if ((best >> 30) == 3) T[i] = 0;
+        }
+        __syncthreads();
+    }
+    for (int64_t i = threadIdx.x; i <= n; i += 1024) {  // (mis_flag_roots)
+        uint32_t f = 0;
+        if (i < n) {
+            const uint32_t own = T[i];
+            if ((own >> 30) == 3) f = 1;
+            else if ((own >> 30) == 1) {
+                bool near = false;
+                const int32_t l = A.len[i];
+                for (int32_t s = 0; s < l; ++s) near = near || (T[A.col[(int64_t)s * A.ld + i]] >> 30) == 3;
+                f = near ? 0u : 1u;
+            }
+        }
+        flag[i] = f;
+    }
+}
+
 // roots and their neighbours (the root of highest priority if there are several)
 __global__ __launch_bounds__(TB) void assign_near(Ell A, const uint32_t *__restrict__ T,
                                                   const uint32_t *__restrict__ flag,
@@ -1066,7 +1115,10 @@ int galerkin_product(nodal_ctx *h, SHierarchy *H, int l) {
     if (g_env >= 8 && g_env <= 64 && apw == 16) G = g_env & ~7;
     const int pcap = G * apw + 8;
     const size_t lds = 1024 + (size_t)pcap * 12;
-    const unsigned gg = (unsigned)(nc < BSTAT_MAX ? nc : BSTAT_MAX);
+    // (at most 16384 workgroups, each walking several rows: the one-workgroup fold of their statistics
+    // reads 2 x 16384 words instead of 2 x 65536 -- 3 instead of 10 us)
+    static const int64_t gcap = getenv("NODAL_SA_GCAP") ? atoll(getenv("NODAL_SA_GCAP")) : 16384;
+    const unsigned gg = (unsigned)(nc < gcap ? nc : (gcap < BSTAT_MAX ? gcap : BSTAT_MAX));
     galerkin<NUMERIC><<<gg, 64, lds, st>>>(
         ld, apcol, apval, aplen, nc, L->rld, L->rcol.as<int32_t>(), L->rval.as<double>(), L->rlen.as<int32_t>(),
         C->ld, C->acol.as<int32_t>(), C->aval.as<double>(), C->avalf.as<float>(), C->alen.as<int32_t>(),
@@ -1103,14 +1155,18 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     const unsigned g = grid_for(n);
     static const bool trace_mis = getenv("NODAL_TRACE") != nullptr;
     if (trace_mis) NODAL_HIP_TRY(h, hipMemsetAsync(cnt, 0, (MIS_ROUNDS + 2) * 8, st));
-    mis_init<<<g, TB, 0, st>>>(n, T);
     static const int mis_rounds = getenv("NODAL_SA_MIS") ? std::min(MIS_ROUNDS, std::max(1, atoi(getenv("NODAL_SA_MIS")))) : MIS_ROUNDS;
-    for (int r = 0; r < mis_rounds; ++r) {
-        mis_max<<<g, TB, 0, st>>>(A, T, M);
-        mis_update<<<g, TB, 0, st>>>(A, T, M);
-        if (trace_mis) mis_count<<<g, TB, 0, st>>>(n, T, cnt + r + 1);
+    if (n <= MIS_SMALL_MAX && !trace_mis) {
+        mis_small<<<1, 1024, 0, st>>>(A, T, M, flag, mis_rounds);
+    } else {
+        mis_init<<<g, TB, 0, st>>>(n, T);
+        for (int r = 0; r < mis_rounds; ++r) {
+            mis_max<<<g, TB, 0, st>>>(A, T, M);
+            mis_update<<<g, TB, 0, st>>>(A, T, M);
+            if (trace_mis) mis_count<<<g, TB, 0, st>>>(n, T, cnt + r + 1);
+        }
+        mis_flag_roots<<<grid_for(n + 1), TB, 0, st>>>(A, T, flag);
     }
-    mis_flag_roots<<<grid_for(n + 1), TB, 0, st>>>(A, T, flag);
     NODAL_HIP_TRY(h, hipGetLastError());
     NODAL_TRY(scan_exclusive_u32(h, flag, id, n + 1, nullptr, scan_tmp));
     // the one round trip of this level: the number of aggregates, and what the Galerkin kernel
