@@ -448,6 +448,10 @@ def summary(st, world, with_cpu):
         if asm_ms > 0:
             out["assembly"] = {"what": "B_asm / (symbolic + numeric), SURVEY.md 8d", "B_asm": b_asm, "ms": asm_ms,
                                "GB_per_s": b_asm / asm_ms / 1e6, "frac_of_hbm_peak": b_asm / asm_ms / 1e6 / HBM_PEAK_GBS}
+    if st["name"] == "cfg5":
+        out["h2d_note"] = ("h2d_ms is the whole nodal_upload_components call: DMA of the eight columns plus, because the "
+                           "table has branches, the host copy the presolve plans on and the listing of its branch rows "
+                           "(outside `value`, inside pcie_inclusive)")
     if st["name"] != "cfg4" and st.get("h2d_ms") is not None:
         # table up (pinned host memory -> HBM by DMA) and x down for EVERY circuit: what `value` leaves out
         per = st["elapsed"] / st["circuits"] * 1e3 + st["h2d_ms"] + st["d2h_ms"]
@@ -581,7 +585,7 @@ def main():
                                    else f"independent circuits x{world}")},
     }
     for key in ("phase_ms", "h2d_ms", "d2h_ms", "h2d_bytes", "d2h_bytes", "scaled_residual", "solver",
-                "roofline", "assembly", "pcie_inclusive", "cpu_baseline", "speedup_vs_cpu_baseline",
+                "roofline", "assembly", "pcie_inclusive", "h2d_note", "cpu_baseline", "speedup_vs_cpu_baseline",
                 "gather_ms_per_step", "gathered_ok"):
         if key in head:
             out[key] = head[key]
