@@ -185,8 +185,10 @@ int nodal_synchronize(nodal_handle h);
 
 /* ---- options -------------------------------------------------------------
  * NODAL_OPT_FORCE_PIVOTING (0/1): dense LU always searches pivots, even on
- *   passive networks (column diagonally dominant G) where it provably never swaps. */
-enum { NODAL_OPT_FORCE_PIVOTING = 1 };
+ *   passive networks (column diagonally dominant G) where it provably never swaps.
+ * NODAL_OPT_GEPP_PANEL (0/1, default 1): partial pivoting factors a 32-column panel in one launch
+ *   (registers) instead of two launches per column; both forms give the same bits (cross-check). */
+enum { NODAL_OPT_FORCE_PIVOTING = 1, NODAL_OPT_GEPP_PANEL = 2 };
 int nodal_set_option(nodal_handle h, int32_t option, int32_t value);
 
 /* ---- testing hooks (not part of the reference-facing surface) -------------

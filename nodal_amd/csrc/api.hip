@@ -15,7 +15,8 @@ namespace {
 // thread its own current device back afterwards
 struct DeviceGuard {
     int prev = -1;
-    explicit DeviceGuard(nodal_ctx *h) {
+    FillStreamScope fill;
+    explicit DeviceGuard(nodal_ctx *h) : fill(h->stream) {
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != h->device) (void)hipSetDevice(h->device);
         else prev = -1;
@@ -92,6 +93,7 @@ int nodal_create(int device_id, nodal_handle *out) {
         }
     if (const char *e = getenv("NODAL_DENSE_BLOCKINV")) h->dense_blockinv = atoi(e) != 0;
     if (const char *e = getenv("NODAL_GJ_SCALAR")) h->gj_scalar = atoi(e);
+    if (const char *e = getenv("NODAL_GEPP_PANEL")) h->gepp_panel = atoi(e) != 0;
     if (const char *e = getenv("NODAL_PRESOLVE")) h->use_presolve = atoi(e) != 0;  // 0: branch equations stay in the system
     *out = h;
     return NODAL_OK;
@@ -548,6 +550,10 @@ int nodal_set_option(nodal_handle h, int32_t option, int32_t value) {
     if (!h) return NODAL_E_INVALID;
     if (option == NODAL_OPT_FORCE_PIVOTING) {
         h->force_pivoting = value != 0;
+        return NODAL_OK;
+    }
+    if (option == NODAL_OPT_GEPP_PANEL) {
+        h->gepp_panel = value != 0;
         return NODAL_OK;
     }
     return nodal_fail(h, NODAL_E_INVALID, "unknown option");

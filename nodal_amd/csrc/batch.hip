@@ -288,6 +288,7 @@ int nodal_run_batch(nodal_handle h, int32_t first, int32_t count, int32_t reuse_
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(h->device);
     struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
+    FillStreamScope fill(h->stream);
     hipStream_t st = h->stream;
     const int64_t n = h->n, ncomp = h->ncomp;
     h->batch_count = 0;

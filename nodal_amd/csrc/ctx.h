@@ -13,6 +13,18 @@
 
 // A device allocation that grows on demand and is reused across calls, so the
 // launch path never calls hipMalloc once sizes have settled.
+// The stream of the handle whose API call is running on this thread (set by FillStreamScope at the
+// entry points): a growing DevBuf zero-fills itself on it, in order with every kernel the call launches
+// afterwards.  Null outside an API call: the fill then runs on the null stream and is waited for.
+inline thread_local hipStream_t nodal_fill_stream = nullptr;
+struct FillStreamScope {
+    hipStream_t prev;
+    explicit FillStreamScope(hipStream_t s) : prev(nodal_fill_stream) { nodal_fill_stream = s; }
+    ~FillStreamScope() { nodal_fill_stream = prev; }
+    FillStreamScope(const FillStreamScope &) = delete;
+    FillStreamScope &operator=(const FillStreamScope &) = delete;
+};
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -32,9 +44,12 @@ struct DevBuf {
         // to make such reads show (expect out-of-bounds faults: run single cases, not the suite).
         static const bool poison = getenv("NODAL_POISON") != nullptr;
         static const bool nofill = getenv("NODAL_NOFILL") != nullptr;
-        if (e == hipSuccess && !nofill) e = hipMemset(p, poison ? 0xFF : 0, want);
-        // (the fill runs on the null stream; the contexts' streams do not wait for that one by themselves)
-        if (e == hipSuccess && !nofill) e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess || nofill) return e;
+        if (nodal_fill_stream) return hipMemsetAsync(p, poison ? 0xFF : 0, want, nodal_fill_stream);
+        // (outside an API call the fill runs on the null stream; the contexts' streams do not wait for
+        // that one by themselves)
+        e = hipMemset(p, poison ? 0xFF : 0, want);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
         return e;
     }
     void release() {
@@ -134,6 +149,7 @@ struct nodal_ctx {
     // ---- numeric assembly results ----
     bool have_numeric = false;
     bool force_pivoting = false;   // testing: use the tournament path even when passive
+    bool gepp_panel = true;        // partial pivoting: one launch per 32-column panel (dense_lu.hip)
     bool passive_network = false;  // B == 0 and all R > 0 (set by stamp_numeric)
     DevBuf data;            // f64[nnz]
     DevBuf rhs;             // f64[n]

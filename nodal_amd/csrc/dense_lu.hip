@@ -127,6 +127,198 @@ __global__ __launch_bounds__(256) void lu_scale_update(double *__restrict__ A, i
     }
 }
 
+// The same panel in ONE launch: rows [j0, n) x columns [j0, j1) (at most NB columns, at most
+// GEPP_PANEL_ROWS rows) live in registers, RPT rows per thread.  Per column ONE workgroup barrier: every
+// wave finds its best row ((|a|, position) pairs: larger magnitude wins, on ties the smaller position --
+// idamax), the owning lane publishes the pair, the rest of the row and 1 / pivot to LDS (double buffered by
+// the column's parity), after the barrier every wave picks the winning wave from the published pairs and
+// every thread eliminates its rows with the winner's.  Rows do not move while the panel is in registers: a
+// thread tracks the POSITION its row has after the interchanges LAPACK would have made so far (pivot row <->
+// row at position c), which is what the tie rule looks at, and writes the row there at the end.  Arithmetic
+// per element exactly as lu_scale_update (l = a * (1 / pivot), then fma(-l, u, a) column by column): the two
+// forms give the same bits (`NODAL_OPT_GEPP_PANEL` / `NODAL_GEPP_PANEL=0` selects the per-column kernels;
+// tested equal).
+// Clock stamps (`NODAL_GEPP_PROBE`) for n = 992, cycles per column at 2.4 GHz: search 510 (a DPP reduction +
+// readlane is 108 cycles -- tools/clock_probe.hip --, three of them when several lanes hold the maximal high
+// word), publish + barrier 1060 (the wait for the slowest wave included), winner 500, elimination 920
+// (instruction issue: every wave of a SIMD takes 4 cycles per fp64 FMA, and every wave repeats the search and
+// the selection -- hence few waves, two rows per thread above 256 rows): 1.25 us per column, 45 us per panel
+// where the per-column kernels took 2 x 32 launches = 300 us.  Measured and not kept: the column loop rolled up, rows shifting through the registers
+// instead of being indexed by the unrolled loop's counter (2 KB of code instead of 75 KB: 1.2 instead of
+// 0.8 us per column -- the always-full-length update and the rotation of finished rows cost more than the
+// instruction fetch of straight-line code).
+constexpr int GEPP_PANEL_ROWS = 1024;
+
+__device__ __forceinline__ unsigned wave_umax(unsigned v);  // (below, with the tournament kernels)
+
+// maximum over the first row of 16 lanes (DPP row_shr 1, 2, 4, 8), uniform
+__device__ __forceinline__ unsigned row16_umax(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 15);
+}
+
+// key of a candidate: 0 none, 1 a NaN (chosen only if nothing else is left), bits(|a|) + 2 otherwise (an
+// order-preserving image of the magnitude)
+__device__ __forceinline__ unsigned long long pivot_key(double a, bool done) {
+    const double av = fabs(a);
+    return done ? 0ull : (av != av ? 1ull : (unsigned long long)__double_as_longlong(av) + 2ull);
+}
+
+template <int RPT>
+__global__ __launch_bounds__(GEPP_PANEL_ROWS / 2) void gepp_panel(double *__restrict__ A, int64_t n, int64_t lda,
+                                                                  int j0, int j1, int32_t *__restrict__ piv,
+                                                                  int32_t *__restrict__ info,
+                                                                  long long *__restrict__ probe) {
+    constexpr int MAXW = GEPP_PANEL_ROWS / 2 / 64;  // 8 waves at most
+    __shared__ __attribute__((aligned(16))) unsigned long long wkey[2][16];  // (entries MAXW .. 15 never win)
+    __shared__ __attribute__((aligned(16))) int wpos[2][16];
+    // the wave's candidate row; slot k (the pivot itself) carries 1 / pivot, computed by the row's owner
+    // before the search: off the critical path
+    __shared__ __attribute__((aligned(16))) double wrow[2][MAXW][NB];
+    __shared__ int spiv[NB];
+    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int wp = j1 - j0;
+    if ((int)threadIdx.x < 32 && (int)(threadIdx.x & 15) >= nwaves) {  // waves that do not exist never win
+        wkey[threadIdx.x >> 4][threadIdx.x & 15] = 0ull;
+        wpos[threadIdx.x >> 4][threadIdx.x & 15] = 0x7fffffff;
+    }
+    // (two separate arrays, not a[RPT][NB]: the two-dimensional form ended up in scratch memory)
+    double a0[NB], a1[NB];
+    const int row0 = j0 + (int)threadIdx.x, row1 = row0 + (int)blockDim.x;
+    int pos0 = row0, pos1 = row1;
+    bool done0 = !(row0 < n), done1 = !(RPT == 2 && row1 < n);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        a0[q] = (row0 < n && q < wp) ? A[(int64_t)(j0 + q) * lda + row0] : 0.0;
+        a1[q] = (RPT == 2 && row1 < n && q < wp) ? A[(int64_t)(j0 + q) * lda + row1] : 0.0;
+    }
+    int zero_at = 0;
+    long long ph[5] = {0, 0, 0, 0, 0}, tlast = probe ? clock64() : 0;  // NODAL_GEPP_PROBE: cycles per phase
+#define GEPP_STAMP(i)                        \
+    if (probe) {                             \
+        const long long tnow = clock64();    \
+        ph[i] += tnow - tlast;               \
+        tlast = tnow;                        \
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        if (k < wp) {  // (uniform)
+            const int c = j0 + k, par = k & 1;
+            // the thread's candidate
+            unsigned long long key = pivot_key(a0[k], done0);
+            int mypos = pos0;
+            bool second = false;
+            if (RPT == 2) {
+                const unsigned long long k1 = pivot_key(a1[k], done1);
+                second = k1 > key || (k1 == key && pos1 < mypos);
+                key = second ? k1 : key;
+                mypos = second ? pos1 : mypos;
+            }
+            const double myrcp = 1.0 / (second ? a1[k] : a0[k]);
+            // the wave's maximum by 32-bit DPP reductions: high word; if one lane holds it, that lane is the
+            // winner, otherwise low word among the lanes that hold the high maximum, then the smallest position
+            // among the lanes that hold the maximum (idamax)
+            const unsigned khi = (unsigned)(key >> 32);
+            const unsigned mhi = wave_umax(khi);
+            const unsigned long long at_hi = __ballot(khi == mhi);
+            unsigned long long best;
+            int bpos;
+            if (__popcll(at_hi) == 1) {  // (uniform)
+                const int src = __ffsll(at_hi) - 1;
+                best = ((unsigned long long)mhi << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, src);
+                bpos = __builtin_amdgcn_readlane(mypos, src);
+            } else {
+                const unsigned mlo = wave_umax(khi == mhi ? (unsigned)key : 0u);
+                best = ((unsigned long long)mhi << 32) | mlo;
+                bpos = (int)~wave_umax(key == best ? ~(unsigned)mypos : 0u);
+            }
+            GEPP_STAMP(0)  // candidate + the wave's search
+            if (best == 0ull) {
+                if ((threadIdx.x & 63) == 0) {
+                    wkey[par][wave] = 0ull;
+                    wpos[par][wave] = 0x7fffffff;
+                }
+            } else if (key == best && mypos == bpos) {  // one lane: positions are distinct
+                wkey[par][wave] = best;
+                wpos[par][wave] = bpos;
+                wrow[par][wave][k] = myrcp;
+#pragma unroll
+                for (int q = k + 1; q < NB; ++q) wrow[par][wave][q] = second ? a1[q] : a0[q];
+            }
+            __syncthreads();
+            GEPP_STAMP(1)  // publish + barrier
+            // the winner among the waves: lane l looks at wave l & 15, the same reductions inside a row of 16
+            // lanes (every wave does this for itself: one barrier per column)
+            const unsigned long long ek = wkey[par][threadIdx.x & 15];
+            const int ep = wpos[par][threadIdx.x & 15];
+            const unsigned ehi = (unsigned)(ek >> 32);
+            const unsigned whi = row16_umax(ehi);
+            const unsigned long long w_hi = __ballot(ehi == whi) & 0xffffull;
+            unsigned long long win;
+            int winpos, ww;
+            if (__popcll(w_hi) == 1) {
+                ww = __ffsll(w_hi) - 1;
+                win = ((unsigned long long)whi << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)ek, ww);
+                winpos = __builtin_amdgcn_readlane(ep, ww);
+            } else {
+                const unsigned wlo = row16_umax(ehi == whi ? (unsigned)ek : 0u);
+                win = ((unsigned long long)whi << 32) | wlo;
+                winpos = (int)~row16_umax(ek == win ? ~(unsigned)ep : 0u);
+                ww = __ffsll((unsigned long long)__ballot(ek == win && ep == winpos)) - 1;
+            }
+            // (position c is always among the candidates, so there is a winner; no global store inside the
+            // loop: the next step's loads would wait for it)
+            if (threadIdx.x == 0) {
+                spiv[k] = winpos;
+                if (win <= 2ull && zero_at == 0) zero_at = c + 1;  // exact zero pivot (or a column of NaNs)
+            }
+            lds_cptr u = opaque_lds(&wrow[par][ww][0]);  // (a VGPR base: the reads take immediate offsets)
+            const double rcp = u[k];
+            const bool eliminate = win != 2ull;  // not an exact zero (a NaN pivot spreads, as in the per-column form)
+            GEPP_STAMP(2)  // the winner among the waves
+#define GEPP_ROW(a_, pos_, done_)                                                                        \
+            if (!done_) {                                                                                \
+                if (pos_ == winpos) {                                                                    \
+                    done_ = true;                                                                        \
+                    pos_ = c;                                                                            \
+                } else {                                                                                 \
+                    if (pos_ == c) pos_ = winpos;                                                        \
+                    if (eliminate) {                                                                     \
+                        const double l = a_[k] * rcp;                                                    \
+                        a_[k] = l;                                                                       \
+                        _Pragma("unroll") for (int q = k + 1; q < NB; ++q) a_[q] = fma(-l, u[q], a_[q]); \
+                    }                                                                                    \
+                }                                                                                        \
+            }
+            GEPP_ROW(a0, pos0, done0)
+            if (RPT == 2) { GEPP_ROW(a1, pos1, done1) }
+#undef GEPP_ROW
+            GEPP_STAMP(3)  // elimination
+        }
+    }
+    if (row0 < n) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+            if (q < wp) A[(int64_t)(j0 + q) * lda + pos0] = a0[q];
+    }
+    if (RPT == 2 && row1 < n) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+            if (q < wp) A[(int64_t)(j0 + q) * lda + pos1] = a1[q];
+    }
+    if (threadIdx.x == 0 && zero_at) atomicCAS(info, 0, zero_at);
+    if ((int)threadIdx.x < wp) piv[j0 + threadIdx.x] = spiv[threadIdx.x];  // (written by thread 0 of the same wave)
+    GEPP_STAMP(4)  // write-back
+    if (probe && threadIdx.x == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd((unsigned long long *)&probe[i], (unsigned long long)ph[i]);
+        atomicAdd((unsigned long long *)&probe[5], 1ull);
+    }
+}
+#undef GEPP_STAMP
+
 // ---------------------------------------------------------------------------------
 // shared pieces
 // ---------------------------------------------------------------------------------
@@ -575,8 +767,20 @@ int trailing_update(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
 int factor_gepp(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncols, int32_t *piv,
                 int32_t *dinfo, GemmTimer &tm) {
     hipStream_t st = h->stream;
+    static const bool probing = getenv("NODAL_GEPP_PROBE") != nullptr;
+    long long *probe = nullptr;
+    if (probing) {
+        NODAL_HIP_TRY(h, h->work3.reserve(256));
+        probe = h->work3.as<long long>();
+        NODAL_HIP_TRY(h, hipMemsetAsync(probe, 0, 64, st));
+    }
     for (int64_t j0 = 0; j0 < n; j0 += NB) {
         const int64_t j1 = j0 + NB < n ? j0 + NB : n;
+        if (h->gepp_panel && n - j0 <= GEPP_PANEL_ROWS) {
+            const int64_t rows = n - j0;
+            if (rows <= 256) gepp_panel<1><<<1, (int)((rows + 63) / 64) * 64, 0, st>>>(A, n, lda, (int)j0, (int)j1, piv, dinfo, probe);
+            else gepp_panel<2><<<1, (int)((rows + 127) / 128) * 64, 0, st>>>(A, n, lda, (int)j0, (int)j1, piv, dinfo, probe);
+        } else
         for (int64_t c = j0; c < j1; ++c) {
             lu_pivot_swap<<<1, 1024, 0, st>>>(A, n, lda, (int)c, (int)j0, (int)j1, piv, dinfo);
             if (c + 1 < n)
@@ -597,6 +801,15 @@ int factor_gepp(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncols, 
                                    A + j1 * lda + j0, lda, n - j1, ncols - j1, j1 - j0));
             NODAL_TRY(tm.end(st, 2.0 * (double)(j1 - j0) * (double)(n - j1) * (double)(ncols - j1)));
         }
+    }
+    if (probe) {
+        long long host[8];
+        NODAL_HIP_TRY(h, hipMemcpyAsync(host, probe, 64, hipMemcpyDeviceToHost, st));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        if (host[5] > 0)
+            fprintf(stderr, "[gepp] n %lld: %lld panels, cycles per panel: search %lld, publish + barrier %lld, winner %lld, "
+                            "elimination %lld, write-back %lld\n", (long long)n, host[5], host[0] / host[5], host[1] / host[5],
+                    host[2] / host[5], host[3] / host[5], host[4] / host[5]);
     }
     return NODAL_OK;
 }

@@ -64,6 +64,53 @@ def test_dense_lu_tournament_on_general_matrix():
     h.close()
 
 
+@pytest.mark.parametrize("side", [3, 8, 16, 22, 31, 44])  # n = 10 .. 1990: one row per thread up to 1024 rows
+def test_dense_partial_pivoting_panel_kernel_matches_the_per_column_kernels(side):
+    """Partial pivoting with the 32-column panel in registers (one launch per panel, the default) against
+    the two-launches-per-column form: same pivots (idamax ties included: the +-1 incidence entries of the
+    voltage sources tie all the time), same arithmetic, hence the same bits; and the oracle's dgesv."""
+    from nodal_amd import generators as gen
+    from oracle import nodal_oracle as oracle
+    table = gen.cfg5_table(side)
+    out = []
+    for panel in (1, 0):
+        h = _ffi.Handle(0)
+        h.set_option(_ffi.OPT_FORCE_PIVOTING, 1)  # (above 512 unknowns the default route presolves)
+        h.set_option(_ffi.OPT_GEPP_PANEL, panel)
+        h.upload(table)
+        h.assemble_symbolic()
+        assert h.assemble_numeric()[0] == _ffi.OK
+        x, info = h.solve_dense()
+        assert info == 0 and h.residual() <= 1e-14
+        out.append(x)
+        h.close()
+    assert np.array_equal(out[0], out[1])
+    G, A = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(G.toarray(), A, False)
+    assert np.abs(out[0] - xo).max() <= 1e-10 * np.abs(xo).max()
+
+
+def test_dense_partial_pivoting_panel_kernel_reports_the_zero_pivot_column():
+    """Two voltage sources across the same node pair: dgesv stops at an exact zero pivot and both forms
+    of the panel factorisation name the same column."""
+    from nodal_amd.lowering import lower
+    from nodal_amd.netlist import Netlist
+    rows = [["r%d" % i, "R", "1", str(i), str(i + 1)] for i in range(1, 40)]
+    rows += [["rg", "R", "1", "40", "g"], ["e1", "E", "1", "1", "g"], ["e2", "E", "2", "1", "g"]]
+    table = lower(Netlist.from_rows(rows))
+    infos = []
+    for panel in (1, 0):
+        h = _ffi.Handle(0)
+        h.set_option(_ffi.OPT_GEPP_PANEL, panel)
+        h.upload(table)
+        h.assemble_symbolic()
+        assert h.assemble_numeric()[0] == _ffi.OK
+        _, info = h.solve_dense()
+        infos.append(info)
+        h.close()
+    assert infos[0] == infos[1] and infos[0] > 0
+
+
 @pytest.mark.parametrize("side", [17, 23, 32, 46, 47, 50])  # n = 288 .. 2499; last blocks of 32 .. 255 columns
 def test_dense_block_inverse_elimination_on_passive_network(side, monkeypatch):
     """Passive networks above GEPP_MAX: block elimination with inverted diagonal blocks

@@ -185,7 +185,8 @@ def cycle(levels, l, b, cfg):
     rc = L.R @ r
     C = levels[l + 1]
     k = cfg["klevels"]
-    if l < k and C.n > TAIL_MAX_N and l + 1 != len(levels) - 1:
+    use_k = (l + 1) in cfg["kset"] if "kset" in cfg else l < k
+    if use_k and (C.n > TAIL_MAX_N or cfg.get("ktail")) and l + 1 != len(levels) - 1:
         c1 = cycle(levels, l + 1, rc, cfg)
         v1 = C.A @ c1
         rho1, alpha1 = c1 @ v1, c1 @ rc
@@ -257,6 +258,12 @@ VARIANTS = {
     "k2_212": dict(nu=[2, 1, 2], tail_nu=3, klevels=2),
     "k2_112": dict(nu=[1, 1, 2], tail_nu=3, klevels=2),
     "k3_212": dict(nu=[2, 1, 2], tail_nu=3, klevels=3),
+    "kat2": dict(nu=[1, 1, 2], tail_nu=3, klevels=0, kset={2}),
+    "kat2_122": dict(nu=[1, 2, 2], tail_nu=3, klevels=0, kset={2}),
+    "kat2_212": dict(nu=[2, 1, 2], tail_nu=3, klevels=0, kset={2}),
+    "kat2_113": dict(nu=[1, 1, 3], tail_nu=3, klevels=0, kset={2}),
+    "kat23": dict(nu=[1, 1, 2], tail_nu=3, klevels=0, kset={2, 3}, ktail=True),
+    "kat3": dict(nu=[1, 1, 2], tail_nu=3, klevels=0, kset={3}, ktail=True),
     "kcheb2": dict(nu=[2, 2, 2], tail_nu=3, klevels=1, smoother="cheb"),
 }
 
