@@ -1,5 +1,6 @@
 // extern "C" entry points of libnodal_hip.so (see include/nodal_hip.h).
 #include <stdlib.h>
+#include <string.h>
 
 #include "ctx.h"
 
@@ -102,6 +103,23 @@ int nodal_create(int device_id, nodal_handle *out) {
 }  // extern "C"
 
 
+void *nodal_pinned(nodal_ctx *ctx) {
+    nodal_ctx *h = ctx->stream_owner ? ctx->stream_owner : ctx;
+    if (!h->pinned && hipHostMalloc(&h->pinned, NODAL_PINNED_BYTES, hipHostMallocDefault) != hipSuccess) {
+        h->pinned = nullptr;
+        (void)hipGetLastError();
+    }
+    return h->pinned;
+}
+
+int nodal_read_words(nodal_ctx *h, void *dst, const void *dev_src, size_t bytes) {
+    void *pin = bytes <= NODAL_PINNED_BYTES ? nodal_pinned(h) : nullptr;
+    NODAL_HIP_TRY(h, hipMemcpyAsync(pin ? pin : dst, dev_src, bytes, hipMemcpyDeviceToHost, h->stream));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (pin) memcpy(dst, pin, bytes);
+    return NODAL_OK;
+}
+
 int nodal_ensure_aux_streams(nodal_ctx *ctx) {
     nodal_ctx *h = ctx->stream_owner ? ctx->stream_owner : ctx;
     if (!h->stream2 || !h->stream3) {
@@ -194,6 +212,7 @@ int nodal_destroy(nodal_handle h) {
     if (h->stream3) (void)hipStreamDestroy(h->stream3);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->pinned) (void)hipHostFree(h->pinned);
     delete h;
     return NODAL_OK;
 }

@@ -108,6 +108,7 @@ struct nodal_ctx {
     uint64_t reduced_key = 0;      // (on the reduced context) fingerprint of the topology its symbolic lists belong to
     bool owns_streams = true;
     nodal_ctx *stream_owner = nullptr;  // (child contexts) the context whose streams and events this one borrows
+    void *pinned = nullptr;             // small page-locked scratch for read-backs of a few words (nodal_pinned)
     bool use_presolve = true;
     bool use_graphs = false;       // hipGraph replay of the FCG iteration: measured no gain (kernels are not host-bound)
     DevBuf ps_buf, ps_newidx, ps_hits;
@@ -303,4 +304,12 @@ void nodal_free_buffers(nodal_ctx *h);  // api.hip
 // that only ever solves sparse systems holds ONE hardware queue, so that four of them in flight still
 // get a queue each (the runtime multiplexes streams beyond its hardware queues: erratic throughput).
 int nodal_ensure_aux_streams(nodal_ctx *h);  // api.hip
+// NODAL_PINNED_BYTES of page-locked host memory of the handle (child contexts use their parent's): the
+// destination of every read-back of a few words -- a copy to a stack variable is staged by the runtime
+// through its own pinned buffer and costs 15-20 us more.  One API call at a time per handle, and every use is
+// copy, wait, read: users need not coordinate.  Null if the allocation failed (callers fall back to the stack).
+constexpr size_t NODAL_PINNED_BYTES = 4096;
+void *nodal_pinned(nodal_ctx *h);  // api.hip
+// read `bytes` (<= NODAL_PINNED_BYTES) from the device into `dst` through the pinned scratch, and wait
+int nodal_read_words(nodal_ctx *h, void *dst, const void *dev_src, size_t bytes);  // api.hip
 void nodal_free_block_child(nodal_ctx *h);  // batch.hip

@@ -992,8 +992,7 @@ int dense_factor_solve_multi(nodal_ctx *h, int32_t nrhs, double *xout, int64_t l
     }
     NODAL_HIP_TRY(h, hipGetLastError());
     int32_t hinfo = 0;
-    NODAL_HIP_TRY(h, hipMemcpyAsync(&hinfo, dinfo, 4, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    NODAL_TRY(nodal_read_words(h, &hinfo, dinfo, 4));
     *info = hinfo;
     tm.collect();
     return NODAL_OK;

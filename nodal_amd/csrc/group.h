@@ -318,8 +318,7 @@ int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int
         C = en.nitems * E::SLOTS;
     } else {
         uint32_t C32 = 0;
-        NODAL_HIP_TRY(h, hipMemcpyAsync(&C32, &counts[2], 4, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_TRY(nodal_read_words(h, &C32, &counts[2], 4));
         C = C32;
     }
     if (C > 0x7fffffffll)
@@ -383,8 +382,7 @@ int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int
     int64_t nent = known_nent;
     if (nent < 0) {
         uint32_t nent32 = 0;
-        NODAL_HIP_TRY(h, hipMemcpyAsync(&nent32, eidx + C, 4, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_TRY(nodal_read_words(h, &nent32, eidx + C, 4));
         nent = nent32;
     }
     *nent_out = nent;

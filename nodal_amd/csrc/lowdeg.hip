@@ -283,8 +283,7 @@ int csr_small_floating_check(nodal_ctx *h, int32_t *floating) {
     small_floating_check<<<1, 1024, 0, h->stream>>>(view_of(h), h->grounded.as<uint8_t>(), flag);
     NODAL_HIP_TRY(h, hipGetLastError());
     uint32_t f = 0;
-    NODAL_HIP_TRY(h, hipMemcpyAsync(&f, flag, 4, hipMemcpyDeviceToHost, h->stream));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    NODAL_TRY(nodal_read_words(h, &f, flag, 4));
     *floating = (int32_t)f;
     return NODAL_OK;
 }
@@ -367,8 +366,7 @@ int lowdeg_solve(nodal_ctx *h, int min_share, bool *done, int32_t *info, int32_t
         select_nodes<<<grid_for(n), TB, 0, st>>>(A, keep, count);
         NODAL_HIP_TRY(h, hipGetLastError());
         uint32_t nelim = 0;
-        NODAL_HIP_TRY(h, hipMemcpyAsync(&nelim, count, 4, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_TRY(nodal_read_words(h, &nelim, count, 4));
         // low-yield rounds are worth their ~0.3 ms while wires are being shortened (each round takes
         // a third to a half of every wire); a network that keeps yielding a trickle of candidates is cut off
         slow = (int64_t)nelim * 32 < n;
@@ -459,8 +457,7 @@ int lowdeg_solve(nodal_ctx *h, int min_share, bool *done, int32_t *info, int32_t
                                                             c->grounded.as<uint8_t>(), count + 1);
         NODAL_HIP_TRY(h, hipGetLastError());
         uint32_t leftover = 0;
-        NODAL_HIP_TRY(h, hipMemcpyAsync(&leftover, count + 1, 4, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_TRY(nodal_read_words(h, &leftover, count + 1, 4));
         remember(leftover ? 3 : 2);
         if (leftover) {
             if (trace) fprintf(stderr, "[lowdeg] a floating sub-network collapsed to a single node: singular\n");

@@ -89,7 +89,7 @@ struct Ell {
 };
 
 enum { ST_MAXLEN = 0, ST_GRADED = 1, ST_BADDIAG = 2, ST_OVERFLOW = 3, ST_NNZ = 4, ST_UNASSIGNED = 5,
-       ST_MAXR = 6, ST_COUNT = 8 };
+       ST_MAXR = 6, ST_NC = 7 /* aggregates of the level (the scan's total) */, ST_COUNT = 8 };
 
 struct SLevel {
     int64_t n = 0, ld = 0, nc = 0;
@@ -1168,11 +1168,12 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
         mis_flag_roots<<<grid_for(n + 1), TB, 0, st>>>(A, T, flag);
     }
     NODAL_HIP_TRY(h, hipGetLastError());
-    NODAL_TRY(scan_exclusive_u32(h, flag, id, n + 1, nullptr, scan_tmp));
+    // (the scan leaves its total -- flag[n] is 0 -- in the level's statistics block: ONE copy to pinned memory
+    // brings everything; a second 4-byte copy to a stack variable was staged by the runtime and cost 18 us)
+    NODAL_TRY(scan_exclusive_u32(h, flag, id, n + 1, reinterpret_cast<uint32_t *>(dstats + (size_t)l * ST_COUNT + ST_NC),
+                                 scan_tmp));
     // the one round trip of this level: the number of aggregates, and what the Galerkin kernel
     // of the level above recorded about THIS level's matrix
-    uint32_t nc32 = 0;
-    NODAL_HIP_TRY(h, hipMemcpyAsync(&nc32, id + n, 4, hipMemcpyDeviceToHost, st));
     NODAL_HIP_TRY(h, hipMemcpyAsync(hs, dstats, (size_t)MAX_LEVELS * ST_COUNT * 8, hipMemcpyDeviceToHost, st));
     unsigned long long hcnt[MIS_ROUNDS + 1] = {0};
     if (trace_mis) NODAL_HIP_TRY(h, hipMemcpyAsync(hcnt, cnt, sizeof hcnt, hipMemcpyDeviceToHost, st));
@@ -1182,7 +1183,7 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
         for (int r = 1; r <= MIS_ROUNDS; ++r) fprintf(stderr, " %llu", hcnt[r]);
         fprintf(stderr, "\n");
     }
-    const int64_t nc = nc32;
+    const int64_t nc = (int64_t)(hs[(size_t)l * ST_COUNT + ST_NC] & 0xffffffffull);
     if (l > 0) {  // what the Galerkin kernel of the level above recorded about this level's matrix
         const unsigned long long *s = hs + (size_t)l * ST_COUNT;
         L->maxlen = (int32_t)s[ST_MAXLEN];
@@ -1564,12 +1565,12 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
         for (int k = 0; k + 1 < H->nlev; ++k) {
             SLevel *L = H->pool[k], *C = H->pool[k + 1];
             NODAL_HIP_TRY(h, C->gflag.reserve((size_t)C->n + 64));
-            NODAL_HIP_TRY(h, hipMemsetAsync(C->gflag.p, 0, (size_t)C->n, st));
+            NODAL_HIP_TRY(h, hipMemsetAsync(C->gflag.p, 0, ((size_t)C->n + 63) & ~(size_t)63, st));  // (one fill kernel)
             flags_up<<<grid_for(L->n), TB, 0, st>>>(L->n, L->agg.as<int32_t>(), L->gflag.as<uint8_t>(),
                                                    C->gflag.as<uint8_t>());
         }
+        // (the verdict's word: zero since this setup cleared the statistics block, nobody else writes it)
         uint32_t *fl = reinterpret_cast<uint32_t *>(dstats + (size_t)(MAX_LEVELS - 1) * ST_COUNT + ST_COUNT - 1);
-        NODAL_HIP_TRY(h, hipMemsetAsync(fl, 0, 8, st));
         if (H->dense_coarsest) last_level_floating<<<1, 64, 0, st>>>(last->A(), last->gflag.as<uint8_t>(), fl);
         else any_unflagged<<<grid_for(last->n), TB, 0, st>>>(last->n, last->gflag.as<uint8_t>(), fl);
         NODAL_HIP_TRY(h, hipGetLastError());
@@ -1892,8 +1893,7 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
                 ++enqueued;
             }
         }
-        NODAL_HIP_TRY(h, hipMemcpyAsync(hs, sb.sc, F_COUNT * 8, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_TRY(nodal_read_words(h, hs, sb.sc, F_COUNT * 8));
         ++polls;
         const bool conv = hs[F_CONV + ((enqueued - 1) & 1)] != 0.0;
         float ms = 0;

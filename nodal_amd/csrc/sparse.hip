@@ -349,8 +349,7 @@ int pcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
                                           nparts_s, sc, (int)it, n);
         }
         NODAL_HIP_TRY(h, hipGetLastError());
-        NODAL_HIP_TRY(h, hipMemcpyAsync(hs, sc, S_COUNT * 8, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_TRY(nodal_read_words(h, hs, sc, S_COUNT * 8));
         float ms = 0;
         if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
             h->kern_ms += ms;
@@ -585,8 +584,7 @@ int amg_fcg_solve_ex(nodal_ctx *h, const double *b, bool do_setup, int32_t *info
             if (exec && !timed) NODAL_HIP_TRY(h, hipGraphLaunch(exec, st));
             else NODAL_TRY(iteration(timed));
         }
-        NODAL_HIP_TRY(h, hipMemcpyAsync(hs, sc, F_COUNT * 8, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_TRY(nodal_read_words(h, hs, sc, F_COUNT * 8));
         float ms = 0;
         if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
             h->kern_ms += ms;
@@ -940,8 +938,7 @@ int sparse_residual(nodal_ctx *h, double *scaled) {
                           h->x.as<double>(), h->rhs.as<double>(), out, n)));
     NODAL_HIP_TRY(h, hipGetLastError());
     double o[5];
-    NODAL_HIP_TRY(h, hipMemcpyAsync(o, out, 40, hipMemcpyDeviceToHost, h->stream));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    NODAL_TRY(nodal_read_words(h, o, out, 40));
     if (o[4] != 0.0) {
         *scaled = __builtin_nan("");
         return NODAL_OK;

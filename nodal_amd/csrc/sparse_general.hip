@@ -444,8 +444,7 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
         find_zero_row<<<grid_for(n), TB, 0, st>>>(indptr, data, n, zr);
         NODAL_HIP_TRY(h, hipGetLastError());
         uint32_t zero_row = 0;
-        NODAL_HIP_TRY(h, hipMemcpyAsync(&zero_row, zr, 4, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_TRY(nodal_read_words(h, &zero_row, zr, 4));
         if (zero_row) {
             *info = 1;
             return NODAL_OK;
@@ -480,8 +479,7 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
     NODAL_HIP_TRY(h, hipGetLastError());
     NODAL_TRY(scan_exclusive_u32(h, cnt, cnt, (int64_t)K + 1, nullptr, scan_tmp));
     uint32_t gn_nnz = 0;
-    NODAL_HIP_TRY(h, hipMemcpyAsync(&gn_nnz, cnt + K, 4, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    NODAL_TRY(nodal_read_words(h, &gn_nnz, cnt + K, 4));
     NODAL_HIP_TRY(h, h->gn_indptr.reserve((size_t)(K + 1) * 4));
     NODAL_HIP_TRY(h, h->gn_indices.reserve((size_t)gn_nnz * 4 + 4));
     NODAL_HIP_TRY(h, h->gn_rowidx.reserve((size_t)gn_nnz * 4 + 4));
@@ -556,8 +554,7 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
     auto device_norm = [&](double *out) -> int {  // sqrt(sum partial2) -> host
         gs_reduce<<<1, TB, 0, st>>>(partial, 0, 0, hdev, partial2, (int)gd);
         double v = 0.0;
-        NODAL_HIP_TRY(h, hipMemcpyAsync(&v, hdev + MAXV, 8, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_TRY(nodal_read_words(h, &v, hdev + MAXV, 8));
         *out = std::sqrt(v);
         return NODAL_OK;
     };
@@ -622,8 +619,7 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
                 scale_by_device<<<gv, TB, 0, st>>>(w, gst, V + (int64_t)(j + 1) * ld, n);
                 NODAL_HIP_TRY(h, hipGetLastError());
             }
-            NODAL_HIP_TRY(h, hipMemcpyAsync(hst, gst + G_INV_H, sizeof hst, hipMemcpyDeviceToHost, st));
-            NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+            NODAL_TRY(nodal_read_words(h, hst, gst + G_INV_H, sizeof hst));
             float ms = 0;
             if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { h->kern_ms += ms; h->kern_launches += 1; }
             const double est = hst[G_EST - G_INV_H];

@@ -300,7 +300,9 @@ int stamp_numeric(nodal_ctx *h, int32_t member, int64_t *bad_component) {
     unsigned long long *status = h->status.as<unsigned long long>();
     NODAL_HIP_TRY(h, hipMemsetAsync(status, 0xff, 16, st));
     NODAL_HIP_TRY(h, hipMemsetAsync(status + 2, 0, 8, st));
-    NODAL_HIP_TRY(h, hipMemsetAsync(h->rhs.p, 0, (size_t)h->n * 8, st));
+    // (rounded up to 64 bytes -- a DevBuf holds at least 256 bytes more than was asked for --: otherwise the
+    // runtime splits the fill into an aligned part and a tail, two kernels)
+    NODAL_HIP_TRY(h, hipMemsetAsync(h->rhs.p, 0, ((size_t)h->n * 8 + 63) & ~(size_t)63, st));
     if (h->nnz > 0) {
         fold_matrix<<<grid_for(h->nnz), TB, 0, st>>>(tb, value, h->cptr.as<int32_t>(),
                                                     h->contrib.as<uint32_t>(),
@@ -315,8 +317,7 @@ int stamp_numeric(nodal_ctx *h, int32_t member, int64_t *bad_component) {
         NODAL_HIP_TRY(h, hipGetLastError());
     }
     unsigned long long st_host[3];
-    NODAL_HIP_TRY(h, hipMemcpyAsync(st_host, status, 24, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    NODAL_TRY(nodal_read_words(h, st_host, status, 24));
     h->have_numeric = true;
     h->have_x = false;
     h->member = member;
@@ -351,7 +352,8 @@ int stamp_to_dense(nodal_ctx *h, double *G_dev, int64_t ld, bool col_major) {
 }
 
 int stamp_grounded_flags(nodal_ctx *h, uint8_t *flags_dev) {
-    NODAL_HIP_TRY(h, hipMemsetAsync(flags_dev, 0, (size_t)h->n, h->stream));
+    // (every caller reserves at least n + 64 bytes; a size that is not a multiple of 4 costs a second fill kernel)
+    NODAL_HIP_TRY(h, hipMemsetAsync(flags_dev, 0, ((size_t)h->n + 63) & ~(size_t)63, h->stream));
     if (h->ncomp > 0) {
         grounded_flags<<<grid_for(h->ncomp), TB, 0, h->stream>>>(table_of(h), flags_dev);
         NODAL_HIP_TRY(h, hipGetLastError());
