@@ -812,24 +812,26 @@ __device__ __forceinline__ int galerkin_products(int64_t ld, const int32_t *__re
     }
     int np = 0;
     int o = wave_excl_scan(len, &np);
-    for (int32_t s0 = 0; s0 < len; s0 += 4) {  // four slots in flight
-        int32_t cj[4];
-        double cv[4];
+    constexpr int INFL = 8;  // slots in flight (a row of A P has 9-13 entries on a grid: two dependent rounds instead of four)
+    for (int32_t s0 = 0; s0 < len; s0 += INFL) {
+        int32_t cj[INFL];
+        double cv[INFL];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < INFL; ++q) {
             const int32_t s = s0 + q < len ? s0 + q : s0;
             cj[q] = apcol[(int64_t)s * ld + i];
             cv[q] = apval[(int64_t)s * ld + i];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < INFL; ++q)
             if (s0 + q < len) {
                 lJ[o] = cj[q];
                 lV[o] = w * cv[q];
                 ++o;
             }
     }
-    for (int p = lane + np; p < ((np + 7) & ~7); p += 64) lJ[p] = -1;  // pad to a multiple of 8 (accumulation loop)
+    for (int p = lane + np; p < np + 72; p += 64) lJ[p] = -1;  // empty products behind the list (the accumulation
+                                                              // loop reads whole segments of multiples of 8)
     __syncthreads();
     return np;
 }
@@ -846,7 +848,7 @@ __global__ __launch_bounds__(64) void galerkin(int64_t ld, const int32_t *__rest
                                                float *__restrict__ cvalf,
                                                int32_t *__restrict__ clen, double *__restrict__ cdinv,
                                                unsigned long long *__restrict__ stats, uint32_t *__restrict__ bstat,
-                                               int G, int pcap) {
+                                               int G, int pcap, int maxseg) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     int32_t *set = reinterpret_cast<int32_t *>(gsm);         // [256]
     double *lV = reinterpret_cast<double *>(gsm + 1024);     // [pcap]
@@ -913,12 +915,23 @@ __global__ __launch_bounds__(64) void galerkin(int64_t ld, const int32_t *__rest
         }
         }  // !NUMERIC
         // pass 2: eight products per step, loaded unconditionally (a compare-then-load loop pays the
-        // LDS latency twice per product); + 0.0 for the others leaves the sum, and its order, unchanged
+        // LDS latency twice per product); + 0.0 for the others leaves the sum, and its order, unchanged.
+        // Every lane reading every product made the kernel LDS-bandwidth-bound (a wave-wide 8-byte read takes
+        // 4 cycles whether it is a broadcast or not: 1500 cycles per coarse row of 250 products, 336 us at 1e6
+        // nodes).  A row of at most 16 (32) columns is therefore summed by 4 (2) SEGMENTS of lanes: lane
+        // (seg, c) sums the products of column c in segment seg of the list -- a quarter (half) of the reads,
+        // four (two) addresses per read instruction -- and the partial sums are combined in a fixed order.
+        const int nseg = min(maxseg, total <= 16 ? 4 : (total <= 32 ? 2 : 1)), segw = 64 / nseg;
+        const int seg = lane / segw;
+        const int32_t segJ = __shfl(myJ, lane % segw, 64);  // (lane c < total holds column c)
         double acc = 0.0;
         for (int g = 0; g < ngroups; ++g) {
             if (ngroups > 1 || NUMERIC)
                 np = galerkin_products(ld, apcol, apval, aplen, rld, rcol, rval, I, g * G, min(G, rl - g * G), lJ, lV);
-            for (int p = 0; p < np; p += 8) {
+            int chunk = (((np + nseg - 1) / nseg) + 7) & ~7;
+            if (nseg > 1 && ((chunk >> 3) & 1) == 0) chunk += 8;  // an odd number of 64-byte lines between the segments' reads: fewer bank conflicts
+            // (nseg * chunk <= np + 64: behind the list there are empty products)
+            for (int p = seg * chunk; p < (seg + 1) * chunk; p += 8) {
                 int32_t j8[8];
                 double v8[8];
 #pragma unroll
@@ -927,9 +940,15 @@ __global__ __launch_bounds__(64) void galerkin(int64_t ld, const int32_t *__rest
                     v8[u] = lV[p + u];
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc += j8[u] == myJ ? v8[u] : 0.0;
+                for (int u = 0; u < 8; ++u) acc += j8[u] == segJ ? v8[u] : 0.0;
             }
             __syncthreads();
+        }
+        if (nseg == 4) {
+            const double a1 = __shfl(acc, lane + 16, 64), a2 = __shfl(acc, lane + 32, 64), a3 = __shfl(acc, lane + 48, 64);
+            acc = (acc + a1) + (a2 + a3);
+        } else if (nseg == 2) {
+            acc += __shfl(acc, lane + 32, 64);
         }
         if (lane >= total && lane < APAD) {  // zero padding: fixed-trip-count row loops (tail, unrolled kernels)
             ccol[(int64_t)lane * cld + I] = (int32_t)I;
@@ -1113,16 +1132,17 @@ int galerkin_product(nodal_ctx *h, SHierarchy *H, int l) {
     // 8.80 -> 8.66 ms per fresh solve of the 1e6-node grid, 7.45 -> 7.22 ms with the patterns kept)
     static const int g_env = getenv("NODAL_SA_GG") ? atoi(getenv("NODAL_SA_GG")) : 40;
     if (g_env >= 8 && g_env <= 64 && apw == 16) G = g_env & ~7;
-    const int pcap = G * apw + 8;
+    const int pcap = G * apw + 72;  // (the list is padded with empty products up to the segments' common length)
     const size_t lds = 1024 + (size_t)pcap * 12;
     // (at most 16384 workgroups, each walking several rows: the one-workgroup fold of their statistics
     // reads 2 x 16384 words instead of 2 x 65536 -- 3 instead of 10 us)
     static const int64_t gcap = getenv("NODAL_SA_GCAP") ? atoll(getenv("NODAL_SA_GCAP")) : 16384;
+    static const int maxseg = getenv("NODAL_SA_GSEG") ? atoi(getenv("NODAL_SA_GSEG")) : 4;
     const unsigned gg = (unsigned)(nc < gcap ? nc : (gcap < BSTAT_MAX ? gcap : BSTAT_MAX));
     galerkin<NUMERIC><<<gg, 64, lds, st>>>(
         ld, apcol, apval, aplen, nc, L->rld, L->rcol.as<int32_t>(), L->rval.as<double>(), L->rlen.as<int32_t>(),
         C->ld, C->acol.as<int32_t>(), C->aval.as<double>(), C->avalf.as<float>(), C->alen.as<int32_t>(),
-        C->dinv.as<double>(), dstats + (size_t)(l + 1) * ST_COUNT, H->bstat.as<uint32_t>(), G, pcap);
+        C->dinv.as<double>(), dstats + (size_t)(l + 1) * ST_COUNT, H->bstat.as<uint32_t>(), G, pcap, maxseg);
     if (!NUMERIC)
         reduce_bstat<<<1, 1024, 0, st>>>((int)gg, H->bstat.as<uint32_t>(), dstats + (size_t)(l + 1) * ST_COUNT,
                                          ST_MAXLEN, ST_NNZ);
