@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void validate_table(int64_t ncomp, int32_t K, 
                                                       const int32_t *__restrict__ b, const int32_t *__restrict__ c,
                                                       const int32_t *__restrict__ d, const int32_t *__restrict__ drv,
                                                       const int32_t *__restrict__ k, unsigned long long *__restrict__ bad) {
+    unsigned sources = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ncomp; i += (int64_t)gridDim.x * 256) {
         const uint8_t t = type[i];
         const bool branch = t >= NODAL_T_E && t <= NODAL_T_CCCS;
@@ -53,6 +54,17 @@ __global__ __launch_bounds__(256) void validate_table(int64_t ncomp, int32_t K, 
         const bool ok = t <= NODAL_T_GM && a[i] >= -1 && a[i] < K && b[i] >= -1 && b[i] < K && ci >= -1 && ci < K &&
                         di >= -1 && di < K && ri >= -1 && ri < ncomp && ki >= -1 && ki < B && (branch == (ki >= 0));
         if (!ok) atomicMin(bad, (unsigned long long)i);
+        sources += (t == NODAL_T_A || t == NODAL_T_E) ? 1u : 0u;
+    }
+    // how many components stamp the right-hand side (bad[1]): lets the symbolic phase group a handful of rhs
+    // stamps with two launches instead of thirteen.  One atomic per workgroup that has any.
+    __shared__ unsigned wsum[4];
+    for (int off = 32; off > 0; off >>= 1) sources += __shfl_down(sources, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sources;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (tot) atomicAdd(bad + 1, (unsigned long long)tot);
     }
 }
 
@@ -266,8 +278,9 @@ int nodal_upload_internal(nodal_ctx *h, int64_t ncomp, const uint8_t *type, cons
     // the range check runs on the device, behind the copies; its verdict is the one word that comes back
     NODAL_HIP_TRY(h, h->status.reserve(64));
     unsigned long long *bad_dev = h->status.as<unsigned long long>() + 4;
-    unsigned long long bad = ~0ull;
+    unsigned long long bad[2] = {~0ull, 0ull};
     NODAL_HIP_TRY(h, hipMemsetAsync(bad_dev, 0xFF, 8, h->stream));
+    NODAL_HIP_TRY(h, hipMemsetAsync(bad_dev + 1, 0, 8, h->stream));
     if (ncomp > 0) {
         const int64_t blocks = (ncomp + 255) / 256;
         validate_table<<<(unsigned)(blocks > 4096 ? 4096 : blocks), 256, 0, h->stream>>>(
@@ -276,9 +289,9 @@ int nodal_upload_internal(nodal_ctx *h, int64_t ncomp, const uint8_t *type, cons
             plain ? nullptr : h->drv.as<int32_t>(), plain ? nullptr : h->k.as<int32_t>(), bad_dev);
         NODAL_HIP_TRY(h, hipGetLastError());
     }
-    NODAL_HIP_TRY(h, hipMemcpyAsync(&bad, bad_dev, 8, hipMemcpyDeviceToHost, h->stream));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (bad != ~0ull) {
+    NODAL_TRY(nodal_read_words(h, bad, bad_dev, 16));
+    h->rhs_items = (int64_t)bad[1];
+    if (bad[0] != ~0ull) {
         h->ncomp = 0;  // (nothing may run on this table)
         return nodal_fail(h, NODAL_E_INVALID, "component table row out of range");
     }

@@ -132,6 +132,8 @@ struct nodal_ctx {
     bool have_symbolic = false;
     uint64_t sym_sizes_epoch = 0;  // table_epoch the sizes below were read back for (stamp_symbolic)
     int64_t sym_sizes[4] = {0, 0, 0, 0};  // nnz, ncontrib, nrhs, nrhs_contrib
+    int sym_long_rows = -1;        // the matrix grouping of this table found rows of more than 16 stamps (1) / none (0)
+    int64_t rhs_items = -1;        // components that stamp the right-hand side (counted at upload; -1: unknown)
     int64_t nnz = 0;        // matrix entries
     int64_t ncontrib = 0;   // matrix contributions
     int64_t nrhs = 0;       // rhs entries (rows with at least one contribution)

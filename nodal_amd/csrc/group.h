@@ -33,8 +33,11 @@ inline unsigned grid_for(int64_t n) {
 // One atomic per DISTINCT row of an item, not per tuple: a resistor's four stamps fall in two rows,
 // so half the atomics (and none of them colliding inside the lane).  `s` is a compile-time
 // constant after the enumerator's unrolled loop is inlined: rows[] / cols[] stay in registers.
+// `pos` (optional): the value the counting atomic returns IS the tuple's place inside its row's segment -- any
+// order will do, the segments are sorted afterwards -- so it is kept (one word per leader slot, slot-major: coalesced) and
+// emit_tuples needs no atomics of its own, nor a second array of fill counters.
 template <class E>
-__global__ __launch_bounds__(TB) void count_rows(E en, uint32_t *__restrict__ rowcount) {
+__global__ __launch_bounds__(TB) void count_rows(E en, uint32_t *__restrict__ rowcount, uint32_t *__restrict__ pos) {
     constexpr int S = E::SLOTS;
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < en.nitems;
          i += (int64_t)gridDim.x * TB) {
@@ -52,14 +55,14 @@ __global__ __launch_bounds__(TB) void count_rows(E en, uint32_t *__restrict__ ro
                 if (t < s && rows[t] == rows[s]) leader = false;
                 if (t > s && rows[t] == rows[s]) ++cnt;
             }
-            if (leader) atomicAdd(&rowcount[rows[s]], cnt);
+            if (leader) pos[(int64_t)s * en.nitems + i] = atomicAdd(&rowcount[rows[s]], cnt);
         }
     }
 }
 
 template <class E>
 __global__ __launch_bounds__(TB) void emit_tuples(E en, const uint32_t *__restrict__ rowstart,
-                                                  uint32_t *__restrict__ fill,
+                                                  const uint32_t *__restrict__ pos,
                                                   uint64_t *__restrict__ skey,
                                                   int32_t *__restrict__ srow) {
     constexpr int S = E::SLOTS;
@@ -74,13 +77,11 @@ __global__ __launch_bounds__(TB) void emit_tuples(E en, const uint32_t *__restri
         for (int s = 0; s < S; ++s) {
             if (rows[s] < 0) continue;
             int first = s;
-            unsigned before = 0, cnt = 1;
+            unsigned before = 0;
 #pragma unroll
-            for (int t = S - 1; t >= 0; --t) {
+            for (int t = S - 1; t >= 0; --t)
                 if (t < s && rows[t] == rows[s]) { first = t; ++before; }
-                if (t > s && rows[t] == rows[s]) ++cnt;
-            }
-            at[s] = first == s ? atomicAdd(&fill[rows[s]], cnt) : 0u;
+            at[s] = first == s ? pos[(int64_t)s * en.nitems + i] : 0u;
 #pragma unroll
             for (int t = 0; t < S; ++t)
                 if (t == first && t < s) at[s] = at[t] + before;
@@ -290,25 +291,28 @@ struct emits_exactly<E, std::void_t<decltype(E::EXACT)>> : std::bool_constant<E:
 template <class E>
 int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int64_t *ncon_out,
                 DevBuf &indices, DevBuf &rowidx, DevBuf &cptr, DevBuf &contrib, DevBuf *indptr,
-                DevBuf *diag_pos, int64_t known_nent = -1, int64_t known_C = -1) {
+                DevBuf *diag_pos, int64_t known_nent = -1, int64_t known_C = -1, int *long_rows = nullptr) {
+    // long_rows (optional): in, 0 = the caller knows that no row has more than SHORT_MAX tuples (the same
+    // items grouped before): the two sorts of longer rows are not launched; out, what this grouping found
+    // (only when it reads the number of entries back anyway), -1 otherwise.
     hipStream_t st = h->stream;
     if (en.nitems >= (1ll << 29) || nrows >= (1ll << 31) - 2)
         return nodal_fail(h, NODAL_E_UNSUPPORTED, "too many items for 32-bit grouping keys");
 
-    // work layout: rowcount/rowstart [nrows+1] | fill [nrows] | counts[4] | scan tmp
+    // work layout: rowcount/rowstart [nrows+1] | counts[4] | scan tmp | pos [nitems x SLOTS] (leader slots only)
     const size_t off_start = 0;
-    const size_t off_fill = align_up((size_t)(nrows + 1) * 4);
-    const size_t off_counts = off_fill + align_up((size_t)nrows * 4);
+    const size_t off_counts = align_up((size_t)(nrows + 1) * 4);
     const size_t off_scan = off_counts + 256;
     const size_t scan_bytes = scan_tmp_bytes(nrows + 1);
-    NODAL_HIP_TRY(h, h->work.reserve(off_scan + scan_bytes));
+    const size_t off_pos = off_scan + align_up(scan_bytes);
+    NODAL_HIP_TRY(h, h->work.reserve(off_pos + (size_t)en.nitems * E::SLOTS * 4 + 64));
     char *w = h->work.as<char>();
     uint32_t *rowstart = reinterpret_cast<uint32_t *>(w + off_start);
-    uint32_t *fill = reinterpret_cast<uint32_t *>(w + off_fill);
     uint32_t *counts = reinterpret_cast<uint32_t *>(w + off_counts);  // [0] medium [1] long [2] C [3] nent
+    uint32_t *pos = reinterpret_cast<uint32_t *>(w + off_pos);
     NODAL_HIP_TRY(h, hipMemsetAsync(w, 0, off_scan, st));
 
-    count_rows<E><<<grid_for(en.nitems), TB, 0, st>>>(en, rowstart);
+    count_rows<E><<<grid_for(en.nitems), TB, 0, st>>>(en, rowstart, pos);
     NODAL_HIP_TRY(h, hipGetLastError());
     NODAL_TRY(scan_exclusive_u32(h, rowstart, rowstart, nrows + 1, &counts[2], w + off_scan));
     int64_t C;
@@ -356,7 +360,7 @@ int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int
     int32_t *medium_list = reinterpret_cast<int32_t *>(w2 + o_med);
     int32_t *long_list = reinterpret_cast<int32_t *>(w2 + o_long);
 
-    emit_tuples<E><<<grid_for(en.nitems), TB, 0, st>>>(en, rowstart, fill, skey, srow);
+    emit_tuples<E><<<grid_for(en.nitems), TB, 0, st>>>(en, rowstart, pos, skey, srow);
     NODAL_HIP_TRY(h, hipGetLastError());
     sort_rows_short<<<grid_for(nrows), TB, 0, st>>>(rowstart, skey, nrows, medium_list, long_list,
                                                    counts);
@@ -364,7 +368,9 @@ int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int
     // The medium / long row lists are counted on the device (counts[0], counts[1]) and both
     // kernels loop over them with a grid stride: launched unconditionally with a bounded grid
     // (an empty list costs two idle launches, a round trip to learn the counts ~100 us).
-    {
+    const bool no_long_rows = long_rows && *long_rows == 0;
+    if (long_rows) *long_rows = no_long_rows ? 0 : -1;
+    if (!no_long_rows) {
         const unsigned gm = (unsigned)(nrows < 1024 ? (nrows > 0 ? nrows : 1) : 1024);
         sort_rows_medium<<<gm, TB, 0, st>>>(rowstart, skey, medium_list, counts);
         NODAL_HIP_TRY(h, hipGetLastError());
@@ -378,12 +384,13 @@ int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int
     NODAL_HIP_TRY(h, hipGetLastError());
     // scanned over C+1 slots: slot C (zero) receives the number of entries
     NODAL_HIP_TRY(h, hipMemsetAsync(head + C, 0, 4, st));
-    NODAL_TRY(scan_exclusive_u32(h, head, eidx, C + 1, nullptr, w2 + o_scan2));
+    NODAL_TRY(scan_exclusive_u32(h, head, eidx, C + 1, &counts[3], w2 + o_scan2));  // (head[C] is 0: the total is eidx[C])
     int64_t nent = known_nent;
     if (nent < 0) {
-        uint32_t nent32 = 0;
-        NODAL_TRY(nodal_read_words(h, &nent32, eidx + C, 4));
-        nent = nent32;
+        uint32_t back[4] = {0, 0, 0, 0};  // medium rows, long rows, contributions, entries
+        NODAL_TRY(nodal_read_words(h, back, counts, 16));
+        nent = back[3];
+        if (long_rows && !no_long_rows) *long_rows = (back[0] | back[1]) ? 1 : 0;
     }
     *nent_out = nent;
 
@@ -411,6 +418,119 @@ int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int
     return NODAL_OK;
 }
 
+
+// ---- a handful of tuples --------------------------------------------------------
+// The right-hand side of a netlist with one current source is two stamps, and the pipeline above
+// spends thirteen launches on them (every one a pass over the rows or a 5-us launch of nothing).  When an
+// upper bound of at most FEW_MAX tuples is known beforehand -- the sizes of the same table's last grouping,
+// or the number of source components counted at upload -- two launches do: every item's tuples go to a
+// small buffer (in the order the atomics hand out, which the sort makes irrelevant), then ONE workgroup
+// sorts them by (row, col, item, slot), marks the runs and writes entries and contributions.
+constexpr int FEW_MAX = 1024;
+
+template <class E>
+__global__ __launch_bounds__(TB) void collect_tuples(E en, uint32_t *__restrict__ count, uint32_t *__restrict__ frow,
+                                                     uint64_t *__restrict__ fkey) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < en.nitems; i += (int64_t)gridDim.x * TB)
+        en.for_each(i, [&](int s, int row, int col) {
+            const uint32_t p = atomicAdd(count, 1u);
+            if (p < (uint32_t)FEW_MAX) {
+                frow[p] = (uint32_t)row;
+                fkey[p] = ((uint64_t)(uint32_t)col << 32) | ((uint64_t)i << 3) | (uint64_t)s;
+            }
+        });
+}
+
+// counts: [0] tuples collected (in), [2] contributions, [3] entries (out; [2] > FEW_MAX: the bound was wrong)
+__global__ __launch_bounds__(FEW_MAX) void group_few(uint32_t *__restrict__ counts, const uint32_t *__restrict__ frow,
+                                                     const uint64_t *__restrict__ fkey, int32_t *__restrict__ indices,
+                                                     int32_t *__restrict__ rowidx, int32_t *__restrict__ cptr,
+                                                     uint32_t *__restrict__ contrib) {
+    __shared__ uint32_t srow_[FEW_MAX];
+    __shared__ uint64_t skey_[FEW_MAX];
+    __shared__ uint32_t wsum[FEW_MAX / 64];
+    const int t = threadIdx.x;
+    const uint32_t total = counts[0];
+    const uint32_t C = total < (uint32_t)FEW_MAX ? total : (uint32_t)FEW_MAX;
+    srow_[t] = (uint32_t)t < C ? frow[t] : 0xffffffffu;
+    skey_[t] = (uint32_t)t < C ? fkey[t] : ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= FEW_MAX; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int l = t ^ stride;
+            if (l > t) {
+                const uint32_t ra = srow_[t], rb = srow_[l];
+                const uint64_t ka = skey_[t], kb = skey_[l];
+                const bool a_less = ra < rb || (ra == rb && ka < kb);
+                const bool up = (t & size) == 0;
+                if (a_less != up) {
+                    srow_[t] = rb;
+                    srow_[l] = ra;
+                    skey_[t] = kb;
+                    skey_[l] = ka;
+                }
+            }
+            __syncthreads();
+        }
+    // runs of equal (row, col) are entries
+    const bool valid = (uint32_t)t < C;
+    const bool head = valid && (t == 0 || srow_[t] != srow_[t - 1] || (skey_[t] >> 32) != (skey_[t - 1] >> 32));
+    const unsigned long long hb = __ballot(head);
+    const int lane = t & 63, wave = t >> 6;
+    if (lane == 0) wsum[wave] = (uint32_t)__popcll(hb);
+    __syncthreads();
+    uint32_t before = 0, nent = 0;
+    for (int w = 0; w < FEW_MAX / 64; ++w) {
+        if (w < wave) before += wsum[w];
+        nent += wsum[w];
+    }
+    const uint32_t e = before + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
+    if (valid) contrib[t] = (uint32_t)(skey_[t] & 0xffffffffull);
+    if (head) {
+        rowidx[e] = (int32_t)srow_[t];
+        indices[e] = (int32_t)(skey_[t] >> 32);
+        cptr[e] = t;
+    }
+    if (t == 0) {
+        cptr[nent] = (int32_t)C;
+        counts[2] = total;
+        counts[3] = nent;
+    }
+}
+
+// `bound`: an upper bound (<= FEW_MAX) of the number of tuples the items emit.  Matrix-free outputs only
+// (no indptr / diagonal positions: the right-hand side's grouping).
+template <class E>
+int build_lists_few(nodal_ctx *h, const E &en, int64_t bound, int64_t *nent_out, int64_t *ncon_out, DevBuf &indices,
+                    DevBuf &rowidx, DevBuf &cptr, DevBuf &contrib, int64_t known_nent, int64_t known_C) {
+    hipStream_t st = h->stream;
+    if (en.nitems >= (1ll << 29)) return nodal_fail(h, NODAL_E_UNSUPPORTED, "too many items for 32-bit grouping keys");
+    NODAL_HIP_TRY(h, h->work.reserve(256 + (size_t)FEW_MAX * 12));
+    uint32_t *counts = h->work.as<uint32_t>();
+    uint64_t *fkey = reinterpret_cast<uint64_t *>(h->work.as<char>() + 256);
+    uint32_t *frow = reinterpret_cast<uint32_t *>(h->work.as<char>() + 256 + (size_t)FEW_MAX * 8);
+    NODAL_HIP_TRY(h, indices.reserve((size_t)(bound + 1) * 4 + 4));
+    NODAL_HIP_TRY(h, rowidx.reserve((size_t)(bound + 1) * 4 + 4));
+    NODAL_HIP_TRY(h, cptr.reserve((size_t)(bound + 2) * 4));
+    NODAL_HIP_TRY(h, contrib.reserve((size_t)(bound + 1) * 4));
+    NODAL_HIP_TRY(h, hipMemsetAsync(counts, 0, 64, st));
+    collect_tuples<E><<<grid_for(en.nitems), TB, 0, st>>>(en, counts, frow, fkey);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    group_few<<<1, FEW_MAX, 0, st>>>(counts, frow, fkey, indices.as<int32_t>(), rowidx.as<int32_t>(), cptr.as<int32_t>(),
+                                     contrib.as<uint32_t>());
+    NODAL_HIP_TRY(h, hipGetLastError());
+    if (known_nent >= 0 && known_C >= 0) {
+        *nent_out = known_nent;
+        *ncon_out = known_C;
+        return NODAL_OK;
+    }
+    uint32_t out[2] = {0, 0};
+    NODAL_TRY(nodal_read_words(h, out, counts + 2, 8));
+    if ((int64_t)out[0] > bound) return nodal_fail(h, NODAL_E_INVALID, "grouping: more stamps than the table's sources allow");
+    *ncon_out = out[0];
+    *nent_out = out[1];
+    return NODAL_OK;
+}
 
 }  // namespace grp
 }  // namespace

@@ -268,11 +268,21 @@ int stamp_symbolic(nodal_ctx *h) {
     // symbolic phase of the SAME uploaded table (table_epoch), they spare the four size read-backs --
     // each one drains the stream -- of a repeated assembly.
     const bool known = h->sym_sizes_epoch == h->table_epoch;
+    int long_rows = known ? h->sym_long_rows : -1;  // (0: no node with more than 16 stamps in a row last time)
     NODAL_TRY(grp::build_lists(h, MatrixStamps{tb, tb.ncomp}, n, &h->nnz, &h->ncontrib, h->indices,
                                h->rowidx, h->cptr, h->contrib, &h->indptr, &h->diag_pos,
-                               known ? h->sym_sizes[0] : -1, known ? h->sym_sizes[1] : -1));
+                               known ? h->sym_sizes[0] : -1, known ? h->sym_sizes[1] : -1, &long_rows));
+    if (!known || long_rows >= 0) h->sym_long_rows = long_rows;
     // (rhs entries have no column index: the column list lands in a scratch buffer the context keeps --
     // a local one meant a hipMalloc and a hipFree, which waits for the whole device, per symbolic phase)
+    // A handful of sources (the usual netlist; the bound is the last grouping's count or twice the number of
+    // source components counted at upload) are grouped by two launches.
+    const int64_t rhs_bound = known ? h->sym_sizes[3] : (h->rhs_items >= 0 ? 2 * h->rhs_items : -1);
+    if (rhs_bound >= 0 && rhs_bound <= grp::FEW_MAX)
+        NODAL_TRY(grp::build_lists_few(h, RhsStamps{tb, tb.ncomp}, rhs_bound, &h->nrhs, &h->nrhs_contrib, h->rhs_none,
+                                       h->rhs_row, h->rhs_cptr, h->rhs_contrib, known ? h->sym_sizes[2] : -1,
+                                       known ? h->sym_sizes[3] : -1));
+    else
     NODAL_TRY(grp::build_lists(h, RhsStamps{tb, tb.ncomp}, n, &h->nrhs, &h->nrhs_contrib, h->rhs_none,
                                h->rhs_row, h->rhs_cptr, h->rhs_contrib, nullptr, nullptr,
                                known ? h->sym_sizes[2] : -1, known ? h->sym_sizes[3] : -1));
