@@ -63,8 +63,7 @@ __global__ __launch_bounds__(TB) void count_rows(E en, uint32_t *__restrict__ ro
 template <class E>
 __global__ __launch_bounds__(TB) void emit_tuples(E en, const uint32_t *__restrict__ rowstart,
                                                   const uint32_t *__restrict__ pos,
-                                                  uint64_t *__restrict__ skey,
-                                                  int32_t *__restrict__ srow) {
+                                                  uint64_t *__restrict__ skey) {
     constexpr int S = E::SLOTS;
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < en.nitems;
          i += (int64_t)gridDim.x * TB) {
@@ -91,7 +90,6 @@ __global__ __launch_bounds__(TB) void emit_tuples(E en, const uint32_t *__restri
             if (rows[s] < 0) continue;
             const uint32_t p = rowstart[rows[s]] + at[s];
             skey[p] = ((uint64_t)(uint32_t)cols[s] << 32) | ((uint64_t)i << 3) | (uint64_t)s;
-            srow[p] = rows[s];
         }
     }
 }
@@ -119,34 +117,59 @@ __device__ __forceinline__ void sort_network(uint64_t (&k)[N]) {
     }
 }
 
+constexpr int SHORT_MAX = 16;
+constexpr int MEDIUM_MAX = 2048;
+
+// A short row (at most 16 tuples) lives in one lane's registers: loaded and sorted by a network.
 template <int N>
-__device__ __forceinline__ void sort_short_row(uint64_t *seg, int len) {
-    uint64_t k[N];
+__device__ __forceinline__ void load_sorted(const uint64_t *__restrict__ seg, int len, uint64_t (&k)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) k[i] = i < len ? seg[i] : ~0ull;
     sort_network<N>(k);
+}
+
+// (in place: the multigrid setup sorts the rows of its restriction operator with it)
+template <int N>
+__device__ __forceinline__ void sort_short_row(uint64_t *seg, int len) {
+    uint64_t k[N];
+    load_sorted<N>(seg, len, k);
 #pragma unroll
     for (int i = 0; i < N; ++i)
         if (i < len) seg[i] = k[i];
 }
 
-constexpr int SHORT_MAX = 16;
-constexpr int MEDIUM_MAX = 2048;
+template <int N>
+__device__ __forceinline__ uint32_t short_row_heads(const uint64_t *__restrict__ seg, int len) {
+    uint64_t k[N];
+    load_sorted<N>(seg, len, k);
+    uint32_t nh = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (i < len && (i == 0 || (k[i] >> 32) != (k[i - 1] >> 32))) ++nh;
+    return nh;
+}
 
-// one lane per row; rows longer than SHORT_MAX are appended to work lists
-__global__ __launch_bounds__(TB) void sort_rows_short(const uint32_t *__restrict__ rowstart,
-                                                      uint64_t *__restrict__ skey, int64_t nrows,
+// Pass 1 over the ROWS: one lane per row sorts its tuples in registers and counts the runs of equal columns
+// -- the row's entries; the sorted keys are NOT written back (pass 2 sorts the row again: cheaper than 8 bytes
+// per tuple out and in).  Rows longer than SHORT_MAX are appended to work lists; their sorts leave the count.
+__global__ __launch_bounds__(TB) void row_heads_short(const uint32_t *__restrict__ rowstart,
+                                                      const uint64_t *__restrict__ skey, int64_t nrows,
+                                                      uint32_t *__restrict__ rowheads,
                                                       int32_t *__restrict__ medium_list,
                                                       int32_t *__restrict__ long_list,
                                                       uint32_t *__restrict__ list_counts) {
-    for (int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x; r < nrows;
+    for (int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x; r <= nrows;
          r += (int64_t)gridDim.x * TB) {
+        if (r == nrows) {  // (the scan runs over nrows + 1 slots: the last one receives the number of entries)
+            rowheads[r] = 0;
+            continue;
+        }
         const uint32_t s = rowstart[r];
         const int len = (int)(rowstart[r + 1] - s);
-        if (len < 2) continue;
-        if (len <= 4) sort_short_row<4>(skey + s, len);
-        else if (len <= 8) sort_short_row<8>(skey + s, len);
-        else if (len <= SHORT_MAX) sort_short_row<16>(skey + s, len);
+        if (len < 2) rowheads[r] = (uint32_t)len;
+        else if (len <= 4) rowheads[r] = short_row_heads<4>(skey + s, len);
+        else if (len <= 8) rowheads[r] = short_row_heads<8>(skey + s, len);
+        else if (len <= SHORT_MAX) rowheads[r] = short_row_heads<16>(skey + s, len);
         else if (len <= MEDIUM_MAX) medium_list[atomicAdd(&list_counts[0], 1u)] = (int32_t)r;
         else long_list[atomicAdd(&list_counts[1], 1u)] = (int32_t)r;
     }
@@ -156,8 +179,10 @@ __global__ __launch_bounds__(TB) void sort_rows_short(const uint32_t *__restrict
 __global__ __launch_bounds__(TB) void sort_rows_medium(const uint32_t *__restrict__ rowstart,
                                                        uint64_t *__restrict__ skey,
                                                        const int32_t *__restrict__ list,
-                                                       const uint32_t *__restrict__ list_counts) {
+                                                       const uint32_t *__restrict__ list_counts,
+                                                       uint32_t *__restrict__ rowheads) {
     __shared__ uint64_t buf[MEDIUM_MAX];
+    __shared__ uint32_t nheads;
     const uint32_t count = list_counts[0];
     for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
         const int32_t r = list[it];
@@ -180,7 +205,16 @@ __global__ __launch_bounds__(TB) void sort_rows_medium(const uint32_t *__restric
                 __syncthreads();
             }
         }
-        for (int i = threadIdx.x; i < len; i += TB) skey[s + i] = buf[i];
+        uint32_t mine = 0;
+        for (int i = threadIdx.x; i < len; i += TB) {
+            skey[s + i] = buf[i];
+            mine += (i == 0 || (buf[i] >> 32) != (buf[i - 1] >> 32)) ? 1u : 0u;
+        }
+        if (threadIdx.x == 0) nheads = 0;
+        __syncthreads();
+        if (mine) atomicAdd(&nheads, mine);  // (an integer count: the order of the additions does not matter)
+        __syncthreads();
+        if (threadIdx.x == 0) rowheads[r] = nheads;
         __syncthreads();
     }
 }
@@ -192,7 +226,9 @@ __global__ __launch_bounds__(1024) void sort_rows_long(const uint32_t *__restric
                                                        uint64_t *__restrict__ skey,
                                                        uint64_t *__restrict__ scratch,
                                                        const int32_t *__restrict__ list,
-                                                       const uint32_t *__restrict__ list_counts) {
+                                                       const uint32_t *__restrict__ list_counts,
+                                                       uint32_t *__restrict__ rowheads) {
+    __shared__ uint32_t nheads;
     const uint32_t count = list_counts[1];
     for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
         const int32_t r = list[it];
@@ -216,56 +252,129 @@ __global__ __launch_bounds__(1024) void sort_rows_long(const uint32_t *__restric
                 __syncthreads();  // one workgroup: global writes are visible after the barrier
             }
         }
-        for (int64_t i = threadIdx.x; i < len; i += 1024) skey[s + i] = buf[i];
+        uint32_t mine = 0;
+        for (int64_t i = threadIdx.x; i < len; i += 1024) {
+            skey[s + i] = buf[i];
+            mine += (i == 0 || (buf[i] >> 32) != (buf[i - 1] >> 32)) ? 1u : 0u;
+        }
+        if (threadIdx.x == 0) nheads = 0;
+        __syncthreads();
+        if (mine) atomicAdd(&nheads, mine);
+        __syncthreads();
+        if (threadIdx.x == 0) rowheads[r] = nheads;
         __syncthreads();
     }
 }
 
 // ---- runs of equal (row, col) -> CSR entries -------------------------------------
-
-__global__ __launch_bounds__(TB) void mark_heads(const uint64_t *__restrict__ skey,
-                                                 const int32_t *__restrict__ srow,
-                                                 const uint32_t *__restrict__ rowstart,
-                                                 uint32_t *__restrict__ head, int64_t C) {
-    for (int64_t p = (int64_t)blockIdx.x * TB + threadIdx.x; p < C; p += (int64_t)gridDim.x * TB) {
-        const bool first = p == (int64_t)rowstart[srow[p]];
-        head[p] = (first || (skey[p] >> 32) != (skey[p - 1] >> 32)) ? 1u : 0u;
-    }
-}
-
-__global__ __launch_bounds__(TB) void fill_entries(const uint64_t *__restrict__ skey,
-                                                   const int32_t *__restrict__ srow,
-                                                   const uint32_t *__restrict__ head,
-                                                   const uint32_t *__restrict__ eidx, int64_t C,
-                                                   int32_t *__restrict__ indices,
-                                                   int32_t *__restrict__ rowidx,
-                                                   int32_t *__restrict__ cptr,
-                                                   uint32_t *__restrict__ contrib,
-                                                   int32_t *__restrict__ diag_pos) {
-    for (int64_t p = (int64_t)blockIdx.x * TB + threadIdx.x; p < C; p += (int64_t)gridDim.x * TB) {
-        const uint64_t key = skey[p];
-        contrib[p] = (uint32_t)key;
-        if (head[p]) {
-            const uint32_t e = eidx[p];
-            const int32_t col = (int32_t)(key >> 32), row = srow[p];
-            if (indices) indices[e] = col;
-            rowidx[e] = row;
-            cptr[e] = (int32_t)p;
-            if (diag_pos && col == row) diag_pos[row] = (int32_t)e;
+// Pass 2 over the rows, behind the scan of the rows' entry counts (`eptr`, which IS the CSR row pointer): the
+// lane sorts its row again and writes its entries (column, row, first contribution), the contributions in
+// sorted order, and the position of the diagonal entry.
+template <int N>
+__device__ __forceinline__ void fill_short_row(const uint64_t *__restrict__ seg, int len, uint32_t s, int32_t r,
+                                               uint32_t e, int32_t *__restrict__ indices,
+                                               int32_t *__restrict__ rowidx, int32_t *__restrict__ cptr,
+                                               uint32_t *__restrict__ contrib, int32_t &dp) {
+    uint64_t k[N];
+    load_sorted<N>(seg, len, k);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (i < len) {
+            contrib[s + i] = (uint32_t)k[i];
+            if (i == 0 || (k[i] >> 32) != (k[i - 1] >> 32)) {
+                const int32_t col = (int32_t)(k[i] >> 32);
+                if (indices) indices[e] = col;
+                rowidx[e] = r;
+                cptr[e] = (int32_t)(s + i);
+                if (col == r) dp = (int32_t)e;
+                ++e;
+            }
         }
+}
+
+__global__ __launch_bounds__(TB) void fill_rows_short(const uint32_t *__restrict__ rowstart,
+                                                      const uint64_t *__restrict__ skey,
+                                                      const uint32_t *__restrict__ eptr, int64_t nrows, int64_t C,
+                                                      int32_t *__restrict__ indices, int32_t *__restrict__ rowidx,
+                                                      int32_t *__restrict__ cptr, uint32_t *__restrict__ contrib,
+                                                      int32_t *__restrict__ diag_pos) {
+    for (int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x; r < nrows;
+         r += (int64_t)gridDim.x * TB) {
+        if (r == 0) cptr[eptr[nrows]] = (int32_t)C;  // (the list of entries ends where the contributions end)
+        const uint32_t s = rowstart[r];
+        const int len = (int)(rowstart[r + 1] - s);
+        if (len > SHORT_MAX) continue;  // (fill_rows_listed)
+        const uint32_t e = eptr[r];
+        int32_t dp = -1;
+        if (len == 1) {
+            const uint64_t key = skey[s];
+            contrib[s] = (uint32_t)key;
+            const int32_t col = (int32_t)(key >> 32);
+            if (indices) indices[e] = col;
+            rowidx[e] = (int32_t)r;
+            cptr[e] = (int32_t)s;
+            if (col == (int32_t)r) dp = (int32_t)e;
+        } else if (len >= 2) {
+            if (len <= 4) fill_short_row<4>(skey + s, len, s, (int32_t)r, e, indices, rowidx, cptr, contrib, dp);
+            else if (len <= 8) fill_short_row<8>(skey + s, len, s, (int32_t)r, e, indices, rowidx, cptr, contrib, dp);
+            else fill_short_row<16>(skey + s, len, s, (int32_t)r, e, indices, rowidx, cptr, contrib, dp);
+        }
+        if (diag_pos) diag_pos[r] = dp;
     }
 }
 
-// indptr[r] = entry index of the first stamp of row r (eidx has C+1 values)
-__global__ __launch_bounds__(TB) void fill_indptr(const uint32_t *__restrict__ rowstart,
-                                                  const uint32_t *__restrict__ eidx,
-                                                  int32_t *__restrict__ indptr, int64_t nrows) {
-    for (int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x; r <= nrows;
-         r += (int64_t)gridDim.x * TB)
-        indptr[r] = (int32_t)eidx[rowstart[r]];
+// the same for the listed rows (sorted in place by their own kernels): one workgroup per row, TB tuples per
+// step, entry numbers by a ballot scan
+__global__ __launch_bounds__(TB) void fill_rows_listed(const uint32_t *__restrict__ rowstart,
+                                                       const uint64_t *__restrict__ skey,
+                                                       const uint32_t *__restrict__ eptr,
+                                                       const int32_t *__restrict__ medium_list,
+                                                       const int32_t *__restrict__ long_list,
+                                                       const uint32_t *__restrict__ list_counts,
+                                                       int32_t *__restrict__ indices, int32_t *__restrict__ rowidx,
+                                                       int32_t *__restrict__ cptr, uint32_t *__restrict__ contrib,
+                                                       int32_t *__restrict__ diag_pos) {
+    __shared__ uint32_t wcount[TB / 64];
+    __shared__ int32_t dpos;
+    const uint32_t nm = list_counts[0], total = nm + list_counts[1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t it = blockIdx.x; it < total; it += gridDim.x) {
+        const int32_t r = it < nm ? medium_list[it] : long_list[it - nm];
+        const uint32_t s = rowstart[r];
+        const int64_t len = (int64_t)rowstart[r + 1] - s;
+        uint32_t e0 = eptr[r];
+        if (threadIdx.x == 0) dpos = -1;
+        __syncthreads();
+        for (int64_t base = 0; base < len; base += TB) {
+            const int64_t i = base + threadIdx.x;
+            const bool in = i < len;
+            const uint64_t key = in ? skey[s + i] : 0ull;
+            const bool head = in && (i == 0 || (key >> 32) != (skey[s + i - 1] >> 32));
+            const unsigned long long hb = __ballot(head);
+            if (lane == 0) wcount[wave] = (uint32_t)__popcll(hb);
+            __syncthreads();
+            uint32_t before = 0, all = 0;
+#pragma unroll
+            for (int w = 0; w < TB / 64; ++w) {
+                if (w < wave) before += wcount[w];
+                all += wcount[w];
+            }
+            if (in) contrib[s + i] = (uint32_t)key;
+            if (head) {
+                const uint32_t e = e0 + before + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
+                const int32_t col = (int32_t)(key >> 32);
+                if (indices) indices[e] = col;
+                rowidx[e] = r;
+                cptr[e] = (int32_t)(s + i);
+                if (col == r) dpos = (int32_t)e;  // (one entry per column: one writer)
+            }
+            e0 += all;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0 && diag_pos) diag_pos[r] = dpos;
+        __syncthreads();
+    }
 }
-
-__global__ void set_tail(int32_t *cptr, int64_t nent, int64_t C) { cptr[nent] = (int32_t)C; }
 
 __global__ __launch_bounds__(TB) void fill_i32(int32_t *p, int32_t v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
@@ -343,48 +452,42 @@ int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int
         return NODAL_OK;
     }
 
-    // work2 layout: skey [C] u64 | srow [C] i32 | head/eidx [C+1] u32 | lists 2 x [nrows] | scan tmp
+    // work2 layout: skey [C] u64 | rowheads / eptr [nrows+1] u32 | lists 2 x [nrows] | scan tmp
     const size_t o_key = 0;
-    const size_t o_row = o_key + align_up((size_t)C * 8);
-    const size_t o_head = o_row + align_up((size_t)C * 4);
-    const size_t o_eidx = o_head + align_up((size_t)(C + 1) * 4);
-    const size_t o_med = o_eidx + align_up((size_t)(C + 1) * 4);
+    const size_t o_heads = o_key + align_up((size_t)C * 8);
+    const size_t o_med = o_heads + align_up((size_t)(nrows + 1) * 4);
     const size_t o_long = o_med + align_up((size_t)nrows * 4);
     const size_t o_scan2 = o_long + align_up((size_t)nrows * 4);
-    NODAL_HIP_TRY(h, h->work2.reserve(o_scan2 + scan_tmp_bytes(C + 1)));
+    NODAL_HIP_TRY(h, h->work2.reserve(o_scan2 + scan_tmp_bytes(nrows + 1)));
     char *w2 = h->work2.as<char>();
     uint64_t *skey = reinterpret_cast<uint64_t *>(w2 + o_key);
-    int32_t *srow = reinterpret_cast<int32_t *>(w2 + o_row);
-    uint32_t *head = reinterpret_cast<uint32_t *>(w2 + o_head);
-    uint32_t *eidx = reinterpret_cast<uint32_t *>(w2 + o_eidx);
+    uint32_t *rowheads = reinterpret_cast<uint32_t *>(w2 + o_heads);
     int32_t *medium_list = reinterpret_cast<int32_t *>(w2 + o_med);
     int32_t *long_list = reinterpret_cast<int32_t *>(w2 + o_long);
+    // the rows' entry counts are scanned into the CSR row pointer itself when the caller wants one
+    if (indptr) NODAL_HIP_TRY(h, indptr->reserve((size_t)(nrows + 1) * 4));
+    uint32_t *eptr = indptr ? indptr->as<uint32_t>() : rowheads;
 
-    emit_tuples<E><<<grid_for(en.nitems), TB, 0, st>>>(en, rowstart, pos, skey, srow);
+    emit_tuples<E><<<grid_for(en.nitems), TB, 0, st>>>(en, rowstart, pos, skey);
     NODAL_HIP_TRY(h, hipGetLastError());
-    sort_rows_short<<<grid_for(nrows), TB, 0, st>>>(rowstart, skey, nrows, medium_list, long_list,
-                                                   counts);
+    row_heads_short<<<grid_for(nrows + 1), TB, 0, st>>>(rowstart, skey, nrows, rowheads, medium_list, long_list, counts);
     NODAL_HIP_TRY(h, hipGetLastError());
-    // The medium / long row lists are counted on the device (counts[0], counts[1]) and both
-    // kernels loop over them with a grid stride: launched unconditionally with a bounded grid
-    // (an empty list costs two idle launches, a round trip to learn the counts ~100 us).
+    // The medium / long row lists are counted on the device (counts[0], counts[1]) and the kernels loop over
+    // them with a grid stride: launched unconditionally with a bounded grid (an empty list costs three idle
+    // launches, a round trip to learn the counts ~100 us) unless the caller knows that there is no such row.
     const bool no_long_rows = long_rows && *long_rows == 0;
     if (long_rows) *long_rows = no_long_rows ? 0 : -1;
+    const unsigned gm = (unsigned)(nrows < 1024 ? (nrows > 0 ? nrows : 1) : 1024);
     if (!no_long_rows) {
-        const unsigned gm = (unsigned)(nrows < 1024 ? (nrows > 0 ? nrows : 1) : 1024);
-        sort_rows_medium<<<gm, TB, 0, st>>>(rowstart, skey, medium_list, counts);
+        sort_rows_medium<<<gm, TB, 0, st>>>(rowstart, skey, medium_list, counts, rowheads);
         NODAL_HIP_TRY(h, hipGetLastError());
         NODAL_HIP_TRY(h, h->work3.reserve((size_t)C * 16));  // padded scratch of the long sort
         sort_rows_long<<<gm < 128 ? gm : 128, 1024, 0, st>>>(rowstart, skey, h->work3.as<uint64_t>(),
-                                                            long_list, counts);
+                                                            long_list, counts, rowheads);
         NODAL_HIP_TRY(h, hipGetLastError());
     }
-
-    mark_heads<<<grid_for(C), TB, 0, st>>>(skey, srow, rowstart, head, C);
-    NODAL_HIP_TRY(h, hipGetLastError());
-    // scanned over C+1 slots: slot C (zero) receives the number of entries
-    NODAL_HIP_TRY(h, hipMemsetAsync(head + C, 0, 4, st));
-    NODAL_TRY(scan_exclusive_u32(h, head, eidx, C + 1, &counts[3], w2 + o_scan2));  // (head[C] is 0: the total is eidx[C])
+    // entries per row -> first entry of every row; slot nrows (zero) receives the number of entries
+    NODAL_TRY(scan_exclusive_u32(h, rowheads, eptr, nrows + 1, &counts[3], w2 + o_scan2));
     int64_t nent = known_nent;
     if (nent < 0) {
         uint32_t back[4] = {0, 0, 0, 0};  // medium rows, long rows, contributions, entries
@@ -398,26 +501,19 @@ int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int
     NODAL_HIP_TRY(h, rowidx.reserve((size_t)nent * 4 + 4));
     NODAL_HIP_TRY(h, cptr.reserve((size_t)(nent + 1) * 4));
     NODAL_HIP_TRY(h, contrib.reserve((size_t)C * 4));
-    if (diag_pos) {
-        NODAL_HIP_TRY(h, diag_pos->reserve((size_t)nrows * 4 + 4));
-        fill_i32<<<grid_for(nrows), TB, 0, st>>>(diag_pos->as<int32_t>(), -1, nrows);
-        NODAL_HIP_TRY(h, hipGetLastError());
-    }
-    fill_entries<<<grid_for(C), TB, 0, st>>>(skey, srow, head, eidx, C, indices.as<int32_t>(),
-                                            rowidx.as<int32_t>(), cptr.as<int32_t>(),
-                                            contrib.as<uint32_t>(),
+    if (diag_pos) NODAL_HIP_TRY(h, diag_pos->reserve((size_t)nrows * 4 + 4));
+    fill_rows_short<<<grid_for(nrows), TB, 0, st>>>(rowstart, skey, eptr, nrows, C, indices.as<int32_t>(),
+                                                   rowidx.as<int32_t>(), cptr.as<int32_t>(), contrib.as<uint32_t>(),
+                                                   diag_pos ? diag_pos->as<int32_t>() : nullptr);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    if (!no_long_rows) {
+        fill_rows_listed<<<gm, TB, 0, st>>>(rowstart, skey, eptr, medium_list, long_list, counts, indices.as<int32_t>(),
+                                            rowidx.as<int32_t>(), cptr.as<int32_t>(), contrib.as<uint32_t>(),
                                             diag_pos ? diag_pos->as<int32_t>() : nullptr);
-    NODAL_HIP_TRY(h, hipGetLastError());
-    set_tail<<<1, 1, 0, st>>>(cptr.as<int32_t>(), nent, C);
-    NODAL_HIP_TRY(h, hipGetLastError());
-    if (indptr) {
-        NODAL_HIP_TRY(h, indptr->reserve((size_t)(nrows + 1) * 4));
-        fill_indptr<<<grid_for(nrows + 1), TB, 0, st>>>(rowstart, eidx, indptr->as<int32_t>(), nrows);
         NODAL_HIP_TRY(h, hipGetLastError());
     }
     return NODAL_OK;
 }
-
 
 // ---- a handful of tuples --------------------------------------------------------
 // The right-hand side of a netlist with one current source is two stamps, and the pipeline above
@@ -455,10 +551,12 @@ __global__ __launch_bounds__(FEW_MAX) void group_few(uint32_t *__restrict__ coun
     srow_[t] = (uint32_t)t < C ? frow[t] : 0xffffffffu;
     skey_[t] = (uint32_t)t < C ? fkey[t] : ~0ull;
     __syncthreads();
-    for (int size = 2; size <= FEW_MAX; size <<= 1)
+    int P = 64;  // (the padding sorts behind every tuple: a power of two that holds them all is enough)
+    while (P < (int)C) P <<= 1;
+    for (int size = 2; size <= P; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             const int l = t ^ stride;
-            if (l > t) {
+            if (l > t && l < P) {
                 const uint32_t ra = srow_[t], rb = srow_[l];
                 const uint64_t ka = skey_[t], kb = skey_[l];
                 const bool a_less = ra < rb || (ra == rb && ka < kb);
