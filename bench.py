@@ -193,13 +193,15 @@ class BatchShard:
         self.kern_ms = self.kern_n = 0
         self.kern_alg = 0.0
         self.circuits_done = 0
+        self.reuse = False  # True: the block system's symbolic phases (one member's lists, replicated; the
+        # hierarchy's patterns) are kept from step to step: a long value sweep on one topology
 
     @property
     def gather_ms(self):
         return self.shard.gather_ms
 
     def step(self):
-        self.shard.step(reuse_symbolic=False)
+        self.shard.step(reuse_symbolic=self.reuse)
         h = self.shard.session.h
         ms, launches, alg = h.kernel_stats()
         self.kern_ms += ms
@@ -616,6 +618,12 @@ def main():
             s2 = time_workload(other, 0, 1, local, None, {"cfg4": 6, "cfg5": 2, "cfg2": 1}[other], 1,
                                {"cfg4": 128, "cfg5": 4, "cfg2": 4}[other])
             also[other] = summary(s2, 1, with_cpu=not args.no_cpu)
+            if other == "cfg4":  # config 4 IS a value sweep on one topology: the next 128 members with the block
+                # system's symbolic phases kept (nodal_run_batch(reuse_symbolic = 1))
+                s3 = time_workload(other, 0, 1, local, None, 6, 1, 128, reuse=True)
+                r3 = summary(s3, 1, with_cpu=False)
+                also[other]["reuse_symbolic"] = {k: r3[k] for k in ("circuits_per_sec", "ms_per_solve", "phase_ms", "solver",
+                                                                     "scaled_residual")}
             if other == "cfg5":  # the general path with the symbolic phases kept (stamping lists, the presolved
                 # netlist's lists, the hierarchy's patterns); the presolve's plan and rewrite are redone: they read values
                 s3 = time_workload(other, 0, 1, local, None, 2, 1, 4, reuse=True)

@@ -191,6 +191,12 @@ def cycle(levels, l, b, cfg):
         v1 = C.A @ c1
         rho1, alpha1 = c1 @ v1, c1 @ rc
         r2 = rc - (alpha1 / rho1) * v1
+        cfg.setdefault("_kstat", [0, 0])
+        cfg["_kstat"][0] += 1
+        if cfg.get("kskip") and np.linalg.norm(r2) <= cfg["kskip"] * np.linalg.norm(rc):
+            cfg["_kstat"][1] += 1
+            x = x + L.P @ ((alpha1 / rho1) * c1)
+            return smooth(L, b, x, nu, om, kind)
         c2 = cycle(levels, l + 1, r2, cfg)
         v2 = C.A @ c2
         gamma, beta, alpha2 = c2 @ v1, c2 @ v2, c2 @ r2
@@ -258,6 +264,9 @@ VARIANTS = {
     "k2_212": dict(nu=[2, 1, 2], tail_nu=3, klevels=2),
     "k2_112": dict(nu=[1, 1, 2], tail_nu=3, klevels=2),
     "k3_212": dict(nu=[2, 1, 2], tail_nu=3, klevels=3),
+    "kskip25": dict(nu=[1, 1, 2], tail_nu=3, klevels=1, kskip=0.25),
+    "kskip35": dict(nu=[1, 1, 2], tail_nu=3, klevels=1, kskip=0.35),
+    "kskip50": dict(nu=[1, 1, 2], tail_nu=3, klevels=1, kskip=0.5),
     "kat2": dict(nu=[1, 1, 2], tail_nu=3, klevels=0, kset={2}),
     "kat2_122": dict(nu=[1, 2, 2], tail_nu=3, klevels=0, kset={2}),
     "kat2_212": dict(nu=[2, 1, 2], tail_nu=3, klevels=0, kset={2}),
@@ -282,7 +291,7 @@ def main():
         cfg = VARIANTS[nm]
         t0 = time.time()
         it, res = fcg(levels, b, cfg)
-        print(f"{nm:10s} iterations {it:3d}  relres {res:.1e}  ({time.time() - t0:.1f} s)")
+        print(f"{nm:10s} iterations {it:3d}  relres {res:.1e}  ({time.time() - t0:.1f} s)  K-cycle second steps skipped {cfg.get('_kstat', [0, 0])[1]} of {cfg.get('_kstat', [0, 0])[0]}")
 
 
 if __name__ == "__main__":
