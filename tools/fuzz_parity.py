@@ -1,0 +1,57 @@
+"""Differential campaign: random netlists with every component type, HIP path against the CPU restatement of
+the reference (oracle) -- G and A bit for bit, x to 1e-9 norm-wise -- over more seeds and larger sizes than
+the test suite runs.   python tools/fuzz_parity.py [first_seed] [count]"""
+import os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import nodal_amd as n
+from oracle import nodal_oracle as oracle
+from tests.test_gpu_parity import random_netlist, normwise, TOL
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+bad = 0
+t0 = time.time()
+for seed in range(first, first + count):
+    rng = random.Random(seed)
+    nodes = rng.choice([5, 17, 60, 200, 700, 1500, 3000, 6000])
+    rows = random_netlist(rng, nodes, rng.randrange(3, max(4, nodes // 2)))
+    nl = n.Netlist.from_rows(rows)
+    for sparse in (False, True):
+        if not sparse and nodes > 3000:
+            continue
+        try:
+            Go, Ao, cur = oracle.build_model(nl, sparse)
+        except AssertionError:
+            try:
+                n.Circuit(nl, sparse=sparse)
+                print(f"seed {seed} sparse {sparse}: the oracle asserts, the HIP path does not")
+                bad += 1
+            except AssertionError:
+                pass
+            continue
+        try:
+            circ = n.Circuit(nl, sparse=sparse)
+            G = circ.G.toarray() if sparse else circ.G
+            ok = circ.currents == cur and np.array_equal(G, Go.toarray() if sparse else Go) and np.array_equal(circ.A, Ao)
+            if not ok:
+                print(f"seed {seed} nodes {nodes} sparse {sparse}: G / A / currents differ")
+                bad += 1
+                continue
+            xo, warns = oracle.solve(Go, Ao, sparse)
+            x = circ.solve().result
+            if np.isfinite(xo).all() and nodes <= 3000 and np.linalg.cond(G) < 1e8:
+                err = normwise(x, xo)
+                if not err <= TOL:
+                    print(f"seed {seed} nodes {nodes} sparse {sparse}: x differs, {err:.2e}")
+                    bad += 1
+            elif np.isfinite(xo).all():
+                err = normwise(x, xo)
+                if not err <= 1e-7:
+                    print(f"seed {seed} nodes {nodes} sparse {sparse}: x differs (size / conditioning beyond the bar), {err:.2e}")
+        except Exception as e:  # noqa: BLE001
+            print(f"seed {seed} nodes {nodes} sparse {sparse}: {type(e).__name__}: {str(e)[:200]}")
+            bad += 1
+    if (seed - first) % 20 == 19:
+        print(f"... {seed - first + 1} netlists, {bad} failures, {time.time() - t0:.0f} s", flush=True)
+print(f"{count} netlists from seed {first}: {bad} failures")
