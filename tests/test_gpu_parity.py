@@ -665,6 +665,41 @@ def test_hub_node_long_row_sorts():
     assert normwise(x, xo) <= TOL
 
 
+@pytest.mark.parametrize("kind", ["grid", "hub", "no sources", "many sources"])
+def test_repeated_symbolic_phase_of_one_table_gives_the_same_lists(kind):
+    """A second symbolic phase of the same uploaded table takes the short cuts of a known table (no size
+    read-backs, no launches for rows of more than 16 stamps when there are none, the few-stamps grouping of
+    the right-hand side): entries and values must not change, and a new upload starts from scratch."""
+    rng = random.Random(11)
+    if kind == "grid":
+        table = gen.grid_table(40)
+    elif kind == "hub":
+        rows = [[f"r{i}", "R", repr(rng.uniform(0.5, 2)), "hub", str(i)] for i in range(2500)]
+        rows += [[f"q{i}", "R", repr(rng.uniform(0.5, 2)), str(i), "g"] for i in range(2500)]
+        rows += [["a1", "A", "1", "hub", "g"], ["e1", "E", "2", "7", "g"]]
+        table = lower(n.Netlist.from_rows(rows))
+    elif kind == "no sources":
+        table = lower(n.Netlist.from_rows([["r1", "R", "1", "1", "g"], ["r2", "R", "2", "1", "2"], ["r3", "R", "3", "2", "g"]]))
+    else:  # more right-hand-side stamps than the few-stamps grouping takes
+        rows = [[f"r{i}", "R", "1", str(i), str(i + 1)] for i in range(1, 900)] + [["rg", "R", "1", "900", "g"]]
+        rows += [[f"a{i}", "A", repr(0.001 * i), str(i), "g"] for i in range(1, 700)]
+        table = lower(n.Netlist.from_rows(rows))
+    Go, Ao = oracle.assemble_fast(table)
+    Go = Go.tocsr()
+    Go.sort_indices()
+    h = _ffi.Handle(0)
+    for upload in range(2):
+        h.upload(table)
+        for rep in range(3):
+            h.assemble_symbolic()
+            assert h.assemble_numeric()[0] == _ffi.OK
+            indptr, indices, data, rhs = h.export_csr()
+            assert np.array_equal(rhs, Ao)
+            assert np.array_equal(indptr, Go.indptr) and np.array_equal(indices, Go.indices)
+            assert np.array_equal(data, Go.data)
+    h.close()
+
+
 def test_value_sweep_batch_reuses_symbolic():
     """BASELINE.json config 4 in miniature: one topology, per-member values."""
     N, members = 10, 4
