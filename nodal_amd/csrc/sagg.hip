@@ -509,24 +509,26 @@ __global__ __launch_bounds__(TB) void build_P(Ell A, const double *__restrict__ 
 }
 
 // ---- R = P^T by coarse row: count, scan, fill, sort each row's (node << 2 | slot) keys ----
+// (the counting atomic's return value is the entry's place inside its row -- any order will do, the rows
+// are sorted afterwards --: kept per (slot, fine row), so that the fill needs no atomics of its own)
 __global__ __launch_bounds__(TB) void r_count(int64_t n, int64_t ld, const int32_t *__restrict__ pcol,
-                                              uint32_t *__restrict__ cnt) {
+                                              uint32_t *__restrict__ cnt, uint32_t *__restrict__ place) {
     for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
 #pragma unroll
         for (int k = 0; k < PW; ++k) {
             const int32_t J = pcol[(int64_t)k * ld + i];
-            if (J >= 0) atomicAdd(&cnt[J], 1u);
+            if (J >= 0) place[(int64_t)k * ld + i] = atomicAdd(&cnt[J], 1u);
         }
     }
 }
 __global__ __launch_bounds__(TB) void r_fill(int64_t n, int64_t ld, const int32_t *__restrict__ pcol,
-                                             const uint32_t *__restrict__ rstart, uint32_t *__restrict__ cursor,
+                                             const uint32_t *__restrict__ rstart, const uint32_t *__restrict__ place,
                                              uint64_t *__restrict__ keys) {
     for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
 #pragma unroll
         for (int k = 0; k < PW; ++k) {
             const int32_t J = pcol[(int64_t)k * ld + i];
-            if (J >= 0) keys[rstart[J] + atomicAdd(&cursor[J], 1u)] = ((uint64_t)i << 2) | (uint64_t)k;
+            if (J >= 0) keys[rstart[J] + place[(int64_t)k * ld + i]] = ((uint64_t)i << 2) | (uint64_t)k;
         }
     }
 }
@@ -1237,18 +1239,19 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
 
     // R = P^T by coarse row
     const size_t a4 = (((size_t)(nc + 1) * 4) + 255) & ~(size_t)255;
-    NODAL_HIP_TRY(h, H->rstart.reserve(2 * a4 + 256 + scan_tmp_bytes(nc + 1)));
+    const size_t scan2 = (scan_tmp_bytes(nc + 1) + 255) & ~(size_t)255;
+    NODAL_HIP_TRY(h, H->rstart.reserve(a4 + 256 + scan2 + (size_t)PW * ld * 4 + 64));
     NODAL_HIP_TRY(h, H->keys.reserve((size_t)PW * n * 8 + 64));
     char *rs = H->rstart.as<char>();
     uint32_t *rstart = reinterpret_cast<uint32_t *>(rs);
-    uint32_t *cursor = reinterpret_cast<uint32_t *>(rs + a4);
-    void *scan_tmp2 = rs + 2 * a4 + 256;
-    NODAL_HIP_TRY(h, hipMemsetAsync(rs, 0, 2 * a4 + 256, st));
-    r_count<<<g, TB, 0, st>>>(n, ld, L->pcol.as<int32_t>(), rstart);
+    void *scan_tmp2 = rs + a4 + 256;
+    uint32_t *place = reinterpret_cast<uint32_t *>(rs + a4 + 256 + scan2);
+    NODAL_HIP_TRY(h, hipMemsetAsync(rs, 0, a4 + 256, st));
+    r_count<<<g, TB, 0, st>>>(n, ld, L->pcol.as<int32_t>(), rstart, place);
     NODAL_HIP_TRY(h, hipGetLastError());
     NODAL_TRY(scan_exclusive_u32(h, rstart, rstart, nc + 1, nullptr, scan_tmp2));
     uint64_t *keys = H->keys.as<uint64_t>();
-    r_fill<<<g, TB, 0, st>>>(n, ld, L->pcol.as<int32_t>(), rstart, cursor, keys);
+    r_fill<<<g, TB, 0, st>>>(n, ld, L->pcol.as<int32_t>(), rstart, place, keys);
     r_sort_short<<<grid_for(nc), TB, 0, st>>>(rstart, keys, nc);
     r_sort_medium<<<(unsigned)(nc < 8192 ? nc : 8192), 64, 0, st>>>(rstart, keys, nc);
     NODAL_HIP_TRY(h, hipGetLastError());
