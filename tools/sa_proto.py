@@ -210,6 +210,26 @@ def cycle(levels, l, b, cfg):
     return smooth(L, b, x, nu, om, kind)
 
 
+def additive_cycle(levels, b, cfg):
+    """Additive (BPX-like) cycle: every level smooths the restricted residual independently (symmetric: nu Jacobi
+    sweeps from zero, which is a polynomial in D^-1 A applied to the residual), the corrections are summed up the
+    hierarchy.  One restriction chain down, one prolongation chain up, all smoothing in parallel."""
+    rs = [b]
+    for l in range(len(levels) - 1):
+        rs.append(levels[l].R @ rs[-1])
+    es = []
+    for l, L in enumerate(levels):
+        if l == len(levels) - 1:
+            es.append(L.inv @ rs[l])
+        else:
+            nu = cfg["tail_nu"] if L.n <= TAIL_MAX_N else cfg["nu"][min(l, len(cfg["nu"]) - 1)]
+            es.append(smooth(L, rs[l], np.zeros_like(rs[l]), cfg.get("add_nu", 2 * nu), cfg.get("omega", OMEGA), "jacobi"))
+    e = es[-1]
+    for l in range(len(levels) - 2, -1, -1):
+        e = es[l] + levels[l].P @ e
+    return e
+
+
 def fcg(levels, b, cfg, tol=1e-13, maxit=300):
     A = levels[0].A
     x = np.zeros_like(b)
@@ -222,7 +242,7 @@ def fcg(levels, b, cfg, tol=1e-13, maxit=300):
         rr = r @ r
         if rr <= tol * tol * bb:
             return it, np.sqrt(rr / bb)
-        z = cycle(levels, 0, r, cfg)
+        z = additive_cycle(levels, r, cfg) if cfg.get("additive") else cycle(levels, 0, r, cfg)
         rz = z @ r
         if it == 0:
             p = z.copy()
@@ -267,6 +287,9 @@ VARIANTS = {
     "kskip25": dict(nu=[1, 1, 2], tail_nu=3, klevels=1, kskip=0.25),
     "kskip35": dict(nu=[1, 1, 2], tail_nu=3, klevels=1, kskip=0.35),
     "kskip50": dict(nu=[1, 1, 2], tail_nu=3, klevels=1, kskip=0.5),
+    "add2": dict(nu=[1, 1, 2], tail_nu=3, klevels=0, additive=True, add_nu=2),
+    "add1": dict(nu=[1, 1, 2], tail_nu=3, klevels=0, additive=True, add_nu=1),
+    "add3": dict(nu=[1, 1, 2], tail_nu=3, klevels=0, additive=True, add_nu=3),
     "kat2": dict(nu=[1, 1, 2], tail_nu=3, klevels=0, kset={2}),
     "kat2_122": dict(nu=[1, 2, 2], tail_nu=3, klevels=0, kset={2}),
     "kat2_212": dict(nu=[2, 1, 2], tail_nu=3, klevels=0, kset={2}),
