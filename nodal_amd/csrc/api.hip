@@ -124,6 +124,22 @@ void *nodal_pinned(nodal_ctx *ctx) {
     return h->pinned;
 }
 
+void *nodal_pinned_arena(nodal_ctx *ctx, size_t bytes) {
+    nodal_ctx *h = ctx->stream_owner ? ctx->stream_owner : ctx;
+    if (bytes <= h->arena_bytes) return h->arena;
+    if (h->arena) (void)hipHostFree(h->arena);
+    h->arena = nullptr;
+    h->arena_bytes = 0;
+    const size_t want = bytes + (bytes >> 2) + 4096;
+    if (hipHostMalloc(&h->arena, want, hipHostMallocDefault) != hipSuccess) {
+        h->arena = nullptr;
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    h->arena_bytes = want;
+    return h->arena;
+}
+
 int nodal_read_words(nodal_ctx *h, void *dst, const void *dev_src, size_t bytes) {
     void *pin = bytes <= NODAL_PINNED_BYTES ? nodal_pinned(h) : nullptr;
     NODAL_HIP_TRY(h, hipMemcpyAsync(pin ? pin : dst, dev_src, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -225,6 +241,7 @@ int nodal_destroy(nodal_handle h) {
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->arena) (void)hipHostFree(h->arena);
     delete h;
     return NODAL_OK;
 }

@@ -68,6 +68,8 @@ struct HostTable {
     std::vector<double> values_batch;
     std::vector<int64_t> branch_rows;  // rows of the components that own a branch unknown (types E .. CCCS),
                                        // in file order: what the presolve's planning pass looks at
+    mutable std::vector<int32_t> node_slot;  // K entries, all -1 between uses: the presolve's direct map from a
+                                             // node to its place in a short list (lead nodes, pivots)
 };
 
 struct nodal_ctx {
@@ -109,6 +111,8 @@ struct nodal_ctx {
     bool owns_streams = true;
     nodal_ctx *stream_owner = nullptr;  // (child contexts) the context whose streams and events this one borrows
     void *pinned = nullptr;             // small page-locked scratch for read-backs of a few words (nodal_pinned)
+    void *arena = nullptr;              // page-locked staging area that grows on demand (nodal_pinned_arena)
+    size_t arena_bytes = 0;
     bool use_presolve = true;
     bool use_graphs = false;       // hipGraph replay of the FCG iteration: measured no gain (kernels are not host-bound)
     DevBuf ps_buf, ps_newidx, ps_hits;
@@ -312,6 +316,11 @@ int nodal_ensure_aux_streams(nodal_ctx *h);  // api.hip
 // copy, wait, read: users need not coordinate.  Null if the allocation failed (callers fall back to the stack).
 constexpr size_t NODAL_PINNED_BYTES = 4096;
 void *nodal_pinned(nodal_ctx *h);  // api.hip
+// At least `bytes` of page-locked host memory of the handle (child contexts: their parent's), grown on demand
+// and kept: the staging area of host-built tables that go up in several pieces (a copy from a std::vector is
+// staged by the runtime piece by piece, 30-60 us each).  The caller owns it until it has waited for its
+// copies; contents do not survive a call that grows it.  Null if the allocation failed.
+void *nodal_pinned_arena(nodal_ctx *h, size_t bytes);  // api.hip
 // read `bytes` (<= NODAL_PINNED_BYTES) from the device into `dst` through the pinned scratch, and wait
 int nodal_read_words(nodal_ctx *h, void *dst, const void *dev_src, size_t bytes);  // api.hip
 void nodal_free_block_child(nodal_ctx *h);  // batch.hip

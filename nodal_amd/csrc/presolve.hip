@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
 
 #include "ctx.h"
 
@@ -134,6 +135,18 @@ __global__ __launch_bounds__(TB) void make_newidx(int K, const uint32_t *__restr
         newidx[j] = survive[j] ? (int32_t)scan[j] : -1;
 }
 
+// the rewritten rows arrive with the original system's node numbers (ground = -1 stays)
+__global__ __launch_bounds__(TB) void renumber_nodes(int64_t nx, const int32_t *__restrict__ newidx, int32_t *__restrict__ a,
+                                                     int32_t *__restrict__ b, int32_t *__restrict__ c,
+                                                     int32_t *__restrict__ d) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < nx; i += (int64_t)gridDim.x * TB) {
+        a[i] = a[i] >= 0 ? newidx[a[i]] : -1;
+        b[i] = b[i] >= 0 ? newidx[b[i]] : -1;
+        c[i] = c[i] >= 0 ? newidx[c[i]] : -1;
+        d[i] = d[i] >= 0 ? newidx[d[i]] : -1;
+    }
+}
+
 struct DevTable {
     const uint8_t *type;
     const double *value;
@@ -204,6 +217,13 @@ __global__ __launch_bounds__(TB) void compact(DevTable t, int64_t nc,
 
 // Host analysis: pivots and expressions from the (few) branch components.
 static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan &plan) {
+    static const bool trace_plan = getenv("NODAL_TRACE") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (trace_plan)
+            fprintf(stderr, "[presolve]   plan: %s at %.3f ms\n", what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
+    };
     const HostTable &t = h->host;
     const int64_t nc = h->ncomp;
     const int K = h->K, B = h->B;
@@ -264,12 +284,24 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
         if (r.a >= 0) ids.push_back(r.a);
         if (r.b >= 0) ids.push_back(r.b);
     }
+    lap("branches listed");
     std::sort(ids.begin() + 1, ids.end());
     ids.erase(std::unique(ids.begin() + 1, ids.end()), ids.end());
     const int nn = (int)ids.size();
-    auto id_of = [&](int node) {
-        return node < 0 ? 0 : (int)(std::lower_bound(ids.begin() + 1, ids.end(), node) - ids.begin());
-    };
+    // node -> id through a direct map (K entries kept with the host table, -1 between uses: the binary searches
+    // it replaces were most of the plan's 1.3 ms on config 5's 3e4 lead nodes)
+    std::vector<int32_t> &slot = t.node_slot;
+    if ((int)slot.size() != K) slot.assign((size_t)K, -1);
+    struct SlotGuard {
+        std::vector<int32_t> &slot;
+        const std::vector<int32_t> &nodes;
+        ~SlotGuard() {
+            for (size_t i = 1; i < nodes.size(); ++i) slot[(size_t)nodes[i]] = -1;
+        }
+    } slot_guard{slot, ids};
+    for (int i = 1; i < nn; ++i) slot[(size_t)ids[i]] = i;
+    lap("lead nodes sorted");
+    auto id_of = [&](int node) { return node < 0 ? 0 : (int)slot[(size_t)node]; };
     // adjacency in CSR form (two flat arrays: a vector per node costs an allocation per node, 1 ms at
     // 3e4 lead nodes): neighbours of id u are adj_nb / adj_raw [adj_start[u], adj_start[u + 1])
     std::vector<int> adj_start(nn + 1, 0), adj_nb(2 * raws.size()), adj_raw(2 * raws.size()), lead_a(raws.size()),
@@ -290,6 +322,7 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
             adj_raw[fill[lead_b[m]]++] = m;
         }
     }
+    lap("adjacency");
     std::vector<int> parent(nn, -1), via(nn, -1), order;
     std::vector<char> visited(nn, 0);
     order.reserve(nn);
@@ -312,6 +345,7 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
         }
     }
 
+    lap("trees oriented");
     // ---- resolution: every pivot in terms of SURVIVING nodes, one control term at most ----
     struct Res { int base; double cst; int c, d; double g; };  // base / c / d are node numbers
     std::vector<Res> res(nn);
@@ -319,11 +353,7 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
     bool failed = false;
     auto is_pivot_id = [&](int id) { return via[id] >= 0; };
     // id of a node that is a lead of some branch, -1 for ground and for plain surviving nodes
-    auto lead_id = [&](int node) {
-        if (node < 0) return -1;
-        const auto it = std::lower_bound(ids.begin() + 1, ids.end(), node);
-        return (it != ids.end() && *it == node) ? (int)(it - ids.begin()) : -1;
-    };
+    auto lead_id = [&](int node) { return node < 0 ? -1 : (int)slot[(size_t)node]; };
     // explicit stack instead of recursion (chains can be long)
     std::vector<int> stack;
     auto resolve = [&](int start) {
@@ -384,6 +414,7 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
         if (failed) return;
     }
 
+    lap("pivots resolved");
     // ---- the plan: expressions, rows and levels for the current recovery ----
     std::vector<int> height(nn, 0);
     for (size_t i = order.size(); i-- > 0;) {
@@ -407,44 +438,61 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
         if (plan.row_of[kk] < 0) return;
     std::sort(taken.begin(), taken.end());
     // bases and controls must be surviving nodes by construction
+    auto is_taken = [&](int node) {
+        const int id = lead_id(node);
+        return id >= 0 && is_pivot_id(id);
+    };
     for (const Expr &e : plan.exprs)
-        if ((e.q >= 0 && std::binary_search(taken.begin(), taken.end(), e.q)) ||
-            (e.c >= 0 && std::binary_search(taken.begin(), taken.end(), e.c)) ||
-            (e.d >= 0 && std::binary_search(taken.begin(), taken.end(), e.d)))
-            return;
+        if (is_taken(e.q) || is_taken(e.c) || is_taken(e.d)) return;
     plan.pivots = taken;
     plan.Kr = K - (int32_t)taken.size();
     plan.ok = true;
+    lap("done");
 }
 
 // Rewrite of the components that touch an eliminated node (host; they are few).
+// (arrays in the handle's page-locked arena: they go up to the device as they are; at most four rows per hit)
 struct Extras {
-    std::vector<uint8_t> type;
-    std::vector<double> value;
-    std::vector<int32_t> a, b, c, d;
+    uint8_t *type = nullptr;
+    double *value = nullptr;
+    int32_t *a = nullptr, *b = nullptr, *c = nullptr, *d = nullptr;
+    int64_t n = 0, cap = 0;
 };
 static bool rewrite_hits(const nodal_ctx *h, const double *value, const PresolvePlan &plan,
-                         const std::vector<int32_t> &hits, Extras &x) {
+                         const int32_t *hits_begin, int64_t nhits, Extras &x) {
     const HostTable &t = h->host;
-    std::vector<std::pair<int32_t, int32_t>> by_pivot(plan.exprs.size());
-    for (size_t i = 0; i < plan.exprs.size(); ++i) by_pivot[i] = {plan.exprs[i].p, (int32_t)i};
-    std::sort(by_pivot.begin(), by_pivot.end());
+    // pivot node -> its expression through the host table's direct map (see presolve_plan)
+    std::vector<int32_t> &slot = t.node_slot;
+    if ((int)slot.size() != h->K) slot.assign((size_t)h->K, -1);
+    struct SlotGuard {
+        std::vector<int32_t> &slot;
+        const std::vector<Expr> &exprs;
+        ~SlotGuard() {
+            for (const Expr &e : exprs) slot[(size_t)e.p] = -1;
+        }
+    } slot_guard{slot, plan.exprs};
+    for (size_t i = 0; i < plan.exprs.size(); ++i) slot[(size_t)plan.exprs[i].p] = (int32_t)i;
     auto expr_of = [&](int node) -> const Expr * {
         if (node < 0) return nullptr;
-        auto it = std::lower_bound(by_pivot.begin(), by_pivot.end(), std::make_pair((int32_t)node, (int32_t)-1));
-        return (it != by_pivot.end() && it->first == node) ? &plan.exprs[it->second] : nullptr;
+        const int32_t at = slot[(size_t)node];
+        return at >= 0 ? &plan.exprs[(size_t)at] : nullptr;
     };
+    bool overflow = false;
     auto emit = [&](int ty, double v, int a, int b, int c, int d) {
-        x.type.push_back((uint8_t)ty); x.value.push_back(v);
-        x.a.push_back(plan.newidx(a)); x.b.push_back(plan.newidx(b));
-        x.c.push_back(plan.newidx(c)); x.d.push_back(plan.newidx(d));
+        if (x.n >= x.cap) { overflow = true; return; }
+        const int64_t at = x.n++;
+        x.type[at] = (uint8_t)ty; x.value[at] = v;
+        // (node numbers of the ORIGINAL system: a kernel renumbers them on the device, where the map is)
+        x.a[at] = a; x.b[at] = b;
+        x.c[at] = c; x.d[at] = d;
     };
     struct Side { int base; double cst; int c, d; double g; };
     auto side = [&](int node) {
         if (const Expr *e = expr_of(node)) return Side{e->q, e->cst, e->c, e->d, e->g};
         return Side{node, 0.0, -1, -1, 0.0};
     };
-    for (int32_t i : hits) {
+    for (int64_t hh = 0; hh < nhits; ++hh) {
+        const int32_t i = hits_begin[hh];
         const int ty = t.type[i];
         const double v = value[i];
         if (ty == NODAL_T_R) {
@@ -472,7 +520,7 @@ static bool rewrite_hits(const nodal_ctx *h, const double *value, const Presolve
             if (rc.base != rd.base) emit(NODAL_T_GM, gm, sa.base, sb.base, rc.base, rd.base);
         }
     }
-    return true;
+    return !overflow;
 }
 
 // Build the reduced component table directly in the child context's device arrays.
@@ -501,7 +549,14 @@ static int presolve_build_reduced(nodal_ctx *h, nodal_ctx *r, const double *valu
     NODAL_HIP_TRY(h, h->ps_newidx.reserve((size_t)K * 4 + 64));
     int32_t *newidx = h->ps_newidx.as<int32_t>();
 
-    NODAL_HIP_TRY(h, hipMemcpyAsync(d_piv, plan.pivots.data(), (size_t)np * 4, hipMemcpyHostToDevice, st));
+    // (host-built pieces go through the handle's page-locked arena: a copy from pageable memory is staged by
+    // the runtime, 30-60 us apiece -- there were a dozen of them per solve)
+    if (np) {
+        void *stage = nodal_pinned_arena(h, (size_t)np * 4);
+        if (stage) memcpy(stage, plan.pivots.data(), (size_t)np * 4);
+        NODAL_HIP_TRY(h, hipMemcpyAsync(d_piv, stage ? stage : (const void *)plan.pivots.data(), (size_t)np * 4,
+                                        hipMemcpyHostToDevice, st));
+    }
     NODAL_HIP_TRY(h, hipMemsetAsync(flags, 0, 16, st));
     fill_u32<<<grid_for(K + 1), TB, 0, st>>>(survive, 1u, K);
     NODAL_HIP_TRY(h, hipMemsetAsync(survive + K, 0, 4, st));
@@ -514,16 +569,21 @@ static int presolve_build_reduced(nodal_ctx *h, nodal_ctx *r, const double *valu
     NODAL_HIP_TRY(h, hipGetLastError());
     NODAL_HIP_TRY(h, hipMemsetAsync(keep + nc, 0, 4, st));
     NODAL_HIP_TRY(h, hipMemsetAsync(hit + nc, 0, 4, st));
-    NODAL_TRY(scan_exclusive_u32(h, keep, kpos, nc + 1, nullptr, tmp));
-    NODAL_TRY(scan_exclusive_u32(h, hit, hpos, nc + 1, nullptr, tmp));
-    uint32_t counts[2] = {0, 0};
-    int32_t invalid = 0;
-    NODAL_HIP_TRY(h, hipMemcpyAsync(&counts[0], kpos + nc, 4, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipMemcpyAsync(&counts[1], hpos + nc, 4, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipMemcpyAsync(&invalid, flags, 4, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
-    if (invalid) return NODAL_OK;  // a dependent source is controlled by a pivot node
-    const int64_t nkeep = counts[0], nhit = counts[1];
+    // (the scans leave their totals next to the flag: one read-back of three words)
+    NODAL_TRY(scan_exclusive_u32(h, keep, kpos, nc + 1, reinterpret_cast<uint32_t *>(flags) + 1, tmp));
+    NODAL_TRY(scan_exclusive_u32(h, hit, hpos, nc + 1, reinterpret_cast<uint32_t *>(flags) + 2, tmp));
+    int32_t back[3] = {0, 0, 0};  // invalid, components kept, components hit
+    NODAL_TRY(nodal_read_words(h, back, flags, 12));
+    if (back[0]) return NODAL_OK;  // a dependent source is controlled by a pivot node
+    const int64_t nkeep = (uint32_t)back[1], nhit = (uint32_t)back[2];
+    static const bool trace_build = getenv("NODAL_TRACE") != nullptr;
+    const auto tb0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (trace_build)
+            fprintf(stderr, "[presolve]   rewrite: %s at %.3f ms (%lld kept, %lld hit)\n", what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(),
+                    (long long)nkeep, (long long)nhit);
+    };
     // worst case 4 rewritten components per hit
     const int64_t cap = nkeep + 4 * nhit + 16;
     NODAL_HIP_TRY(h, r->type.reserve((size_t)cap + 16));
@@ -535,25 +595,42 @@ static int presolve_build_reduced(nodal_ctx *h, nodal_ctx *r, const double *valu
                   r->c.as<int32_t>(), r->d.as<int32_t>(), r->drv.as<int32_t>(), r->k.as<int32_t>()};
     compact<<<grid_for(nc), TB, 0, st>>>(t, nc, newidx, keep, kpos, hit, hpos, o, h->ps_hits.as<int32_t>());
     NODAL_HIP_TRY(h, hipGetLastError());
-    std::vector<int32_t> hits((size_t)nhit);
-    if (nhit)
-        NODAL_HIP_TRY(h, hipMemcpyAsync(hits.data(), h->ps_hits.p, (size_t)nhit * 4, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    // arena: hits [nhit] | value [cx] | a, b, c, d, minus [cx] each | type [cx]   (cx = 4 rows per hit at most)
+    const int64_t cx = 4 * nhit + 16;
+    const size_t a_hits = (((size_t)nhit * 4) + 63) & ~(size_t)63, a_i = (((size_t)cx * 4) + 63) & ~(size_t)63;
+    char *arena = static_cast<char *>(nodal_pinned_arena(h, a_hits + (size_t)cx * 8 + 5 * a_i + (size_t)cx + 64));
+    if (!arena) return nodal_fail(h, NODAL_E_HIP, "presolve: no page-locked staging memory");
+    int32_t *hits = reinterpret_cast<int32_t *>(arena);
     Extras x;
-    if (!rewrite_hits(h, value_host, plan, hits, x)) return NODAL_OK;  // not expressible: fall back
-    const int64_t nx = (int64_t)x.type.size();
+    x.value = reinterpret_cast<double *>(arena + a_hits);
+    x.a = reinterpret_cast<int32_t *>(arena + a_hits + (size_t)cx * 8);
+    x.b = reinterpret_cast<int32_t *>(arena + a_hits + (size_t)cx * 8 + a_i);
+    x.c = reinterpret_cast<int32_t *>(arena + a_hits + (size_t)cx * 8 + 2 * a_i);
+    x.d = reinterpret_cast<int32_t *>(arena + a_hits + (size_t)cx * 8 + 3 * a_i);
+    int32_t *minus = reinterpret_cast<int32_t *>(arena + a_hits + (size_t)cx * 8 + 4 * a_i);
+    x.type = reinterpret_cast<uint8_t *>(arena + a_hits + (size_t)cx * 8 + 5 * a_i);
+    x.cap = cx;
+    if (nhit) NODAL_HIP_TRY(h, hipMemcpyAsync(hits, h->ps_hits.p, (size_t)nhit * 4, hipMemcpyDeviceToHost, st));
+    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    lap("components compacted, hits on the host");
+    if (!rewrite_hits(h, value_host, plan, hits, nhit, x)) return NODAL_OK;  // not expressible: fall back
+    const int64_t nx = x.n;
+    lap("hits rewritten");
     if (nx) {
-        std::vector<int32_t> minus((size_t)nx, -1);
-        NODAL_HIP_TRY(h, hipMemcpyAsync(o.type + nkeep, x.type.data(), (size_t)nx, hipMemcpyHostToDevice, st));
-        NODAL_HIP_TRY(h, hipMemcpyAsync(o.value + nkeep, x.value.data(), (size_t)nx * 8, hipMemcpyHostToDevice, st));
-        NODAL_HIP_TRY(h, hipMemcpyAsync(o.a + nkeep, x.a.data(), (size_t)nx * 4, hipMemcpyHostToDevice, st));
-        NODAL_HIP_TRY(h, hipMemcpyAsync(o.b + nkeep, x.b.data(), (size_t)nx * 4, hipMemcpyHostToDevice, st));
-        NODAL_HIP_TRY(h, hipMemcpyAsync(o.c + nkeep, x.c.data(), (size_t)nx * 4, hipMemcpyHostToDevice, st));
-        NODAL_HIP_TRY(h, hipMemcpyAsync(o.d + nkeep, x.d.data(), (size_t)nx * 4, hipMemcpyHostToDevice, st));
-        NODAL_HIP_TRY(h, hipMemcpyAsync(o.drv + nkeep, minus.data(), (size_t)nx * 4, hipMemcpyHostToDevice, st));
-        NODAL_HIP_TRY(h, hipMemcpyAsync(o.k + nkeep, minus.data(), (size_t)nx * 4, hipMemcpyHostToDevice, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        for (int64_t i = 0; i < nx; ++i) minus[i] = -1;
+        NODAL_HIP_TRY(h, hipMemcpyAsync(o.type + nkeep, x.type, (size_t)nx, hipMemcpyHostToDevice, st));
+        NODAL_HIP_TRY(h, hipMemcpyAsync(o.value + nkeep, x.value, (size_t)nx * 8, hipMemcpyHostToDevice, st));
+        NODAL_HIP_TRY(h, hipMemcpyAsync(o.a + nkeep, x.a, (size_t)nx * 4, hipMemcpyHostToDevice, st));
+        NODAL_HIP_TRY(h, hipMemcpyAsync(o.b + nkeep, x.b, (size_t)nx * 4, hipMemcpyHostToDevice, st));
+        NODAL_HIP_TRY(h, hipMemcpyAsync(o.c + nkeep, x.c, (size_t)nx * 4, hipMemcpyHostToDevice, st));
+        NODAL_HIP_TRY(h, hipMemcpyAsync(o.d + nkeep, x.d, (size_t)nx * 4, hipMemcpyHostToDevice, st));
+        NODAL_HIP_TRY(h, hipMemcpyAsync(o.drv + nkeep, minus, (size_t)nx * 4, hipMemcpyHostToDevice, st));
+        NODAL_HIP_TRY(h, hipMemcpyAsync(o.k + nkeep, minus, (size_t)nx * 4, hipMemcpyHostToDevice, st));
+        renumber_nodes<<<grid_for(nx), TB, 0, st>>>(nx, newidx, o.a + nkeep, o.b + nkeep, o.c + nkeep, o.d + nkeep);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));  // (the arena is free again)
     }
+    lap("extras on the device");
     // Fingerprint of the reduced netlist's TOPOLOGY: the parent's (struct_epoch: a value sweep on an
     // assembled topology keeps it, a fresh symbolic assembly does not), the pivots, and the integer columns
     // of the rewritten rows (which rows get emitted depends on values: a zero constant emits no source).
@@ -581,6 +658,7 @@ static int presolve_build_reduced(nodal_ctx *h, nodal_ctx *r, const double *valu
         r->have_symbolic = false;
         r->reduced_key = key;
     }
+    lap("fingerprint");
     *ok = true;
     return NODAL_OK;
 }
@@ -590,16 +668,11 @@ static int presolve_recover(nodal_ctx *h, const PresolvePlan &plan, const double
     hipStream_t st = h->stream;
     const int K = h->K, B = h->B;
     const int ne = (int)plan.exprs.size();
-    // upload the small recovery tables
-    std::vector<int32_t> p(ne), q(ne), c(ne), d(ne);
-    std::vector<double> cst(ne), g(ne);
-    for (int i = 0; i < ne; ++i) {
-        const Expr &e = plan.exprs[i];
-        p[i] = e.p; q[i] = e.q; c[i] = e.c; d[i] = e.d; cst[i] = e.cst; g[i] = e.g;
-    }
+    // the small recovery tables: one image in the page-locked arena, laid out like the device block, ONE copy
     const size_t a4k = ((size_t)K * 4 + 255) & ~(size_t)255, a4e = ((size_t)ne * 4 + 255) & ~(size_t)255;
     const size_t a8e = ((size_t)ne * 8 + 255) & ~(size_t)255, a4b = ((size_t)B * 4 + 255) & ~(size_t)255;
-    NODAL_HIP_TRY(h, h->ps_buf.reserve(a4k + 4 * a4e + 2 * a8e + 2 * a4b + 256));
+    const size_t image = 4 * a4e + 2 * a8e + 2 * a4b;
+    NODAL_HIP_TRY(h, h->ps_buf.reserve(a4k + image + 256));
     char *w = h->ps_buf.as<char>();
     const int32_t *d_new = h->ps_newidx.as<int32_t>();  // built by presolve_build_reduced
     int32_t *d_p = reinterpret_cast<int32_t *>(w + a4k);
@@ -610,17 +683,20 @@ static int presolve_recover(nodal_ctx *h, const PresolvePlan &plan, const double
     double *d_g = reinterpret_cast<double *>(w + a4k + 4 * a4e + a8e);
     int32_t *d_row = reinterpret_cast<int32_t *>(w + a4k + 4 * a4e + 2 * a8e);
     int32_t *d_level = reinterpret_cast<int32_t *>(w + a4k + 4 * a4e + 2 * a8e + a4b);
-    auto up = [&](void *dst, const void *src, size_t bytes) {
-        return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess;
-    };
-    NODAL_HIP_TRY(h, up(d_p, p.data(), (size_t)ne * 4));
-    NODAL_HIP_TRY(h, up(d_q, q.data(), (size_t)ne * 4));
-    NODAL_HIP_TRY(h, up(d_c, c.data(), (size_t)ne * 4));
-    NODAL_HIP_TRY(h, up(d_d, d.data(), (size_t)ne * 4));
-    NODAL_HIP_TRY(h, up(d_cst, cst.data(), (size_t)ne * 8));
-    NODAL_HIP_TRY(h, up(d_g, g.data(), (size_t)ne * 8));
-    NODAL_HIP_TRY(h, up(d_row, plan.row_of.data(), (size_t)B * 4));
-    NODAL_HIP_TRY(h, up(d_level, plan.level_of.data(), (size_t)B * 4));
+    char *img = static_cast<char *>(nodal_pinned_arena(h, image + 64));
+    if (!img) return nodal_fail(h, NODAL_E_HIP, "presolve: no page-locked staging memory");
+    {
+        int32_t *p = reinterpret_cast<int32_t *>(img), *q = reinterpret_cast<int32_t *>(img + a4e);
+        int32_t *c = reinterpret_cast<int32_t *>(img + 2 * a4e), *d = reinterpret_cast<int32_t *>(img + 3 * a4e);
+        double *cst = reinterpret_cast<double *>(img + 4 * a4e), *g = reinterpret_cast<double *>(img + 4 * a4e + a8e);
+        for (int i = 0; i < ne; ++i) {
+            const Expr &e = plan.exprs[i];
+            p[i] = e.p; q[i] = e.q; c[i] = e.c; d[i] = e.d; cst[i] = e.cst; g[i] = e.g;
+        }
+        memcpy(img + 4 * a4e + 2 * a8e, plan.row_of.data(), (size_t)B * 4);
+        memcpy(img + 4 * a4e + 2 * a8e + a4b, plan.level_of.data(), (size_t)B * 4);
+    }
+    NODAL_HIP_TRY(h, hipMemcpyAsync(w + a4k, img, image, hipMemcpyHostToDevice, st));
     double *x = h->x.as<double>();
     scatter_nodes<<<grid_for(K), TB, 0, st>>>(K, d_new, y, x);
     if (ne) eval_pivots<<<grid_for(ne), TB, 0, st>>>(ne, d_p, d_q, d_cst, d_c, d_d, d_g, x);
@@ -629,7 +705,7 @@ static int presolve_recover(nodal_ctx *h, const PresolvePlan &plan, const double
                                                     h->indices.as<int32_t>(), h->data.as<double>(),
                                                     h->rhs.as<double>(), x);
     NODAL_HIP_TRY(h, hipGetLastError());
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));  // host vectors above go out of scope
+    NODAL_HIP_TRY(h, hipStreamSynchronize(st));  // (the arena is free again)
     return NODAL_OK;
 }
 
