@@ -28,7 +28,8 @@ constexpr int MAXV = RESTART + 1;
 constexpr int DOT_GRID = 1024;
 // the small least-squares problem's state on the device (see gs_finish)
 enum { G_H = 0, G_CS = G_H + MAXV * RESTART, G_SN = G_CS + RESTART, G_G = G_SN + RESTART,
-       G_INV_H = G_G + MAXV, G_EST, G_DONE, G_COUNT, G_INFO, G_TOLB, G_WORDS };
+       G_INV_H = G_G + MAXV, G_EST, G_DONE, G_COUNT, G_INFO, G_TOLB,
+       G_LOG /* per column: |w after the projections|^2 / |w|^2 (NODAL_TRACE) */, G_WORDS = G_LOG + RESTART };
 
 inline unsigned grid_for(int64_t n, unsigned cap = 4096) {
     int64_t g = (n + TB - 1) / TB;
@@ -340,8 +341,13 @@ __global__ __launch_bounds__(TB) void gs_finish(const double *__restrict__ h1, c
     const int nv = j + 1;
     double *H = gst + G_H, *cs = gst + G_CS, *sn = gst + G_SN, *g = gst + G_G;
     const double hnext = sqrt(s);
-    for (int i = 0; i < nv; ++i) H[i * RESTART + j] = h1[i] + h2[i];
+    double proj = 0.0;
+    for (int i = 0; i < nv; ++i) {
+        H[i * RESTART + j] = h1[i] + h2[i];
+        proj = fma(H[i * RESTART + j], H[i * RESTART + j], proj);
+    }
     H[nv * RESTART + j] = hnext;
+    gst[G_LOG + j] = s / (proj + s);
     for (int i = 0; i < j; ++i) {
         const double a = H[i * RESTART + j], b = H[(i + 1) * RESTART + j];
         H[i * RESTART + j] = cs[i] * a + sn[i] * b;
@@ -639,6 +645,13 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
             at_prev = enq;
         }
         total += (int)hst[G_COUNT - G_INV_H];
+        if (getenv("NODAL_TRACE")) {
+            double lg[RESTART];
+            NODAL_TRY(nodal_read_words(h, lg, gst + G_LOG, sizeof lg));
+            fprintf(stderr, "[fgmres] |w after Gram-Schmidt|^2 / |w|^2 per column:");
+            for (int i = 0; i < (int)hst[G_COUNT - G_INV_H] && i < RESTART; ++i) fprintf(stderr, " %.2g", lg[i]);
+            fprintf(stderr, "\n");
+        }
         if (*info) break;
         // y = H^-1 g ; x += Z y
         gst_solve<<<1, 64, 0, st>>>(gst, ydev);
