@@ -74,6 +74,13 @@ __global__ __launch_bounds__(TB) void eval_pivots(int ne, const int32_t *__restr
     }
 }
 
+// currents of the branches that stayed in the reduced system: its unknowns Kr + k'
+__global__ __launch_bounds__(TB) void copy_kept(int nkept, const int32_t *__restrict__ kept_kk, int K, int Kr,
+                                                const double *__restrict__ y, double *__restrict__ x) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < nkept; i += (int64_t)gridDim.x * TB)
+        x[K + kept_kk[i]] = y[Kr + i];
+}
+
 // branch currents from the ORIGINAL system.  pass 0: branches whose own row defines
 // them (CCCS: row K+k has a unit diagonal); pass 1 + h: voltage-defined branches whose pivot
 // sits at height h of its source tree, from the KCL row of the pivot node (the currents of
@@ -102,9 +109,20 @@ __global__ __launch_bounds__(TB) void recover_currents(int pass, int K, int B,
 
 }  // namespace
 
+// A voltage-defined branch the presolve leaves IN the reduced system (its tree of sources has a loop, or
+// one of its pivots cannot be expressed: two control terms, a control that carries a term itself ...):
+// e_a - e_b = value [+ value (e_c - e_d) for a VCVS; a CCVS becomes a VCVS on its driver's nodes].
+struct KeptBranch {
+    int kk;       // branch number in the original system
+    int type;     // NODAL_T_E or NODAL_T_VCVS
+    double value;
+    int a, b, c, d;
+};
+
 struct PresolvePlan {
     bool ok = false;
     std::vector<Expr> exprs;
+    std::vector<KeptBranch> kept;  // in branch order: the reduced system's branch k' is kept[k']
     std::vector<int32_t> pivots;   // sorted pivot nodes
     std::vector<int32_t> row_of;   // B: row that determines each branch current
     std::vector<int32_t> level_of; // B: pass of the current recovery (0 = own row, 1 + height in the source tree)
@@ -229,6 +247,7 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
     const int K = h->K, B = h->B;
     plan.ok = false;
     plan.exprs.clear();
+    plan.kept.clear();
     plan.row_of.assign(B, -1);
     plan.level_of.assign(B, 0);
     plan.max_level = 0;
@@ -237,6 +256,7 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
     // ---- the voltage-defined branches: e_a - e_b = cst + gain (e_c - e_d) ----
     struct Raw { int kk, a, b, c, d; double cst, gain; };
     std::vector<Raw> raws;
+    std::vector<int64_t> cccs_rows;
     const uint8_t *ty_arr = t.type.data();
     // (the rows with a branch unknown were listed once at upload: 2e4 of the 2e6 rows of config 5)
     std::vector<int64_t> scanned;
@@ -255,6 +275,7 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
         if (ty == NODAL_T_CCCS) {
             if (t.drv[i] < 0) return;
             plan.row_of[kk] = K + kk;  // its own row defines the current (level 0)
+            cccs_rows.push_back(i);
             continue;
         }
         Raw r{kk, t.a[i], t.b[i], -1, -1, 0.0, 0.0};
@@ -323,116 +344,192 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
         }
     }
     lap("adjacency");
-    std::vector<int> parent(nn, -1), via(nn, -1), order;
-    std::vector<char> visited(nn, 0);
+    // Ground is a fixed potential, not a junction: the sub-trees hanging off it are independent.  Every
+    // connected piece of the branch graph WITHOUT ground is a "tree" of its own (comp), whose branches are
+    // eliminated together or stay together (bad: set below when one of its pivots cannot be expressed; a
+    // loop -- among its own nodes or through a second connection to ground -- ends the presolve).
+    std::vector<int> parent(nn, -1), via(nn, -1), comp(nn, -1), order;
+    std::vector<char> visited(nn, 0), bad;
     order.reserve(nn);
-    for (int root = 0; root < nn; ++root) {  // id 0 = ground goes first
-        if (visited[root] || adj_start[root] == adj_start[root + 1]) continue;
-        visited[root] = 1;
+    auto grow = [&](int start) {  // BFS of one tree from `start` (already labelled), never through ground
+        const int cid = comp[start];
         size_t head = order.size();
-        order.push_back(root);
+        order.push_back(start);
         while (head < order.size()) {
             const int u = order[head++];
             for (int e = adj_start[u]; e < adj_start[u + 1]; ++e) {
                 const int v = adj_nb[e], m = adj_raw[e];
                 if (m == via[u]) continue;
-                if (visited[v]) return;  // a loop of voltage-defined branches
+                if (v == 0 || visited[v]) {  // a second way to ground, or a loop
+                    bad[cid] = 1;
+                    continue;
+                }
                 visited[v] = 1;
+                comp[v] = cid;
                 parent[v] = u;
                 via[v] = m;
                 order.push_back(v);
             }
         }
+    };
+    visited[0] = 1;
+    for (int e = adj_start[0]; e < adj_start[1]; ++e) {  // the trees rooted at ground
+        const int v = adj_nb[e], m = adj_raw[e];
+        if (visited[v]) {  // (v == 0: a branch from ground to ground was refused above)
+            if (v != 0) bad[comp[v]] = 1;  // its tree reaches ground twice
+            continue;
+        }
+        visited[v] = 1;
+        comp[v] = (int)bad.size();
+        bad.push_back(0);
+        parent[v] = 0;
+        via[v] = m;
+        grow(v);
     }
-
+    for (int root = 1; root < nn; ++root) {  // floating trees: the root survives
+        if (visited[root] || adj_start[root] == adj_start[root + 1]) continue;
+        visited[root] = 1;
+        comp[root] = (int)bad.size();
+        bad.push_back(0);
+        grow(root);
+    }
     lap("trees oriented");
-    // ---- resolution: every pivot in terms of SURVIVING nodes, one control term at most ----
+    // A loop of voltage-defined branches makes the system singular whatever the values (its circulating
+    // current appears in no other equation): no presolve; the caller's verdicts / full-system solve decide.
+    for (const char b : bad)
+        if (b) return;
+
+    // ---- resolution: every pivot in terms of SURVIVING nodes, one control term at most.  A pivot that
+    // cannot be expressed spoils its tree (all of its branches stay); the others are resolved again, until
+    // nothing changes (a pass per level of such a cascade: normally one).
     struct Res { int base; double cst; int c, d; double g; };  // base / c / d are node numbers
     std::vector<Res> res(nn);
     std::vector<char> state(nn, 0);  // 0 = open, 1 = in progress, 2 = done
-    bool failed = false;
-    auto is_pivot_id = [&](int id) { return via[id] >= 0; };
+    auto is_pivot_id = [&](int id) { return id > 0 && via[id] >= 0 && !bad[comp[id]]; };
     // id of a node that is a lead of some branch, -1 for ground and for plain surviving nodes
     auto lead_id = [&](int node) { return node < 0 ? -1 : (int)slot[(size_t)node]; };
-    // explicit stack instead of recursion (chains can be long)
+    auto comp_of_raw = [&](int m) { return comp[lead_a[m] ? lead_a[m] : lead_b[m]]; };
     std::vector<int> stack;
-    auto resolve = [&](int start) {
-        stack.clear();
-        stack.push_back(start);
-        while (!stack.empty() && !failed) {
-            const int v = stack.back();
-            if (state[v] == 2) { stack.pop_back(); continue; }
-            if (!is_pivot_id(v)) {
-                res[v] = Res{ids[v], 0.0, -1, -1, 0.0};
+    bool changed = true;
+    int passes = 0;
+    while (changed) {
+        changed = false;
+        ++passes;
+        std::fill(state.begin(), state.end(), 0);
+        auto spoil = [&](int id) {
+            if (!bad[comp[id]]) {
+                bad[comp[id]] = 1;
+                changed = true;
+            }
+        };
+        auto resolve = [&](int start) {
+            stack.clear();
+            stack.push_back(start);
+            while (!stack.empty()) {
+                const int v = stack.back();
+                if (state[v] == 2) { stack.pop_back(); continue; }
+                if (!is_pivot_id(v)) {
+                    res[v] = Res{ids[v], 0.0, -1, -1, 0.0};
+                    state[v] = 2;
+                    stack.pop_back();
+                    continue;
+                }
+                const Raw &r = raws[via[v]];
+                int deps[3] = {parent[v], -1, -1};
+                if (r.gain != 0.0) {
+                    deps[1] = lead_id(r.c);
+                    deps[2] = lead_id(r.d);
+                }
+                bool ready = true, broken = false;
+                state[v] = 1;
+                for (int dpd : deps) {
+                    if (dpd < 0 || state[dpd] == 2) continue;
+                    if (state[dpd] == 1) { broken = true; break; }  // circular definition
+                    stack.push_back(dpd);
+                    ready = false;
+                }
+                Res out{ids[v], 0.0, -1, -1, 0.0};
+                if (!broken && !ready) continue;  // stays "in progress"; revisited when the dependencies are done
+                if (!broken) {
+                    const double sign = ids[v] == r.a ? 1.0 : -1.0;
+                    out = res[parent[v]];
+                    out.cst += sign * r.cst;
+                    if (r.gain != 0.0) {
+                        auto ctl = [&](int node) -> Res {
+                            if (node < 0) return Res{-1, 0.0, -1, -1, 0.0};
+                            const int id = lead_id(node);
+                            return id >= 0 ? res[id] : Res{node, 0.0, -1, -1, 0.0};
+                        };
+                        const Res rc = ctl(r.c), rd = ctl(r.d);
+                        if (rc.g != 0.0 || rd.g != 0.0) broken = true;  // nested control terms
+                        const double g = sign * r.gain;
+                        out.cst += g * (rc.cst - rd.cst);
+                        if (!broken && rc.base != rd.base) {
+                            if (out.g != 0.0) broken = true;  // two control terms
+                            out.c = rc.base;
+                            out.d = rd.base;
+                            out.g = g;
+                        }
+                    }
+                    // a pivot that (after resolution) still controls itself cannot be substituted
+                    if (!broken && out.g != 0.0 && (out.c == ids[v] || out.d == ids[v])) broken = true;
+                }
+                if (broken) {  // its tree stays: the node survives (the pass is repeated without the tree)
+                    spoil(v);
+                    out = Res{ids[v], 0.0, -1, -1, 0.0};
+                    while (!stack.empty() && stack.back() != v) stack.pop_back();
+                }
+                res[v] = out;
                 state[v] = 2;
                 stack.pop_back();
-                continue;
             }
-            const Raw &r = raws[via[v]];
-            int deps[3] = {parent[v], -1, -1};
-            if (r.gain != 0.0) {
-                deps[1] = lead_id(r.c);
-                deps[2] = lead_id(r.d);
+        };
+        for (int v : order)
+            if (state[v] != 2) resolve(v);
+        if (changed) continue;
+        // a CCCS (a transconductance after the rewrite) or a kept VCVS controlled by a pivot whose own
+        // expression carries a control term -- or, for the kept VCVS, by any pivot -- cannot be written as
+        // one row: that pivot's tree stays as well
+        for (const int64_t i : cccs_rows)
+            for (const int node : {t.c[i], t.d[i]}) {
+                const int id = lead_id(node);
+                if (id > 0 && is_pivot_id(id) && res[id].g != 0.0) spoil(id);
             }
-            bool ready = true;
-            state[v] = 1;
-            for (int dpd : deps) {
-                if (dpd < 0 || state[dpd] == 2) continue;
-                if (state[dpd] == 1) { failed = true; break; }  // circular definition
-                stack.push_back(dpd);
-                ready = false;
+        for (int m = 0; m < (int)raws.size(); ++m) {
+            if (!bad[comp_of_raw(m)] || raws[m].gain == 0.0) continue;
+            for (const int node : {raws[m].c, raws[m].d}) {
+                const int id = lead_id(node);
+                if (id > 0 && is_pivot_id(id)) spoil(id);
             }
-            if (failed) break;
-            if (!ready) continue;  // stays "in progress"; revisited when the dependencies are done
-            const double sign = ids[v] == r.a ? 1.0 : -1.0;
-            Res out = res[parent[v]];
-            out.cst += sign * r.cst;
-            if (r.gain != 0.0) {
-                auto ctl = [&](int node) -> Res {
-                    if (node < 0) return Res{-1, 0.0, -1, -1, 0.0};
-                    const int id = lead_id(node);
-                    return id >= 0 ? res[id] : Res{node, 0.0, -1, -1, 0.0};
-                };
-                const Res rc = ctl(r.c), rd = ctl(r.d);
-                if (rc.g != 0.0 || rd.g != 0.0) { failed = true; break; }  // nested control terms
-                const double g = sign * r.gain;
-                out.cst += g * (rc.cst - rd.cst);
-                if (rc.base != rd.base) {
-                    if (out.g != 0.0) { failed = true; break; }  // two control terms
-                    out.c = rc.base;
-                    out.d = rd.base;
-                    out.g = g;
-                }
-            }
-            res[v] = out;
-            state[v] = 2;
-            stack.pop_back();
         }
-    };
-    for (int v : order) {
-        if (state[v] != 2) resolve(v);
-        if (failed) return;
     }
-
     lap("pivots resolved");
+
     // ---- the plan: expressions, rows and levels for the current recovery ----
     std::vector<int> height(nn, 0);
     for (size_t i = order.size(); i-- > 0;) {
         const int v = order[i];
-        if (parent[v] >= 0) height[parent[v]] = std::max(height[parent[v]], height[v] + 1);
+        if (is_pivot_id(v) && parent[v] >= 0) height[parent[v]] = std::max(height[parent[v]], height[v] + 1);
     }
     std::vector<int32_t> taken;
     for (int v : order) {
         if (!is_pivot_id(v)) continue;
         const Res &r = res[v];
-        // a pivot that (after resolution) still controls itself cannot be substituted
-        if (r.g != 0.0 && (r.c == ids[v] || r.d == ids[v])) return;
         plan.exprs.push_back(Expr{ids[v], r.base, r.cst, r.c, r.d, r.g});
         taken.push_back(ids[v]);
         const int kk = raws[via[v]].kk;
         plan.row_of[kk] = ids[v];
         plan.level_of[kk] = 1 + height[v];
         plan.max_level = std::max(plan.max_level, 1 + height[v]);
+    }
+    if (taken.empty()) return;  // nothing can be eliminated: the full-system solve
+    for (int m = 0; m < (int)raws.size(); ++m) {  // the branches that stay (raws are in branch order)
+        if (!bad[comp_of_raw(m)]) continue;
+        const Raw &r = raws[m];
+        plan.kept.push_back(KeptBranch{r.kk, r.gain != 0.0 ? NODAL_T_VCVS : NODAL_T_E, r.gain != 0.0 ? r.gain : r.cst,
+                                       r.a, r.b, r.gain != 0.0 ? r.c : -1, r.gain != 0.0 ? r.d : -1});
+        plan.row_of[r.kk] = K + r.kk;  // (its current is an unknown of the reduced system: copied back)
+        plan.level_of[r.kk] = -1;
     }
     for (int kk = 0; kk < B; ++kk)
         if (plan.row_of[kk] < 0) return;
@@ -447,6 +544,9 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
     plan.pivots = taken;
     plan.Kr = K - (int32_t)taken.size();
     plan.ok = true;
+    if (trace_plan && !plan.kept.empty())
+        fprintf(stderr, "[presolve]   plan: %d of %d voltage-defined branches stay in the reduced system (%d passes)\n",
+                (int)plan.kept.size(), (int)raws.size(), passes);
     lap("done");
 }
 
@@ -455,7 +555,7 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
 struct Extras {
     uint8_t *type = nullptr;
     double *value = nullptr;
-    int32_t *a = nullptr, *b = nullptr, *c = nullptr, *d = nullptr;
+    int32_t *a = nullptr, *b = nullptr, *c = nullptr, *d = nullptr, *k = nullptr;
     int64_t n = 0, cap = 0;
 };
 static bool rewrite_hits(const nodal_ctx *h, const double *value, const PresolvePlan &plan,
@@ -478,10 +578,10 @@ static bool rewrite_hits(const nodal_ctx *h, const double *value, const Presolve
         return at >= 0 ? &plan.exprs[(size_t)at] : nullptr;
     };
     bool overflow = false;
-    auto emit = [&](int ty, double v, int a, int b, int c, int d) {
+    auto emit = [&](int ty, double v, int a, int b, int c, int d, int k = -1) {
         if (x.n >= x.cap) { overflow = true; return; }
         const int64_t at = x.n++;
-        x.type[at] = (uint8_t)ty; x.value[at] = v;
+        x.type[at] = (uint8_t)ty; x.value[at] = v; x.k[at] = k;
         // (node numbers of the ORIGINAL system: a kernel renumbers them on the device, where the map is)
         x.a[at] = a; x.b[at] = b;
         x.c[at] = c; x.d[at] = d;
@@ -519,6 +619,12 @@ static bool rewrite_hits(const nodal_ctx *h, const double *value, const Presolve
             if (cst != 0.0) emit(NODAL_T_A, cst, sb.base, sa.base, -1, -1);
             if (rc.base != rd.base) emit(NODAL_T_GM, gm, sa.base, sb.base, rc.base, rd.base);
         }
+    }
+    // the branches that stay: their leads and controls are surviving nodes (presolve_plan saw to that)
+    for (size_t kp = 0; kp < plan.kept.size(); ++kp) {
+        const KeptBranch &kb = plan.kept[kp];
+        if (expr_of(kb.a) || expr_of(kb.b) || expr_of(kb.c) || expr_of(kb.d)) return false;
+        emit(kb.type, kb.value, kb.a, kb.b, kb.c, kb.d, (int)kp);
     }
     return !overflow;
 }
@@ -584,8 +690,8 @@ static int presolve_build_reduced(nodal_ctx *h, nodal_ctx *r, const double *valu
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(),
                     (long long)nkeep, (long long)nhit);
     };
-    // worst case 4 rewritten components per hit
-    const int64_t cap = nkeep + 4 * nhit + 16;
+    // worst case 4 rewritten components per hit, and the branches that stay
+    const int64_t cap = nkeep + 4 * nhit + (int64_t)plan.kept.size() + 16;
     NODAL_HIP_TRY(h, r->type.reserve((size_t)cap + 16));
     NODAL_HIP_TRY(h, r->value.reserve((size_t)cap * 8 + 16));
     DevBuf *icols[] = {&r->a, &r->b, &r->c, &r->d, &r->drv, &r->k};
@@ -595,10 +701,11 @@ static int presolve_build_reduced(nodal_ctx *h, nodal_ctx *r, const double *valu
                   r->c.as<int32_t>(), r->d.as<int32_t>(), r->drv.as<int32_t>(), r->k.as<int32_t>()};
     compact<<<grid_for(nc), TB, 0, st>>>(t, nc, newidx, keep, kpos, hit, hpos, o, h->ps_hits.as<int32_t>());
     NODAL_HIP_TRY(h, hipGetLastError());
-    // arena: hits [nhit] | value [cx] | a, b, c, d, minus [cx] each | type [cx]   (cx = 4 rows per hit at most)
-    const int64_t cx = 4 * nhit + 16;
+    // arena: hits [nhit] | value [cx] | a, b, c, d, minus, k [cx] each | type [cx]
+    // (cx = 4 rows per hit at most + the branches that stay)
+    const int64_t cx = 4 * nhit + (int64_t)plan.kept.size() + 16;
     const size_t a_hits = (((size_t)nhit * 4) + 63) & ~(size_t)63, a_i = (((size_t)cx * 4) + 63) & ~(size_t)63;
-    char *arena = static_cast<char *>(nodal_pinned_arena(h, a_hits + (size_t)cx * 8 + 5 * a_i + (size_t)cx + 64));
+    char *arena = static_cast<char *>(nodal_pinned_arena(h, a_hits + (size_t)cx * 8 + 6 * a_i + (size_t)cx + 64));
     if (!arena) return nodal_fail(h, NODAL_E_HIP, "presolve: no page-locked staging memory");
     int32_t *hits = reinterpret_cast<int32_t *>(arena);
     Extras x;
@@ -608,7 +715,8 @@ static int presolve_build_reduced(nodal_ctx *h, nodal_ctx *r, const double *valu
     x.c = reinterpret_cast<int32_t *>(arena + a_hits + (size_t)cx * 8 + 2 * a_i);
     x.d = reinterpret_cast<int32_t *>(arena + a_hits + (size_t)cx * 8 + 3 * a_i);
     int32_t *minus = reinterpret_cast<int32_t *>(arena + a_hits + (size_t)cx * 8 + 4 * a_i);
-    x.type = reinterpret_cast<uint8_t *>(arena + a_hits + (size_t)cx * 8 + 5 * a_i);
+    x.k = reinterpret_cast<int32_t *>(arena + a_hits + (size_t)cx * 8 + 5 * a_i);
+    x.type = reinterpret_cast<uint8_t *>(arena + a_hits + (size_t)cx * 8 + 6 * a_i);
     x.cap = cx;
     if (nhit) NODAL_HIP_TRY(h, hipMemcpyAsync(hits, h->ps_hits.p, (size_t)nhit * 4, hipMemcpyDeviceToHost, st));
     NODAL_HIP_TRY(h, hipStreamSynchronize(st));
@@ -625,7 +733,7 @@ static int presolve_build_reduced(nodal_ctx *h, nodal_ctx *r, const double *valu
         NODAL_HIP_TRY(h, hipMemcpyAsync(o.c + nkeep, x.c, (size_t)nx * 4, hipMemcpyHostToDevice, st));
         NODAL_HIP_TRY(h, hipMemcpyAsync(o.d + nkeep, x.d, (size_t)nx * 4, hipMemcpyHostToDevice, st));
         NODAL_HIP_TRY(h, hipMemcpyAsync(o.drv + nkeep, minus, (size_t)nx * 4, hipMemcpyHostToDevice, st));
-        NODAL_HIP_TRY(h, hipMemcpyAsync(o.k + nkeep, minus, (size_t)nx * 4, hipMemcpyHostToDevice, st));
+        NODAL_HIP_TRY(h, hipMemcpyAsync(o.k + nkeep, x.k, (size_t)nx * 4, hipMemcpyHostToDevice, st));
         renumber_nodes<<<grid_for(nx), TB, 0, st>>>(nx, newidx, o.a + nkeep, o.b + nkeep, o.c + nkeep, o.d + nkeep);
         NODAL_HIP_TRY(h, hipGetLastError());
         NODAL_HIP_TRY(h, hipStreamSynchronize(st));  // (the arena is free again)
@@ -639,17 +747,21 @@ static int presolve_build_reduced(nodal_ctx *h, nodal_ctx *r, const double *valu
     uint64_t key = 1469598103934665603ull;
     auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
     mix(h->table_epoch); mix(h->struct_epoch); mix((uint64_t)np); mix((uint64_t)nkeep); mix((uint64_t)nx); mix((uint64_t)plan.Kr);
+    mix((uint64_t)plan.kept.size());
     for (int32_t pv : plan.pivots) mix((uint64_t)(uint32_t)pv);
     for (int64_t i = 0; i < nx; ++i) {
         mix(x.type[(size_t)i]);
         mix((uint64_t)(uint32_t)x.a[(size_t)i] << 32 | (uint32_t)x.b[(size_t)i]);
         mix((uint64_t)(uint32_t)x.c[(size_t)i] << 32 | (uint32_t)x.d[(size_t)i]);
+        mix((uint64_t)(uint32_t)x.k[(size_t)i]);
     }
-    const bool same_topology = r->have_symbolic && r->reduced_key == key && r->ncomp == nkeep + nx && r->K == plan.Kr;
+    const int32_t nkept = (int32_t)plan.kept.size();
+    const bool same_topology = r->have_symbolic && r->reduced_key == key && r->ncomp == nkeep + nx && r->K == plan.Kr &&
+                               r->B == nkept;
     r->ncomp = nkeep + nx;
     r->K = plan.Kr;
-    r->B = 0;
-    r->n = plan.Kr;
+    r->B = nkept;
+    r->n = plan.Kr + nkept;
     r->batch = 0;
     r->have_table = true;
     r->have_numeric = r->have_x = false;
@@ -671,7 +783,9 @@ static int presolve_recover(nodal_ctx *h, const PresolvePlan &plan, const double
     // the small recovery tables: one image in the page-locked arena, laid out like the device block, ONE copy
     const size_t a4k = ((size_t)K * 4 + 255) & ~(size_t)255, a4e = ((size_t)ne * 4 + 255) & ~(size_t)255;
     const size_t a8e = ((size_t)ne * 8 + 255) & ~(size_t)255, a4b = ((size_t)B * 4 + 255) & ~(size_t)255;
-    const size_t image = 4 * a4e + 2 * a8e + 2 * a4b;
+    const int nkept = (int)plan.kept.size();
+    const size_t a4kp = ((size_t)nkept * 4 + 255) & ~(size_t)255;
+    const size_t image = 4 * a4e + 2 * a8e + 2 * a4b + a4kp;
     NODAL_HIP_TRY(h, h->ps_buf.reserve(a4k + image + 256));
     char *w = h->ps_buf.as<char>();
     const int32_t *d_new = h->ps_newidx.as<int32_t>();  // built by presolve_build_reduced
@@ -683,6 +797,7 @@ static int presolve_recover(nodal_ctx *h, const PresolvePlan &plan, const double
     double *d_g = reinterpret_cast<double *>(w + a4k + 4 * a4e + a8e);
     int32_t *d_row = reinterpret_cast<int32_t *>(w + a4k + 4 * a4e + 2 * a8e);
     int32_t *d_level = reinterpret_cast<int32_t *>(w + a4k + 4 * a4e + 2 * a8e + a4b);
+    int32_t *d_kept = reinterpret_cast<int32_t *>(w + a4k + 4 * a4e + 2 * a8e + 2 * a4b);
     char *img = static_cast<char *>(nodal_pinned_arena(h, image + 64));
     if (!img) return nodal_fail(h, NODAL_E_HIP, "presolve: no page-locked staging memory");
     {
@@ -695,11 +810,14 @@ static int presolve_recover(nodal_ctx *h, const PresolvePlan &plan, const double
         }
         memcpy(img + 4 * a4e + 2 * a8e, plan.row_of.data(), (size_t)B * 4);
         memcpy(img + 4 * a4e + 2 * a8e + a4b, plan.level_of.data(), (size_t)B * 4);
+        int32_t *kk = reinterpret_cast<int32_t *>(img + 4 * a4e + 2 * a8e + 2 * a4b);
+        for (int i = 0; i < nkept; ++i) kk[i] = plan.kept[(size_t)i].kk;
     }
     NODAL_HIP_TRY(h, hipMemcpyAsync(w + a4k, img, image, hipMemcpyHostToDevice, st));
     double *x = h->x.as<double>();
     scatter_nodes<<<grid_for(K), TB, 0, st>>>(K, d_new, y, x);
     if (ne) eval_pivots<<<grid_for(ne), TB, 0, st>>>(ne, d_p, d_q, d_cst, d_c, d_d, d_g, x);
+    if (nkept) copy_kept<<<grid_for(nkept), TB, 0, st>>>(nkept, d_kept, K, plan.Kr, y, x);
     for (int pass = 0; pass <= plan.max_level; ++pass)
         recover_currents<<<grid_for(B), TB, 0, st>>>(pass, K, B, d_level, d_row, h->indptr.as<int32_t>(),
                                                     h->indices.as<int32_t>(), h->data.as<double>(),
@@ -767,7 +885,7 @@ int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, doub
         if (r->n == 0) return NODAL_OK;
         *iters = 0;
         *resid = 0.0;
-        r->optimistic_nopivot = !r->passive_network;
+        r->optimistic_nopivot = !r->passive_network && r->B == 0;  // (branches that stayed: the pivoted LU)
         s = dense_prepare(r);
         if (s == NODAL_OK) s = dense_factor_solve(r, &rinfo);
         if (s == NODAL_OK && rinfo > 0 && r->optimistic_nopivot) {
@@ -776,6 +894,12 @@ int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, doub
         }
     } else {
         s = sparse_solve(r, NODAL_SPARSE_AUTO, &rinfo, iters, resid);
+        // with branches left in it the reduced system is a general one: should its iteration not converge,
+        // the original system takes the caller's full route (which has the dense rescue), not an error
+        if (s == NODAL_E_UNSUPPORTED && r->B > 0) {
+            if (trace) fprintf(stderr, "[presolve] the reduced system (%d branches kept) did not converge: full-system route\n", (int)r->B);
+            return NODAL_OK;
+        }
     }
     if (s != NODAL_OK) { h->err = r->err; return s; }
     const auto t4 = now();

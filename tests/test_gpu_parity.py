@@ -437,6 +437,53 @@ def test_general_sparse_path_with_presolve(N, seed):
     h.close()
 
 
+def _stubborn_sources(N, kind):
+    """Dependent sources the presolve cannot substitute, next to the ones it can (grid + sources as above)."""
+    lab = lambda k: "g" if k == N * N - 1 else str(k + 1)  # noqa: E731
+    rows = _grid_with_sources(N, 5)[:-1]
+    if kind == "cascade":  # an amplifier stage controlled by the previous stage's OUTPUT node: nested control terms
+        rows += [["w1", "VCVS", "0.5", "y1", "g", lab(3), lab(N + 7)], ["ry1", "R", "1", "y1", lab(2 * N + 5)],
+                 ["w2", "VCVS", "0.7", "y2", "g", "y1", lab(3 * N + 2)], ["ry2", "R", "1", "y2", lab(4 * N + 9)],
+                 ["w3", "VCVS", "-0.4", "y3", "g", "y2", "y1"], ["ry3", "R", "2", "y3", lab(5 * N + 1)]]
+    elif kind == "feedback":  # a source controlled by its own output node
+        rows += [["w1", "VCVS", "0.5", "y1", "g", "y1", lab(N + 7)], ["ry1", "R", "1", "y1", lab(2 * N + 5)],
+                 ["w2", "VCVS", "-2.5", "y2", lab(7), lab(9), "y2"], ["ry2", "R", "1.5", "y2", lab(3 * N + 4)]]
+    elif kind == "stacked":  # two controlled sources in series: the upper node would need two control terms
+        rows += [["w1", "VCVS", "0.5", "y1", "g", lab(3), lab(N + 7)], ["w2", "VCVS", "0.3", "y2", "y1", lab(5), lab(N + 6)],
+                 ["ry2", "R", "1", "y2", lab(2 * N + 3)], ["w3", "CCVS", "0.4", "y3", "y2", lab(0), lab(1), "rh0_0"],
+                 ["ry3", "R", "1", "y3", lab(4 * N + 4)]]
+    rows.append(["a1", "A", "1", "1", "g"])
+    return rows
+
+
+@pytest.mark.parametrize("kind", ["cascade", "feedback", "stacked"])
+@pytest.mark.parametrize("N,sparse", [(30, False), (80, True)])
+def test_presolve_leaves_the_sources_it_cannot_substitute_in_the_system(N, sparse, kind):
+    """Cascaded amplifier stages (a VCVS controlled by another VCVS's output), a VCVS controlled by its own
+    output node: until round 3 ONE such source made the presolve decline the whole system (full-system FGMRES:
+    hundreds of iterations; pivoted LU on the dense switch).  Now its tree of sources stays in the reduced
+    system as branch equations and everything else is eliminated as before."""
+    nl = n.Netlist.from_rows(_stubborn_sources(N, kind))
+    table = lower(nl)
+    assert table.first_error is None
+    Go, Ao, _ = oracle.build_model(nl, True)  # (a control on the source's own node stamps on top of the +-1)
+    xo, warns = oracle.solve(Go.tocsr(), Ao, True)
+    assert not warns and np.isfinite(xo).all()
+    circ = n.Circuit(nl, sparse=sparse)
+    x = circ.solve().result
+    assert normwise(x, xo) <= TOL
+    assert circ.scaled_residual() <= 1e-12
+    if sparse:  # the reduced system converges like config 5's; the full system needs hundreds of iterations
+        h = _ffi.Handle(0)
+        h.upload(table)
+        h.assemble_symbolic()
+        assert h.assemble_numeric()[0] == _ffi.OK
+        x2, info, iters, _ = h.solve_sparse()
+        h.close()
+        assert info == 0 and normwise(x2, xo) <= TOL
+        assert iters <= 80, iters
+
+
 @pytest.mark.parametrize("rows", [
     [["r1", "R", "1", "g", "g"]],                                                   # no unknown at all
     [["r1", "R", "2", "1", "g"], ["a1", "A", "3", "1", "g"]],                       # one unknown
