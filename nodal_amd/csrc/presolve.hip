@@ -523,6 +523,10 @@ static void presolve_plan(const nodal_ctx *h, const double *value, PresolvePlan 
         plan.max_level = std::max(plan.max_level, 1 + height[v]);
     }
     if (taken.empty()) return;  // nothing can be eliminated: the full-system solve
+    static const bool keep_allowed = !(getenv("NODAL_PRESOLVE_KEEP") && atoi(getenv("NODAL_PRESOLVE_KEEP")) == 0);
+    if (!keep_allowed)  // (round 2's behaviour, for comparisons: one stubborn source ends the presolve)
+        for (const char b : bad)
+            if (b) return;
     for (int m = 0; m < (int)raws.size(); ++m) {  // the branches that stay (raws are in branch order)
         if (!bad[comp_of_raw(m)]) continue;
         const Raw &r = raws[m];
