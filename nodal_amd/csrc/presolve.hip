@@ -15,13 +15,16 @@
 // sparse_general.hip cannot see (360 GMRES iterations on config 5).
 // Afterwards e_p follows from its expression and i_m from the ORIGINAL KCL row of p.
 //
-// Supported pattern (everything else falls back to the full-system solve): the
-// voltage-defined branches form a forest on their lead nodes (no loops of sources); every
-// tree is rooted at ground if it touches ground and every other node of it is a pivot,
-// defined through the branch to its parent.  Chains resolve by substitution (stacked
-// sources add up, a control node that is itself a pivot is replaced by its expression, for
-// the branch-less dependent sources (CCCS) too) as long as every pivot ends with at most
-// one control term on surviving nodes and no substituted control carries a term itself.
+// Supported pattern: the voltage-defined branches form a forest on their lead nodes (a loop of
+// sources ends the presolve: the system is singular); every tree is rooted at ground if it
+// touches ground and every other node of it is a pivot, defined through the branch to its
+// parent.  Chains resolve by substitution (stacked sources add up, a control node that is
+// itself a pivot is replaced by its expression, for the branch-less dependent sources (CCCS)
+// too) as long as every pivot ends with at most one control term on surviving nodes and no
+// substituted control carries a term itself.  A tree with a pivot that breaks these rules
+// (cascaded / self-controlled / stacked dependent sources) is not eliminated: its branches stay
+// in the reduced system as E / VCVS rows with their branch unknowns (B' > 0) -- everything else
+// goes as before, and the reduced system takes the general solver.
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
