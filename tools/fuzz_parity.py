@@ -1,6 +1,7 @@
 """Differential campaign: random netlists with every component type, HIP path against the CPU restatement of
 the reference (oracle) -- G and A bit for bit, x to 1e-9 norm-wise -- over more seeds and larger sizes than
-the test suite runs.   python tools/fuzz_parity.py [first_seed] [count]"""
+the test suite runs.   python tools/fuzz_parity.py [first_seed] [count] [stubborn]
+("stubborn": plus cascaded, self-controlled and stacked dependent sources, which the presolve keeps as branches)"""
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,12 +11,30 @@ from tests.test_gpu_parity import random_netlist, normwise, TOL
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+STUBBORN = len(sys.argv) > 3 and sys.argv[3] == "stubborn"
 bad = 0
 t0 = time.time()
 for seed in range(first, first + count):
     rng = random.Random(seed)
     nodes = rng.choice([5, 17, 60, 200, 700, 1500, 3000, 6000])
     rows = random_netlist(rng, nodes, rng.randrange(3, max(4, nodes // 2)))
+    if STUBBORN:  # dependent sources the presolve cannot substitute: cascades, self-control, stacks
+        outs = [r[3] for r in rows if r[1] in ("VCVS", "VCCS", "CCVS") and r[3].startswith("x")]
+        plain = [str(i) for i in range(1, nodes)]
+        for j in range(rng.randrange(1, 4)):
+            y = f"y{j}"
+            kind = rng.choice(["cascade", "self", "stack"])
+            if kind == "cascade" and outs:
+                rows.append([f"w{j}", "VCVS", repr(rng.uniform(-0.8, 0.8)), y, "g", rng.choice(outs), rng.choice(plain)])
+            elif kind == "self":
+                rows.append([f"w{j}", "VCVS", repr(rng.uniform(-0.8, 0.8)), y, "g", y, rng.choice(plain)])
+            elif outs:
+                rows.append([f"w{j}", "VCVS", repr(rng.uniform(-0.8, 0.8)), y, rng.choice(outs), rng.choice(plain), rng.choice(plain)])
+            else:
+                continue
+            rows.append([f"ry{j}", "R", repr(rng.uniform(0.5, 5)), y, rng.choice(plain)])
+            outs.append(y)
+        rng.shuffle(rows)
     nl = n.Netlist.from_rows(rows)
     for sparse in (False, True):
         if not sparse and nodes > 3000:
