@@ -1,9 +1,9 @@
 """BASELINE.json config 4 at full size on ONE GPU: the 1024 members of the value sweep as the eight shards
 of 128 an 8-GPU node would take, one after the other, every shard through ShardedBatch (the entry bench.py
 and the RCCL path use), sampled members against the CPU restatement of the reference.
-    python tools/cfg4_full.py"""
+    python tests/campaigns/cfg4_full.py"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from nodal_amd import generators as gen
 from nodal_amd.batch import ShardedBatch

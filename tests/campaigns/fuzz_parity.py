@@ -1,9 +1,9 @@
 """Differential campaign: random netlists with every component type, HIP path against the CPU restatement of
 the reference (oracle) -- G and A bit for bit, x to 1e-9 norm-wise -- over more seeds and larger sizes than
-the test suite runs.   python tools/fuzz_parity.py [first_seed] [count] [stubborn]
+the test suite runs.   python tests/campaigns/fuzz_parity.py [first_seed] [count] [stubborn]
 ("stubborn": plus cascaded, self-controlled and stacked dependent sources, which the presolve keeps as branches)"""
 import os, random, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import nodal_amd as n
 from oracle import nodal_oracle as oracle

@@ -1,7 +1,7 @@
 """Wall time of Circuit(netlist) + .solve() for small netlists (what a user of the reference's CLI sees),
-HIP path against the CPU restatement of the reference (oracle): python tools/small_e2e_probe.py"""
+HIP path against the CPU restatement of the reference (oracle): python tests/campaigns/small_e2e_probe.py"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from nodal_amd import generators as gen
 from nodal_amd.netlist import Netlist

@@ -24,9 +24,12 @@ for side in [int(v) for v in sys.argv[1:]] or [3, 8, 16, 22, 31, 44]:
             best = min(best, time.perf_counter() - t0)
         line += f"  panel={panel}: {best * 1e3:8.3f} ms (info {info}, residual {h.residual():.1e})"
         h.close()
-    import scipy.linalg  # noqa: F401  (CPU reference point: LAPACK dgesv on the same matrix)
-    from oracle import nodal_oracle as oracle
-    G, A = oracle.assemble_fast(table)
-    Gd = G.toarray()
+    # CPU reference point: LAPACK dgesv (numpy) on the matrix the library assembled
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    h.assemble_numeric()
+    Gd, A = h.export_dense()
+    h.close()
     t0 = time.perf_counter(); np.linalg.solve(Gd, A); t1 = time.perf_counter() - t0
     print(line + f"  numpy dgesv {t1 * 1e3:.3f} ms", flush=True)
