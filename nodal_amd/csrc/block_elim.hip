@@ -571,7 +571,11 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
     //   sg:                 rest   A[J2:,   J1:]   -= A[J2:,   J0:J1] W(k)       (the bulk)
     // The critical path per block is diag -> inverse -> first columns of W -> next diag; the
     // strip, the wide part of W and the bulk update run beside it.
-    static const bool full_mask = getenv("NODAL_BI_MASKED") == nullptr;  // bulk updates on all CUs
+    // Bulk updates on a CU-masked stream that leaves 32 CUs (NODAL_PANEL_CUS) to the chain's small kernels:
+    // since the symmetric form halved the bulk work the chain bounds 30 of config 2's 39 blocks, and its
+    // workgroups no longer queue behind 58-us GEMM workgroups (14.37 -> 13.92 ms; 8 / 16 / 64 CUs: 14.15 /
+    // 14.12 / 14.69).  NODAL_BI_MASKED=0: bulk updates on all CUs (the default until the symmetric form).
+    static const bool full_mask = getenv("NODAL_BI_MASKED") != nullptr && atoi(getenv("NODAL_BI_MASKED")) == 0;
     hipStream_t sp = h->stream, sg = full_mask ? h->stream3 : h->stream2;
     hipStream_t s3 = full_mask ? h->stream2 : h->stream3;
     hipEvent_t ev_wfirst = h->ev_bi[0], ev_strip = h->ev_bi[1], ev_wrest = h->ev_bi[2],
