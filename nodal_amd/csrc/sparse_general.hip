@@ -331,7 +331,7 @@ __global__ void gst_begin(double *__restrict__ gst, double rnorm, double tolb) {
 // Once G_DONE is raised (converged, happy breakdown or singular operator) later iterations'
 // calls leave the state alone.
 __global__ __launch_bounds__(TB) void gs_finish(const double *__restrict__ h1, const double *__restrict__ h2,
-                                                const double *__restrict__ partial2, int nblocks2, int j,
+                                                const double *__restrict__ partial2, int nblocks2, int j, int s0,
                                                 double *__restrict__ gst) {
     if (gst[G_DONE] != 0.0) return;
     double s = 0.0;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(TB) void gs_finish(const double *__restrict__ h1, c
     const double hnext = sqrt(s);
     double proj = 0.0;
     for (int i = 0; i < nv; ++i) {
-        H[i * RESTART + j] = h1[i] + h2[i];
+        H[i * RESTART + j] = i < s0 ? 0.0 : h1[i] + h2[i];  // (s0 > 0: orthogonalised against a window only)
         proj = fma(H[i * RESTART + j], H[i * RESTART + j], proj);
     }
     H[nv * RESTART + j] = hnext;
@@ -574,6 +574,17 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
 
     const double tol = 1e-13;
     const int max_cycles = 10;
+    // Orthogonalisation window of the FIRST restart cycle.  A system without branch rows (a presolved network:
+    // a conductance matrix plus a few transconductance terms, preconditioned by its own multigrid cycle) is
+    // nearly symmetric, its Hessenberg matrix nearly tridiagonal: orthogonalising against the last 8 basis
+    // vectors costs no iteration (config 5: 23 either way, window 4 too) and saves 43 % of the Gram-Schmidt
+    // passes -- 11.4 -> 10.6 ms.  A saddle-point system (branch rows present) needs all of them: with a window
+    // of 12 or 16 the full-system fallback of config 5 + cascaded stages stalls at 2e-9 after 400 iterations
+    // where full orthogonalisation converges in 240.  So: the window only without branch rows, only in the
+    // first cycle (a system that needs a restart is a hard one: all vectors from then on), and the true
+    // residual at the end of every cycle decides.  NODAL_FGMRES_WINDOW=k forces k everywhere (experiments).
+    static const int window_env = getenv("NODAL_FGMRES_WINDOW") ? std::max(2, atoi(getenv("NODAL_FGMRES_WINDOW"))) : 0;
+    const int window_first = window_env ? window_env : (n == K ? 8 : RESTART + 1);
     double rnorm = bnorm;
     int total = 0;
     bool converged = false;
@@ -583,6 +594,7 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
     double hst[6];  // G_INV_H .. G_TOLB, as polled
 
     for (int cyc = 0; cyc < max_cycles && !converged; ++cyc) {
+        const int window = (cyc == 0 || window_env) ? window_first : RESTART + 1;
         scale_to<<<gv, TB, 0, st>>>(r, 1.0 / rnorm, V, n);
         gst_begin<<<1, 64, 0, st>>>(gst, rnorm, tol * bnorm);
         // Iterations are enqueued in batches; between batches the host reads the estimate and
@@ -614,14 +626,16 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
                     NODAL_TRY(csr_spmv(h, zj, w));
                     if (c == 0) NODAL_HIP_TRY(h, hipEventRecord(e1, st));
                 }
-                // classical Gram-Schmidt, twice
-                const int nv = j + 1;
-                DISPATCH_NV(nv, (gs_dots<NV><<<gd, TB, 0, st>>>(V, ld, nv, w, n, partial)));
-                gs_reduce<<<nv, TB, 0, st>>>(partial, (int)gd, nv, hdev, nullptr, 0);
-                DISPATCH_NV(nv, (gs_update_dots<NV><<<gd, TB, 0, st>>>(V, ld, nv, hdev, w, n, partial)));
-                gs_reduce<<<nv, TB, 0, st>>>(partial, (int)gd, nv, hdev2, nullptr, 0);
-                DISPATCH_NV(nv, (gs_update<NV><<<gd, TB, 0, st>>>(V, ld, nv, hdev2, w, n, partial2)));
-                gs_finish<<<1, TB, 0, st>>>(hdev, hdev2, partial2, (int)gd, j, gst);
+                // classical Gram-Schmidt, twice, against the last `window` basis vectors (see window_first above)
+                const int nv_all = j + 1;
+                const int s0 = nv_all > window ? nv_all - window : 0, nv = nv_all - s0;
+                const double *Vw = V + (int64_t)s0 * ld;
+                DISPATCH_NV(nv, (gs_dots<NV><<<gd, TB, 0, st>>>(Vw, ld, nv, w, n, partial)));
+                gs_reduce<<<nv, TB, 0, st>>>(partial, (int)gd, nv, hdev + s0, nullptr, 0);
+                DISPATCH_NV(nv, (gs_update_dots<NV><<<gd, TB, 0, st>>>(Vw, ld, nv, hdev + s0, w, n, partial)));
+                gs_reduce<<<nv, TB, 0, st>>>(partial, (int)gd, nv, hdev2 + s0, nullptr, 0);
+                DISPATCH_NV(nv, (gs_update<NV><<<gd, TB, 0, st>>>(Vw, ld, nv, hdev2 + s0, w, n, partial2)));
+                gs_finish<<<1, TB, 0, st>>>(hdev, hdev2, partial2, (int)gd, j, s0, gst);
                 scale_by_device<<<gv, TB, 0, st>>>(w, gst, V + (int64_t)(j + 1) * ld, n);
                 NODAL_HIP_TRY(h, hipGetLastError());
             }
