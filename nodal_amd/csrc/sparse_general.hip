@@ -334,42 +334,53 @@ __global__ __launch_bounds__(TB) void gs_finish(const double *__restrict__ h1, c
                                                 const double *__restrict__ partial2, int nblocks2, int j, int s0,
                                                 double *__restrict__ gst) {
     if (gst[G_DONE] != 0.0) return;
+    // (the column, the rotations and g are staged in LDS by all threads: thread 0 walking them through global
+    // memory was a chain of ~150 dependent loads, 11.7 us per iteration)
+    __shared__ double col[MAXV + 1], cs_[RESTART], sn_[RESTART], gj;
+    const int nv = j + 1;
+    for (int i = threadIdx.x; i < nv; i += TB) col[i] = i < s0 ? 0.0 : h1[i] + h2[i];  // (s0 > 0: a window only)
+    for (int i = threadIdx.x; i < j; i += TB) {
+        cs_[i] = gst[G_CS + i];
+        sn_[i] = gst[G_SN + i];
+    }
+    if (threadIdx.x == 0) gj = gst[G_G + j];
     double s = 0.0;
     for (int b = threadIdx.x; b < nblocks2; b += TB) s += partial2[b];
-    s = block_sum(s);
-    if (threadIdx.x != 0) return;
-    const int nv = j + 1;
-    double *H = gst + G_H, *cs = gst + G_CS, *sn = gst + G_SN, *g = gst + G_G;
-    const double hnext = sqrt(s);
-    double proj = 0.0;
-    for (int i = 0; i < nv; ++i) {
-        H[i * RESTART + j] = i < s0 ? 0.0 : h1[i] + h2[i];  // (s0 > 0: orthogonalised against a window only)
-        proj = fma(H[i * RESTART + j], H[i * RESTART + j], proj);
+    s = block_sum(s);  // (its barriers also publish the staged values)
+    __syncthreads();
+    double *H = gst + G_H;
+    if (threadIdx.x == 0) {
+        const double hnext = sqrt(s);
+        double proj = 0.0;
+        for (int i = 0; i < nv; ++i) proj = fma(col[i], col[i], proj);
+        gst[G_LOG + j] = s / (proj + s);
+        col[nv] = hnext;
+        for (int i = 0; i < j; ++i) {
+            const double a = col[i], b = col[i + 1];
+            col[i] = cs_[i] * a + sn_[i] * b;
+            col[i + 1] = -sn_[i] * a + cs_[i] * b;
+        }
+        const double d = hypot(col[j], col[j + 1]);
+        if (!(d > 0.0) || d != d) {  // breakdown: singular operator
+            gst[G_INFO] = 1.0;
+            gst[G_DONE] = 1.0;
+        } else {
+            const double c = col[j] / d, sn = col[j + 1] / d;
+            gst[G_CS + j] = c;
+            gst[G_SN + j] = sn;
+            col[j] = d;
+            col[j + 1] = 0.0;
+            gst[G_G + j + 1] = -sn * gj;
+            gst[G_G + j] = c * gj;
+            const double est = fabs(sn * gj);
+            gst[G_EST] = est;
+            gst[G_COUNT] = (double)(j + 1);
+            gst[G_INV_H] = hnext > 0.0 ? 1.0 / hnext : 0.0;
+            if (est <= gst[G_TOLB] || hnext == 0.0) gst[G_DONE] = 1.0;
+        }
     }
-    H[nv * RESTART + j] = hnext;
-    gst[G_LOG + j] = s / (proj + s);
-    for (int i = 0; i < j; ++i) {
-        const double a = H[i * RESTART + j], b = H[(i + 1) * RESTART + j];
-        H[i * RESTART + j] = cs[i] * a + sn[i] * b;
-        H[(i + 1) * RESTART + j] = -sn[i] * a + cs[i] * b;
-    }
-    const double d = hypot(H[j * RESTART + j], H[(j + 1) * RESTART + j]);
-    if (!(d > 0.0) || d != d) {  // breakdown: singular operator
-        gst[G_INFO] = 1.0;
-        gst[G_DONE] = 1.0;
-        return;
-    }
-    cs[j] = H[j * RESTART + j] / d;
-    sn[j] = H[(j + 1) * RESTART + j] / d;
-    H[j * RESTART + j] = d;
-    H[(j + 1) * RESTART + j] = 0.0;
-    g[j + 1] = -sn[j] * g[j];
-    g[j] = cs[j] * g[j];
-    const double est = fabs(g[j + 1]);
-    gst[G_EST] = est;
-    gst[G_COUNT] = (double)(j + 1);
-    gst[G_INV_H] = hnext > 0.0 ? 1.0 / hnext : 0.0;
-    if (est <= gst[G_TOLB] || hnext == 0.0) gst[G_DONE] = 1.0;
+    __syncthreads();
+    for (int i = threadIdx.x; i <= nv; i += TB) H[i * RESTART + j] = col[i];
 }
 
 // v_{j+1} = w / h_{j+1,j}
