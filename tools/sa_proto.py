@@ -74,14 +74,17 @@ def aggregate(A, rounds=MIS_ROUNDS, dist=2):
     g = key[A.indices]
     best = np.maximum.reduceat(g, A.indptr[:-1])
     agg1 = np.where(flag, ident, np.where(best >= 0, best & ((1 << 31) - 1), -1)).astype(np.int64)
-    # the rest joins the aggregate of its strongest assigned neighbour
+    # the rest joins the aggregate of its strongest assigned neighbour (repeated for distance-3 / -4 sets)
     rows = np.repeat(np.arange(n), np.diff(A.indptr))
-    w = np.abs(A.data) * (A.indices != rows) * (agg1[A.indices] >= 0)
-    # argmax per row
-    order = np.lexsort((-w, rows))
-    first = order[A.indptr[:-1]]
-    far = np.where(w[first] > 0, agg1[A.indices[first]], -1)
-    agg = np.where(agg1 >= 0, agg1, far)
+    agg = agg1
+    for _ in range(max(1, dist - 1) + 2):
+        if (agg >= 0).all():
+            break
+        w = np.abs(A.data) * (A.indices != rows) * (agg[A.indices] >= 0)
+        order = np.lexsort((-w, rows))
+        first = order[A.indptr[:-1]]
+        far = np.where(w[first] > 0, agg[A.indices[first]], -1)
+        agg = np.where(agg >= 0, agg, far)
     assert (agg >= 0).all()
     return agg, nc
 
@@ -111,7 +114,7 @@ class Level:
     pass
 
 
-def setup(A, trace=True, pw=PW, dist=2, rounds=MIS_ROUNDS):
+def setup(A, trace=True, pw=PW, dist=2, rounds=MIS_ROUNDS, dist_by_level=None, smooth_twice_from=None):
     levels = []
     while True:
         L = Level()
@@ -122,8 +125,14 @@ def setup(A, trace=True, pw=PW, dist=2, rounds=MIS_ROUNDS):
         if L.n <= COARSEST and len(levels) > 1:
             L.inv = np.linalg.inv(A.toarray())
             break
-        agg, nc = aggregate(L.A, rounds=rounds, dist=dist)
-        L.P = build_P(L.A, agg, nc, pw=pw)
+        lv = len(levels) - 1
+        d_here = dist_by_level[min(lv, len(dist_by_level) - 1)] if dist_by_level else dist
+        agg, nc = aggregate(L.A, rounds=rounds + 2 * (d_here - 2), dist=d_here)
+        L.P = build_P(L.A, agg, nc, pw=pw if d_here == 2 else 0)
+        if smooth_twice_from is not None and lv >= smooth_twice_from and d_here > 2:
+            d = L.A.diagonal()
+            S = sp.identity(L.n, format="csr") - OMEGA_P * sp.diags(1.0 / d) @ L.A
+            L.P = (S @ L.P).tocsr()
         L.R = L.P.T.tocsr()
         A = (L.R @ L.A @ L.P).tocsr()
         A.eliminate_zeros()
@@ -305,7 +314,9 @@ def main():
     names = sys.argv[2:] or ["base", "v"]
     A, b = grid_matrix(N)
     t0 = time.time()
-    levels = setup(A)
+    import os
+    dbl = [int(v) for v in os.environ["SA_DIST"].split(",")] if os.environ.get("SA_DIST") else None
+    levels = setup(A, dist_by_level=dbl, smooth_twice_from=1 if os.environ.get("SA_TWICE") else None)
     for L in levels[:-1]:
         L.rho = est_rho(L)
         L.cheb_ratio = 4.0
