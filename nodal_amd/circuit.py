@@ -80,6 +80,19 @@ class Circuit:
         self._G = self._A = None
         self.currents = self.build_model()
 
+    @classmethod
+    def _clone_of(cls, other):
+        """A second device context holding the same assembled system as `other` (no second lowering of the
+        netlist): the lanes of a long equivalent-resistance sweep (equiv.py)."""
+        self = cls.__new__(cls)
+        self.netlist, self.sparse, self._device = other.netlist, other.sparse, other._device
+        self._handle = None
+        self._G = self._A = None
+        self.table = other.table
+        self.currents = other.currents
+        self._assemble(self.table)
+        return self
+
     def __del__(self):
         try:
             handle, self._handle = self._handle, None

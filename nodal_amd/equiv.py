@@ -16,6 +16,12 @@ parser.add_argument("netlist_path", metavar="FILE", help="csv file describing th
 parser.add_argument("-s", "--sparse", action="store_true", help="use a sparse matrix")
 
 
+# sparse sweeps of at least this many pairs over more than this many unknowns run on several device contexts
+SWEEP_LANES = 3
+SWEEP_LANES_MIN_PAIRS = 12
+SWEEP_LANES_MIN_UNKNOWNS = 50_000
+
+
 def check_resistive(netlist):
     """True iff every component of the netlist is a resistor."""
     if getattr(netlist, "_fast", False):
@@ -67,7 +73,39 @@ def equivalent_resistance_sweep(netlist, pairs, sparse=False):
         ia.append(-1 if a == "g" else netlist.nodenum[a])
         ib.append(-1 if b == "g" else netlist.nodenum[b])
     circuit = n.Circuit(netlist, sparse=sparse)
-    res, info = circuit._handle.solve_pairs(ia, ib, dense=not sparse)
+    lanes = 1
+    if sparse and len(ia) >= SWEEP_LANES_MIN_PAIRS and circuit._handle.n > SWEEP_LANES_MIN_UNKNOWNS:
+        lanes = SWEEP_LANES
+    if lanes == 1:
+        res, info = circuit._handle.solve_pairs(ia, ib, dense=not sparse)
+    else:
+        # A long sweep over a large network: every pair is one multigrid-preconditioned CG solve, whose coarse
+        # levels leave most of the GPU idle.  Several device contexts (each with its own copy of the matrix and
+        # of the hierarchy: a GB at 1e6 nodes, of 288), one host thread each, take the pairs in turn: three
+        # solves in flight deliver 1.6 x the pairs per second of one (`concurrent`).
+        import threading
+        circuits = [circuit] + [n.Circuit._clone_of(circuit) for _ in range(lanes - 1)]
+        parts = [list(range(k, len(ia), lanes)) for k in range(lanes)]
+        out, infos, errors = [None] * lanes, [0] * lanes, []
+
+        def work(k):
+            try:
+                sel = parts[k]
+                out[k], infos[k] = circuits[k]._handle.solve_pairs([ia[i] for i in sel], [ib[i] for i in sel], dense=False)
+            except BaseException as e:  # noqa: BLE001  (re-raised on the calling thread)
+                errors.append(e)
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(lanes)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        res = np.empty(len(ia))
+        for k in range(lanes):
+            res[parts[k]] = out[k]
+        info = max(infos)
     if info > 0 and not sparse:
         if not n.is_connected(netlist):
             raise n.UnconnectedCircuitError

@@ -621,6 +621,32 @@ def test_equivalent_resistance_sweep_matches_the_oracle(N, sparse):
         equiv.equivalent_resistance_sweep(nl, [("1", "nope")], sparse=sparse)
 
 
+def test_long_sparse_resistance_sweep_over_several_device_contexts():
+    """A sweep of many pairs over a large network is spread over three device contexts (one host thread
+    each): same resistances as one factorisation of the oracle's matrix gives, in the pairs' order."""
+    import scipy.sparse.linalg as spla
+    N = 240
+    nl = n.Netlist.from_rows(list(gen.grid_rows(N))[:-1])
+    table = lower(nl)
+    assert table.K > equiv.SWEEP_LANES_MIN_UNKNOWNS
+    rng = random.Random(4)
+    labels = list(nl.nodenum) + ["g"]
+    pairs = [("1", "g")] + [tuple(rng.sample(labels, 2)) for _ in range(equiv.SWEEP_LANES_MIN_PAIRS + 7)]
+    got = equiv.equivalent_resistance_sweep(nl, pairs, sparse=True)
+    Go, _ = oracle.assemble_fast(table)
+    lu = spla.splu(Go.tocsc())
+    for (a, b), r in zip(pairs, got):
+        rhs = np.zeros(table.K)
+        if a != "g":
+            rhs[nl.nodenum[a]] += 1.0
+        if b != "g":
+            rhs[nl.nodenum[b]] -= 1.0
+        x = lu.solve(rhs)
+        want = (0.0 if a == "g" else x[nl.nodenum[a]]) - (0.0 if b == "g" else x[nl.nodenum[b]])
+        assert abs(r - want) <= 1e-9 * abs(want), (a, b, r, want)
+    assert abs(got[0] - 7.06) < 0.05  # (corner to corner of a 240 x 240 grid: between N = 100's 5.94 and 316's 7.41)
+
+
 def test_reference_resistance_tests_exact():
     """reference tests.py:24-29 asserts exact equality for resistive_{1,2,3}."""
     want = {"doc/resistive_1": 2.0, "doc/resistive_2": 1.0, "doc/resistive_3": 1.0}
