@@ -1,6 +1,6 @@
 """Differential campaign: random netlists with every component type, HIP path against the CPU restatement of
 the reference (oracle) -- G and A bit for bit, x to 1e-9 norm-wise -- over more seeds and larger sizes than
-the test suite runs.   python tests/campaigns/fuzz_parity.py [first_seed] [count] [stubborn]
+the test suite runs.   python tests/campaigns/fuzz_parity.py [first_seed] [count] [stubborn] [large]
 ("stubborn": plus cascaded, self-controlled and stacked dependent sources, which the presolve keeps as branches)"""
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -11,12 +11,13 @@ from tests.test_gpu_parity import random_netlist, normwise, TOL
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 120
-STUBBORN = len(sys.argv) > 3 and sys.argv[3] == "stubborn"
+STUBBORN = "stubborn" in sys.argv[3:]
+SIZES = [12000, 25000] if "large" in sys.argv[3:] else [5, 17, 60, 200, 700, 1500, 3000, 6000]
 bad = 0
 t0 = time.time()
 for seed in range(first, first + count):
     rng = random.Random(seed)
-    nodes = rng.choice([5, 17, 60, 200, 700, 1500, 3000, 6000])
+    nodes = rng.choice(SIZES)
     rows = random_netlist(rng, nodes, rng.randrange(3, max(4, nodes // 2)))
     if STUBBORN:  # dependent sources the presolve cannot substitute: cascades, self-control, stacks
         outs = [r[3] for r in rows if r[1] in ("VCVS", "VCCS", "CCVS") and r[3].startswith("x")]
@@ -71,6 +72,6 @@ for seed in range(first, first + count):
         except Exception as e:  # noqa: BLE001
             print(f"seed {seed} nodes {nodes} sparse {sparse}: {type(e).__name__}: {str(e)[:200]}")
             bad += 1
-    if (seed - first) % 20 == 19:
+    if (seed - first) % 20 == 19 or "large" in sys.argv[3:]:
         print(f"... {seed - first + 1} netlists, {bad} failures, {time.time() - t0:.0f} s", flush=True)
 print(f"{count} netlists from seed {first}: {bad} failures")
