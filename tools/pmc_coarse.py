@@ -27,7 +27,7 @@ def main():
                     a = acc[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][r["Counter_Name"]]
                     a[0] += 1
                     a[1] += float(r["Counter_Value"])
-    want = re.compile(r"^(k_|f_)")
+    want = re.compile(os.environ.get("PMC_KERNELS", r"^(k_|f_)"))  # PMC_KERNELS: other kernels (setup, stamping)
     res = {}
     for (name, grid), ctrs in sorted(acc.items(), key=lambda kv: (kv[0][0], kv[0][1])):
         if not want.search(name):
@@ -40,13 +40,15 @@ def main():
                          ("active_share", "SQ_ACTIVE_INST_ANY")):
                 if c in m:
                     e[k] = m[c] / wc
+        if "SQ_LDS_BANK_CONFLICT" in m and m.get("SQ_LDS_IDX_ACTIVE"):
+            e["lds_conflict_share"] = m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"]
         if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m and m["TCC_HIT_sum"] + m["TCC_MISS_sum"] > 0:
             e["l2_hit"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
         res[f"{name}:{grid}"] = e
     with open(out, "w") as f:
         json.dump({"note": __doc__.strip().split("\n\n")[0].replace("\n", " "), "kernels": res}, f, indent=1)
     for k, e in res.items():
-        print(k, {x: round(e[x], 3) for x in ("wait_share", "issue_stall_share", "active_share", "l2_hit") if x in e},
+        print(k, {x: round(e[x], 3) for x in ("wait_share", "issue_stall_share", "active_share", "l2_hit", "lds_conflict_share") if x in e},
               "waves", e["counters_mean"].get("SQ_WAVES"))
 
 
