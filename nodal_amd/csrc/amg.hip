@@ -29,6 +29,8 @@
 // Jacobi over the aggregates' diagonal blocks on every level above the tail (block_* kernels
 // below), free nodes propose only over links of at least a tenth of their strongest one (so
 // that aggregates do not cut strong links), two passes per level.
+#include <atomic>
+
 #include "group.h"
 #include "spmv_stream.h"
 
@@ -290,10 +292,16 @@ __global__ __launch_bounds__(TB) void diag_inverse(Csr A, const int32_t *__restr
 }
 
 // dense inverse of the coarsest matrix (n <= COARSEST_MAX) by Gauss-Jordan in LDS;
-// SPD, so no pivoting.  A non-positive pivot (singular network) raises the flag.
+// SPD, so no pivoting.  A non-positive pivot (singular network) raises the flag -- the symmetric
+// positive definite callers then give the hierarchy up -- and the elimination goes on with the row's
+// own diagonal entry (1 if that is not positive either) in its place: the inverse of a perturbed matrix,
+// every entry of `inv` written.  The general path (sparse_general.hip) ignores the flag: its node block
+// may hold an island that only a branch row ties down (a singular diagonal block of a regular system),
+// and its preconditioner must still be a finite operator.
 __global__ __launch_bounds__(256) void coarsest_inverse(Csr A, double *__restrict__ inv,
                                                         double *__restrict__ flag) {
     __shared__ double M[COARSEST_MAX][2 * COARSEST_MAX + 1];
+    __shared__ double dg[COARSEST_MAX];
     const int n = (int)A.n;
     for (int t = threadIdx.x; t < n * 2 * n; t += 256) {
         const int r = t / (2 * n), c = t % (2 * n);
@@ -303,12 +311,14 @@ __global__ __launch_bounds__(256) void coarsest_inverse(Csr A, double *__restric
     for (int r = threadIdx.x; r < n; r += 256)
         for (int32_t e = A.indptr[r]; e < A.indptr[r + 1]; ++e) M[r][A.indices[e]] = A.data[e];
     __syncthreads();
+    for (int r = threadIdx.x; r < n; r += 256) dg[r] = M[r][r];
+    __syncthreads();
     for (int k = 0; k < n; ++k) {
-        const double pv = M[k][k];
-        if (!(pv > 0.0)) {
-            if (threadIdx.x == 0) *flag = 3.0;
-            return;  // uniform: every thread reads the same pivot
-        }
+        double pv = M[k][k];  // uniform: every thread reads the same pivot
+        if (!(pv > 0.0) && threadIdx.x == 0) *flag = 3.0;
+        // (a pivot that cancelled down to rounding noise -- the last node of a floating island -- would put
+        // 1e17 into the inverse: it is replaced like a non-positive one)
+        if (!(pv > 1e-13 * dg[k]) || !(pv > 0.0)) pv = dg[k] > 0.0 ? dg[k] : 1.0;
         const double rp = 1.0 / pv;
         __syncthreads();
         for (int c = threadIdx.x; c < 2 * n; c += 256) M[k][c] *= rp;
@@ -1149,9 +1159,17 @@ int build_tail(nodal_ctx *h, Hierarchy *H) {
         pack_f64<<<grid_for(nco * nco), TB, 0, st>>>(img, d.o_inv, H->coarse_inv.as<double>(),
                                                    (int64_t)nco * nco);
         NODAL_HIP_TRY(h, hipGetLastError());
-        NODAL_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(amg_tail_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             d.total_bytes));
+        {   // the attribute belongs to the device's code object, not to this handle: raised ONCE per device
+            // to the budget (a per-setup value could be lowered by another handle's smaller tail between
+            // this setup and this hierarchy's launches -- the same rule as sagg.hip's tail)
+            static std::atomic<bool> lds_allowed[64];
+            const int dev = h->device >= 0 && h->device < 64 ? h->device : 0;
+            if (!lds_allowed[dev].load(std::memory_order_acquire)) {
+                NODAL_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(amg_tail_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS_BUDGET));
+                lds_allowed[dev].store(true, std::memory_order_release);
+            }
+        }
         H->tdesc = d;
         H->tail = t;
         break;
@@ -1382,6 +1400,11 @@ int cycle(nodal_ctx *h, Hierarchy *H, int l, const double *b, double *out) {
     }
     restrict_sum<<<stream::grid_for_rows(nc), TB, 0, st>>>(nc, L->memptr.as<int32_t>(), L->mem.as<int32_t>(), r, rc);
     NODAL_HIP_TRY(h, hipGetLastError());
+    nodal_nan_probe(h, b, n, "amg cycle b");
+    nodal_nan_probe(h, dinv, n, "amg cycle dinv");
+    nodal_nan_probe(h, x, n, "amg cycle x");
+    nodal_nan_probe(h, r, n, "amg cycle r");
+    nodal_nan_probe(h, rc, nc, "amg cycle rc");
     int nparts = 0;
     const bool coarse_is_last = (l + 1 == (int)H->levels.size() - 1);
     if (l + 1 == H->tail) {
@@ -1390,6 +1413,10 @@ int cycle(nodal_ctx *h, Hierarchy *H, int l, const double *b, double *out) {
         amg_tail_kernel<<<1, TAIL_THREADS, H->tdesc.total_bytes, st>>>(
             H->tdesc, H->tail_image.as<char>(), rc, c1, c2, C->part.as<double>());
         NODAL_HIP_TRY(h, hipGetLastError());
+        nodal_nan_probe(h, c1, nc, "amg tail c1");
+        nodal_nan_probe(h, c2, nc, "amg tail c2");
+        nodal_nan_probe(h, C->part.as<double>(), 5 * DOT_BLOCKS, "amg tail part (only 0,128,..512 matter)");
+        nodal_nan_probe(h, H->coarse_inv.as<double>(), H->levels.back()->A.n * H->levels.back()->A.n, "amg coarse inverse");
     } else if (coarse_is_last || l + 1 > H->kmax) {
         NODAL_TRY(cycle(h, H, l + 1, rc, c1));  // direct coarse solve (exact) or plain V hand-over
     } else {

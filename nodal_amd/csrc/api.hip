@@ -222,6 +222,39 @@ void nodal_free_buffers(nodal_ctx *h) {
     h->evpool.clear();
 }
 
+// NODAL_POISON=2: every buffer that carries nothing from one solve to the next -- the solution, the dense
+// panel, the scratch and Krylov areas -- becomes 0xFF bytes (NaNs / -1) in this context and its child
+// contexts, in order on the handle's stream: the state a pooled handle is in after a singular solve of a
+// larger system.  A kernel that reads a slot of these before writing it shows up as a NaN or a fault.
+void nodal_poison_scratch(nodal_ctx *h) {
+    if (nodal_poison_level() < 2 || !h) return;
+    DevBuf *bufs[] = {&h->x, &h->dense, &h->piv, &h->work, &h->work2, &h->work3, &h->solver, &h->krylov,
+                      &h->ld_work, &h->schur, &h->batch_x, &h->batch_scale, &h->rhs_none};
+    for (DevBuf *b : bufs) b->poison(h->stream);
+    nodal_poison_scratch(h->reduced);
+    nodal_poison_scratch(h->lowdeg);
+    nodal_poison_scratch(h->blocksys);
+}
+
+void nodal_nan_probe(nodal_ctx *h, const double *dev, int64_t n, const char *tag) {
+    static const bool on = getenv("NODAL_NANCHECK") != nullptr;
+    if (!on || !dev || n <= 0) return;
+    std::vector<double> host((size_t)n);
+    if (hipStreamSynchronize(h->stream) != hipSuccess ||
+        hipMemcpy(host.data(), dev, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+        fprintf(stderr, "[nancheck] %s: copy failed\n", tag);
+        return;
+    }
+    int64_t bad = 0, first = -1;
+    for (int64_t i = 0; i < n; ++i)
+        if (!(host[i] - host[i] == 0.0)) {
+            if (first < 0) first = i;
+            ++bad;
+        }
+    fprintf(stderr, "[nancheck] %s: %lld of %lld not finite (first at %lld)\n", tag, (long long)bad, (long long)n,
+            (long long)first);
+}
+
 extern "C" {
 
 int nodal_destroy(nodal_handle h) {
@@ -432,6 +465,7 @@ int nodal_solve_dense(nodal_handle h, double *x, int32_t *info) {
     if (!h || !info) return NODAL_E_INVALID;
     if (!h->have_numeric) return nodal_fail(h, NODAL_E_INVALID, "assemble_numeric not called");
     DeviceGuard g(h);
+    nodal_poison_scratch(h);
     *info = 0;
     h->have_x = false;
     h->last_batch_block = false;
@@ -477,6 +511,7 @@ int nodal_solve_sparse(nodal_handle h, int32_t method, double *x, int32_t *info,
                        double *resid) {
     if (!h || !info) return NODAL_E_INVALID;
     DeviceGuard g(h);
+    nodal_poison_scratch(h);
     int32_t it = 0;
     double rs = 0;
     NODAL_HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
@@ -501,6 +536,7 @@ int nodal_solve_pairs(nodal_handle h, int32_t dense, int32_t npairs, const int32
         return NODAL_E_INVALID;
     if (!h->have_numeric) return nodal_fail(h, NODAL_E_INVALID, "assemble_numeric not called");
     DeviceGuard g(h);
+    nodal_poison_scratch(h);
     *info = 0;
     const int64_t n = h->n;
     for (int32_t q = 0; q < npairs; ++q)

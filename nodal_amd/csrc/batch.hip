@@ -13,6 +13,9 @@
 // singular, has a zero resistance or a stamp collision -- the members are solved one by
 // one on the parent context, so that only the offending members report it, as a loop over
 // the reference would.
+#include <cmath>
+#include <vector>
+
 #include "ctx.h"
 
 namespace {
@@ -31,6 +34,7 @@ __global__ __launch_bounds__(TB) void replicate_rows(
     const uint8_t *__restrict__ type, const double *__restrict__ values,  // values: [batch][ncomp]
     const int32_t *__restrict__ a, const int32_t *__restrict__ b, const int32_t *__restrict__ c,
     const int32_t *__restrict__ d, const int32_t *__restrict__ drv, const int32_t *__restrict__ k,
+    const double *__restrict__ src_scale,  // (null, or [count]: independent sources of member m divided by it)
     uint8_t *__restrict__ otype, double *__restrict__ ovalue, int32_t *__restrict__ oa,
     int32_t *__restrict__ ob, int32_t *__restrict__ oc, int32_t *__restrict__ od,
     int32_t *__restrict__ odrv, int32_t *__restrict__ ok) {
@@ -39,8 +43,10 @@ __global__ __launch_bounds__(TB) void replicate_rows(
         const int32_t m = (int32_t)(i / ncomp);
         const int64_t r = i - (int64_t)m * ncomp;
         auto node = [&](int32_t v) { return v >= 0 ? v + m * K : -1; };
-        otype[i] = type[r];
-        ovalue[i] = values[(int64_t)(first + m) * ncomp + r];
+        const uint8_t t = type[r];
+        const double v = values[(int64_t)(first + m) * ncomp + r];
+        otype[i] = t;
+        ovalue[i] = (src_scale && (t == NODAL_T_A || t == NODAL_T_E)) ? v / src_scale[m] : v;  // (a power of two: exact)
         oa[i] = node(a[r]);
         ob[i] = node(b[r]);
         oc[i] = node(c[r]);
@@ -70,6 +76,12 @@ __global__ __launch_bounds__(TB) void split_members(int32_t count, int32_t K, in
 // solves treats every member alike -- so every member's right-hand side is scaled to [1, 2) by a
 // power of two (exact in floating point; the systems are linear and independent: x_m = s_m x~_m)
 // before the joint solve.  Then the one test bounds every member's relative residual.
+// A block WITH branch unknowns is scaled at its sources instead (source_scales below): its presolve
+// (presolve.hip) rebuilds the reduced system from the component VALUES, host and device copies, so the scale
+// has to be in the table -- the independent sources A and E of member m divided by s_m, nothing else: the
+// systems are linear in them -- or the presolved answer would be checked against a right-hand side it was
+// never computed for (and rejected: every such sweep then paid for the plan, the reduced build, the reduced
+// solve AND the full-system route).
 __device__ __forceinline__ int64_t member_of_row(int64_t i, int32_t count, int32_t K, int32_t B) {
     const int64_t nodes = (int64_t)count * K;
     return i < nodes ? i / K : (i - nodes) / B;
@@ -199,7 +211,7 @@ nodal_ctx *block_child(nodal_ctx *h) {
 }
 
 // host copy of the block table for the presolve (only systems with branch equations keep one)
-void replicate_host(const nodal_ctx *h, nodal_ctx *c, int32_t first, int32_t count) {
+void replicate_host(const nodal_ctx *h, nodal_ctx *c, int32_t first, int32_t count, const double *src_scale) {
     const HostTable &s = h->host;
     HostTable &t = c->host;
     const int64_t nc = h->ncomp, total = nc * count;
@@ -216,10 +228,33 @@ void replicate_host(const nodal_ctx *h, nodal_ctx *c, int32_t first, int32_t cou
             const int64_t i = (int64_t)m * nc + r;
             auto node = [&](int32_t v) { return v >= 0 ? v + m * h->K : -1; };
             t.type[i] = s.type[r];
-            t.value[i] = vals[r];
+            t.value[i] = (src_scale && (s.type[r] == NODAL_T_A || s.type[r] == NODAL_T_E)) ? vals[r] / src_scale[m] : vals[r];
             t.a[i] = node(s.a[r]); t.b[i] = node(s.b[r]); t.c[i] = node(s.c[r]); t.d[i] = node(s.d[r]);
             t.drv[i] = s.drv[r] >= 0 ? (int32_t)(s.drv[r] + (int64_t)m * nc) : -1;
             t.k[i] = s.k[r] >= 0 ? s.k[r] + m * h->B : -1;
+        }
+    }
+}
+
+// s_m = 2^floor(log2 max|v|) over member m's independent sources (1 if it has none or they are all zero / not
+// finite): the same [1, 2) normalisation as member_scales, from the host copy of the value table
+void source_scales(const nodal_ctx *h, int32_t first, int32_t count, std::vector<double> &out) {
+    const HostTable &s = h->host;
+    const int64_t nc = h->ncomp;
+    out.assign((size_t)count, 1.0);
+    for (int32_t m = 0; m < count; ++m) {
+        const double *vals = s.values_batch.data() + (size_t)(first + m) * nc;
+        double mx = 0.0;
+        for (int64_t r = 0; r < nc; ++r)
+            if (s.type[r] == NODAL_T_A || s.type[r] == NODAL_T_E) {
+                const double v = fabs(vals[r]);
+                if (v > mx && v < 1.0 / 0.0) mx = v;
+            }
+        if (mx > 0.0) {
+            int e = 0;
+            (void)frexp(mx, &e);
+            const double sc = ldexp(1.0, e - 1);
+            if (sc > 0.0 && sc < 1.0 / 0.0) out[(size_t)m] = sc;
         }
     }
 }
@@ -289,6 +324,7 @@ int nodal_run_batch(nodal_handle h, int32_t first, int32_t count, int32_t reuse_
     (void)hipSetDevice(h->device);
     struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
     FillStreamScope fill(h->stream);
+    nodal_poison_scratch(h);
     hipStream_t st = h->stream;
     const int64_t n = h->n, ncomp = h->ncomp;
     h->batch_count = 0;
@@ -312,11 +348,24 @@ int nodal_run_batch(nodal_handle h, int32_t first, int32_t count, int32_t reuse_
         DevBuf *dst[] = {&c->type, &c->value, &c->a, &c->b, &c->c, &c->d, &c->drv, &c->k};
         const size_t width[] = {1, 8, 4, 4, 4, 4, 4, 4};
         for (int i = 0; i < 8; ++i) NODAL_HIP_TRY(h, dst[i]->reserve((size_t)total * width[i] + 16));
+        // per-member scales: [count] bit patterns of max |rhs| (device route) | [count] doubles
+        NODAL_HIP_TRY(h, h->batch_scale.reserve((size_t)count * 16 + 64));
+        unsigned long long *absmax = h->batch_scale.as<unsigned long long>();
+        double *scale = reinterpret_cast<double *>(absmax + count);
+        // a block with branch unknowns and a host copy of its values (what its presolve works from) is
+        // scaled at its sources, in the table; every other block at its assembled right-hand side
+        const bool source_scaled = h->B > 0 && !h->host.type.empty() && !h->host.values_batch.empty();
+        std::vector<double> sc_host;
+        if (source_scaled) {
+            source_scales(h, first, count, sc_host);
+            NODAL_HIP_TRY(h, hipMemcpyAsync(scale, sc_host.data(), (size_t)count * 8, hipMemcpyHostToDevice, st));
+            NODAL_HIP_TRY(h, hipStreamSynchronize(st));  // (pageable source: gone when this scope is left early)
+        }
         replicate_rows<<<grid_for(total), TB, 0, st>>>(
             ncomp, count, first, h->K, h->B, h->type.as<uint8_t>(), h->values_batch.as<double>(),
             h->a.as<int32_t>(), h->b.as<int32_t>(), h->c.as<int32_t>(), h->d.as<int32_t>(),
-            h->drv.as<int32_t>(), h->k.as<int32_t>(), c->type.as<uint8_t>(), c->value.as<double>(),
-            c->a.as<int32_t>(), c->b.as<int32_t>(), c->c.as<int32_t>(), c->d.as<int32_t>(),
+            h->drv.as<int32_t>(), h->k.as<int32_t>(), source_scaled ? scale : nullptr, c->type.as<uint8_t>(),
+            c->value.as<double>(), c->a.as<int32_t>(), c->b.as<int32_t>(), c->c.as<int32_t>(), c->d.as<int32_t>(),
             c->drv.as<int32_t>(), c->k.as<int32_t>());
         NODAL_HIP_TRY(h, hipGetLastError());
         c->ncomp = total;
@@ -329,8 +378,8 @@ int nodal_run_batch(nodal_handle h, int32_t first, int32_t count, int32_t reuse_
         c->have_numeric = c->have_x = false;
         if (!(reuse_symbolic && same_shape && c->have_symbolic)) c->have_symbolic = false;
         c->block_epoch = h->table_epoch;
-        c->keep_host_table = h->B > 0 && !h->host.type.empty() && !h->host.values_batch.empty();
-        if (c->keep_host_table) replicate_host(h, c, first, count);
+        c->keep_host_table = source_scaled;
+        if (c->keep_host_table) replicate_host(h, c, first, count, sc_host.data());
         else c->host = HostTable();
         if (!c->have_symbolic) {
             if (h->B == 0) {  // one member's grouping, shifted (the parent's symbolic phase is redone too unless kept)
@@ -345,11 +394,7 @@ int nodal_run_batch(nodal_handle h, int32_t first, int32_t count, int32_t reuse_
         double rs = 0.0;
         int64_t bad = -1;
         if (s == NODAL_OK) s = stamp_numeric(c, 0, &bad);
-        double *scale = nullptr;
-        if (s == NODAL_OK) {  // every member's right-hand side to [1, 2): one stopping test serves them all
-            NODAL_HIP_TRY(h, h->batch_scale.reserve((size_t)count * 16 + 64));
-            unsigned long long *absmax = h->batch_scale.as<unsigned long long>();
-            scale = reinterpret_cast<double *>(absmax + count);
+        if (s == NODAL_OK && !source_scaled) {  // every member's right-hand side to [1, 2): one stopping test serves them all
             NODAL_HIP_TRY(h, hipMemsetAsync(absmax, 0, (size_t)count * 8, st));
             member_absmax<<<grid_for(c->n), TB, 0, st>>>(c->n, count, h->K, h->B, c->rhs.as<double>(), absmax);
             member_scales<<<grid_for(count), TB, 0, st>>>(count, absmax, scale);

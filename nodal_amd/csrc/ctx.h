@@ -25,6 +25,17 @@ struct FillStreamScope {
     FillStreamScope &operator=(const FillStreamScope &) = delete;
 };
 
+// 0: off; 1: growing buffers are filled with 0xFF; 2: scratch buffers too, at every solve entry
+inline int nodal_poison_level() {
+    static const int level = [] {
+        const char *e = getenv("NODAL_POISON");
+        if (!e) return 0;
+        const int v = atoi(e);
+        return v > 1 ? v : 1;
+    }();
+    return level;
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -36,14 +47,13 @@ struct DevBuf {
         size_t want = bytes + (bytes >> 3) + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
-        // A buffer that grows starts from zeros, whatever the allocator hands back (memory this
-        // process freed a moment ago holds old indices, NaN-filled solutions ...): a kernel that reads
-        // a slot nobody has written yet -- padding it multiplies by zero, a row it masks afterwards --
-        // then behaves the same in every run.  Only on growth: the steady state never allocates.
-        // NODAL_POISON=1 (debugging) fills with 0xFF bytes instead -- NaNs as doubles, -1 as integers --
-        // to make such reads show (expect out-of-bounds faults: run single cases, not the suite).
-        static const bool poison = getenv("NODAL_POISON") != nullptr;
+        // A buffer that grows starts from zeros, whatever the allocator hands back: hardening only --
+        // no kernel may depend on it (NODAL_POISON shows the ones that do).
+        // NODAL_POISON=1 (debugging) fills with 0xFF bytes instead -- NaNs as doubles, -1 as integers;
+        // NODAL_POISON=2 also re-poisons every scratch buffer of the handle at the entry of each solve
+        // (nodal_poison_scratch, api.hip): what a pooled handle looks like after somebody else's solve.
         static const bool nofill = getenv("NODAL_NOFILL") != nullptr;
+        const bool poison = nodal_poison_level() > 0;
         if (e != hipSuccess || nofill) return e;
         if (nodal_fill_stream) return hipMemsetAsync(p, poison ? 0xFF : 0, want, nodal_fill_stream);
         // (outside an API call the fill runs on the null stream; the contexts' streams do not wait for
@@ -51,6 +61,10 @@ struct DevBuf {
         e = hipMemset(p, poison ? 0xFF : 0, want);
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
         return e;
+    }
+    // debugging (NODAL_POISON=2): the whole allocation becomes 0xFF bytes, in order on `st`
+    void poison(hipStream_t st) {
+        if (p) (void)hipMemsetAsync(p, 0xFF, cap, st);
     }
     void release() {
         if (p) (void)hipFree(p);
@@ -306,6 +320,10 @@ int sparse_residual(nodal_ctx *h, double *scaled);
 int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, double *resid,
                    bool dense_child = false);
 void nodal_free_buffers(nodal_ctx *h);  // api.hip
+void nodal_poison_scratch(nodal_ctx *h);  // api.hip: NODAL_POISON=2, entry of every solve
+// debugging (NODAL_NANCHECK=1): waits for the stream, copies n doubles to the host and reports on stderr how
+// many are not finite and where the first one sits; a no-op otherwise
+void nodal_nan_probe(nodal_ctx *h, const double *dev, int64_t n, const char *tag);  // api.hip
 // The dense paths' two extra streams (one CU-masked) and their events, created on first use: a handle
 // that only ever solves sparse systems holds ONE hardware queue, so that four of them in flight still
 // get a queue each (the runtime multiplexes streams beyond its hardware queues: erratic throughput).

@@ -622,8 +622,10 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
                 const int j = enq;
                 double *vj = V + (int64_t)j * ld, *zj = Z + (int64_t)j * ld;
                 // z_j = M^-1 v_j
+                if (j == 0) nodal_nan_probe(h, vj, n, "fgmres v0");
                 if (use_sa) NODAL_TRY(sagg_apply(h, vj, zj));
                 else NODAL_TRY(amg_apply(h, vj, zj));
+                if (j == 0) nodal_nan_probe(h, zj, K, "fgmres z0 (node block)");
                 if (n > K) {
                     branch_solve<<<grid_for(n - K), TB, 0, st>>>(indptr, indices, data, K, (int)n,
                                                                 h->schur.as<double>(), vj, zj);
@@ -636,6 +638,10 @@ int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *re
                     if (c == 0) NODAL_HIP_TRY(h, hipEventRecord(e0, st));
                     NODAL_TRY(csr_spmv(h, zj, w));
                     if (c == 0) NODAL_HIP_TRY(h, hipEventRecord(e1, st));
+                }
+                if (j == 0) {
+                    nodal_nan_probe(h, zj, n, "fgmres z0");
+                    nodal_nan_probe(h, w, n, "fgmres w0 = A z0");
                 }
                 // classical Gram-Schmidt, twice, against the last `window` basis vectors (see window_first above)
                 const int nv_all = j + 1;

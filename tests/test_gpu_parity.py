@@ -1209,3 +1209,194 @@ def test_value_sweep_on_the_grid_keeps_the_hierarchy():
         assert normwise(x, xo) <= TOL, m
         assert h.residual() <= 1e-13
     h.close()
+
+
+def test_batch_members_with_voltage_sources_over_decades_take_the_presolve(monkeypatch, capfd):
+    """A value sweep on a topology WITH branch unknowns (E + VCVS): the block system's presolve rebuilds
+    the reduced network from the component values, so the per-member equilibration has to sit in the table
+    (independent sources of member m divided by a power of two, csrc/batch.hip) -- with the right-hand side
+    scaled behind its back the presolved answer was checked against the wrong vector and every such sweep
+    fell through to the full-system iteration.  Members driven by 5 V next to 0.01 V and 3e-6 V: the
+    presolve is ACCEPTED and every member matches a solve of its own (reference: a loop of
+    `Circuit(netlist, sparse=True).solve()`, nodal/nodal.py:306-336)."""
+    from nodal_amd.batch import BatchSolver
+    monkeypatch.setenv("NODAL_TRACE", "1")
+    rows = _large_general_rows(24)
+    nl = n.Netlist.from_rows(rows)
+    table = lower(nl)
+    members = 12
+    assert members * table.n > 4096  # the block takes the large general path
+    e1 = [i for i, r in enumerate(rows) if r[0] == "e1"][0]
+    d1 = [i for i, r in enumerate(rows) if r[0] == "d1"][0]
+    vals = np.tile(table.value, (members, 1))
+    rng = np.random.default_rng(11)
+    vals[:, e1] = [5.0, 0.01, 3e-6, 300.0, 1.0, 0.5, 2.0, 7e-4, 40.0, 1e-2, 9.0, 0.125]
+    vals[:, d1] = rng.uniform(0.2, 0.8, members)
+    vals[:, : len(rows) - 3] *= 10.0 ** rng.uniform(-1, 1, (members, 1))
+    with BatchSolver(table, 0) as s:
+        capfd.readouterr()
+        out = s.solve(vals, sparse=True)
+        err = capfd.readouterr().err
+        assert not np.any(s.last_info)
+    assert "[presolve] accepted" in err, err[-600:]
+    for m in range(members):
+        rows_m = [r[:2] + [repr(float(v))] + r[3:] for r, v in zip(rows, vals[m])]
+        Go, Ao, _ = oracle.build_model(n.Netlist.from_rows(rows_m), True)
+        xo, _ = oracle.solve(Go, Ao, True)
+        assert normwise(out[m], xo) <= TOL, (m, vals[m, e1])
+
+
+def _island_of_resistors(prefix, count):
+    rows = [[f"{prefix}{i}", "R", "1", f"{prefix}n{i}", f"{prefix}n{i + 1}"] for i in range(count)]
+    rows.append([f"{prefix}a", "A", "1", f"{prefix}n3", f"{prefix}n{count - 2}"])
+    return rows
+
+
+def _ladder_rows(sections, seed=3):
+    rng = random.Random(seed)
+    rows = []
+    for k in range(sections):
+        rows.append([f"rs{k}", "R", repr(rng.uniform(0.5, 2.0)), f"n{k}", f"n{k + 1}"])
+        if k % 7 == 0:
+            rows.append([f"rp{k}", "R", repr(rng.uniform(50.0, 200.0)), f"n{k}", "g"])
+    rows.append(["a1", "A", "0.25", f"n{sections}", "g"])
+    return rows
+
+
+def _grid_island(prefix, M):
+    lab = lambda r, c: f"{prefix}{r}_{c}"  # noqa: E731
+    rows = []
+    for r in range(M):
+        for c in range(M):
+            if c + 1 < M:
+                rows.append([f"{prefix}h{r}_{c}", "R", "1", lab(r, c), lab(r, c + 1)])
+            if r + 1 < M:
+                rows.append([f"{prefix}v{r}_{c}", "R", "2", lab(r, c), lab(r + 1, c)])
+    rows.append([f"{prefix}a", "A", "1", lab(0, 0), lab(M - 1, M - 1)])
+    return rows
+
+
+def _singular_then_regular(kind):
+    """(singular netlist rows, dense?, smaller regular netlist rows) for one solver path."""
+    if kind == "multigrid":       # floating grid island next to a grid: the hierarchy's structural verdict
+        return list(gen.grid_rows(110)) + _grid_island("y", 25), False, list(gen.grid_rows(75))
+    if kind == "lowdeg":          # floating chain: met by the exact elimination of low-degree nodes
+        return _ladder_rows(9000) + _island_of_resistors("x", 400), False, _ladder_rows(5000)
+    if kind == "general":         # large general path (presolve + FGMRES), island no branch ties down
+        return _large_general_rows(90) + _island_of_resistors("x", 200), False, _large_general_rows(70)
+    if kind == "dense_passive":   # dense block elimination; the island is found structurally
+        return list(gen.grid_rows(45)) + _island_of_resistors("x", 60), True, list(gen.grid_rows(33))
+    if kind == "dense_pivoted":   # two voltage sources in parallel: exact zero pivot of the pivoted LU
+        big = list(gen.grid_rows(30))[:-1] + [["e1", "E", "5", "1", "g"], ["e2", "E", "5", "1", "g"]]
+        return big, True, list(gen.grid_rows(22))[:-1] + [["e1", "E", "5", "1", "g"]]
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("kind", ["multigrid", "lowdeg", "general", "dense_passive", "dense_pivoted"])
+def test_singular_then_smaller_regular_system_on_one_handle(kind):
+    """A device context is reused: `Circuit` borrows its handle from a pool (nodal_amd/circuit.py) and a
+    sweep keeps one for hours.  A singular solve leaves NaNs in every vector it touched and the next,
+    SMALLER system reuses those buffers without any fill -- no kernel may read a slot the current solve has
+    not written.  The reference has no state between solves at all (nodal/nodal.py:313-336)."""
+    big_rows, dense, small_rows = _singular_then_regular(kind)
+    big, small = lower(n.Netlist.from_rows(big_rows)), lower(n.Netlist.from_rows(small_rows))
+    assert small.n < big.n
+    Go, Ao = oracle.assemble_fast(small)
+    xo, _ = oracle.solve(Go.toarray() if dense else Go.tocsr(), Ao, not dense)
+    h = _ffi.Handle(0)
+    for _ in range(2):  # twice: the second round meets whatever the first one cached
+        h.upload(big)
+        info = h.run(dense)
+        assert info > 0
+        if not dense:
+            assert np.isnan(h.download_x()).all()
+        h.upload(small)
+        assert h.run(dense) == 0
+        assert normwise(h.download_x(), xo) <= TOL
+        assert h.residual() <= 1e-12
+    h.close()
+
+
+def test_pooled_circuit_handle_after_a_singular_circuit():
+    """The same through the public API: the second `Circuit` gets the very handle the first one gave back."""
+    import gc
+    from nodal_amd import circuit as circuit_mod
+    big_rows, _, small_rows = _singular_then_regular("multigrid")
+    c1 = n.Circuit(n.Netlist.from_rows(big_rows), sparse=True)
+    handle = c1._handle
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert np.isnan(c1.solve().result).all()
+    assert any(issubclass(i.category, MatrixRankWarning) for i in w)
+    del c1
+    gc.collect()
+    assert handle in circuit_mod._IDLE_HANDLES[0]
+    nl = n.Netlist.from_rows(small_rows)
+    c2 = n.Circuit(nl, sparse=True)
+    assert c2._handle is handle
+    Go, Ao, _ = oracle.build_model(nl, True)
+    assert normwise(c2.solve().result, oracle.solve(Go, Ao, True)[0]) <= TOL
+
+
+def test_batch_solver_after_a_singular_member_and_with_fewer_members():
+    """One BatchSolver across steps: a shard with a value-singular member (its row is NaN), then a SHORTER
+    shard of regular members on the same device context -- block tables, scales and results of the longer
+    step are still in the buffers."""
+    from nodal_amd.batch import BatchSolver
+    rows = _large_general_rows(20) + [["d2", "VCVS", "0.5", "w1", "g", "w1", "g"], ["rw", "R", "2", "w1", "5"]]
+    nl = n.Netlist.from_rows(rows)
+    table = lower(nl)
+    d2 = [i for i, r in enumerate(rows) if r[0] == "d2"][0]
+
+    def member_oracle(v):
+        rows_m = [r[:2] + [repr(float(x))] + r[3:] for r, x in zip(rows, v)]
+        Go, Ao, _ = oracle.build_model(n.Netlist.from_rows(rows_m), True)
+        return oracle.solve(Go, Ao, True)[0]
+
+    rng = np.random.default_rng(5)
+    with BatchSolver(table, 0) as s:
+        vals = np.tile(table.value, (14, 1))
+        vals[:, d2] = rng.uniform(0.1, 0.9, 14)
+        vals[6, d2] = 1.0  # (1 - gain) e = 0: singular (reference nodal/models.py:53-78)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            out = s.solve(vals, sparse=True)
+        assert any(issubclass(x.category, MatrixRankWarning) for x in w)
+        assert list(s.last_info > 0) == [m == 6 for m in range(14)]
+        assert np.isnan(out[6]).all()
+        for m in (0, 5, 7, 13):
+            assert normwise(out[m], member_oracle(vals[m])) <= TOL, m
+        vals2 = np.tile(table.value, (5, 1))
+        vals2[:, d2] = rng.uniform(0.1, 0.9, 5)
+        out2 = s.solve(vals2, sparse=True)
+        assert not np.any(s.last_info)
+        for m in range(5):
+            assert normwise(out2[m], member_oracle(vals2[m])) <= TOL, m
+    # passive topology: 20 members, then 7
+    table = gen.grid_table(30)
+    with BatchSolver(table, 0) as s:
+        for members in (20, 7):
+            vals = np.ones((members, table.ncomp))
+            for b in range(members):
+                vals[b, :-1] = gen.cfg4_values(b + members, 30)
+            out = s.solve(vals, sparse=True)
+            for b in (0, members - 1):
+                t = table.truncated(table.ncomp)
+                t.value[:] = vals[b]
+                Go, Ao = oracle.assemble_fast(t)
+                assert normwise(out[b], oracle.solve(Go.tocsr(), Ao, True)[0]) <= TOL
+
+
+def test_reused_handle_with_every_scratch_buffer_poisoned():
+    """NODAL_POISON=2 (csrc/ctx.h, csrc/api.hip): growing buffers start as 0xFF bytes and every scratch
+    buffer of the handle is overwritten with 0xFF at the entry of each solve -- NaNs as doubles, -1 as
+    indices.  A child process runs singular and regular systems of changing sizes through every solver
+    path on ONE handle under that regime and compares each answer with the oracle."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, NODAL_POISON="2")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "poison_child.py")], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "poison child ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
