@@ -54,7 +54,10 @@ enum { NODAL_T_R = 0, NODAL_T_A = 1, NODAL_T_E = 2, NODAL_T_VCVS = 3,
 enum { NODAL_SPARSE_AUTO = 0,
        NODAL_SPARSE_PCG = 1,      /* SPD: multigrid-preconditioned flexible CG (Jacobi-CG when small) */
        NODAL_SPARSE_DENSIFY = 2,  /* scatter to a dense panel, LU with pivoting                      */
-       NODAL_SPARSE_LU = 3 };     /* general: block-preconditioned flexible GMRES (historic name)   */
+       NODAL_SPARSE_LU = 3,       /* general: block-preconditioned flexible GMRES (historic name)   */
+       NODAL_SPARSE_DIRECT = 4 }; /* multifrontal LU (static matching, nested dissection, pivoting inside the
+                                     fronts) + fp64 refinement: what AUTO falls back on when an iteration
+                                     gives up -- spsolve's "any non-singular G" (reference nodal/nodal.py:325) */
 
 /* ---- lifetime ---------------------------------------------------------- */
 int nodal_create(int device_id, nodal_handle *out);

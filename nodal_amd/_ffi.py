@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libnodal_hip.so")
 
 OK, E_INVALID, E_HIP, E_ZERO_RESISTANCE, E_STAMP_COLLISION, E_SINGULAR, E_NOMEM, \
     E_UNSUPPORTED = range(8)
-SPARSE_AUTO, SPARSE_PCG, SPARSE_DENSIFY, SPARSE_LU = range(4)
+SPARSE_AUTO, SPARSE_PCG, SPARSE_DENSIFY, SPARSE_LU, SPARSE_DIRECT = range(5)
 OPT_FORCE_PIVOTING = 1
 OPT_GEPP_PANEL = 2
 

@@ -51,8 +51,12 @@ __global__ __launch_bounds__(256) void validate_table(int64_t ncomp, int32_t K, 
         const uint8_t t = type[i];
         const bool branch = t >= NODAL_T_E && t <= NODAL_T_CCCS;
         const int32_t ci = c ? c[i] : -1, di = d ? d[i] : -1, ri = drv ? drv[i] : -1, ki = k ? k[i] : -1;
-        const bool ok = t <= NODAL_T_GM && a[i] >= -1 && a[i] < K && b[i] >= -1 && b[i] < K && ci >= -1 && ci < K &&
-                        di >= -1 && di < K && ri >= -1 && ri < ncomp && ki >= -1 && ki < B && (branch == (ki >= 0));
+        // (a plain table -- no c / d / drv / k columns -- can only hold resistors and current sources: any other
+        // row would stamp nothing, silently)
+        const bool plain_ok = c != nullptr || t == NODAL_T_R || t == NODAL_T_A;
+        const bool ok = t <= NODAL_T_GM && plain_ok && a[i] >= -1 && a[i] < K && b[i] >= -1 && b[i] < K && ci >= -1 &&
+                        ci < K && di >= -1 && di < K && ri >= -1 && ri < ncomp && ki >= -1 && ki < B &&
+                        (branch == (ki >= 0));
         if (!ok) atomicMin(bad, (unsigned long long)i);
         sources += (t == NODAL_T_A || t == NODAL_T_E) ? 1u : 0u;
     }
@@ -199,6 +203,7 @@ int nodal_ensure_aux_streams(nodal_ctx *ctx) {
 void nodal_free_buffers(nodal_ctx *h) {
     amg_destroy(h);
     sagg_destroy(h);
+    slu_destroy(h);
     nodal_free_block_child(h);
     if (h->reduced) {
         nodal_free_buffers(h->reduced);
@@ -231,6 +236,7 @@ void nodal_poison_scratch(nodal_ctx *h) {
     DevBuf *bufs[] = {&h->x, &h->dense, &h->piv, &h->work, &h->work2, &h->work3, &h->solver, &h->krylov,
                       &h->ld_work, &h->schur, &h->batch_x, &h->batch_scale, &h->rhs_none};
     for (DevBuf *b : bufs) b->poison(h->stream);
+    slu_poison(h);
     nodal_poison_scratch(h->reduced);
     nodal_poison_scratch(h->lowdeg);
     nodal_poison_scratch(h->blocksys);
@@ -309,36 +315,48 @@ int nodal_upload_internal(nodal_ctx *h, int64_t ncomp, const uint8_t *type, cons
     h->B = B;
     h->n = n;
     h->batch = 0;
-    NODAL_TRY(upload(h, h->type, type, ncomp));
-    NODAL_TRY(upload(h, h->value, value, ncomp));
-    NODAL_TRY(upload(h, h->a, a, ncomp));
-    NODAL_TRY(upload(h, h->b, b, ncomp));
+    // (an early return must not leave DMA from the caller's columns in flight: the caller may free them)
+    auto fail_synced = [&](int status) {
+        (void)hipStreamSynchronize(h->stream);
+        return status;
+    };
+#define UPLOAD_TRY(expr)                             \
+    do {                                             \
+        const int _s = (expr);                       \
+        if (_s != NODAL_OK) return fail_synced(_s);  \
+    } while (0)
+    UPLOAD_TRY(upload(h, h->type, type, ncomp));
+    UPLOAD_TRY(upload(h, h->value, value, ncomp));
+    UPLOAD_TRY(upload(h, h->a, a, ncomp));
+    UPLOAD_TRY(upload(h, h->b, b, ncomp));
     if (plain) {
         DevBuf *cols[] = {&h->c, &h->d, &h->drv, &h->k};
         for (DevBuf *col : cols) {
-            NODAL_HIP_TRY(h, col->reserve((size_t)ncomp * 4 + 16));
-            if (ncomp > 0) NODAL_HIP_TRY(h, hipMemsetAsync(col->p, 0xFF, (size_t)ncomp * 4, h->stream));  // -1
+            if (col->reserve((size_t)ncomp * 4 + 16) != hipSuccess ||
+                (ncomp > 0 && hipMemsetAsync(col->p, 0xFF, (size_t)ncomp * 4, h->stream) != hipSuccess))  // -1
+                return fail_synced(nodal_fail(h, NODAL_E_NOMEM, "upload: could not allocate a table column"));
         }
     } else {
-        NODAL_TRY(upload(h, h->c, c, ncomp));
-        NODAL_TRY(upload(h, h->d, d, ncomp));
-        NODAL_TRY(upload(h, h->drv, drv, ncomp));
-        NODAL_TRY(upload(h, h->k, k, ncomp));
+        UPLOAD_TRY(upload(h, h->c, c, ncomp));
+        UPLOAD_TRY(upload(h, h->d, d, ncomp));
+        UPLOAD_TRY(upload(h, h->drv, drv, ncomp));
+        UPLOAD_TRY(upload(h, h->k, k, ncomp));
     }
     // the range check runs on the device, behind the copies; its verdict is the one word that comes back
-    NODAL_HIP_TRY(h, h->status.reserve(64));
+    if (h->status.reserve(64) != hipSuccess) return fail_synced(nodal_fail(h, NODAL_E_NOMEM, "upload: status words"));
     unsigned long long *bad_dev = h->status.as<unsigned long long>() + 4;
     unsigned long long bad[2] = {~0ull, 0ull};
-    NODAL_HIP_TRY(h, hipMemsetAsync(bad_dev, 0xFF, 8, h->stream));
-    NODAL_HIP_TRY(h, hipMemsetAsync(bad_dev + 1, 0, 8, h->stream));
+    if (hipMemsetAsync(bad_dev, 0xFF, 8, h->stream) != hipSuccess || hipMemsetAsync(bad_dev + 1, 0, 8, h->stream) != hipSuccess)
+        return fail_synced(nodal_fail(h, NODAL_E_HIP, "upload: could not clear the status words"));
     if (ncomp > 0) {
         const int64_t blocks = (ncomp + 255) / 256;
         validate_table<<<(unsigned)(blocks > 4096 ? 4096 : blocks), 256, 0, h->stream>>>(
             ncomp, K, B, h->type.as<uint8_t>(), h->a.as<int32_t>(), h->b.as<int32_t>(),
             plain ? nullptr : h->c.as<int32_t>(), plain ? nullptr : h->d.as<int32_t>(),
             plain ? nullptr : h->drv.as<int32_t>(), plain ? nullptr : h->k.as<int32_t>(), bad_dev);
-        NODAL_HIP_TRY(h, hipGetLastError());
+        if (hipGetLastError() != hipSuccess) return fail_synced(nodal_fail(h, NODAL_E_HIP, "upload: range check launch failed"));
     }
+#undef UPLOAD_TRY
     NODAL_TRY(nodal_read_words(h, bad, bad_dev, 16));
     h->rhs_items = (int64_t)bad[1];
     if (bad[0] != ~0ull) {

@@ -148,7 +148,7 @@ struct nodal_ctx {
 
     // ---- symbolic assembly results ----
     bool have_symbolic = false;
-    uint64_t sym_sizes_epoch = 0;  // table_epoch the sizes below were read back for (stamp_symbolic)
+    uint64_t sym_sizes_epoch = ~0ull;  // table_epoch the sizes below were read back for (stamp_symbolic); ~0: none yet
     int64_t sym_sizes[4] = {0, 0, 0, 0};  // nnz, ncontrib, nrhs, nrhs_contrib
     int sym_long_rows = -1;        // the matrix grouping of this table found rows of more than 16 stamps (1) / none (0)
     int64_t rhs_items = -1;        // components that stamp the right-hand side (counted at upload; -1: unknown)
@@ -199,6 +199,8 @@ struct nodal_ctx {
 
     void *amg = nullptr;  // multigrid hierarchy (amg.hip)
     void *sagg = nullptr; // smoothed-aggregation hierarchy (sagg.hip)
+    void *slu = nullptr;  // multifrontal LU of the direct route (sparse_direct.hip)
+    bool slu_strict = false;  // refinement judged by |r| / |b| alone (the direct route's second opinion)
     int32_t last_iterations = 0;
     double last_relres = 0;
     int32_t amg_levels = 0;
@@ -319,6 +321,13 @@ int sparse_residual(nodal_ctx *h, double *scaled);
 // dense_child: solve the reduced system by the dense block elimination (only if it is passive)
 int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, double *resid,
                    bool dense_child = false);
+// ---- sparse direct route (sparse_direct.hip): multifrontal LU + FGMRES refinement ----
+// tiny_factor scales (and signs) the value that replaces an unusable pivot
+int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor = 1.0);
+int slu_apply(nodal_ctx *h, const double *r, double *z);
+void slu_destroy(nodal_ctx *h);
+void slu_poison(nodal_ctx *h);
+int sparse_direct_solve(nodal_ctx *h, const double *b, double *x, int32_t *info, int32_t *iters, double *resid);
 void nodal_free_buffers(nodal_ctx *h);  // api.hip
 void nodal_poison_scratch(nodal_ctx *h);  // api.hip: NODAL_POISON=2, entry of every solve
 // debugging (NODAL_NANCHECK=1): waits for the stream, copies n doubles to the host and reports on stderr how

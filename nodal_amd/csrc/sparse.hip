@@ -649,6 +649,7 @@ int dense_prepare_pairs(nodal_ctx *h, int32_t nrhs, const int32_t *ia, const int
 }
 
 int sparse_general_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid);  // sparse_general.hip
+int general_krylov_direct(nodal_ctx *h, const double *b, double *x, int32_t *info, int32_t *iters, double *resid);  // sparse_general.hip
 
 int amg_fcg_solve(nodal_ctx *h, int32_t *info, int32_t *iters, double *resid) {
     return amg_fcg_solve_ex(h, h->rhs.as<double>(), true, info, iters, resid);
@@ -675,18 +676,45 @@ int sparse_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const in
     NODAL_HIP_TRY(h, h->ps_buf.reserve((size_t)n * 8 + 64));
     double *b = h->ps_buf.as<double>();
     *info = 0;
+    bool direct = false;  // the multigrid CG broke down on this network: one sparse LU serves every pair from then on
+    if (getenv("NODAL_PAIRS_DIRECT")) {  // (testing: the fallback from the first pair on)
+        int32_t inf = 0;
+        NODAL_TRY(slu_factor(h, &inf));
+        if (inf > 0) {
+            *info = 1;
+            return NODAL_OK;
+        }
+        direct = true;
+    }
     for (int32_t q = 0; q < npairs; ++q) {
         NODAL_HIP_TRY(h, hipMemsetAsync(b, 0, (size_t)n * 8, st));
         pair_rhs<<<1, 1, 0, st>>>(b, ia[q], ib[q]);
         int32_t it = 0, inf = 0;
         double rs = 0;
-        int s = amg_fcg_solve_ex(h, b, q == 0, &inf, &it, &rs);
-        if (s == -2) {  // floating island: every pair is singular, as in the reference
-            *info = 1;
-            return NODAL_OK;
+        if (!direct) {
+            const int s = amg_fcg_solve_ex(h, b, q == 0, &inf, &it, &rs);
+            if (s == -2) {  // floating island: every pair is singular, as in the reference
+                *info = 1;
+                return NODAL_OK;
+            }
+            if (s < 0) {
+                direct = true;
+                NODAL_TRY(slu_factor(h, &inf));
+                if (inf > 0) {
+                    *info = 1;
+                    return NODAL_OK;
+                }
+            } else if (s != NODAL_OK) {
+                return s;
+            }
         }
-        if (s < 0) return nodal_fail(h, NODAL_E_UNSUPPORTED, "pair sweep: multigrid CG broke down");
-        if (s != NODAL_OK) return s;
+        if (direct) {
+            NODAL_TRY(general_krylov_direct(h, b, h->x.as<double>(), &inf, &it, &rs));
+            if (inf > 0) {
+                *info = 1;
+                return NODAL_OK;
+            }
+        }
         h->last_iterations = it;
         pair_read<<<1, 1, 0, st>>>(h->x.as<double>(), ia[q], ib[q], res_dev + q);
     }
@@ -769,16 +797,21 @@ const double *host_values(const nodal_ctx *h) {
 }
 }  // namespace
 
+// A loop of voltage-defined branches (E, VCVS, CCVS -- independent or dependent alike): the current that
+// circulates in it enters and leaves every node of the loop and appears in no other equation, a null vector of
+// G whatever the values and gains.  (Round 3 looked at independent sources only; a ring of three VCVS branches
+// next to a 1e5-node grid "converged" to a circulating current of 2e16 A.)
 bool general_source_loop(const nodal_ctx *h) {
     const HostTable &t = h->host;
     if (t.type.empty()) return false;
     const int32_t K = h->K;
     UnionFind uf((int64_t)K + 1);
-    for (int64_t i = 0; i < h->ncomp; ++i)
-        if (t.type[(size_t)i] == NODAL_T_E) {
-            const int32_t a = t.a[(size_t)i] < 0 ? K : t.a[(size_t)i], b = t.b[(size_t)i] < 0 ? K : t.b[(size_t)i];
-            if (!uf.unite(a, b)) return true;
-        }
+    for (const int64_t i : t.branch_rows) {
+        const uint8_t ty = t.type[(size_t)i];
+        if (ty != NODAL_T_E && ty != NODAL_T_VCVS && ty != NODAL_T_CCVS) continue;
+        const int32_t a = t.a[(size_t)i] < 0 ? K : t.a[(size_t)i], b = t.b[(size_t)i] < 0 ? K : t.b[(size_t)i];
+        if (!uf.unite(a, b)) return true;  // (a == b included: the reference asserts on it at stamping time)
+    }
     return false;
 }
 
@@ -821,7 +854,7 @@ int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, do
         return NODAL_OK;
     }
     const int64_t densify_max = 4096;
-    const int64_t dense_rescue_max = 32768;  // a general system the iteration gives up on is decided by the dense LU up to here
+    const int64_t dense_rescue_max = 8192;  // a general system the iteration gives up on is decided by the dense LU up to here, by the sparse direct solve beyond
     const int64_t lowdeg_min = 1024;  // below this a direct solve costs less than an elimination round
     bool auto_passive = false;
     if (method == NODAL_SPARSE_AUTO) {
@@ -876,20 +909,23 @@ int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, do
             NODAL_TRY(dense_prepare(h));
             NODAL_TRY(dense_factor_solve(h, info));
         }
+    } else if (method == NODAL_SPARSE_DIRECT) {
+        NODAL_TRY(sparse_direct_solve(h, h->rhs.as<double>(), h->x.as<double>(), info, iters, resid));
     } else if (method == NODAL_SPARSE_LU) {
-        if (h->csr_only) return nodal_fail(h, NODAL_E_UNSUPPORTED, "matrix-only context: no general solver");
-        const int s = sparse_general_solve(h, info, iters, resid);
-        if (s == NODAL_E_UNSUPPORTED && (general_floating_island(h) || general_source_loop(h))) {
+        static const bool trace = getenv("NODAL_TRACE") != nullptr;
+        // (a matrix-only context -- what an elimination round of lowdeg.hip left -- has no component table
+        // for the presolve and the verdicts below: the direct route takes it)
+        const int s = h->csr_only ? NODAL_E_UNSUPPORTED : sparse_general_solve(h, info, iters, resid);
+        if (s == NODAL_E_UNSUPPORTED && !h->csr_only && (general_floating_island(h) || general_source_loop(h))) {
             // the iteration gave up on a matrix that is singular by construction: the reference's
             // answer is NaNs + a warning (quirk 3), not an exception
             *info = 1;
-        } else if (s == NODAL_E_UNSUPPORTED && n <= dense_rescue_max) {
+        } else if (s == NODAL_E_UNSUPPORTED && !h->csr_only && n <= dense_rescue_max) {
             // The iteration did not converge and nothing in the STRUCTURE says why: singular for its
             // particular values (a gain of exactly 1 around a loop), or too ill-conditioned for the
             // iterative path.  The reference's spsolve decides by pivoting (reference nodal/nodal.py:325:
             // an exact zero pivot -> NaNs + MatrixRankWarning, else the LU's answer); up to
-            // dense_rescue_max unknowns (8.6 GB as a dense panel, ~1.5 s) the pivoted dense LU here does
-            // the same.  Larger ones keep the loud error.
+            // dense_rescue_max unknowns the pivoted dense LU here does the same with LAPACK's own rule.
             const std::string why = h->err;
             const bool forced = h->force_pivoting;
             h->force_pivoting = true;  // (the tournament LU's exact-zero-pivot test, not the pivot-free paths)
@@ -899,8 +935,13 @@ int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, do
             if (d != NODAL_OK) return d;
             *iters = 0;
             *resid = 0.0;
-            static const bool trace = getenv("NODAL_TRACE") != nullptr;
             if (trace) fprintf(stderr, "[general] %s -- decided by the pivoted dense LU: info %d\n", why.c_str(), *info);
+        } else if (s == NODAL_E_UNSUPPORTED) {
+            // Larger than that (round 4): the multifrontal sparse LU of sparse_direct.hip with fp64 refinement --
+            // any non-singular G is solved, a singular one (the refinement stalls on perturbed pivots, or no
+            // perfect matching exists) gives NaNs + MatrixRankWarning like the reference's SuperLU, at every size.
+            if (trace && !h->csr_only) fprintf(stderr, "[general] %s -- handed to the sparse direct solve\n", h->err.c_str());
+            NODAL_TRY(sparse_direct_solve(h, h->rhs.as<double>(), h->x.as<double>(), info, iters, resid));
         } else if (s != NODAL_OK) {
             return s;
         }
@@ -921,9 +962,8 @@ int csr_spmv(nodal_ctx *h, const double *x, double *y) {
     return NODAL_OK;
 }
 
-int sparse_residual(nodal_ctx *h, double *scaled) {
-    if (!h->have_numeric || !h->have_x)
-        return nodal_fail(h, NODAL_E_INVALID, "no assembled system / solution on the device");
+// |G x - b|_inf / (|G|_inf |x|_inf + |b|_inf) for any device vectors (NaN if x holds one)
+int csr_scaled_residual(nodal_ctx *h, const double *x, const double *b, double *scaled) {
     const int64_t n = h->n;
     if (n == 0) {
         *scaled = 0.0;
@@ -934,8 +974,7 @@ int sparse_residual(nodal_ctx *h, double *scaled) {
     NODAL_HIP_TRY(h, hipMemsetAsync(out, 0, 40, h->stream));
     const int lpr = lanes_per_row(h);
     DISPATCH_LPR(lpr, (residual_kernel<L><<<grid_rows(n, lpr), TB, 0, h->stream>>>(
-                          h->indptr.as<int32_t>(), h->indices.as<int32_t>(), h->data.as<double>(),
-                          h->x.as<double>(), h->rhs.as<double>(), out, n)));
+                          h->indptr.as<int32_t>(), h->indices.as<int32_t>(), h->data.as<double>(), x, b, out, n)));
     NODAL_HIP_TRY(h, hipGetLastError());
     double o[5];
     NODAL_TRY(nodal_read_words(h, o, out, 40));
@@ -946,4 +985,10 @@ int sparse_residual(nodal_ctx *h, double *scaled) {
     const double den = o[1] * o[2] + o[3];
     *scaled = den > 0 ? o[0] / den : 0.0;
     return NODAL_OK;
+}
+
+int sparse_residual(nodal_ctx *h, double *scaled) {
+    if (!h->have_numeric || !h->have_x)
+        return nodal_fail(h, NODAL_E_INVALID, "no assembled system / solution on the device");
+    return csr_scaled_residual(h, h->x.as<double>(), h->rhs.as<double>(), scaled);
 }

@@ -1,0 +1,601 @@
+// Sparse direct solve: the route that cannot say "unsupported".
+//
+// The reference hands every sparse system to SuperLU (scipy.sparse.linalg.spsolve, reference
+// nodal/nodal.py:325): supernodal LU with partial pivoting behind a COLAMD ordering -- any non-singular G is
+// solved, an exactly singular one gives NaNs + MatrixRankWarning.  The iterative routes of sparse.hip /
+// sparse_general.hip are faster on the networks they converge on; this file is what stands behind them:
+// a multifrontal LU of the CSR matrix of the context, used as the preconditioner of the flexible GMRES of
+// sparse_general.hip (= iterative refinement in fp64 with a true-residual test).
+//
+//   host, per sparsity pattern (kept while the context's struct_epoch stands):
+//     1. row matching: a maximum transversal that prefers large entries (diagonal first, then the
+//        largest free entry, then augmenting paths) -- the branch rows of voltage-defined components
+//        have a zero diagonal (reference nodal/models.py:35-78) and get the +-1 incidence entry of one
+//        of their lead nodes instead; no perfect matching = structurally singular;
+//     2. nested dissection of the graph of P A + (P A)^T by breadth-first level structures from a
+//        pseudo-peripheral vertex (George's automatic nested dissection): pieces of at most LEAF
+//        vertices and the separators between them are the supernodes, numbered pieces first;
+//        vertices of very high degree (hub nets) are set aside as a last supernode;
+//     3. symbolic factorisation over the supernodes: the boundary of every front, the assembly tree
+//        (parent = owner of the boundary's first vertex), levels, the index maps of the extend-add
+//        and the destination of every CSR entry inside its front.
+//   device, per set of values:
+//     4. row / column equilibration (max-norm), fronts zeroed, entries scattered;
+//     5. level by level up the assembly tree: extend-add of the children's Schur complements (one
+//        workgroup per parent, children in a fixed order: deterministic), then a blocked right-looking
+//        partial LU of the front's pivot block -- partial pivoting RESTRICTED to the fully summed rows
+//        of the front, a pivot below sqrt(eps) |A| replaced by that bound (SuperLU_DIST's static-pivot
+//        rule; the refinement absorbs it or, if the matrix is singular, fails to converge);
+//     6. apply: forward substitution up the tree (contribution vectors pulled by the parents),
+//        backward substitution down the tree.
+// All fronts live in one buffer (sum of dim^2 doubles: ~2 GB for the 1e6-node grid; the 288 GB of
+// the MI355X are what makes "no stack management" a reasonable design).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+#include <vector>
+
+#include "ctx.h"
+#include "slu_analyse.h"
+
+int general_krylov_direct(nodal_ctx *h, const double *b, double *x, int32_t *info, int32_t *iters,
+                          double *resid);  // sparse_general.hip
+
+namespace {
+
+using slu::Symbolic;
+using slu::analyse;
+constexpr int TB = 256;
+
+struct SluState {
+    uint64_t epoch = 0;           // struct_epoch of the context the symbolic part belongs to
+    int64_t n = 0, nnz = 0;
+    bool have_symbolic = false, have_numeric = false;
+    int32_t nsn = 0, nlev = 0;
+    int64_t front_doubles = 0, vec_doubles = 0;
+    int32_t max_dim = 0;
+    std::vector<int32_t> lvl_ptr;  // [nlev + 1] into d_lvl_sn
+    std::vector<int32_t> lvl_maxdim;
+    // device copies of the symbolic part
+    DevBuf rowof, colof, newrow;   // permuted position -> original row / column; original row -> position
+    DevBuf sn_start, struct_ptr, struct_idx, front_off, vec_off, lvl_sn, child_ptr, child_idx, cmap, dest;
+    // numeric part
+    DevBuf fronts, vec, lperm, rs, cs, xb, stats;
+    double amax = 0.0;
+    int64_t perturbed = 0;
+};
+
+SluState *state_of(nodal_ctx *h) { return static_cast<SluState *>(h->slu); }
+
+// ---------------------------------------------------------------------------------------------
+// device
+// ---------------------------------------------------------------------------------------------
+
+inline unsigned grid_for(int64_t n, unsigned cap = 8192) {
+    int64_t g = (n + TB - 1) / TB;
+    if (g < 1) g = 1;
+    return (unsigned)(g > cap ? cap : g);
+}
+
+// row / column max-norm equilibration: rs[i] = 1 / max_j |a_ij|, cs[j] = 1 / max_i |rs_i a_ij|
+__global__ __launch_bounds__(TB) void row_scales(int64_t n, const int32_t *__restrict__ indptr,
+                                                 const double *__restrict__ data, double *__restrict__ rs) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        double m = 0.0;
+        for (int32_t e = indptr[i]; e < indptr[i + 1]; ++e) m = fmax(m, fabs(data[e]));
+        rs[i] = (m > 0.0 && m < 1.0 / 0.0) ? 1.0 / m : 1.0;
+    }
+}
+__global__ __launch_bounds__(TB) void col_maxima(int64_t n, const int32_t *__restrict__ indptr,
+                                                 const int32_t *__restrict__ indices, const double *__restrict__ data,
+                                                 const double *__restrict__ rs, unsigned long long *__restrict__ cmax) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        const double r = rs[i];
+        for (int32_t e = indptr[i]; e < indptr[i + 1]; ++e) {
+            const double v = fabs(data[e]) * r;
+            if (v > 0.0 && v == v)  // (non-negative doubles order like their bit patterns: exact, order-independent)
+                atomicMax(&cmax[indices[e]], (unsigned long long)__double_as_longlong(v));
+        }
+    }
+}
+__global__ __launch_bounds__(TB) void col_scales(int64_t n, const unsigned long long *__restrict__ cmax,
+                                                 double *__restrict__ cs) {
+    for (int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x; j < n; j += (int64_t)gridDim.x * TB) {
+        const double m = __longlong_as_double((long long)cmax[j]);
+        cs[j] = (m > 0.0 && m < 1.0 / 0.0) ? 1.0 / m : 1.0;
+    }
+}
+
+__global__ __launch_bounds__(TB) void scatter_entries(int64_t n, const int32_t *__restrict__ indptr,
+                                                      const int32_t *__restrict__ indices,
+                                                      const double *__restrict__ data, const double *__restrict__ rs,
+                                                      const double *__restrict__ cs, const int64_t *__restrict__ dest,
+                                                      double *__restrict__ fronts) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        const double r = rs[i];
+        for (int32_t e = indptr[i]; e < indptr[i + 1]; ++e) fronts[dest[e]] = data[e] * r * cs[indices[e]];
+    }
+}
+
+struct Tree {
+    const int32_t *sn_start;
+    const int64_t *struct_ptr;
+    const int32_t *struct_idx;
+    const int64_t *front_off, *vec_off;
+    const int32_t *child_ptr, *child_idx, *cmap;
+};
+
+// parent front += the Schur complements of its children (children in list order: a fixed summation order)
+template <int BS>
+__global__ __launch_bounds__(BS) void extend_add(Tree T, const int32_t *__restrict__ sns, double *__restrict__ fronts) {
+    const int32_t p = sns[blockIdx.x];
+    const int64_t pdim = (T.sn_start[p + 1] - T.sn_start[p]) + (T.struct_ptr[p + 1] - T.struct_ptr[p]);
+    double *P = fronts + T.front_off[p];
+    for (int32_t q = T.child_ptr[p]; q < T.child_ptr[p + 1]; ++q) {
+        const int32_t c = T.child_idx[q];
+        const int32_t s = T.sn_start[c + 1] - T.sn_start[c];
+        const int64_t b = T.struct_ptr[c + 1] - T.struct_ptr[c];
+        const int64_t cdim = s + b;
+        const double *C = fronts + T.front_off[c];
+        const int32_t *map = T.cmap + T.struct_ptr[c];
+        // columns over the waves, rows over the lanes (column-major: the lanes read contiguous words)
+        for (int64_t j = threadIdx.x >> 6; j < b; j += BS >> 6) {
+            const int64_t pj = (int64_t)map[j] * pdim;
+            const double *col = C + (s + j) * cdim + s;
+            for (int64_t i = threadIdx.x & 63; i < b; i += 64) P[pj + map[i]] += col[i];
+        }
+        __syncthreads();  // (two children may add to the same entry: one after the other)
+    }
+}
+
+// Blocked right-looking partial LU of the s leading columns of a front (column-major, ld = dim), partial
+// pivoting restricted to the s fully summed rows; lperm[k] = local row that ended at position k.
+constexpr int NB = 16;
+template <int BS>
+__global__ __launch_bounds__(BS) void factor_fronts(Tree T, const int32_t *__restrict__ sns, double *__restrict__ fronts,
+                                                    int32_t *__restrict__ lperm, double tiny, double repl,
+                                                    unsigned long long *__restrict__ stats) {
+    const int32_t t = sns[blockIdx.x];
+    const int s = T.sn_start[t + 1] - T.sn_start[t];
+    const int dim = s + (int)(T.struct_ptr[t + 1] - T.struct_ptr[t]);
+    double *F = fronts + T.front_off[t];
+    int32_t *perm = lperm + T.sn_start[t];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = BS / 64;
+    __shared__ double red_v[NW];
+    __shared__ int red_i[NW];
+    __shared__ int piv_row;
+    __shared__ double Ls[NB][NB + 1];
+    for (int i = tid; i < s; i += BS) perm[i] = i;
+    __syncthreads();
+    for (int k0 = 0; k0 < s; k0 += NB) {
+        const int nb = s - k0 < NB ? s - k0 : NB;
+        for (int k = k0; k < k0 + nb; ++k) {
+            // pivot search in column k among the fully summed rows k .. s-1 (first row of maximal |a|)
+            double best = -1.0;
+            int bi = k;
+            for (int i = k + tid; i < s; i += BS) {
+                const double v = fabs(F[i + (int64_t)k * dim]);
+                if (v > best) { best = v; bi = i; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ov = __shfl_down(best, off, 64);
+                const int oi = __shfl_down(bi, off, 64);
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            if (lane == 0) { red_v[wave] = best; red_i[wave] = bi; }
+            __syncthreads();
+            if (tid == 0) {
+                double bv = red_v[0];
+                int br = red_i[0];
+                for (int w = 1; w < NW; ++w)
+                    if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < br)) { bv = red_v[w]; br = red_i[w]; }
+                const double d = F[k + (int64_t)k * dim];
+                if (!(bv >= tiny)) {  // nothing usable in the pivot block: SuperLU_DIST's static-pivot rule
+                    F[k + (int64_t)k * dim] = d < 0.0 ? -repl : repl;  // (|repl| >= tiny; the second opinion uses another value)
+                    br = k;
+                    atomicAdd(stats, 1ull);
+                } else if (fabs(d) >= 0.25 * bv) {
+                    br = k;  // (threshold pivoting: the diagonal stays when it is within a factor 4 of the best)
+                }
+                piv_row = br;
+                if (br != k) {
+                    const int32_t tmp = perm[k];
+                    perm[k] = perm[br];
+                    perm[br] = tmp;
+                }
+            }
+            __syncthreads();
+            const int p = piv_row;
+            if (p != k) {
+                for (int j = tid; j < dim; j += BS) {
+                    const double a = F[k + (int64_t)j * dim], b2 = F[p + (int64_t)j * dim];
+                    F[k + (int64_t)j * dim] = b2;
+                    F[p + (int64_t)j * dim] = a;
+                }
+                __syncthreads();
+            }
+            const double rp = 1.0 / F[k + (int64_t)k * dim];
+            const int jend = k0 + nb;
+            for (int i = k + 1 + tid; i < dim; i += BS) {
+                const double l = F[i + (int64_t)k * dim] * rp;
+                F[i + (int64_t)k * dim] = l;
+                for (int j = k + 1; j < jend; ++j) F[i + (int64_t)j * dim] = fma(-l, F[k + (int64_t)j * dim], F[i + (int64_t)j * dim]);
+            }
+            __syncthreads();
+        }
+        const int j0 = k0 + nb;
+        if (j0 >= dim) break;
+        // U12 = L11^-1 A12: rows k0 .. j0-1, columns j0 .. dim-1
+        for (int idx = tid; idx < nb * nb; idx += BS) {
+            const int r = idx % nb, q = idx / nb;
+            Ls[r][q] = F[(k0 + r) + (int64_t)(k0 + q) * dim];
+        }
+        __syncthreads();
+        for (int j = j0 + tid; j < dim; j += BS) {
+            double u[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) u[r] = r < nb ? F[(k0 + r) + (int64_t)j * dim] : 0.0;
+#pragma unroll
+            for (int r = 1; r < NB; ++r)
+#pragma unroll
+                for (int q = 0; q < r; ++q)
+                    if (r < nb) u[r] = fma(-Ls[r][q], u[q], u[r]);
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+                if (r < nb) F[(k0 + r) + (int64_t)j * dim] = u[r];
+        }
+        __syncthreads();
+        // trailing update: rows and columns j0 .. dim-1 (columns over the waves, rows over the lanes)
+        for (int j = j0 + wave; j < dim; j += NW) {
+            double u[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) u[q] = q < nb ? F[(k0 + q) + (int64_t)j * dim] : 0.0;
+            for (int i = j0 + lane; i < dim; i += 64) {
+                double acc = F[i + (int64_t)j * dim];
+#pragma unroll
+                for (int q = 0; q < NB; ++q)
+                    if (q < nb) acc = fma(-F[i + (int64_t)(k0 + q) * dim], u[q], acc);
+                F[i + (int64_t)j * dim] = acc;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// a fixed pseudo-random vector in [-1, 1) (the second opinion of sparse_direct_solve)
+__global__ __launch_bounds__(TB) void hashed_rhs(int64_t n, double *__restrict__ b) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+        z ^= z >> 31;
+        z *= 0xBF58476D1CE4E5B9ull;
+        z ^= z >> 29;
+        b[i] = (double)(int64_t)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;
+    }
+}
+
+// b' = P (rs .* b) in elimination order
+__global__ __launch_bounds__(TB) void permute_rhs(int64_t n, const int32_t *__restrict__ rowof,
+                                                  const double *__restrict__ rs, const double *__restrict__ b,
+                                                  double *__restrict__ xb) {
+    for (int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x; k < n; k += (int64_t)gridDim.x * TB) {
+        const int32_t i = rowof[k];
+        xb[k] = b[i] * rs[i];
+    }
+}
+__global__ __launch_bounds__(TB) void unpermute_solution(int64_t n, const int32_t *__restrict__ colof,
+                                                         const double *__restrict__ cs, const double *__restrict__ xb,
+                                                         double *__restrict__ x) {
+    for (int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x; k < n; k += (int64_t)gridDim.x * TB) {
+        const int32_t j = colof[k];
+        x[j] = xb[k] * cs[j];
+    }
+}
+
+// forward substitution of one level: v = [b'_S ; 0] + children's contributions, rows permuted like the
+// factorisation's, y_S = L11^-1 v_S, v_B -= L21 y_S.  y_S stays in v[0:s), the contribution in v[s:dim).
+template <int BS>
+__global__ __launch_bounds__(BS) void forward_level(Tree T, const int32_t *__restrict__ sns,
+                                                    const double *__restrict__ fronts,
+                                                    const int32_t *__restrict__ lperm, const double *__restrict__ xb,
+                                                    double *__restrict__ vec) {
+    const int32_t t = sns[blockIdx.x];
+    const int start = T.sn_start[t];
+    const int s = T.sn_start[t + 1] - start;
+    const int dim = s + (int)(T.struct_ptr[t + 1] - T.struct_ptr[t]);
+    const double *F = fronts + T.front_off[t];
+    double *v = vec + T.vec_off[t];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < dim; i += BS) v[i] = i < s ? xb[start + i] : 0.0;
+    __syncthreads();
+    for (int32_t q = T.child_ptr[t]; q < T.child_ptr[t + 1]; ++q) {
+        const int32_t c = T.child_idx[q];
+        const int cs_ = T.sn_start[c + 1] - T.sn_start[c];
+        const int64_t cb = T.struct_ptr[c + 1] - T.struct_ptr[c];
+        const double *cv = vec + T.vec_off[c] + cs_;
+        const int32_t *map = T.cmap + T.struct_ptr[c];
+        for (int64_t i = tid; i < cb; i += BS) v[map[i]] += cv[i];
+        __syncthreads();
+    }
+    // the row interchanges of the factorisation (through the s scratch words behind the front's vector)
+    const int32_t *perm = lperm + start;
+    double *tmp = v + dim;
+    for (int i = tid; i < s; i += BS) tmp[i] = v[perm[i]];
+    __syncthreads();
+    for (int i = tid; i < s; i += BS) v[i] = tmp[i];
+    __syncthreads();
+    for (int k = 0; k < s; ++k) {
+        const double yk = v[k];
+        for (int i = k + 1 + tid; i < dim; i += BS) v[i] = fma(-F[i + (int64_t)k * dim], yk, v[i]);
+        __syncthreads();
+    }
+}
+
+// backward substitution of one level: x_S = U11^-1 (y_S - U12 x_B), x_B gathered from the ancestors' solution
+template <int BS>
+__global__ __launch_bounds__(BS) void backward_level(Tree T, const int32_t *__restrict__ sns,
+                                                     const double *__restrict__ fronts, double *__restrict__ xb,
+                                                     double *__restrict__ vec) {
+    const int32_t t = sns[blockIdx.x];
+    const int start = T.sn_start[t];
+    const int s = T.sn_start[t + 1] - start;
+    const int dim = s + (int)(T.struct_ptr[t + 1] - T.struct_ptr[t]);
+    const double *F = fronts + T.front_off[t];
+    double *v = vec + T.vec_off[t];
+    const int32_t *bidx = T.struct_idx + T.struct_ptr[t];
+    const int tid = threadIdx.x;
+    for (int i = s + tid; i < dim; i += BS) v[i] = xb[bidx[i - s]];
+    __syncthreads();
+    // v_S -= U12 x_B: rows over the threads, columns in sequence (column-major: coalesced)
+    for (int i = tid; i < s; i += BS) {
+        double acc = v[i];
+        for (int j = s; j < dim; ++j) acc = fma(-F[i + (int64_t)j * dim], v[j], acc);
+        v[i] = acc;
+    }
+    __syncthreads();
+    for (int k = s - 1; k >= 0; --k) {
+        const double xk = v[k] / F[k + (int64_t)k * dim];
+        __syncthreads();
+        if (tid == 0) v[k] = xk;
+        for (int i = tid; i < k; i += BS) v[i] = fma(-F[i + (int64_t)k * dim], xk, v[i]);
+        __syncthreads();
+    }
+    for (int i = tid; i < s; i += BS) xb[start + i] = v[i];
+}
+
+template <class T>
+int upload_vec(nodal_ctx *h, DevBuf &buf, const std::vector<T> &v) {
+    NODAL_HIP_TRY(h, buf.reserve(v.size() * sizeof(T) + 64));
+    if (!v.empty())
+        NODAL_HIP_TRY(h, hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    return NODAL_OK;
+}
+
+Tree tree_of(const SluState *S) {
+    Tree T;
+    T.sn_start = S->sn_start.as<int32_t>();
+    T.struct_ptr = S->struct_ptr.as<int64_t>();
+    T.struct_idx = S->struct_idx.as<int32_t>();
+    T.front_off = S->front_off.as<int64_t>();
+    T.vec_off = S->vec_off.as<int64_t>();
+    T.child_ptr = S->child_ptr.as<int32_t>();
+    T.child_idx = S->child_idx.as<int32_t>();
+    T.cmap = S->cmap.as<int32_t>();
+    return T;
+}
+
+}  // namespace
+
+// NODAL_POISON=2: the numeric part (fronts, vectors, interchanges, scales) holds nothing between solves
+void slu_poison(nodal_ctx *h) {
+    SluState *S = state_of(h);
+    if (!S) return;
+    DevBuf *bufs[] = {&S->fronts, &S->vec, &S->lperm, &S->rs, &S->cs, &S->xb, &S->stats};
+    for (DevBuf *b : bufs) b->poison(h->stream);
+    S->have_numeric = false;
+}
+
+void slu_destroy(nodal_ctx *h) {
+    SluState *S = state_of(h);
+    if (!S) return;
+    DevBuf *bufs[] = {&S->rowof, &S->colof, &S->newrow, &S->sn_start, &S->struct_ptr, &S->struct_idx, &S->front_off,
+                      &S->vec_off, &S->lvl_sn, &S->child_ptr, &S->child_idx, &S->cmap, &S->dest, &S->fronts,
+                      &S->vec, &S->lperm, &S->rs, &S->cs, &S->xb, &S->stats};
+    for (DevBuf *b : bufs) b->release();
+    delete S;
+    h->slu = nullptr;
+}
+
+// Analysis (kept per struct_epoch) + numeric factorisation of the context's CSR matrix.
+// *info = 1: structurally singular (no perfect matching).
+int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
+    *info = 0;
+    const bool trace = getenv("NODAL_TRACE") != nullptr;
+    const int64_t n = h->n, nnz = h->nnz;
+    hipStream_t st = h->stream;
+    if (n >= (1ll << 31) - 2 || nnz >= (1ll << 31) - 2) return nodal_fail(h, NODAL_E_UNSUPPORTED, "direct solve: more than 2^31 rows or entries");
+    SluState *S = state_of(h);
+    if (!S) {
+        S = new SluState();
+        h->slu = S;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [&](auto t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    if (!(S->have_symbolic && S->epoch == h->struct_epoch && S->n == n && S->nnz == nnz)) {
+        S->have_symbolic = S->have_numeric = false;
+        std::vector<int32_t> indptr((size_t)n + 1), indices((size_t)nnz);
+        std::vector<double> data((size_t)nnz);
+        NODAL_HIP_TRY(h, hipMemcpyAsync(indptr.data(), h->indptr.p, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost, st));
+        if (nnz) {
+            NODAL_HIP_TRY(h, hipMemcpyAsync(indices.data(), h->indices.p, (size_t)nnz * 4, hipMemcpyDeviceToHost, st));
+            NODAL_HIP_TRY(h, hipMemcpyAsync(data.data(), h->data.p, (size_t)nnz * 8, hipMemcpyDeviceToHost, st));
+        }
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        Symbolic sym;
+        if (!analyse(n, indptr.data(), indices.data(), data.data(), sym, trace)) {
+            if (trace) fprintf(stderr, "[direct] no perfect matching: structurally singular\n");
+            *info = 1;
+            return NODAL_OK;
+        }
+        S->nsn = (int32_t)sym.sn_start.size() - 1;
+        S->nlev = (int32_t)sym.lvl_ptr.size() - 1;
+        S->front_doubles = sym.front_off.back();
+        S->vec_doubles = sym.vec_off.back();
+        S->max_dim = sym.max_dim;
+        S->lvl_ptr = sym.lvl_ptr;
+        S->lvl_maxdim = sym.lvl_maxdim;
+        // memory the fronts may take: half of what is free on the device (NODAL_DIRECT_MAX_GB overrides)
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        double cap = 0.5 * (double)free_b;
+        if (const char *e = getenv("NODAL_DIRECT_MAX_GB")) cap = atof(e) * 1e9;
+        if ((double)S->front_doubles * 8.0 > cap) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "direct solve: the fronts of this matrix need %.1f GB (limit %.1f GB)",
+                     (double)S->front_doubles * 8e-9, cap * 1e-9);
+            return nodal_fail(h, NODAL_E_NOMEM, msg);
+        }
+        NODAL_TRY(upload_vec(h, S->rowof, sym.rowof));
+        NODAL_TRY(upload_vec(h, S->colof, sym.colof));
+        NODAL_TRY(upload_vec(h, S->newrow, sym.newrow));
+        NODAL_TRY(upload_vec(h, S->sn_start, sym.sn_start));
+        NODAL_TRY(upload_vec(h, S->struct_ptr, sym.struct_ptr));
+        NODAL_TRY(upload_vec(h, S->struct_idx, sym.struct_idx));
+        NODAL_TRY(upload_vec(h, S->front_off, sym.front_off));
+        NODAL_TRY(upload_vec(h, S->vec_off, sym.vec_off));
+        NODAL_TRY(upload_vec(h, S->lvl_sn, sym.lvl_sn));
+        NODAL_TRY(upload_vec(h, S->child_ptr, sym.child_ptr));
+        NODAL_TRY(upload_vec(h, S->child_idx, sym.child_idx));
+        NODAL_TRY(upload_vec(h, S->cmap, sym.cmap));
+        NODAL_TRY(upload_vec(h, S->dest, sym.dest));
+        NODAL_HIP_TRY(h, hipStreamSynchronize(st));  // (the host vectors go out of scope)
+        double amax = 0.0;
+        for (double v : data) amax = std::max(amax, std::fabs(v));
+        S->amax = amax;
+        S->epoch = h->struct_epoch;
+        S->n = n;
+        S->nnz = nnz;
+        S->have_symbolic = true;
+    }
+    const double t_sym = ms_since(t0);
+    // ---- numeric ----
+    NODAL_HIP_TRY(h, S->fronts.reserve((size_t)S->front_doubles * 8 + 64));
+    NODAL_HIP_TRY(h, S->vec.reserve((size_t)S->vec_doubles * 8 + 64));
+    NODAL_HIP_TRY(h, S->lperm.reserve((size_t)n * 4 + 64));
+    NODAL_HIP_TRY(h, S->rs.reserve((size_t)n * 8 + 64));
+    NODAL_HIP_TRY(h, S->cs.reserve((size_t)n * 8 + 64));
+    NODAL_HIP_TRY(h, S->xb.reserve((size_t)n * 8 + 64));
+    NODAL_HIP_TRY(h, S->stats.reserve(64));
+    const int32_t *indptr = h->indptr.as<int32_t>();
+    const int32_t *indices = h->indices.as<int32_t>();
+    const double *data = h->data.as<double>();
+    NODAL_HIP_TRY(h, hipMemsetAsync(S->stats.p, 0, 16, st));
+    NODAL_HIP_TRY(h, hipMemsetAsync(S->fronts.p, 0, (size_t)S->front_doubles * 8, st));
+    // (the column maxima use cs as their integer scratch first)
+    NODAL_HIP_TRY(h, hipMemsetAsync(S->xb.p, 0, (size_t)n * 8, st));
+    row_scales<<<grid_for(n), TB, 0, st>>>(n, indptr, data, S->rs.as<double>());
+    col_maxima<<<grid_for(n), TB, 0, st>>>(n, indptr, indices, data, S->rs.as<double>(), S->xb.as<unsigned long long>());
+    col_scales<<<grid_for(n), TB, 0, st>>>(n, S->xb.as<unsigned long long>(), S->cs.as<double>());
+    scatter_entries<<<grid_for(n), TB, 0, st>>>(n, indptr, indices, data, S->rs.as<double>(), S->cs.as<double>(),
+                                                S->dest.as<int64_t>(), S->fronts.as<double>());
+    NODAL_HIP_TRY(h, hipGetLastError());
+    const Tree T = tree_of(S);
+    // after the equilibration every row and column has max-norm <= 1: the static-pivot bound is sqrt(eps)
+    const double tiny = 1.4901161193847656e-08, repl = tiny * tiny_factor;
+    for (int32_t l = 0; l < S->nlev; ++l) {
+        const int32_t cnt = S->lvl_ptr[(size_t)l + 1] - S->lvl_ptr[(size_t)l];
+        const int32_t *sns = S->lvl_sn.as<int32_t>() + S->lvl_ptr[(size_t)l];
+        const bool big = S->lvl_maxdim[(size_t)l] > 192;
+        if (l > 0) {
+            if (big) extend_add<1024><<<cnt, 1024, 0, st>>>(T, sns, S->fronts.as<double>());
+            else extend_add<256><<<cnt, 256, 0, st>>>(T, sns, S->fronts.as<double>());
+        }
+        if (big) factor_fronts<1024><<<cnt, 1024, 0, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl,
+                                                          S->stats.as<unsigned long long>());
+        else factor_fronts<256><<<cnt, 256, 0, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl,
+                                                    S->stats.as<unsigned long long>());
+        NODAL_HIP_TRY(h, hipGetLastError());
+    }
+    unsigned long long pert = 0;
+    NODAL_TRY(nodal_read_words(h, &pert, S->stats.p, 8));
+    S->perturbed = (int64_t)pert;
+    S->have_numeric = true;
+    if (trace)
+        fprintf(stderr, "[direct] analysis %.1f ms (%s), numeric factorisation %.1f ms, %lld perturbed pivots\n", t_sym,
+                t_sym < 0.5 ? "kept" : "new", ms_since(t0) - t_sym, (long long)pert);
+    return NODAL_OK;
+}
+
+// z ~= A^-1 r with the factorisation of the last slu_factor
+int slu_apply(nodal_ctx *h, const double *r, double *z) {
+    SluState *S = state_of(h);
+    if (!S || !S->have_numeric) return nodal_fail(h, NODAL_E_INVALID, "direct solve: no factorisation");
+    hipStream_t st = h->stream;
+    const int64_t n = S->n;
+    const Tree T = tree_of(S);
+    permute_rhs<<<grid_for(n), TB, 0, st>>>(n, S->rowof.as<int32_t>(), S->rs.as<double>(), r, S->xb.as<double>());
+    for (int32_t l = 0; l < S->nlev; ++l) {
+        const int32_t cnt = S->lvl_ptr[(size_t)l + 1] - S->lvl_ptr[(size_t)l];
+        const int32_t *sns = S->lvl_sn.as<int32_t>() + S->lvl_ptr[(size_t)l];
+        if (S->lvl_maxdim[(size_t)l] > 192)
+            forward_level<1024><<<cnt, 1024, 0, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(),
+                                                      S->xb.as<double>(), S->vec.as<double>());
+        else
+            forward_level<256><<<cnt, 256, 0, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(),
+                                                    S->xb.as<double>(), S->vec.as<double>());
+    }
+    for (int32_t l = S->nlev - 1; l >= 0; --l) {
+        const int32_t cnt = S->lvl_ptr[(size_t)l + 1] - S->lvl_ptr[(size_t)l];
+        const int32_t *sns = S->lvl_sn.as<int32_t>() + S->lvl_ptr[(size_t)l];
+        if (S->lvl_maxdim[(size_t)l] > 192)
+            backward_level<1024><<<cnt, 1024, 0, st>>>(T, sns, S->fronts.as<double>(), S->xb.as<double>(), S->vec.as<double>());
+        else
+            backward_level<256><<<cnt, 256, 0, st>>>(T, sns, S->fronts.as<double>(), S->xb.as<double>(), S->vec.as<double>());
+    }
+    unpermute_solution<<<grid_for(n), TB, 0, st>>>(n, S->colof.as<int32_t>(), S->cs.as<double>(), S->xb.as<double>(), z);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
+}
+
+// G x = b by the multifrontal LU + flexible GMRES refinement.  *info > 0: singular (structurally, or the
+// refinement does not converge on the statically pivoted factors): the caller fills NaNs, as the
+// reference's spsolve does (reference nodal/nodal.py:323-336: NaNs + MatrixRankWarning, no exception).
+int sparse_direct_solve(nodal_ctx *h, const double *b, double *x, int32_t *info, int32_t *iters, double *resid) {
+    *info = 0;
+    *iters = 0;
+    *resid = 0.0;
+    NODAL_TRY(slu_factor(h, info));
+    if (*info > 0) return NODAL_OK;
+    NODAL_TRY(general_krylov_direct(h, b, x, info, iters, resid));
+    SluState *S = state_of(h);
+    if (*info > 0 || S->perturbed == 0) return NODAL_OK;
+    // Pivots were replaced and the refinement converged all the same.  Either G is regular and the pivot it
+    // needed sat outside the fully summed rows of its front (the refinement has made up for it), or G is
+    // singular and the equations happen to be CONSISTENT -- then the answer is one of infinitely many
+    // solutions, where the reference's SuperLU meets the zero pivot (NaNs + MatrixRankWarning, reference
+    // nodal/nodal.py:323-336).  (Another replacement value does not tell them apart: for a consistent right-hand
+    // side the solution of the perturbed system does not depend on it to first order.)  A pseudo-random
+    // right-hand side does: a singular matrix makes it inconsistent and the refinement on the same factors
+    // stalls; a regular one solves it like any other.
+    const int64_t n = h->n;
+    NODAL_HIP_TRY(h, h->work2.reserve((size_t)n * 8 + 64));
+    NODAL_HIP_TRY(h, h->work3.reserve((size_t)n * 8 + 64));
+    hashed_rhs<<<grid_for(n), TB, 0, h->stream>>>(n, h->work2.as<double>());
+    NODAL_HIP_TRY(h, hipGetLastError());
+    int32_t info2 = 0, it2 = 0;
+    double rs2 = 0.0;
+    h->slu_strict = true;
+    const int s2 = general_krylov_direct(h, h->work2.as<double>(), h->work3.as<double>(), &info2, &it2, &rs2);
+    h->slu_strict = false;
+    NODAL_TRY(s2);
+    if (getenv("NODAL_TRACE"))
+        fprintf(stderr, "[direct] %lld replaced pivots: a pseudo-random right-hand side %s\n", (long long)S->perturbed,
+                info2 > 0 ? "does not refine: singular" : "is solved too: regular");
+    if (info2 > 0) *info = 1;
+    *iters += it2;
+    return NODAL_OK;
+}
