@@ -148,6 +148,7 @@ struct SHierarchy {
                                  // iterations on the 1e6-node grid too, but 16.9 instead of 14.9 ms.)
     bool dense_coarsest = true;  // last level: dense inverse; false: nothing but isolated nodes (diagonal)
     DevBuf tail_stamps, tail_image, apcol, apval, aplen, bstat;
+    DevBuf mvec;  // vectors, partials and scalars of the block iteration (sagg_multi.h)
     DevBuf stats, coarse_inv, mis_t, mis_m, mis_flag, mis_id, agg1, keys, rstart, cursor, lists;
     TailDesc td;
     uint64_t *host_stats = nullptr;  // pinned
@@ -188,6 +189,7 @@ struct SHierarchy {
             delete l;
         }
         tail_image.release();
+        mvec.release();
         tail_stamps.release();
         bstat.release();
         apcol.release();
@@ -1643,9 +1645,9 @@ int cycle(nodal_ctx *h, SHierarchy *H, int l, const double *b, const double *x0,
     SLevel *L = H->pool[l];
     const int64_t n = L->n;
     if (l == H->tail) {
-        if (H->td.slots <= 8) k_tail<8><<<1, 1024, (size_t)H->td.lds_bytes, st>>>(H->td, H->tail_image.as<char>(), b, out);
-        else if (H->td.slots <= 16) k_tail<16><<<1, 1024, (size_t)H->td.lds_bytes, st>>>(H->td, H->tail_image.as<char>(), b, out);
-        else k_tail<32><<<1, 1024, (size_t)H->td.lds_bytes, st>>>(H->td, H->tail_image.as<char>(), b, out);
+        if (H->td.slots <= 8) k_tail<8><<<1, 1024, (size_t)H->td.lds_bytes, st>>>(H->td, H->tail_image.as<char>(), b, out, 1);
+        else if (H->td.slots <= 16) k_tail<16><<<1, 1024, (size_t)H->td.lds_bytes, st>>>(H->td, H->tail_image.as<char>(), b, out, 1);
+        else k_tail<32><<<1, 1024, (size_t)H->td.lds_bytes, st>>>(H->td, H->tail_image.as<char>(), b, out, 1);
         NODAL_HIP_TRY(h, hipGetLastError());
         return NODAL_OK;
     }
@@ -1974,3 +1976,5 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     *info = 0;
     return NODAL_OK;
 }
+
+#include "sagg_multi.h"

@@ -438,9 +438,12 @@ __device__ __forceinline__ double reg_row(const double (&v)[SLOTS], const uint32
 // SLOTS >= ceil(width / lpr) of the first tail level (8, 16 or 32)
 template <int SLOTS>
 __global__ __launch_bounds__(1024) void k_tail(TailDesc d, const char *__restrict__ image,
-                                               const double *__restrict__ rc, double *__restrict__ out) {
+                                               const double *__restrict__ rc, double *__restrict__ out, int vs) {
+    // vs: stride of the vectors' elements; vs > 1 = a block of interleaved right-hand sides (sagg_multi.h), one
+    // workgroup per column
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
+    const int voff = vs > 1 ? (int)blockIdx.x : 0;
     const int last = d.nlev - 1;
     const int TAIL_NU = d.nu;
     // LDS holds the image from d.skip on (the first level's matrix, which leads the image, goes to
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(1024) void k_tail(TailDesc d, const char *__restric
         for (int u = 0; u < FLY; ++u)
             if (tid + u * 1024 < pieces) dst[tid + u * 1024] = v[u];
     }
-    for (int i = tid; i < d.lv[0].n; i += 1024) f64(d.lv[0].o_B)[i] = rc[i];
+    for (int i = tid; i < d.lv[0].n; i += 1024) f64(d.lv[0].o_B)[i] = rc[(int64_t)i * vs + voff];
     __syncthreads();
     stamp();
     // ---- down ----
@@ -602,7 +605,7 @@ __global__ __launch_bounds__(1024) void k_tail(TailDesc d, const char *__restric
         Ec = Y;  // the last sweep's result
         stamp();
     }
-    for (int i = tid; i < d.lv[0].n; i += 1024) out[i] = Ec[i];
+    for (int i = tid; i < d.lv[0].n; i += 1024) out[(int64_t)i * vs + voff] = Ec[i];
     stamp();
     if (d.stamps && tid == 0) d.stamps[63] = stamp_no;
 }

@@ -1,0 +1,602 @@
+// Block (multi-vector) flexible CG on the smoothed-aggregation hierarchy: MK right-hand sides per iteration.
+// (Third part of sagg.hip; included there, same translation unit.)
+//
+// Why: an equivalent-resistance sweep (reference nodal/equiv.py:31-61: one deepcopy + rebuild + solve per
+// node pair) changes only the right-hand side.  One hierarchy already served all pairs, but every pair still
+// paid for its own iterations -- and half of an iteration is the launch-latency floor of the coarse levels
+// (33 dependent launches of 4-7 us), the other half bandwidth-bound passes over level-0 matrices that are the
+// same for every pair.  Here MK = 16 pairs share every launch and every matrix read:
+//   * vectors are interleaved by row, element (i, y) at v[i * MK + y]: thread t of a row kernel owns row
+//     t / MK of column t % MK, so the 16 lanes of a row read each matrix entry ONCE (one address, one
+//     transaction) and gather 128 contiguous bytes of the vector block per neighbour;
+//   * every column has its own scalars -- alpha, beta, the K-cycle's coefficients, the convergence flag -- in
+//     the same parity-slot protocol as the single-vector iteration (sagg_cycle.h): the columns are independent
+//     Krylov processes that merely travel together; a converged column's updates are predicated off;
+//   * dot products leave per-workgroup partials laid out [quantity][block][column]; a one-workgroup-per-
+//     quantity kernel folds them in a fixed order (deterministic), the consumers read 16 totals;
+//   * the tail levels run in one launch of MK workgroups (k_tail, one column each).
+// The single-vector kernels of sagg_cycle.h are untouched: the headline path does not go through here.
+#pragma once
+
+namespace {
+
+constexpr int MK = 16;        // columns of a block
+constexpr int MK_SHIFT = 4;
+constexpr int MPARTS = 1024;  // workgroups that leave dot partials (grid cap of the level-0 kernels that do)
+
+// per-column sum over the workgroup of NQ quantities; result written to part[(q * nblocks_cap + block) * MK + y]
+template <int NQ>
+__device__ __forceinline__ void column_partials(double (&a)[NQ], double *__restrict__ part, int cap) {
+    __shared__ double ws[NQ][TB / 64][MK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        double v = a[q];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < MK) ws[q][wave][lane] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < MK) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < TB / 64; ++w) s += ws[q][w][threadIdx.x];
+            part[((int64_t)q * cap + blockIdx.x) * MK + threadIdx.x] = s;
+        }
+    }
+}
+
+// totals[q * MK + y] = sum over the blocks of part[(q * cap + block) * MK + y]; one workgroup per quantity
+__global__ __launch_bounds__(TB) void m_reduce(const double *__restrict__ part, int cap, int count,
+                                               double *__restrict__ totals) {
+    __shared__ double ws[TB / 64][MK];
+    const int q = blockIdx.x, y = threadIdx.x & (MK - 1), r = threadIdx.x >> MK_SHIFT;
+    const double *p = part + (int64_t)q * cap * MK;
+    double s = 0.0;
+    for (int k = r; k < count; k += TB / MK) s += p[(int64_t)k * MK + y];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if ((threadIdx.x & 63) < MK) ws[threadIdx.x >> 6][y] = s;
+    __syncthreads();
+    if (threadIdx.x < MK) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < TB / 64; ++w) t += ws[w][threadIdx.x];
+        totals[q * MK + threadIdx.x] = t;
+    }
+}
+
+inline unsigned mgrid(int64_t rows, unsigned cap = 65536) {  // one thread per (row, column)
+    int64_t g = (rows * MK + TB - 1) / TB;
+    if (g < 1) g = 1;
+    if (g >= 64) g = (g + 7) & ~(int64_t)7;
+    return (unsigned)(g > cap ? cap : g);
+}
+
+template <int W>
+__global__ __launch_bounds__(TB) void m_smooth_residual(Ell A, const double *__restrict__ b,
+                                                        const double *__restrict__ x0, double *__restrict__ r, bool f32) {
+    const int64_t total = A.n * MK;
+    for (int64_t t = (int64_t)xcd_block() * TB + threadIdx.x; t < total; t += (int64_t)gridDim.x * TB) {
+        const int64_t i = t >> MK_SHIFT;
+        const int y = (int)(t & (MK - 1));
+        const double s = f32 ? ell_row_w<W>(A, A.valf, i, 0, [&](int32_t j) { return x0[(int64_t)j * MK + y]; })
+                             : ell_row_w<W>(A, A.val, i, 0, [&](int32_t j) { return x0[(int64_t)j * MK + y]; });
+        r[t] = b[t] - s;
+    }
+}
+
+// rc = R r (one thread per coarse row and column; the 16 lanes of a row read every block of R once)
+__global__ __launch_bounds__(TB) void m_restrict(int64_t nc, int64_t rld, const int32_t *__restrict__ rcol,
+                                                 const float *__restrict__ rvalf, const double *__restrict__ rval,
+                                                 const int32_t *__restrict__ rlen, const double *__restrict__ r,
+                                                 double *__restrict__ rc, const double *__restrict__ cdinv,
+                                                 double *__restrict__ x0c) {
+    const int64_t total = nc * MK;
+    for (int64_t t = (int64_t)xcd_block() * TB + threadIdx.x; t < total; t += (int64_t)gridDim.x * TB) {
+        const int64_t I = t >> MK_SHIFT;
+        const int y = (int)(t & (MK - 1));
+        const int32_t len = rlen[I];
+        double s = 0.0;
+        for (int32_t q = 0; q * RL < len; ++q) {
+            const int64_t at = ((int64_t)q * rld + I) * RL;
+            int32_t c[RL];
+            double v[RL];
+#pragma unroll
+            for (int u = 0; u < RL; ++u) {
+                c[u] = rcol[at + u];
+                v[u] = rvalf ? (double)rvalf[at + u] : rval[at + u];
+            }
+#pragma unroll
+            for (int u = 0; u < RL; ++u) s = fma(v[u], r[(int64_t)c[u] * MK + y], s);
+        }
+        rc[t] = s;
+        if (x0c) x0c[t] = OMEGA * cdinv[I] * s;
+    }
+}
+
+// xp = x + P (s1 c1 + s2 c2) per column (coef: [MK][2]; nullptr: plain V hand-over)
+__global__ __launch_bounds__(TB) void m_prolong(int64_t n, int64_t ld, const int32_t *__restrict__ pcol,
+                                                const float *__restrict__ pvalf, const double *__restrict__ pval,
+                                                const double *__restrict__ x, const double *__restrict__ c1,
+                                                const double *__restrict__ c2, const double *__restrict__ coef,
+                                                double *__restrict__ xp) {
+    const int64_t total = n * MK;
+    for (int64_t t = (int64_t)xcd_block() * TB + threadIdx.x; t < total; t += (int64_t)gridDim.x * TB) {
+        const int64_t i = t >> MK_SHIFT;
+        const int y = (int)(t & (MK - 1));
+        const bool two = coef != nullptr;
+        const double s1 = two ? coef[y * 2] : 1.0, s2 = two ? coef[y * 2 + 1] : 0.0;
+        int32_t J[PW];
+        double w[PW];
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+            J[q] = pcol[(int64_t)q * ld + i];
+            w[q] = pvalf ? (double)pvalf[(int64_t)q * ld + i] : pval[(int64_t)q * ld + i];
+        }
+        double s = x[t];
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+            const int64_t j = (int64_t)(J[q] < 0 ? 0 : J[q]) * MK + y;
+            const double e = two ? s1 * c1[j] + s2 * c2[j] : c1[j];
+            s = fma(J[q] < 0 ? 0.0 : w[q], e, s);
+        }
+        xp[t] = s;
+    }
+}
+
+// out = xp + w D^-1 (b - A xp); DOTS: per-column partials of out.b and out.u
+template <int W, bool DOTS>
+__global__ __launch_bounds__(TB) void m_post(Ell A, const double *__restrict__ dinv, const double *__restrict__ b,
+                                             const double *__restrict__ xp, double *__restrict__ out,
+                                             const double *__restrict__ u, double *__restrict__ part, int cap,
+                                             bool f32) {
+    double a[2] = {0.0, 0.0};
+    const int64_t total = A.n * MK;
+    for (int64_t t = (int64_t)xcd_block() * TB + threadIdx.x; t < total; t += (int64_t)gridDim.x * TB) {
+        const int64_t i = t >> MK_SHIFT;
+        const int y = (int)(t & (MK - 1));
+        const double s = f32 ? ell_row_w<W>(A, A.valf, i, 0, [&](int32_t j) { return xp[(int64_t)j * MK + y]; })
+                             : ell_row_w<W>(A, A.val, i, 0, [&](int32_t j) { return xp[(int64_t)j * MK + y]; });
+        const double bi = b[t];
+        const double o = fma(OMEGA * dinv[i], bi - s, xp[t]);
+        out[t] = o;
+        if (DOTS) {
+            a[0] = fma(o, bi, a[0]);
+            a[1] = fma(o, u[t], a[1]);
+        }
+    }
+    if (DOTS) column_partials<2>(a, part, cap);
+}
+
+// v = A c and the per-column partials c.v, c.u1, c.u2 (u2 may be null)
+template <int W>
+__global__ __launch_bounds__(TB) void m_spmv_dots(Ell A, const double *__restrict__ c, double *__restrict__ v,
+                                                  const double *__restrict__ u1, const double *__restrict__ u2,
+                                                  double *__restrict__ part, int cap, bool f32) {
+    double a[3] = {0.0, 0.0, 0.0};
+    const int64_t total = A.n * MK;
+    for (int64_t t = (int64_t)xcd_block() * TB + threadIdx.x; t < total; t += (int64_t)gridDim.x * TB) {
+        const int64_t i = t >> MK_SHIFT;
+        const int y = (int)(t & (MK - 1));
+        const double s = f32 ? ell_row_w<W>(A, A.valf, i, 0, [&](int32_t j) { return c[(int64_t)j * MK + y]; })
+                             : ell_row_w<W>(A, A.val, i, 0, [&](int32_t j) { return c[(int64_t)j * MK + y]; });
+        v[t] = s;
+        const double ci = c[t];
+        a[0] = fma(ci, s, a[0]);
+        a[1] = fma(ci, u1[t], a[1]);
+        if (u2) a[2] = fma(ci, u2[t], a[2]);
+    }
+    column_partials<3>(a, part, cap);
+}
+
+// r2 = rc - (alpha1 / rho1) v1 per column; tot: [0] rho1 = c1.v1, [1] alpha1 = c1.rc
+__global__ __launch_bounds__(TB) void m_second_residual(int64_t n, const double *__restrict__ rc,
+                                                        const double *__restrict__ v1, const double *__restrict__ tot,
+                                                        double *__restrict__ r2, const double *__restrict__ dinv,
+                                                        double *__restrict__ x0) {
+    const int64_t total = n * MK;
+    for (int64_t t = (int64_t)xcd_block() * TB + threadIdx.x; t < total; t += (int64_t)gridDim.x * TB) {
+        const int y = (int)(t & (MK - 1));
+        const double rho1 = tot[y], alpha1 = tot[MK + y];
+        const double tt = rho1 > 0.0 ? alpha1 / rho1 : 0.0;
+        const double v = fma(-tt, v1[t], rc[t]);
+        r2[t] = v;
+        x0[t] = OMEGA * dinv[t >> MK_SHIFT] * v;
+    }
+}
+
+// K-cycle coefficients per column from the totals: first [rho1, alpha1, -] then second [beta, gamma, alpha2]
+__global__ void m_kcoef(const double *__restrict__ tot1, const double *__restrict__ tot2, double *__restrict__ coef) {
+    const int y = threadIdx.x;
+    if (y >= MK) return;
+    const double rho1 = tot1[y], alpha1 = tot1[MK + y];
+    const double beta = tot2[y], gamma = tot2[MK + y], alpha2 = tot2[2 * MK + y];
+    double s1 = 0.0, s2 = 0.0;
+    if (rho1 > 0.0) {
+        const double rho2 = beta - gamma * gamma / rho1;
+        if (rho2 > 0.0) {
+            s1 = alpha1 / rho1 - gamma * alpha2 / (rho1 * rho2);
+            s2 = alpha2 / rho2;
+        } else {
+            s1 = alpha1 / rho1;
+        }
+    }
+    coef[y * 2] = s1;
+    coef[y * 2 + 1] = s2;
+}
+
+__global__ __launch_bounds__(TB) void m_coarsest(int64_t n, const double *__restrict__ inv,
+                                                 const double *__restrict__ dinv, const double *__restrict__ b,
+                                                 double *__restrict__ out) {
+    const int64_t total = n * MK;
+    for (int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x; t < total; t += (int64_t)gridDim.x * TB) {
+        const int64_t i = t >> MK_SHIFT;
+        const int y = (int)(t & (MK - 1));
+        double s = 0.0;
+        if (inv)
+            for (int64_t j = 0; j < n; ++j) s = fma(inv[i * n + j], b[j * MK + y], s);
+        else
+            s = dinv[i] * b[t];
+        out[t] = s;
+    }
+}
+
+// ---- the outer iteration, per column ---------------------------------------------------------------
+// sc: [MK][F_COUNT] (the single-vector iteration's scalar block per column, same parity protocol)
+
+__global__ void m_set_scalars(double *__restrict__ sc, double tol2) {
+    const int y = threadIdx.x;
+    if (y >= MK) return;
+    for (int k = 0; k < F_COUNT; ++k) sc[y * F_COUNT + k] = 0.0;
+    sc[y * F_COUNT + F_TOL2] = tol2;
+}
+
+// b_y = e(ia[y]) - e(ib[y]) (a 1 A probe enters ia and leaves ib, reference nodal/models.py:27-32; -1 = ground)
+__global__ __launch_bounds__(TB) void m_init(int64_t n, const int32_t *__restrict__ ia, const int32_t *__restrict__ ib,
+                                             double *__restrict__ x, double *__restrict__ r, double *__restrict__ Ap,
+                                             const double *__restrict__ dinv, double *__restrict__ x0,
+                                             double *__restrict__ part, int cap) {
+    double a[1] = {0.0};
+    const int64_t total = n * MK;
+    for (int64_t t = (int64_t)xcd_block() * TB + threadIdx.x; t < total; t += (int64_t)gridDim.x * TB) {
+        const int64_t i = t >> MK_SHIFT;
+        const int y = (int)(t & (MK - 1));
+        const double ri = ((int64_t)ia[y] == i ? 1.0 : 0.0) - ((int64_t)ib[y] == i ? 1.0 : 0.0);
+        x[t] = 0.0;
+        r[t] = ri;
+        x0[t] = OMEGA * dinv[i] * ri;
+        Ap[t] = 0.0;
+        a[0] = fma(ri, ri, a[0]);
+    }
+    column_partials<1>(a, part, cap);
+}
+
+// tot: [0] z.r, [1] z.Ap, [2] r.r per column
+__global__ __launch_bounds__(TB) void m_direction(const double *__restrict__ z, double *__restrict__ p,
+                                                  const double *__restrict__ tot, double *__restrict__ scs, int parity,
+                                                  int64_t n) {
+    const int cur = parity & 1, prev = cur ^ 1;
+    const int y = threadIdx.x & (MK - 1);
+    double *sc = scs + y * F_COUNT;
+    const int iter = (int)sc[F_ITNO + prev];
+    const bool writer = blockIdx.x == 0 && threadIdx.x < MK;
+    const bool was_done = iter > 0 && sc[F_CONV + prev] != 0.0;
+    const double rz_new = tot[y], zap = tot[MK + y], rr = tot[2 * MK + y];
+    const double rz_old = iter > 0 ? sc[F_RZ + prev] : 1.0;
+    const double beta = (iter > 0 && rz_old != 0.0) ? -sc[F_ALPHA + prev] * zap / rz_old : 0.0;
+    const double bb = iter == 0 ? rr : sc[F_BB];
+    const bool bad = !(rz_new >= 0.0) || !(rr == rr);
+    const bool converged = was_done || bb == 0.0 || rr <= sc[F_TOL2] * bb || bad;
+    __syncthreads();  // (block 0: every lane has read the previous parity's words before the writers go on)
+    if (writer) {
+        sc[F_ITNO + cur] = (double)(iter + 1);
+        if (was_done) {
+            sc[F_CONV + cur] = 1.0;
+        } else {
+            sc[F_RZ + cur] = rz_new;
+            sc[F_RR] = rr;
+            if (iter == 0) sc[F_BB] = rr;
+            if (bad) sc[F_FLAG] = 1.0;
+            sc[F_CONV + cur] = converged ? 1.0 : 0.0;
+            if (converged) sc[F_ITERS] = (double)iter;
+        }
+    }
+    if (converged) return;  // (per column: the lanes of the other columns go on)
+    const int64_t total = n * MK;
+    // (a thread's column is fixed: the stride of the loop is a multiple of MK)
+    for (int64_t t = (int64_t)xcd_block() * TB + threadIdx.x; t < total; t += (int64_t)gridDim.x * TB)
+        p[t] = iter > 0 ? fma(beta, p[t], z[t]) : z[t];
+}
+
+template <int W>
+__global__ __launch_bounds__(TB) void m_spmv(Ell A, const double *__restrict__ p, double *__restrict__ Ap,
+                                             double *__restrict__ part, int cap, const double *__restrict__ scs,
+                                             int iter) {
+    double a[1] = {0.0};
+    const int yy = threadIdx.x & (MK - 1);
+    const bool done = scs[yy * F_COUNT + F_CONV + (iter & 1)] != 0.0;
+    const int64_t total = A.n * MK;
+    if (!done)
+        for (int64_t t = (int64_t)xcd_block() * TB + threadIdx.x; t < total; t += (int64_t)gridDim.x * TB) {
+            const int64_t i = t >> MK_SHIFT;
+            const double s = ell_row_w<W>(A, A.val, i, 0, [&](int32_t j) { return p[(int64_t)j * MK + yy]; });
+            Ap[t] = s;
+            a[0] = fma(p[t], s, a[0]);
+        }
+    column_partials<1>(a, part, cap);
+}
+
+// tot_pap: p.Ap per column
+__global__ __launch_bounds__(TB) void m_update(double *__restrict__ x, double *__restrict__ r,
+                                               const double *__restrict__ p, const double *__restrict__ Ap,
+                                               const double *__restrict__ tot_pap, const double *__restrict__ dinv,
+                                               double *__restrict__ x0, double *__restrict__ part, int cap,
+                                               double *__restrict__ scs, int iter, int64_t n) {
+    const int cur = iter & 1;
+    const int y = threadIdx.x & (MK - 1);
+    double *sc = scs + y * F_COUNT;
+    const bool done = sc[F_CONV + cur] != 0.0;
+    const double pap = tot_pap[y];
+    const double rz = sc[F_RZ + cur];
+    const bool bad = !(pap > 0.0) && rz != 0.0;
+    const double alpha = (pap > 0.0) ? rz / pap : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x < MK && !done) {
+        sc[F_ALPHA + cur] = alpha;
+        if (bad) sc[F_FLAG] = 1.0;
+    }
+    double a[1] = {0.0};
+    const int64_t total = n * MK;
+    for (int64_t t = (int64_t)xcd_block() * TB + threadIdx.x; t < total; t += (int64_t)gridDim.x * TB) {
+        double ri = r[t];
+        if (!done) {
+            x[t] = fma(alpha, p[t], x[t]);
+            ri = fma(-alpha, Ap[t], ri);
+            r[t] = ri;
+            x0[t] = OMEGA * dinv[t >> MK_SHIFT] * ri;
+        }
+        a[0] = fma(ri, ri, a[0]);
+    }
+    column_partials<1>(a, part, cap);
+}
+
+// res[q0 + y] = x_y[ia] - x_y[ib]
+__global__ void m_read_pairs(int count, const int32_t *__restrict__ ia, const int32_t *__restrict__ ib,
+                             const double *__restrict__ x, double *__restrict__ res) {
+    const int y = threadIdx.x;
+    if (y >= count) return;
+    const double ea = ia[y] >= 0 ? x[(int64_t)ia[y] * MK + y] : 0.0;
+    const double eb = ib[y] >= 0 ? x[(int64_t)ib[y] * MK + y] : 0.0;
+    res[y] = ea - eb;
+}
+
+// ---- buffers and the cycle -----------------------------------------------------------------------------
+struct MLevel {
+    double *vec = nullptr;   // V_COUNT vectors of ld * MK doubles
+    double *part = nullptr;  // K-cycle partials: 2 x [3][DOT cap][MK]
+    double *tot = nullptr;   // 2 x [3][MK] totals + [MK][2] coefficients
+    int64_t ld = 0;
+    double *v(int which) const { return vec + (int64_t)which * ld * MK; }
+};
+struct MBufs {
+    MLevel lv[MAX_LEVELS];
+    double *x, *r, *z, *p, *Ap, *x0;  // n * MK each
+    double *part;                      // [3][MPARTS][MK]: z.r, z.Ap | r.r ; and [1][MPARTS][MK] p.Ap behind
+    double *tot;                       // [4][MK]
+    double *sc;                        // [MK][F_COUNT]
+    int32_t *ia, *ib;
+    int g0;
+};
+constexpr int MDOT = 1024;  // partial blocks of the K-cycle level's dot kernels
+
+int m_cycle(nodal_ctx *h, SHierarchy *H, const MBufs &M, int l, const double *b, const double *x0, double *out,
+            bool outer) {
+    hipStream_t st = h->stream;
+    SLevel *L = H->pool[l];
+    const int64_t n = L->n;
+    if (l == H->tail) {
+        // one workgroup per column; vectors strided by MK
+        if (H->td.slots <= 8) k_tail<8><<<MK, 1024, (size_t)H->td.lds_bytes, st>>>(H->td, H->tail_image.as<char>(), b, out, MK);
+        else if (H->td.slots <= 16) k_tail<16><<<MK, 1024, (size_t)H->td.lds_bytes, st>>>(H->td, H->tail_image.as<char>(), b, out, MK);
+        else k_tail<32><<<MK, 1024, (size_t)H->td.lds_bytes, st>>>(H->td, H->tail_image.as<char>(), b, out, MK);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        return NODAL_OK;
+    }
+    if (l == H->nlev - 1) {
+        m_coarsest<<<mgrid(n), TB, 0, st>>>(n, H->dense_coarsest ? H->coarse_inv.as<double>() : nullptr,
+                                            L->dinv.as<double>(), b, out);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        return NODAL_OK;
+    }
+    SLevel *C = H->pool[l + 1];
+    const int64_t nc = C->n;
+    const Ell A = L->A();
+    const bool f32 = L->avalf.p != nullptr;  // (levels outside the tail carry f32 copies of A, P, R)
+    const double *dinv = L->dinv.as<double>();
+    const MLevel &ML = M.lv[l], &MC = M.lv[l + 1];
+    const double *x = x0;
+    double *r = ML.v(V_R), *xp = ML.v(V_XP);
+    double *rc = MC.v(V_RC), *c1 = MC.v(V_C1), *c2 = MC.v(V_C2);
+    const unsigned g = mgrid(n);                                  // kernels without dot partials: as wide as the rows
+    const unsigned gp = outer ? (unsigned)M.g0 : mgrid(n);        // the one that leaves them
+    const int nu = H->nu[l < 2 ? l : 2];
+    // (levels whose rows are ragged -- wfix == 0 -- take the W = 0 instantiation like the single-vector kernels)
+    if (nu >= 2) {
+        double *x1 = ML.v(V_X1);
+        SAGG_DISPATCH_W(L->wfix, (m_post<W, false><<<g, TB, 0, st>>>(A, dinv, b, x0, x1, nullptr, nullptr, 0, f32)));
+        x = x1;
+    }
+    SAGG_DISPATCH_W(L->wfix, (m_smooth_residual<W><<<g, TB, 0, st>>>(A, b, x, r, f32)));
+    double *x0c = MC.v(V_X);
+    m_restrict<<<mgrid(nc), TB, 0, st>>>(nc, L->rld, L->rcol.as<int32_t>(), f32 ? L->rvalf.as<float>() : nullptr, L->rval.as<double>(),
+                                         L->rlen.as<int32_t>(), r, rc, C->dinv.as<double>(), x0c);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    const bool kcycle = l < H->klevels && H->kcycle && l + 1 != H->tail && l + 1 != H->nlev - 1;
+    const double *coef = nullptr;
+    if (kcycle) {
+        double *v1 = MC.v(V_V1), *v2 = MC.v(V_V2), *r2 = MC.v(V_R2);
+        const Ell Ac = C->A();
+        const bool cf32 = C->avalf.p != nullptr;
+        const unsigned gd = mgrid(nc, MDOT);
+        double *part1 = MC.part, *part2 = MC.part + (int64_t)3 * MDOT * MK;
+        double *tot1 = MC.tot, *tot2 = MC.tot + 3 * MK, *cf = MC.tot + 6 * MK;
+        NODAL_TRY(m_cycle(h, H, M, l + 1, rc, x0c, c1, false));
+        // [0] c1.v1 (rho1), [1] c1.rc (alpha1)
+        SAGG_DISPATCH_W(C->wfix, (m_spmv_dots<W><<<gd, TB, 0, st>>>(Ac, c1, v1, rc, nullptr, part1, MDOT, cf32)));
+        m_reduce<<<2, TB, 0, st>>>(part1, MDOT, (int)gd, tot1);
+        m_second_residual<<<mgrid(nc), TB, 0, st>>>(nc, rc, v1, tot1, r2, C->dinv.as<double>(), x0c);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        NODAL_TRY(m_cycle(h, H, M, l + 1, r2, x0c, c2, false));
+        // [0] c2.v2 (beta), [1] c2.v1 (gamma), [2] c2.r2 (alpha2)
+        SAGG_DISPATCH_W(C->wfix, (m_spmv_dots<W><<<gd, TB, 0, st>>>(Ac, c2, v2, v1, r2, part2, MDOT, cf32)));
+        m_reduce<<<3, TB, 0, st>>>(part2, MDOT, (int)gd, tot2);
+        m_kcoef<<<1, 64, 0, st>>>(tot1, tot2, cf);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        coef = cf;
+    } else {
+        NODAL_TRY(m_cycle(h, H, M, l + 1, rc, x0c, c1, false));
+    }
+    m_prolong<<<mgrid(n), TB, 0, st>>>(n, L->ld, L->pcol.as<int32_t>(), f32 ? L->pvalf.as<float>() : nullptr, L->pval.as<double>(), x, c1,
+                                      c2, coef, xp);
+    const double *cur = xp;
+    if (nu >= 2) {
+        double *mid = ML.v(V_T);
+        SAGG_DISPATCH_W(L->wfix, (m_post<W, false><<<g, TB, 0, st>>>(A, dinv, b, cur, mid, nullptr, nullptr, 0, f32)));
+        cur = mid;
+    }
+    if (outer) {
+        SAGG_DISPATCH_W(L->wfix, (m_post<W, true><<<gp, TB, 0, st>>>(A, dinv, b, cur, out, M.Ap, M.part, MPARTS, f32)));
+    } else {
+        SAGG_DISPATCH_W(L->wfix, (m_post<W, false><<<g, TB, 0, st>>>(A, dinv, b, cur, out, nullptr, nullptr, 0, f32)));
+    }
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
+}
+
+}  // namespace
+
+// Pairs [0, count), count <= MK, on the hierarchy of the last setup: res_dev[q] = e(ia[q]) - e(ib[q]) for a
+// 1 A probe.  Return NODAL_OK (all columns converged), -1 breakdown / no convergence (the caller falls back
+// to the single-vector iteration and what stands behind it), > 0 a status.
+int sagg_fcg_solve_pairs_block(nodal_ctx *h, int32_t count, const int32_t *ia_host, const int32_t *ib_host,
+                               double *res_dev, int32_t *iters) {
+    const bool trace = getenv("NODAL_TRACE") != nullptr;  // (per call: tests switch it on for one sweep)
+    SHierarchy *H = hierarchy_of(h);
+    const int64_t n = h->n;
+    hipStream_t st = h->stream;
+    if (!H->ready || H->pool[0]->n != n || count < 1 || count > MK) return -1;
+    // ---- buffers: one allocation in the hierarchy, grown on demand ----
+    size_t bytes = 0;
+    auto take = [&](size_t b) { const size_t at = bytes; bytes += (b + 255) & ~(size_t)255; return at; };
+    size_t o_vec[MAX_LEVELS], o_part[MAX_LEVELS], o_tot[MAX_LEVELS];
+    const int last_outside = H->tail >= 0 ? H->tail : H->nlev - 1;  // levels [0, last_outside] hold vectors
+    for (int l = 0; l <= last_outside && l < H->nlev; ++l) {
+        o_vec[l] = take((size_t)V_COUNT * H->pool[l]->ld * MK * 8);
+        o_part[l] = take((size_t)6 * MDOT * MK * 8);
+        o_tot[l] = take((size_t)8 * MK * 8);
+    }
+    const size_t o_outer = take((size_t)6 * n * MK * 8 + 6 * 256);
+    const size_t o_opart = take((size_t)4 * MPARTS * MK * 8);
+    const size_t o_otot = take((size_t)4 * MK * 8);
+    const size_t o_sc = take((size_t)MK * F_COUNT * 8);
+    const size_t o_pairs = take((size_t)2 * MK * 4);
+    NODAL_HIP_TRY(h, H->mvec.reserve(bytes + 256));
+    char *base = H->mvec.as<char>();
+    MBufs M;
+    for (int l = 0; l <= last_outside && l < H->nlev; ++l) {
+        M.lv[l].vec = reinterpret_cast<double *>(base + o_vec[l]);
+        M.lv[l].part = reinterpret_cast<double *>(base + o_part[l]);
+        M.lv[l].tot = reinterpret_cast<double *>(base + o_tot[l]);
+        M.lv[l].ld = H->pool[l]->ld;
+    }
+    const int64_t nv = (n * MK + 31) & ~(int64_t)31;
+    double *ov = reinterpret_cast<double *>(base + o_outer);
+    M.x = ov; M.r = ov + nv; M.z = ov + 2 * nv; M.p = ov + 3 * nv; M.Ap = ov + 4 * nv; M.x0 = ov + 5 * nv;
+    M.part = reinterpret_cast<double *>(base + o_opart);
+    M.tot = reinterpret_cast<double *>(base + o_otot);
+    M.sc = reinterpret_cast<double *>(base + o_sc);
+    M.ia = reinterpret_cast<int32_t *>(base + o_pairs);
+    M.ib = M.ia + MK;
+    M.g0 = (int)mgrid(n, MPARTS);
+    // pairs: unused columns get the pair (-1, -1): a zero right-hand side, converged at once
+    int32_t pairs[2 * MK];
+    for (int y = 0; y < MK; ++y) {
+        pairs[y] = y < count ? ia_host[y] : -1;
+        pairs[MK + y] = y < count ? ib_host[y] : -1;
+    }
+    int32_t *pin = static_cast<int32_t *>(nodal_pinned(h));
+    if (pin) memcpy(pin, pairs, sizeof pairs);
+    NODAL_HIP_TRY(h, hipMemcpyAsync(M.ia, pin ? pin : pairs, sizeof pairs, hipMemcpyHostToDevice, st));
+    if (!pin) NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+
+    const SLevel *L0 = H->pool[0];
+    const Ell A0 = L0->A();
+    const double *dinv0 = L0->dinv.as<double>();
+    const double tol = 1e-13;
+    double *part_rr = M.part + (int64_t)2 * MPARTS * MK, *part_pap = M.part + (int64_t)3 * MPARTS * MK;
+    m_set_scalars<<<1, 64, 0, st>>>(M.sc, tol * tol);
+    m_init<<<M.g0, TB, 0, st>>>(n, M.ia, M.ib, M.x, M.r, M.Ap, dinv0, M.x0, part_rr, MPARTS);
+    NODAL_HIP_TRY(h, hipGetLastError());
+
+    auto iteration = [&](int it) -> int {
+        NODAL_TRY(m_cycle(h, H, M, 0, M.r, M.x0, M.z, true));  // leaves z.r, z.Ap partials in part[0..1]
+        m_reduce<<<3, TB, 0, st>>>(M.part, MPARTS, M.g0, M.tot);  // [0] z.r [1] z.Ap [2] r.r
+        m_direction<<<M.g0, TB, 0, st>>>(M.z, M.p, M.tot, M.sc, it & 1, n);
+        SAGG_DISPATCH_W(L0->wfix, (m_spmv<W><<<M.g0, TB, 0, st>>>(A0, M.p, M.Ap, part_pap, MPARTS, M.sc, it & 1)));
+        m_reduce<<<1, TB, 0, st>>>(part_pap, MPARTS, M.g0, M.tot + 3 * MK);
+        m_update<<<M.g0, TB, 0, st>>>(M.x, M.r, M.p, M.Ap, M.tot + 3 * MK, dinv0, M.x0, part_rr, MPARTS, M.sc, it & 1, n);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        return NODAL_OK;
+    };
+    const int64_t maxit = getenv("NODAL_FCG_MAXIT") ? atoll(getenv("NODAL_FCG_MAXIT")) : 2000;
+    double hs[MK * F_COUNT];
+    int64_t enqueued = 0;
+    int batch = H->last_iters > 6 ? (H->last_iters + 1 > 40 ? 40 : H->last_iters + 1) : 8;
+    int status = 0, polls = 0;
+    double worst_prev = -1.0;
+    int64_t it_prev = 0;
+    while (status == 0) {
+        for (int c = 0; c < batch; ++c, ++enqueued) NODAL_TRY(iteration((int)enqueued));
+        NODAL_TRY(nodal_read_words(h, hs, M.sc, sizeof hs));
+        ++polls;
+        bool all = true, flag = false;
+        double worst = 0.0;  // largest |r|^2 / (tol^2 |b|^2) among the running columns
+        for (int y = 0; y < MK; ++y) {
+            const double *s = hs + y * F_COUNT;
+            const bool conv = s[F_CONV + ((enqueued - 1) & 1)] != 0.0;
+            flag = flag || s[F_FLAG] != 0.0 || !(s[F_RR] == s[F_RR]);
+            if (!conv) {
+                all = false;
+                if (s[F_BB] > 0.0) worst = std::max(worst, s[F_RR] / (tol * tol * s[F_BB]));
+            }
+        }
+        if (flag) status = 2;
+        else if (all) status = 1;
+        else if (enqueued >= maxit) status = 3;
+        else {
+            int next = 2;
+            if (worst_prev > 0.0 && worst > 0.0 && worst < worst_prev && enqueued > it_prev) {
+                const double rate = log(worst / worst_prev) / (double)(enqueued - it_prev);  // < 0
+                next = (int)floor(0.75 * log(1.0 / worst) / rate);
+            } else if (worst_prev <= 0.0) {
+                next = (int)enqueued;
+            }
+            if (next > enqueued) next = (int)enqueued;
+            batch = next < 1 ? 1 : (next > 32 ? 32 : next);
+            worst_prev = worst;
+            it_prev = enqueued;
+        }
+    }
+    int its = 0;
+    for (int y = 0; y < count; ++y) its = std::max(its, (int)hs[y * F_COUNT + F_ITERS]);
+    if (iters) *iters = its;
+    if (trace)
+        fprintf(stderr, "[sagg] block of %d pairs: %d iterations (%lld enqueued, %d polls), status %d\n", count, its,
+                (long long)enqueued, polls, status);
+    if (status != 1) return -1;
+    m_read_pairs<<<1, 64, 0, st>>>(count, M.ia, M.ib, M.x, res_dev);
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
+}

@@ -686,7 +686,22 @@ int sparse_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const in
         }
         direct = true;
     }
-    for (int32_t q = 0; q < npairs; ++q) {
+    const bool block_allowed = !(getenv("NODAL_PAIRS_BLOCK") && atoi(getenv("NODAL_PAIRS_BLOCK")) == 0);
+    for (int32_t q = 0; q < npairs;) {
+        // Once the first pair has set the smoothed-aggregation hierarchy up, the others go sixteen at a time
+        // through the block iteration (sagg_multi.h: one launch sequence and one pass over every matrix per block
+        // instead of per pair).  A block that breaks down is redone pair by pair below.
+        if (!direct && block_allowed && q > 0 && sagg_ready(h, n) && npairs - q >= 2) {
+            const int32_t cnt = npairs - q < 16 ? npairs - q : 16;
+            int32_t it = 0;
+            const int s = sagg_fcg_solve_pairs_block(h, cnt, ia + q, ib + q, res_dev + q, &it);
+            if (s == NODAL_OK) {
+                h->last_iterations = it;
+                q += cnt;
+                continue;
+            }
+            if (s > 0) return s;
+        }
         NODAL_HIP_TRY(h, hipMemsetAsync(b, 0, (size_t)n * 8, st));
         pair_rhs<<<1, 1, 0, st>>>(b, ia[q], ib[q]);
         int32_t it = 0, inf = 0;
@@ -717,6 +732,7 @@ int sparse_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const in
         }
         h->last_iterations = it;
         pair_read<<<1, 1, 0, st>>>(h->x.as<double>(), ia[q], ib[q], res_dev + q);
+        ++q;
     }
     NODAL_HIP_TRY(h, hipGetLastError());
     return NODAL_OK;

@@ -2,6 +2,7 @@
 command line entry (reference nodal/equiv.py:22-85)."""
 
 import argparse
+import os
 import sys
 from copy import deepcopy
 
@@ -17,7 +18,10 @@ parser.add_argument("-s", "--sparse", action="store_true", help="use a sparse ma
 
 
 # sparse sweeps of at least this many pairs over more than this many unknowns run on several device contexts
-SWEEP_LANES = 3
+SWEEP_LANES = 1  # device contexts a long sparse sweep is spread over.  1 since round 4: the block iteration
+                 # (csrc/sagg_multi.h, sixteen pairs per launch sequence on ONE hierarchy) beats three contexts with a
+                 # hierarchy each -- 192 pairs on the 1e6-node grid: 0.54 s against 0.66 s, 40 pairs at 5.8e4 nodes: 22
+                 # against ~70 ms.  NODAL_SWEEP_LANES=3 brings the lanes back (tests keep them exercised).
 SWEEP_LANES_MIN_PAIRS = 12
 SWEEP_LANES_MIN_UNKNOWNS = 50_000
 
@@ -75,7 +79,7 @@ def equivalent_resistance_sweep(netlist, pairs, sparse=False):
     circuit = n.Circuit(netlist, sparse=sparse)
     lanes = 1
     if sparse and len(ia) >= SWEEP_LANES_MIN_PAIRS and circuit._handle.n > SWEEP_LANES_MIN_UNKNOWNS:
-        lanes = SWEEP_LANES
+        lanes = int(os.environ.get("NODAL_SWEEP_LANES", SWEEP_LANES))
     if lanes == 1:
         res, info = circuit._handle.solve_pairs(ia, ib, dense=not sparse)
     else:

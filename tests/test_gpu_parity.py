@@ -621,18 +621,30 @@ def test_equivalent_resistance_sweep_matches_the_oracle(N, sparse):
         equiv.equivalent_resistance_sweep(nl, [("1", "nope")], sparse=sparse)
 
 
-def test_long_sparse_resistance_sweep_over_several_device_contexts():
-    """A sweep of many pairs over a large network is spread over three device contexts (one host thread
-    each): same resistances as one factorisation of the oracle's matrix gives, in the pairs' order."""
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_long_sparse_resistance_sweep_block_iteration_and_device_contexts(lanes, monkeypatch, capfd):
+    """A sweep of many pairs over a large network (reference nodal/equiv.py:31-61: one rebuild + solve per pair).
+    lanes = 1 (default): after the first pair the others go sixteen at a time through the block iteration on
+    one hierarchy (csrc/sagg_multi.h); lanes = 3: spread over three device contexts, one host thread each
+    (round 3's form).  Same resistances as one factorisation of the oracle's matrix gives, in the pairs' order."""
     import scipy.sparse.linalg as spla
+    monkeypatch.setenv("NODAL_SWEEP_LANES", str(lanes))
+    monkeypatch.setenv("NODAL_TRACE", "1")
     N = 240
     nl = n.Netlist.from_rows(list(gen.grid_rows(N))[:-1])
     table = lower(nl)
     assert table.K > equiv.SWEEP_LANES_MIN_UNKNOWNS
     rng = random.Random(4)
     labels = list(nl.nodenum) + ["g"]
-    pairs = [("1", "g")] + [tuple(rng.sample(labels, 2)) for _ in range(equiv.SWEEP_LANES_MIN_PAIRS + 7)]
+    pairs = [("1", "g")] + [tuple(rng.sample(labels, 2)) for _ in range(equiv.SWEEP_LANES_MIN_PAIRS + 30)]
+    pairs[5] = (pairs[5][0], pairs[5][0])  # a pair of one node: resistance 0, a zero right-hand side in its block
+    capfd.readouterr()
     got = equiv.equivalent_resistance_sweep(nl, pairs, sparse=True)
+    err = capfd.readouterr().err
+    if lanes == 1:  # 43 pairs: the first alone, then 16 + 16 + 10
+        assert "block of 16 pairs" in err and "block of 10 pairs" in err, err[-600:]
+    else:
+        assert "block of" in err, err[-600:]
     Go, _ = oracle.assemble_fast(table)
     lu = spla.splu(Go.tocsc())
     for (a, b), r in zip(pairs, got):
@@ -643,8 +655,32 @@ def test_long_sparse_resistance_sweep_over_several_device_contexts():
             rhs[nl.nodenum[b]] -= 1.0
         x = lu.solve(rhs)
         want = (0.0 if a == "g" else x[nl.nodenum[a]]) - (0.0 if b == "g" else x[nl.nodenum[b]])
-        assert abs(r - want) <= 1e-9 * abs(want), (a, b, r, want)
+        assert abs(r - want) <= 1e-9 * max(abs(want), 1e-12), (a, b, r, want)
+    assert got[5] == 0.0
     assert abs(got[0] - 7.06) < 0.05  # (corner to corner of a 240 x 240 grid: between N = 100's 5.94 and 316's 7.41)
+
+
+def test_block_iteration_matches_one_solve_per_pair(monkeypatch):
+    """The same sweep with and without the block iteration (NODAL_PAIRS_BLOCK=0): the columns of a block are
+    independent Krylov processes with their own alpha / beta / convergence flags, so every pair must come out
+    as converged as a solve of its own."""
+    table = gen.grid_table(150)
+    rng = np.random.RandomState(9)
+    ia = rng.randint(0, table.K, size=37).astype(np.int32)
+    ib = rng.randint(-1, table.K, size=37).astype(np.int32)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NODAL_PAIRS_BLOCK", mode)
+        h = _ffi.Handle(0)
+        h.upload(table)
+        h.assemble_symbolic()
+        assert h.assemble_numeric()[0] == _ffi.OK
+        out[mode], info = h.solve_pairs(ia, ib, dense=False)
+        assert info == 0
+        h.close()
+    same = ia == ib
+    assert np.all(out["1"][same] == 0.0)
+    assert np.abs(out["1"] - out["0"]).max() <= 1e-11 * np.abs(out["0"]).max()
 
 
 def test_reference_resistance_tests_exact():
