@@ -157,6 +157,17 @@ def solve_members(table, values, sparse=True, device=0, solver=None, session=Non
         return s.solve(values, sparse)
 
 
+def local_device_index(rank):
+    """The HIP device of this rank: LOCAL_RANK (torchrun) or the rank, modulo the devices VISIBLE to the
+    process -- a launcher that gives every rank one visible device (ROCR_VISIBLE_DEVICES per rank) makes that
+    device 0 for all of them."""
+    import os
+    import torch
+    count = torch.cuda.device_count()
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    return local % count if count > 0 else 0
+
+
 class ShardedBatch:
     """This rank's shard of a value sweep, kept across steps: the one entry the benchmark
     (`bench.py` config 4), `solve_batch_distributed` and the tests share.
@@ -170,9 +181,11 @@ class ShardedBatch:
     solver: there is no GPU in the build container).  `force_collective` runs the gather even with a
     single rank (the RCCL path on a one-GPU box)."""
 
-    def __init__(self, table, total, dist=None, device=None, solver=None, force_collective=False):
+    def __init__(self, table, total, dist=None, device=None, solver=None, force_collective=False, session=None,
+                 sparse=True):
         import torch
         self.table, self.total, self.dist, self.solver = table, total, dist, solver
+        self.sparse = sparse
         grouped = dist is not None and dist.is_initialized()
         self.rank = dist.get_rank() if grouped else 0
         self.world = dist.get_world_size() if grouped else 1
@@ -180,9 +193,14 @@ class ShardedBatch:
         self.lo, self.hi = shard_range(total, self.rank, self.world)
         self.width = -(-total // self.world) if total else 0  # all_gather needs equal blocks
         on_gpu = solver is None
-        dev_index = device if device is not None else (self.rank if self.backend == "nccl" else 0)
-        self.dev = torch.device("cuda", dev_index) if (on_gpu or self.backend == "nccl") else torch.device("cpu")
-        self.session = BatchSolver(table, dev_index) if on_gpu else None
+        needs_gpu = on_gpu or self.backend == "nccl"
+        if session is not None:
+            dev_index = session.device
+        else:
+            dev_index = device if device is not None else (local_device_index(self.rank) if needs_gpu else 0)
+        self.dev = torch.device("cuda", dev_index) if needs_gpu else torch.device("cpu")
+        self._own_session = on_gpu and session is None
+        self.session = (session if session is not None else BatchSolver(table, dev_index)) if on_gpu else None
         # short shards are padded with NaN rows (written once: a step only rewrites the members)
         self.block = torch.full((self.width, table.n), float("nan"), dtype=torch.float64, device=self.dev)
         collective = grouped and (self.world > 1 or force_collective)
@@ -200,9 +218,9 @@ class ShardedBatch:
             torch.cuda.current_stream(self.dev).synchronize()
 
     def close(self):
-        if self.session is not None:
+        if self.session is not None and self._own_session:
             self.session.close()
-            self.session = None
+        self.session = None
 
     def __enter__(self):
         return self
@@ -222,12 +240,16 @@ class ShardedBatch:
         import time
         import torch
         if self.hi > self.lo:
-            if self.session is not None:
+            if self.session is not None and self.sparse:
                 self.session.run(sparse=True, reuse_symbolic=reuse_symbolic, download=False)
                 self._sync_torch()
                 self.session.copy_to_device(self.block)  # returns once the copy has finished
+            elif self.session is not None:  # dense members: one factorisation each, this rank's shard only
+                mine = self.session.run(sparse=False)
+                self._sync_torch()
+                self.block[: self.hi - self.lo] = torch.from_numpy(np.ascontiguousarray(mine)).to(self.dev)
             else:
-                mine = self.solver(self.table, self.values, True)
+                mine = self.solver(self.table, self.values, self.sparse)
                 self.block[: self.hi - self.lo] = torch.from_numpy(np.ascontiguousarray(mine)).to(self.dev)
         if self.gathered is not None:
             t0 = time.perf_counter()
@@ -260,9 +282,9 @@ def solve_batch_distributed(table, values, sparse=True, device=None, solver=None
                             session=None):
     """Every rank passes the same `table` and the full `values`; each solves its
     shard and all ranks return the gathered [members, n] array."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1 or not sparse:
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return solve_members(table, values, sparse, device or 0, solver, session)
-    with ShardedBatch(table, values.shape[0], dist, device, solver) as shard:
+    with ShardedBatch(table, values.shape[0], dist, device, solver, session=session, sparse=sparse) as shard:
         shard.upload(values[shard.lo:shard.hi])
         shard.step()
         return shard.result()

@@ -14,6 +14,7 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 STUBBORN = "stubborn" in sys.argv[3:]
 SIZES = [12000, 25000] if "large" in sys.argv[3:] else [5, 17, 60, 200, 700, 1500, 3000, 6000]
 bad = 0
+distances = []
 t0 = time.time()
 for seed in range(first, first + count):
     rng = random.Random(seed)
@@ -60,18 +61,23 @@ for seed in range(first, first + count):
                 continue
             xo, warns = oracle.solve(Go, Ao, sparse)
             x = circ.solve().result
-            if np.isfinite(xo).all() and nodes <= 3000 and np.linalg.cond(G) < 1e8:
+            if np.isfinite(xo).all():
+                # the 1e-9 bar holds where the problem allows it (kappa eps << 1e-9); beyond that the reference's
+                # own two solvers stop agreeing to 1e-9 and the bar is 1e-7 -- a miss of
+                # EITHER bar is a failure, and the distance is kept for the campaign's summary
+                cond = np.linalg.cond(G) if nodes <= 3000 else float("nan")  # (dense cond of a 6000-node G: minutes)
+                strict = nodes <= 3000 and cond < 1e8
                 err = normwise(x, xo)
-                if not err <= TOL:
-                    print(f"seed {seed} nodes {nodes} sparse {sparse}: x differs, {err:.2e}")
+                distances.append((err, nodes, sparse, cond, seed))
+                if not err <= (TOL if strict else 1e-7):
+                    print(f"seed {seed} nodes {nodes} sparse {sparse}: x differs, {err:.2e} (bar {TOL if strict else 1e-7:g}, cond {cond:.2e})")
                     bad += 1
-            elif np.isfinite(xo).all():
-                err = normwise(x, xo)
-                if not err <= 1e-7:
-                    print(f"seed {seed} nodes {nodes} sparse {sparse}: x differs (size / conditioning beyond the bar), {err:.2e}")
         except Exception as e:  # noqa: BLE001
             print(f"seed {seed} nodes {nodes} sparse {sparse}: {type(e).__name__}: {str(e)[:200]}")
             bad += 1
     if (seed - first) % 20 == 19 or "large" in sys.argv[3:]:
         print(f"... {seed - first + 1} netlists, {bad} failures, {time.time() - t0:.0f} s", flush=True)
-print(f"{count} netlists from seed {first}: {bad} failures")
+big = sorted(d for d in distances if not (d[1] <= 3000 and d[3] < 1e8))
+print(f"{count} netlists from seed {first}: {bad} failures; {len(distances)} solutions compared, "
+      f"{len(big)} of them on the 1e-7 bar (large or ill-conditioned): worst "
+      + ", ".join(f"{d[0]:.1e} (n {d[1]}, {'sparse' if d[2] else 'dense'}, cond {d[3]:.1e}, seed {d[4]})" for d in big[-3:][::-1]))

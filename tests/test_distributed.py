@@ -116,6 +116,58 @@ def test_two_rank_sharded_batch_steps(members):
         assert np.array_equal(own, want[lo:hi])
 
 
+def _uneven_worker(rank, world, port, members, sparse, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    table = gen.grid_table(4)
+    vals = np.ones((members, table.ncomp))
+    for b in range(members):
+        vals[b, :-1] = gen.cfg4_values(b, 4)
+    out = batch.solve_batch_distributed(table, vals, sparse, solver=oracle_solver, dist=dist)
+    lo, hi = batch.shard_range(members, rank, world)
+    q.put((rank, (lo, hi), np.array_equal(out, oracle_solver(table, vals, sparse)), out.shape))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,members,sparse", [(3, 1024, True), (8, 1024, True), (8, 5, True), (3, 7, False)])
+def test_uneven_shards_pad_and_reassemble(world, members, sparse):
+    """BASELINE config 4's 1024 members over 3 ranks (342 / 341 / 341: the all_gather needs equal blocks, short
+    shards are padded), over the 8 ranks of a node, fewer members than ranks (three ranks hold nothing), and the
+    dense switch -- which shards like the sparse one since round 4.  gloo on CPU with the oracle as the solver."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, members, sparse, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    spans = sorted(g[1] for g in got)
+    assert spans[0][0] == 0 and spans[-1][1] == members
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    for _rank, _span, same, shape in got:
+        assert same and shape[0] == members
+
+
+def test_local_device_index_wraps_to_the_visible_devices(monkeypatch):
+    """A launcher that makes one device visible per rank: LOCAL_RANK 5 must select device 0 of 1."""
+    import torch
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert batch.local_device_index(5) == 0
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    assert batch.local_device_index(5) == 5
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)
+    assert batch.local_device_index(5) == 0
+
+
 def test_single_process_sharded_batch_without_group():
     """No process group: one shard holding everything, no collective."""
     table = gen.grid_table(5)

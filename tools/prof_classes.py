@@ -12,14 +12,14 @@ level-0 passes: rows x bytes per row of what the kernel reads and writes (DESIGN
 import glob, json, sqlite3, sys
 
 
-def main():
-    path, workload, n, nnz = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+def classify(path, workload, n, nnz, verbose=False):
+    """Classes of kernels of one rocprofv3 --kernel-trace results.db (a directory is searched for it)."""
     dbs = glob.glob(path + "/**/*.db", recursive=True) if not path.endswith(".db") else [path]
     c = sqlite3.connect(dbs[0])
     tables = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
     kt = "kernels" if "kernels" in tables else [t for t in tables if "kernel" in t.lower()][0]
     cols = [r[1] for r in c.execute(f"pragma table_info({kt})")]
-    if "--columns" in sys.argv:
+    if verbose:
         print(kt, cols, file=sys.stderr)
     gcol = next((x for x in ("grid_size_x", "grid_x", "grid_size") if x in cols), None)
     wcol = next((x for x in ("workgroup_size_x", "workgroup_x", "workgroup_size") if x in cols), None)
@@ -75,7 +75,9 @@ def main():
                                        base in ("f_spmv", "f_direction", "f_update", "f_init")):
             add("level0_passes", dur, level0_bytes[base] * n)
         elif base.startswith("k_") or base.startswith("f_"):
-            add("coarse_levels", dur)
+            # (a coarse level's row kernel: one thread per row; 64 B per row is what a 5-to-16-entry f32 ELL row plus
+            # its vectors comes to -- an estimate, the class is latency-bound whatever the bytes)
+            add("coarse_levels", dur, 64.0 * (grid if gcol else 0))
         else:
             add("other", dur)
     out_classes = {}
@@ -92,7 +94,12 @@ def main():
                                              "avg_us": top[1][1] / top[1][0] / 1e3},
                       "by_class": out_classes, "total_kernel_ms": total / 1e6,
                       "source": "rocprofv3 --kernel-trace of bench.py --workload %s" % workload}}
-    print(json.dumps(res, indent=1))
+    return res
+
+
+def main():
+    path, workload, n, nnz = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    print(json.dumps(classify(path, workload, n, nnz, "--columns" in sys.argv), indent=1))
 
 
 if __name__ == "__main__":
