@@ -59,6 +59,12 @@ struct SluState {
     int32_t max_dim = 0;
     std::vector<int32_t> lvl_ptr;  // [nlev + 1] into d_lvl_sn
     std::vector<int32_t> lvl_maxdim;
+    // fronts wider than BIG_DIM are factored by a sequence of launches per front (big_front below): inside
+    // every level's list they come last, lvl_small[l] = how many of the level's fronts take the batched kernel
+    std::vector<int32_t> lvl_small, lvl_maxchildren, lvl_maxdim_all;
+    std::vector<int32_t> h_lvl_sn, h_start, h_dim;   // host copies: level lists, first pivot column, front width
+    std::vector<int64_t> h_front_off;
+    DevBuf bigpiv;                                     // pivot rows of the panel in flight
     // device copies of the symbolic part
     DevBuf rowof, colof, newrow;   // permuted position -> original row / column; original row -> position
     DevBuf sn_start, struct_ptr, struct_idx, front_off, vec_off, lvl_sn, child_ptr, child_idx, cmap, dest;
@@ -267,6 +273,168 @@ __global__ __launch_bounds__(BS) void factor_fronts(Tree T, const int32_t *__res
     }
 }
 
+// ---- fronts wider than BIG_DIM: one front, many workgroups ------------------------------------------------
+// A 1500-wide front holds 7e8 of the factorisation's flops and ONE workgroup needed 30-90 ms for it (a 2944-wide
+// front of a binary tree: 1.5 s).  Such fronts are factored panel by panel from the host: a single-workgroup
+// panel kernel (NBB columns, the same pivoting among the fully summed rows), the panel's interchanges applied to
+// the rest of the front, the U block row by a triangular solve over the columns, and the trailing update
+// A22 -= L21 U12 by the fp64 MFMA GEMM of gemm_f64.hip -- the one place of the sparse path where the matrix cores
+// have work (north_star: MFMA where G is dense enough to be a panel factorisation).
+constexpr int BIG_DIM = 512;
+constexpr int NBB = 64;  // (64: the panel kernel -- one CU's bandwidth -- 694 us and the triangular solve 375 us per panel, its 64 values per thread spilling)
+
+__global__ __launch_bounds__(256) void iota_i32(int32_t *__restrict__ p, int n) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = i;
+}
+
+// columns [k0, k0 + nb) of the front, rows k0 .. dim-1: right-looking within the panel, pivot rows among
+// k .. s-1 recorded in piv[0 .. nb) (rows are interchanged inside the panel only: apply_swaps does the rest)
+__global__ __launch_bounds__(1024) void panel_factor(double *__restrict__ F, int dim, int s, int k0, int nb,
+                                                     int32_t *__restrict__ piv, double tiny, double repl,
+                                                     unsigned long long *__restrict__ stats) {
+    constexpr int BS = 1024, NW = BS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ double red_v[NW];
+    __shared__ int red_i[NW];
+    __shared__ int piv_row;
+    const int jend = k0 + nb;
+    for (int k = k0; k < jend; ++k) {
+        double best = -1.0;
+        int bi = k;
+        for (int i = k + tid; i < s; i += BS) {
+            const double v = fabs(F[i + (int64_t)k * dim]);
+            if (v > best) { best = v; bi = i; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_down(best, off, 64);
+            const int oi = __shfl_down(bi, off, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { red_v[wave] = best; red_i[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            double bv = red_v[0];
+            int br = red_i[0];
+            for (int w = 1; w < NW; ++w)
+                if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < br)) { bv = red_v[w]; br = red_i[w]; }
+            const double d = F[k + (int64_t)k * dim];
+            if (!(bv >= tiny)) {
+                F[k + (int64_t)k * dim] = d < 0.0 ? -repl : repl;
+                br = k;
+                atomicAdd(stats, 1ull);
+            } else if (fabs(d) >= 0.25 * bv) {
+                br = k;
+            }
+            piv_row = br;
+            piv[k - k0] = br;
+        }
+        __syncthreads();
+        const int p = piv_row;
+        if (p != k) {
+            for (int j = k0 + tid; j < jend; j += BS) {
+                const double a = F[k + (int64_t)j * dim], b2 = F[p + (int64_t)j * dim];
+                F[k + (int64_t)j * dim] = b2;
+                F[p + (int64_t)j * dim] = a;
+            }
+            __syncthreads();
+        }
+        const double rp = 1.0 / F[k + (int64_t)k * dim];
+        for (int i = k + 1 + tid; i < dim; i += BS) {
+            const double l = F[i + (int64_t)k * dim] * rp;
+            F[i + (int64_t)k * dim] = l;
+            for (int j = k + 1; j < jend; ++j) F[i + (int64_t)j * dim] = fma(-l, F[k + (int64_t)j * dim], F[i + (int64_t)j * dim]);
+        }
+        __syncthreads();
+    }
+}
+
+// the panel's interchanges on the columns outside it (one thread per column, the nb swaps in order), and on
+// the front's row permutation (one extra thread)
+__global__ __launch_bounds__(256) void apply_swaps(double *__restrict__ F, int dim, int k0, int nb,
+                                                   const int32_t *__restrict__ piv, int32_t *__restrict__ perm) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int outside = dim - nb;
+    if (t < outside) {
+        const int j = t < k0 ? t : t + nb;
+        double *col = F + (int64_t)j * dim;
+        for (int q = 0; q < nb; ++q) {
+            const int p = piv[q];
+            if (p != k0 + q) {
+                const double a = col[k0 + q];
+                col[k0 + q] = col[p];
+                col[p] = a;
+            }
+        }
+    } else if (t == outside) {
+        for (int q = 0; q < nb; ++q) {
+            const int p = piv[q];
+            if (p != k0 + q) {
+                const int32_t a = perm[k0 + q];
+                perm[k0 + q] = perm[p];
+                perm[p] = a;
+            }
+        }
+    }
+}
+
+// U12 = L11^-1 A12: rows k0 .. k0+nb-1 of the columns j >= k0 + nb (one thread per column; L11 unit lower, in LDS).
+// Sixteen rows at a time in registers, the rows above them re-read from the thread's own column: the same code
+// for every panel width.  (A version templated on the width with the whole column of the panel in registers
+// gave wrong values for the width 32 -- and only that one -- with this toolchain; measured, not understood.)
+__global__ __launch_bounds__(256) void trsm_u12(double *__restrict__ F, int dim, int k0, int nb) {
+    __shared__ double Ls[NBB][NBB + 1];
+    for (int idx = threadIdx.x; idx < nb * nb; idx += 256) {
+        const int r = idx % nb, q = idx / nb;
+        Ls[r][q] = F[(k0 + r) + (int64_t)(k0 + q) * dim];
+    }
+    __syncthreads();
+    const int j = k0 + nb + blockIdx.x * 256 + threadIdx.x;
+    if (j >= dim) return;
+    double *col = F + (int64_t)j * dim + k0;
+    for (int rb = 0; rb < nb; rb += 16) {
+        double u[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = rb + r < nb ? col[rb + r] : 0.0;
+        for (int q = 0; q < rb; ++q) {  // the rows already solved
+            const double uq = col[q];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (rb + r < nb) u[r] = fma(-Ls[rb + r][q], uq, u[r]);
+        }
+#pragma unroll
+        for (int r = 1; r < 16; ++r)
+#pragma unroll
+            for (int q = 0; q < r; ++q)
+                if (rb + r < nb) u[r] = fma(-Ls[rb + r][rb + q], u[q], u[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (rb + r < nb) col[rb + r] = u[r];
+    }
+}
+
+// child number `ordinal` of every parent of the list: its Schur complement into the parent's front, columns
+// over blockIdx.y (children of one parent are added by successive launches: a fixed order, no two writers)
+__global__ __launch_bounds__(256) void extend_add_child(Tree T, const int32_t *__restrict__ sns, int ordinal,
+                                                        double *__restrict__ fronts) {
+    const int32_t p = sns[blockIdx.x];
+    const int32_t q = T.child_ptr[p] + ordinal;
+    if (q >= T.child_ptr[p + 1]) return;
+    const int32_t c = T.child_idx[q];
+    const int64_t pdim = (T.sn_start[p + 1] - T.sn_start[p]) + (T.struct_ptr[p + 1] - T.struct_ptr[p]);
+    const int32_t s = T.sn_start[c + 1] - T.sn_start[c];
+    const int64_t b = T.struct_ptr[c + 1] - T.struct_ptr[c];
+    const int64_t cdim = s + b;
+    double *P = fronts + T.front_off[p];
+    const double *C = fronts + T.front_off[c];
+    const int32_t *map = T.cmap + T.struct_ptr[c];
+    for (int64_t j = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6); j < b; j += (int64_t)gridDim.y * 4) {
+        const int64_t pj = (int64_t)map[j] * pdim;
+        const double *col = C + (s + j) * cdim + s;
+        for (int64_t i = threadIdx.x & 63; i < b; i += 64) P[pj + map[i]] += col[i];
+    }
+}
+
 // a fixed pseudo-random vector in [-1, 1) (the second opinion of sparse_direct_solve)
 __global__ __launch_bounds__(TB) void hashed_rhs(int64_t n, double *__restrict__ b) {
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
@@ -404,7 +572,7 @@ void slu_destroy(nodal_ctx *h) {
     if (!S) return;
     DevBuf *bufs[] = {&S->rowof, &S->colof, &S->newrow, &S->sn_start, &S->struct_ptr, &S->struct_idx, &S->front_off,
                       &S->vec_off, &S->lvl_sn, &S->child_ptr, &S->child_idx, &S->cmap, &S->dest, &S->fronts,
-                      &S->vec, &S->lperm, &S->rs, &S->cs, &S->xb, &S->stats};
+                      &S->vec, &S->lperm, &S->rs, &S->cs, &S->xb, &S->stats, &S->bigpiv};
     for (DevBuf *b : bufs) b->release();
     delete S;
     h->slu = nullptr;
@@ -448,6 +616,31 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
         S->max_dim = sym.max_dim;
         S->lvl_ptr = sym.lvl_ptr;
         S->lvl_maxdim = sym.lvl_maxdim;
+        S->lvl_maxdim_all = sym.lvl_maxdim;  // (substitution kernels walk ALL fronts of a level)
+        {   // inside every level: the fronts of the batched kernel first, the wide ones last
+            const int32_t nsn = S->nsn;
+            S->h_start.assign(sym.sn_start.begin(), sym.sn_start.end());
+            S->h_front_off = sym.front_off;
+            S->h_dim.resize((size_t)nsn);
+            for (int32_t t = 0; t < nsn; ++t)
+                S->h_dim[(size_t)t] = (int32_t)((sym.sn_start[(size_t)t + 1] - sym.sn_start[(size_t)t]) +
+                                                (sym.struct_ptr[(size_t)t + 1] - sym.struct_ptr[(size_t)t]));
+            S->lvl_small.assign((size_t)S->nlev, 0);
+            S->lvl_maxchildren.assign((size_t)S->nlev, 0);
+            for (int32_t l = 0; l < S->nlev; ++l) {
+                auto b = sym.lvl_sn.begin() + sym.lvl_ptr[(size_t)l], e = sym.lvl_sn.begin() + sym.lvl_ptr[(size_t)l + 1];
+                auto mid = std::stable_partition(b, e, [&](int32_t t) { return S->h_dim[(size_t)t] <= BIG_DIM; });
+                S->lvl_small[(size_t)l] = (int32_t)(mid - b);
+                int32_t small_max = 0;
+                for (auto it = b; it != e; ++it) {
+                    if (it < mid) small_max = std::max(small_max, S->h_dim[(size_t)*it]);
+                    S->lvl_maxchildren[(size_t)l] = std::max(S->lvl_maxchildren[(size_t)l],
+                                                            sym.child_ptr[(size_t)*it + 1] - sym.child_ptr[(size_t)*it]);
+                }
+                S->lvl_maxdim[(size_t)l] = small_max;  // (of the batched kernel's fronts: selects its block size)
+            }
+            S->h_lvl_sn = sym.lvl_sn;
+        }
         // memory the fronts may take: half of what is free on the device (NODAL_DIRECT_MAX_GB overrides)
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
@@ -467,7 +660,7 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
         NODAL_TRY(upload_vec(h, S->struct_idx, sym.struct_idx));
         NODAL_TRY(upload_vec(h, S->front_off, sym.front_off));
         NODAL_TRY(upload_vec(h, S->vec_off, sym.vec_off));
-        NODAL_TRY(upload_vec(h, S->lvl_sn, sym.lvl_sn));
+        NODAL_TRY(upload_vec(h, S->lvl_sn, S->h_lvl_sn));
         NODAL_TRY(upload_vec(h, S->child_ptr, sym.child_ptr));
         NODAL_TRY(upload_vec(h, S->child_idx, sym.child_idx));
         NODAL_TRY(upload_vec(h, S->cmap, sym.cmap));
@@ -506,27 +699,67 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
     const Tree T = tree_of(S);
     // after the equilibration every row and column has max-norm <= 1: the static-pivot bound is sqrt(eps)
     const double tiny = 1.4901161193847656e-08, repl = tiny * tiny_factor;
+    NODAL_HIP_TRY(h, S->bigpiv.reserve(NBB * 4 + 64));
+    // columns per panel of the wide fronts: 16 measured best (config 5 at 1e6 unknowns, analysis kept: 210 / 230 /
+    // 270 / 260 ms for 16 / 32 / 48 / 64 -- the single-workgroup panel kernel is what a wider panel makes longer);
+    // NODAL_DIRECT_NB = 16 / 32 / 48 / 64
+    int panel_nb = 16;
+    if (const char *e = getenv("NODAL_DIRECT_NB")) {
+        const int v = atoi(e);
+        if (v == 16 || v == 32 || v == 48 || v == 64) panel_nb = v;
+    }
+    int64_t big_fronts = 0;
     for (int32_t l = 0; l < S->nlev; ++l) {
         const int32_t cnt = S->lvl_ptr[(size_t)l + 1] - S->lvl_ptr[(size_t)l];
+        const int32_t nsmall = S->lvl_small[(size_t)l], nbig = cnt - nsmall;
         const int32_t *sns = S->lvl_sn.as<int32_t>() + S->lvl_ptr[(size_t)l];
-        const bool big = S->lvl_maxdim[(size_t)l] > 192;
-        if (l > 0) {
-            if (big) extend_add<1024><<<cnt, 1024, 0, st>>>(T, sns, S->fronts.as<double>());
-            else extend_add<256><<<cnt, 256, 0, st>>>(T, sns, S->fronts.as<double>());
+        const bool wide = S->lvl_maxdim[(size_t)l] > 192;
+        if (l > 0 && nsmall > 0) {
+            if (wide) extend_add<1024><<<nsmall, 1024, 0, st>>>(T, sns, S->fronts.as<double>());
+            else extend_add<256><<<nsmall, 256, 0, st>>>(T, sns, S->fronts.as<double>());
         }
-        if (big) factor_fronts<1024><<<cnt, 1024, 0, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl,
-                                                          S->stats.as<unsigned long long>());
-        else factor_fronts<256><<<cnt, 256, 0, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl,
-                                                    S->stats.as<unsigned long long>());
+        if (l > 0 && nbig > 0)  // wide parents: one launch per child ordinal, columns over the grid's second dimension
+            for (int32_t o = 0; o < S->lvl_maxchildren[(size_t)l]; ++o)
+                extend_add_child<<<dim3((unsigned)nbig, 64), 256, 0, st>>>(T, sns + nsmall, o, S->fronts.as<double>());
+        if (nsmall > 0) {
+            if (wide) factor_fronts<1024><<<nsmall, 1024, 0, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl,
+                                                                  S->stats.as<unsigned long long>());
+            else factor_fronts<256><<<nsmall, 256, 0, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl,
+                                                            S->stats.as<unsigned long long>());
+        }
         NODAL_HIP_TRY(h, hipGetLastError());
+        for (int32_t q = 0; q < nbig; ++q) {  // wide fronts: panel by panel (see big-front kernels above)
+            const int32_t t = S->h_lvl_sn[(size_t)S->lvl_ptr[(size_t)l] + nsmall + q];
+            const int dim = S->h_dim[(size_t)t], start = S->h_start[(size_t)t], sz = S->h_start[(size_t)t + 1] - start;
+            double *F = S->fronts.as<double>() + S->h_front_off[(size_t)t];
+            int32_t *perm = S->lperm.as<int32_t>() + start;
+            int32_t *piv = S->bigpiv.as<int32_t>();
+            iota_i32<<<(unsigned)((sz + 255) / 256), 256, 0, st>>>(perm, sz);
+            for (int k0 = 0; k0 < sz; k0 += panel_nb) {
+                const int nb = sz - k0 < panel_nb ? sz - k0 : panel_nb;
+                panel_factor<<<1, 1024, 0, st>>>(F, dim, sz, k0, nb, piv, tiny, repl, S->stats.as<unsigned long long>());
+                apply_swaps<<<(unsigned)((dim - nb + 1 + 255) / 256), 256, 0, st>>>(F, dim, k0, nb, piv, perm);
+                const int rest = dim - k0 - nb;
+                if (rest > 0) {
+                    const unsigned gt = (unsigned)((rest + 255) / 256);
+                    trsm_u12<<<gt, 256, 0, st>>>(F, dim, k0, nb);
+                    NODAL_HIP_TRY(h, hipGetLastError());
+                    NODAL_TRY(gemm_sub_f64(h, st, F + (k0 + nb) + (int64_t)(k0 + nb) * dim, dim, F + (k0 + nb) + (int64_t)k0 * dim,
+                                           dim, F + k0 + (int64_t)(k0 + nb) * dim, dim, rest, rest, nb));
+                }
+            }
+            NODAL_HIP_TRY(h, hipGetLastError());
+            ++big_fronts;
+        }
     }
     unsigned long long pert = 0;
     NODAL_TRY(nodal_read_words(h, &pert, S->stats.p, 8));
     S->perturbed = (int64_t)pert;
     S->have_numeric = true;
     if (trace)
-        fprintf(stderr, "[direct] analysis %.1f ms (%s), numeric factorisation %.1f ms, %lld perturbed pivots\n", t_sym,
-                t_sym < 0.5 ? "kept" : "new", ms_since(t0) - t_sym, (long long)pert);
+        fprintf(stderr, "[direct] analysis %.1f ms (%s), numeric factorisation %.1f ms (%lld fronts wider than %d panel by "
+                        "panel), %lld perturbed pivots\n", t_sym, t_sym < 0.5 ? "kept" : "new", ms_since(t0) - t_sym,
+                (long long)big_fronts, BIG_DIM, (long long)pert);
     return NODAL_OK;
 }
 
@@ -541,7 +774,7 @@ int slu_apply(nodal_ctx *h, const double *r, double *z) {
     for (int32_t l = 0; l < S->nlev; ++l) {
         const int32_t cnt = S->lvl_ptr[(size_t)l + 1] - S->lvl_ptr[(size_t)l];
         const int32_t *sns = S->lvl_sn.as<int32_t>() + S->lvl_ptr[(size_t)l];
-        if (S->lvl_maxdim[(size_t)l] > 192)
+        if (S->lvl_maxdim_all[(size_t)l] > 192)
             forward_level<1024><<<cnt, 1024, 0, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(),
                                                       S->xb.as<double>(), S->vec.as<double>());
         else
@@ -551,7 +784,7 @@ int slu_apply(nodal_ctx *h, const double *r, double *z) {
     for (int32_t l = S->nlev - 1; l >= 0; --l) {
         const int32_t cnt = S->lvl_ptr[(size_t)l + 1] - S->lvl_ptr[(size_t)l];
         const int32_t *sns = S->lvl_sn.as<int32_t>() + S->lvl_ptr[(size_t)l];
-        if (S->lvl_maxdim[(size_t)l] > 192)
+        if (S->lvl_maxdim_all[(size_t)l] > 192)
             backward_level<1024><<<cnt, 1024, 0, st>>>(T, sns, S->fronts.as<double>(), S->xb.as<double>(), S->vec.as<double>());
         else
             backward_level<256><<<cnt, 256, 0, st>>>(T, sns, S->fronts.as<double>(), S->xb.as<double>(), S->vec.as<double>());

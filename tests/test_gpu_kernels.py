@@ -8,7 +8,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("M,N,K", [(16, 16, 4), (128, 128, 16), (130, 70, 32), (257, 300, 128),
-                                   (1000, 513, 256), (64, 1, 20), (3, 5, 7)])
+                                   (1000, 513, 256), (64, 1, 20), (3, 5, 7),
+                                   # the 128 x 128 tile kernel (M N > 512 K) with few K chunks: the trailing updates of
+                                   # the sparse direct route's wide fronts (sparse_direct.hip: K = panel width)
+                                   (1000, 600, 16), (1000, 600, 32), (1100, 900, 48), (1500, 1400, 64), (900, 800, 20)])
 def test_mfma_f64_gemm(M, N, K):
     """fp64 MFMA fragment layout and edge handling, against numpy in fp64.
     Asymmetric integer-valued data makes any row/col or k-order mix-up exact."""
