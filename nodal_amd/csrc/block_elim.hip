@@ -711,12 +711,19 @@ int dense_block_elimination(nodal_ctx *h, double *A, int64_t n, int64_t lda, int
     {
         int64_t sw = 5632;
         if (const char *e = getenv("NODAL_BI_SWITCH")) sw = atoll(e);
+        // below sw2 rows left the chain of small kernels is far longer than the bulk update: 128-wide blocks need
+        // ONE Gauss-Jordan inversion each instead of the 2 x 2 Schur formula's two inversions + four products
+        int64_t sw2 = 0;
+        if (const char *e = getenv("NODAL_BI_SWITCH2")) sw2 = atoll(e);
         int forced = 0;
-        if (const char *e = getenv("NODAL_BI_WIDTH")) forced = atoi(e) == 512 ? 512 : 256;
+        if (const char *e = getenv("NODAL_BI_WIDTH")) {
+            const int v = atoi(e);
+            forced = v == 512 ? 512 : (v == 128 ? 128 : 256);
+        }
         bnd.push_back(0);
         for (int64_t j = 0; j < n;) {
             const int64_t left = n - j;
-            const int64_t wb = forced ? forced : (left > sw + 512 ? 512 : W);
+            const int64_t wb = forced ? forced : (left > sw + 512 ? 512 : (left <= sw2 ? 128 : W));
             j = j + wb < n ? j + wb : n;
             bnd.push_back(j);
         }

@@ -201,6 +201,65 @@ __global__ __launch_bounds__(TB) void fold_matrix(Table tb, const double *__rest
     }
 }
 
+// The same fold in the shape north_star describes: a workgroup owns FOLD_EPB consecutive CSR entries, i.e. ONE
+// contiguous range of the contribution list (the lists are in entry order).  Its lanes stream that range --
+// coalesced 4-byte reads of `contrib`, then the component's record (type, value, the driver's value: consecutive
+// contributions name components that sit close together in the table) --, evaluate the stamp and stage value +
+// semantics in LDS; after a barrier lane e folds the run of entry e FROM LDS, in list order, with the reference's
+// `+=` / `=` / assert semantics: the same operations in the same order as fold_matrix, so the same bits (the two
+// are cross-checked, tests/test_gpu_parity.py), but every gather of a workgroup is in flight at once instead of
+// one dependent chain per entry.  Ranges beyond FOLD_CAP contributions (a hub node's diagonal) are walked in
+// chunks; a lane keeps its running value across them.
+constexpr int FOLD_EPB = 256;   // entries per workgroup (one per lane)
+constexpr int FOLD_CAP = 2048;  // staged contributions per chunk (18 KB of LDS)
+__global__ __launch_bounds__(TB) void fold_matrix_stream(Table tb, const double *__restrict__ value,
+                                                         const int32_t *__restrict__ cptr,
+                                                         const uint32_t *__restrict__ contrib,
+                                                         double *__restrict__ data, int64_t nnz,
+                                                         unsigned long long *__restrict__ status) {
+    __shared__ double sval[FOLD_CAP];
+    __shared__ uint8_t sflag[FOLD_CAP];  // F_SET | F_ASSERT0
+    const int64_t nblocks = (nnz + FOLD_EPB - 1) / FOLD_EPB;
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const int64_t e0 = blk * FOLD_EPB;
+        const int64_t e1 = e0 + FOLD_EPB < nnz ? e0 + FOLD_EPB : nnz;
+        const int64_t e = e0 + threadIdx.x;
+        const int32_t c_begin = cptr[e0], c_end = cptr[e1];
+        const int32_t p0 = e < e1 ? cptr[e] : c_end, p1 = e < e1 ? cptr[e + 1] : c_end;
+        double x = 0.0;
+        for (int32_t c0 = c_begin; c0 < c_end; c0 += FOLD_CAP) {
+            const int32_t c1 = c0 + FOLD_CAP < c_end ? c0 + FOLD_CAP : c_end;
+            for (int32_t p = c0 + (int32_t)threadIdx.x; p < c1; p += TB) {
+                const uint32_t u = contrib[p];
+                const int64_t comp = u >> 3;
+                const int s = (int)(u & 7u);
+                const int t = tb.type[comp];
+                const double v = value[comp];
+                double Rd = 1.0;
+                if ((t == NODAL_T_CCVS || t == NODAL_T_CCCS) && s >= 3) {
+                    const int32_t dr = tb.drv[comp];
+                    if (dr >= 0) Rd = value[dr];
+                }
+                if (t == NODAL_T_R && v == 0.0) note_min(&status[0], comp);
+                if ((t == NODAL_T_R && !(v > 0.0)) || t == NODAL_T_GM) status[2] = 1;  // not a passive network (benign race)
+                unsigned flags;
+                sval[p - c0] = matrix_value(t, s, v, Rd, flags);
+                sflag[p - c0] = (uint8_t)flags;
+            }
+            __syncthreads();
+            const int32_t a = p0 > c0 ? p0 : c0, b = p1 < c1 ? p1 : c1;
+            for (int32_t p = a; p < b; ++p) {
+                const unsigned flags = sflag[p - c0];
+                const double val = sval[p - c0];
+                if ((flags & F_ASSERT0) && x != 0.0) note_min(&status[1], (int64_t)(contrib[p] >> 3));
+                x = (flags & F_SET) ? val : x + val;
+            }
+            __syncthreads();
+        }
+        if (e < e1) data[e] = x;
+    }
+}
+
 __global__ __launch_bounds__(TB) void fold_rhs(Table tb, const double *__restrict__ value,
                                                const int32_t *__restrict__ rhs_row,
                                                const int32_t *__restrict__ cptr,
@@ -314,9 +373,17 @@ int stamp_numeric(nodal_ctx *h, int32_t member, int64_t *bad_component) {
     // runtime splits the fill into an aligned part and a tail, two kernels)
     NODAL_HIP_TRY(h, hipMemsetAsync(h->rhs.p, 0, ((size_t)h->n * 8 + 63) & ~(size_t)63, st));
     if (h->nnz > 0) {
-        fold_matrix<<<grid_for(h->nnz), TB, 0, st>>>(tb, value, h->cptr.as<int32_t>(),
-                                                    h->contrib.as<uint32_t>(),
-                                                    h->data.as<double>(), h->nnz, status);
+        // NODAL_FOLD_STREAM=0: one lane per entry walking its own run (rounds 1-3; kept as the cross-check)
+        const bool stream_fold = !(getenv("NODAL_FOLD_STREAM") && atoi(getenv("NODAL_FOLD_STREAM")) == 0);
+        if (stream_fold) {
+            const int64_t blocks = (h->nnz + FOLD_EPB - 1) / FOLD_EPB;
+            fold_matrix_stream<<<(unsigned)(blocks > 65536 ? 65536 : blocks), TB, 0, st>>>(
+                tb, value, h->cptr.as<int32_t>(), h->contrib.as<uint32_t>(), h->data.as<double>(), h->nnz, status);
+        } else {
+            fold_matrix<<<grid_for(h->nnz), TB, 0, st>>>(tb, value, h->cptr.as<int32_t>(),
+                                                        h->contrib.as<uint32_t>(),
+                                                        h->data.as<double>(), h->nnz, status);
+        }
         NODAL_HIP_TRY(h, hipGetLastError());
     }
     if (h->nrhs > 0) {

@@ -1436,3 +1436,53 @@ def test_reused_handle_with_every_scratch_buffer_poisoned():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "poison_child.py")], env=env, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "poison child ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("kind", ["grid", "cfg5", "hub", "random", "zero resistance", "collision"])
+def test_stream_fold_matches_the_per_entry_fold(kind, monkeypatch):
+    """The numeric fold in north_star's shape (csrc/stamp.hip fold_matrix_stream: a workgroup streams a contiguous
+    run of the contribution list, stages the stamp values in LDS, every lane folds its entry's run from there in list
+    order) against the one-lane-per-entry fold of rounds 1-3: the same operations in the same order -- identical
+    bits, the same first offending component (reference nodal/models.py:13-24 and its asserts)."""
+    rng = random.Random(11)
+    if kind == "grid":
+        table = gen.grid_table(70, 10.0 ** np.random.default_rng(2).uniform(-2, 2, gen.grid_resistor_count(70)))
+    elif kind == "cfg5":
+        table = gen.cfg5_table(60)
+    elif kind == "hub":  # a diagonal entry with 7000 contributions: several chunks of the staging buffer
+        rows = [[f"r{i}", "R", repr(rng.uniform(0.5, 2)), "hub", str(i)] for i in range(7000)]
+        rows += [[f"q{i}", "R", repr(rng.uniform(0.5, 2)), str(i), "g"] for i in range(0, 7000, 3)]
+        rows.append(["a1", "A", "1", "hub", "g"])
+        rng.shuffle(rows)
+        table = lower(n.Netlist.from_rows(rows))
+    elif kind == "random":
+        table = lower(n.Netlist.from_rows(random_netlist(rng, 200, 150)))
+    elif kind == "zero resistance":
+        rows = list(gen.grid_rows(30))
+        rows[417][2] = "0"
+        rows[77][2] = "0.0"
+        table = lower(n.Netlist.from_rows(rows))
+    else:  # a voltage source with both leads on one node: its second incidence stamp finds the first one
+        # (reference nodal/models.py:43-47: `assert G[m, ib] == 0`)
+        rows = list(gen.grid_rows(30))[:-1] + [["e0", "E", "1", "7", "g"], ["e1", "E", "5", "3", "3"]]
+        table = lower(n.Netlist.from_rows(rows))
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NODAL_FOLD_STREAM", mode)
+        h = _ffi.Handle(0)
+        h.upload(table)
+        h.assemble_symbolic()
+        status, bad = h.assemble_numeric()
+        if status == _ffi.OK:
+            got[mode] = (status, bad, h.export_csr())
+        else:
+            got[mode] = (status, bad, None)
+        h.close()
+    assert got["1"][0] == got["0"][0] and got["1"][1] == got["0"][1]
+    if kind == "zero resistance":
+        assert got["1"][0] == _ffi.E_ZERO_RESISTANCE and got["1"][1] == 77
+    elif kind == "collision":
+        assert got["1"][0] == _ffi.E_STAMP_COLLISION
+    else:
+        a, b = got["1"][2], got["0"][2]
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))  # indptr, indices, data, rhs: bit for bit
