@@ -149,6 +149,7 @@ struct SHierarchy {
     bool dense_coarsest = true;  // last level: dense inverse; false: nothing but isolated nodes (diagonal)
     DevBuf tail_stamps, tail_image, apcol, apval, aplen, bstat;
     DevBuf mvec;  // vectors, partials and scalars of the block iteration (sagg_multi.h)
+    hipEvent_t ev_copy = nullptr;  // behind the statistics read-back of a level (build_level)
     DevBuf stats, coarse_inv, mis_t, mis_m, mis_flag, mis_id, agg1, keys, rstart, cursor, lists;
     TailDesc td;
     uint64_t *host_stats = nullptr;  // pinned
@@ -182,6 +183,7 @@ struct SHierarchy {
     }
     ~SHierarchy() {
         drop_graph();
+        if (ev_copy) (void)hipEventDestroy(ev_copy);
         for (SLevel *l : pool) {
             DevBuf *b[] = {&l->acol, &l->aval, &l->alen, &l->dinv, &l->agg, &l->pcol, &l->pval, &l->rcol,
                            &l->rval, &l->rlen, &l->vec, &l->part, &l->gflag, &l->avalf, &l->pvalf, &l->rvalf};
@@ -1201,7 +1203,21 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     NODAL_HIP_TRY(h, hipMemcpyAsync(hs, dstats, (size_t)MAX_LEVELS * ST_COUNT * 8, hipMemcpyDeviceToHost, st));
     unsigned long long hcnt[MIS_ROUNDS + 1] = {0};
     if (trace_mis) NODAL_HIP_TRY(h, hipMemcpyAsync(hcnt, cnt, sizeof hcnt, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    if (!H->ev_copy) NODAL_HIP_TRY(h, hipEventCreateWithFlags(&H->ev_copy, hipEventDisableTiming));
+    NODAL_HIP_TRY(h, hipEventRecord(H->ev_copy, st));
+    // (round 4) The aggregates' assignment and P depend on the level's size only, not on the count the host is
+    // waiting for: they are enqueued BEFORE the wait, which then costs nothing -- the copy has long finished when
+    // build_P has (the wait used to leave the GPU idle for 25-30 us per level).  If the level turns out to be the
+    // last one, or the hierarchy is declined, three small kernels ran for nothing.
+    NODAL_HIP_TRY(h, L->pcol.reserve((size_t)PW * ld * 4 + 64));
+    NODAL_HIP_TRY(h, L->pval.reserve((size_t)PW * ld * 8 + 64));
+    NODAL_HIP_TRY(h, L->pvalf.reserve((size_t)PW * ld * 4 + 64));
+    assign_near<<<g, TB, 0, st>>>(A, T, flag, id, H->agg1.as<int32_t>());
+    assign_far<<<g, TB, 0, st>>>(A, H->agg1.as<int32_t>(), L->agg.as<int32_t>(), dstats + (size_t)l * ST_COUNT);
+    build_P<<<g, TB, 0, st>>>(A, L->dinv.as<double>(), L->agg.as<int32_t>(), L->pcol.as<int32_t>(),
+                             L->pval.as<double>(), L->pvalf.as<float>());
+    NODAL_HIP_TRY(h, hipGetLastError());
+    NODAL_HIP_TRY(h, hipEventSynchronize(H->ev_copy));  // (the copies, not the three kernels behind them)
     if (trace_mis) {
         fprintf(stderr, "[sagg] level %d: undecided after each MIS round:", l);
         for (int r = 1; r <= MIS_ROUNDS; ++r) fprintf(stderr, " %llu", hcnt[r]);
@@ -1230,14 +1246,6 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
         return NODAL_OK;
     }
     L->nc = nc;
-    assign_near<<<g, TB, 0, st>>>(A, T, flag, id, H->agg1.as<int32_t>());
-    assign_far<<<g, TB, 0, st>>>(A, H->agg1.as<int32_t>(), L->agg.as<int32_t>(), dstats + (size_t)l * ST_COUNT);
-    NODAL_HIP_TRY(h, L->pcol.reserve((size_t)PW * ld * 4 + 64));
-    NODAL_HIP_TRY(h, L->pval.reserve((size_t)PW * ld * 8 + 64));
-    NODAL_HIP_TRY(h, L->pvalf.reserve((size_t)PW * ld * 4 + 64));
-    build_P<<<g, TB, 0, st>>>(A, L->dinv.as<double>(), L->agg.as<int32_t>(), L->pcol.as<int32_t>(),
-                             L->pval.as<double>(), L->pvalf.as<float>());
-    NODAL_HIP_TRY(h, hipGetLastError());
 
     // R = P^T by coarse row
     const size_t a4 = (((size_t)(nc + 1) * 4) + 255) & ~(size_t)255;
@@ -1550,7 +1558,23 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
     if (H->nlev < 2) return NODAL_OK;  // too small for a hierarchy: the caller's other paths
     // statistics of the last level (its Galerkin kernel ran after the last round trip)
     NODAL_HIP_TRY(h, hipMemcpyAsync(hs, dstats, (size_t)MAX_LEVELS * ST_COUNT * 8, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    if (!H->ev_copy) NODAL_HIP_TRY(h, hipEventCreateWithFlags(&H->ev_copy, hipEventDisableTiming));
+    NODAL_HIP_TRY(h, hipEventRecord(H->ev_copy, st));
+    if (check_floating) {
+        // (round 4) the "touches ground" flags go up the aggregate maps while the host waits for that copy: they
+        // need the aggregates of every level, which are all there, and nothing the copy brings
+        NODAL_HIP_TRY(h, H->level(0)->gflag.reserve((size_t)n0 + 64));
+        NODAL_TRY(grounded_flags(h, H->level(0)->gflag.as<uint8_t>()));
+        for (int k = 0; k + 1 < H->nlev; ++k) {
+            SLevel *L = H->pool[k], *C = H->pool[k + 1];
+            NODAL_HIP_TRY(h, C->gflag.reserve((size_t)C->n + 64));
+            NODAL_HIP_TRY(h, hipMemsetAsync(C->gflag.p, 0, ((size_t)C->n + 63) & ~(size_t)63, st));  // (one fill kernel)
+            flags_up<<<grid_for(L->n), TB, 0, st>>>(L->n, L->agg.as<int32_t>(), L->gflag.as<uint8_t>(),
+                                                   C->gflag.as<uint8_t>());
+        }
+        NODAL_HIP_TRY(h, hipGetLastError());
+    }
+    NODAL_HIP_TRY(h, hipEventSynchronize(H->ev_copy));
     for (int k = 0; k < H->nlev; ++k) {
         const unsigned long long *s = hs + (size_t)k * ST_COUNT;
         if (k > 0) {
@@ -1585,15 +1609,7 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
         NODAL_HIP_TRY(h, hipStreamSynchronize(st));
         if (hs[(size_t)l * ST_COUNT + ST_BADDIAG] & 2ull) return NODAL_OK;  // coarsest pivot not positive
     } else {
-        NODAL_HIP_TRY(h, H->level(0)->gflag.reserve((size_t)n0 + 64));
-        NODAL_TRY(grounded_flags(h, H->level(0)->gflag.as<uint8_t>()));
-        for (int k = 0; k + 1 < H->nlev; ++k) {
-            SLevel *L = H->pool[k], *C = H->pool[k + 1];
-            NODAL_HIP_TRY(h, C->gflag.reserve((size_t)C->n + 64));
-            NODAL_HIP_TRY(h, hipMemsetAsync(C->gflag.p, 0, ((size_t)C->n + 63) & ~(size_t)63, st));  // (one fill kernel)
-            flags_up<<<grid_for(L->n), TB, 0, st>>>(L->n, L->agg.as<int32_t>(), L->gflag.as<uint8_t>(),
-                                                   C->gflag.as<uint8_t>());
-        }
+        // (the flags went up the hierarchy in front of the statistics read-back above)
         // (the verdict's word: zero since this setup cleared the statistics block, nobody else writes it)
         uint32_t *fl = reinterpret_cast<uint32_t *>(dstats + (size_t)(MAX_LEVELS - 1) * ST_COUNT + ST_COUNT - 1);
         if (H->dense_coarsest) last_level_floating<<<1, 64, 0, st>>>(last->A(), last->gflag.as<uint8_t>(), fl);
