@@ -55,7 +55,7 @@ def pmc_traffic(workload):
     """HBM bytes per launch of the workload's dominant kernel from the committed rocprofv3
     PMC summary (FETCH_SIZE x2 + WRITE_SIZE, separate passes; profiles/<round>_pmc_traffic.json).
     None if that workload was not profiled."""
-    for rnd in (PROFILE_ROUND, "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")) as f:
                 return json.load(f)["dominant"][workload]["hbm_bytes_per_launch"]

@@ -300,6 +300,14 @@ __global__ __launch_bounds__(TB) void grounded_flags(Table tb, uint8_t *__restri
     }
 }
 
+// status words of a numeric phase ([0], [1] = ~0: no offending component yet; [2] = 0: passive so far) and a zero
+// right-hand side, in ONE launch (three hipMemsetAsync calls cost 7-8 us of host launch latency each)
+__global__ __launch_bounds__(TB) void init_numeric(unsigned long long *__restrict__ status, double *__restrict__ rhs,
+                                                   int64_t n) {
+    if (blockIdx.x == 0 && threadIdx.x < 3) status[threadIdx.x] = threadIdx.x < 2 ? ~0ull : 0ull;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) rhs[i] = 0.0;
+}
+
 Table table_of(nodal_ctx *h) {
     Table tb;
     tb.type = h->type.as<uint8_t>();
@@ -367,11 +375,8 @@ int stamp_numeric(nodal_ctx *h, int32_t member, int64_t *bad_component) {
     const double *value =
         h->batch > 0 ? h->values_batch.as<double>() + (int64_t)member * h->ncomp : tb.value;
     unsigned long long *status = h->status.as<unsigned long long>();
-    NODAL_HIP_TRY(h, hipMemsetAsync(status, 0xff, 16, st));
-    NODAL_HIP_TRY(h, hipMemsetAsync(status + 2, 0, 8, st));
-    // (rounded up to 64 bytes -- a DevBuf holds at least 256 bytes more than was asked for --: otherwise the
-    // runtime splits the fill into an aligned part and a tail, two kernels)
-    NODAL_HIP_TRY(h, hipMemsetAsync(h->rhs.p, 0, ((size_t)h->n * 8 + 63) & ~(size_t)63, st));
+    init_numeric<<<grid_for(h->n), TB, 0, st>>>(status, h->rhs.as<double>(), h->n);
+    NODAL_HIP_TRY(h, hipGetLastError());
     if (h->nnz > 0) {
         // NODAL_FOLD_STREAM=0: one lane per entry walking its own run (rounds 1-3; kept as the cross-check)
         const bool stream_fold = !(getenv("NODAL_FOLD_STREAM") && atoi(getenv("NODAL_FOLD_STREAM")) == 0);

@@ -8,13 +8,13 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_final
 mkdir -p $O
 # where the GPU time of a config-3 solve goes, by class of kernel (read back by bench.py: roofline.by_class)
-timeout -k 10 300 rocprofv3 --kernel-trace -d $O/classes -- python3 bench.py --workload cfg3 --steps 2 --warmup 1 --no-cpu --no-also --concurrent 0 > $O/classes.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace -d $O/classes -- python3 bench.py --workload cfg3 --steps 2 --warmup 1 --no-cpu --no-also --concurrent 0 --no-classes > $O/classes.log 2>&1
 python3 tools/prof_classes.py $O/classes cfg3 999999 4995995 > $O/classes.json
 rm -rf $O/classes
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/default -o default -- python3 bench.py --concurrent 0 > $O/bench_default.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/default -o default -- python3 bench.py --concurrent 0 --no-classes > $O/bench_default.log 2>&1
 for w in cfg2 cfg3 cfg4 cfg5; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${w}_$c -- python3 bench.py --workload $w --steps 1 --warmup 1 --no-cpu --no-also --concurrent 0 > $O/pmc_${w}_$c.log 2>&1
+    timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${w}_$c -- python3 bench.py --workload $w --steps 1 --warmup 1 --no-cpu --no-also --concurrent 0 --no-classes > $O/pmc_${w}_$c.log 2>&1
   done
 done
 tail -1 $O/bench_default.log
