@@ -873,6 +873,8 @@ int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, do
     const int64_t dense_rescue_max = 8192;  // a general system the iteration gives up on is decided by the dense LU up to here, by the sparse direct solve beyond
     const int64_t lowdeg_min = 1024;  // below this a direct solve costs less than an elimination round
     bool auto_passive = false;
+    // NODAL_SPARSE_FORCE_DIRECT=1 (testing): every automatic sparse solve through the direct route
+    if (method == NODAL_SPARSE_AUTO && getenv("NODAL_SPARSE_FORCE_DIRECT")) method = NODAL_SPARSE_DIRECT;
     if (method == NODAL_SPARSE_AUTO) {
         // passive network (B == 0, every R > 0, no transconductance): symmetric M-matrix.
         // Up to densify_max unknowns the direct dense solve is faster than the multigrid
