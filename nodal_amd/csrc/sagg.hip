@@ -175,6 +175,8 @@ struct SHierarchy {
     // them instead of after six (every look drains the queue: ~50 us).  It changes WHEN the host looks, nothing else.
     int hint_iters = 0;
     int64_t hint_n = 0, hint_nnz = 0;
+    int mblock_iters = 0;  // the same for the block iteration of a pair sweep (sagg_multi.h): what the block before took
+    int64_t mblock_n = 0;
     unsigned long long sym_stats[MAX_LEVELS * ST_COUNT] = {0};
     SLevel *level(int l) {
         while ((int)pool.size() <= l) pool.push_back(new SLevel());

@@ -875,6 +875,8 @@ int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, do
     bool auto_passive = false;
     // NODAL_SPARSE_FORCE_DIRECT=1 (testing): every automatic sparse solve through the direct route
     if (method == NODAL_SPARSE_AUTO && getenv("NODAL_SPARSE_FORCE_DIRECT")) method = NODAL_SPARSE_DIRECT;
+    // NODAL_SPARSE_CHILD_DIRECT=1 (testing): the same for matrix-only contexts alone (what lowdeg.hip's rounds leave)
+    if (method == NODAL_SPARSE_AUTO && h->csr_only && getenv("NODAL_SPARSE_CHILD_DIRECT")) method = NODAL_SPARSE_DIRECT;
     if (method == NODAL_SPARSE_AUTO) {
         // passive network (B == 0, every R > 0, no transconductance): symmetric M-matrix.
         // Up to densify_max unknowns the direct dense solve is faster than the multigrid

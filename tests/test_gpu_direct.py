@@ -240,3 +240,22 @@ def test_pair_sweep_falls_back_on_the_direct_factorisation(monkeypatch):
         e = lu.solve(b)
         want = e[ia[q]] - (e[ib[q]] if ib[q] >= 0 else 0.0)
         assert abs(R[q] - want) <= TOL * abs(want)
+
+
+def test_matrix_only_context_left_by_the_low_degree_elimination_takes_the_direct_route(monkeypatch, capfd):
+    """A round of lowdeg.hip leaves a context that holds a CSR matrix and no component table: no presolve, no
+    structural verdicts -- if its own iterations ever give up, the direct route is what solves it (round 3:
+    NODAL_E_UNSUPPORTED "matrix-only context: no general solver").  Forced here on a grid with long wires."""
+    monkeypatch.setenv("NODAL_SPARSE_CHILD_DIRECT", "1")
+    monkeypatch.setenv("NODAL_TRACE", "1")
+    table = gen.grid_with_wires_table(60, 150)
+    G, A = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(G.tocsr(), A, True)
+    h = _ffi.Handle(0)
+    h.upload(table)
+    capfd.readouterr()
+    assert h.run(False) == 0
+    err = capfd.readouterr().err
+    assert "[lowdeg]" in err and "[direct] analysis" in err, err[-600:]
+    assert normwise(h.download_x(), xo) <= TOL and h.residual() <= 1e-13
+    h.close()
