@@ -364,6 +364,36 @@ def direct_route_times(device):
                     "reference's SuperLU takes 33-55 s on this matrix"}
 
 
+def resistance_sweep_times(device, npairs=192):
+    """SURVEY 8f N1 on the sparse path: equivalent resistance of `npairs` random node pairs of config 3's network on
+    one set of stamps and one hierarchy (nodal_solve_pairs; the reference re-reads the netlist, re-stamps and calls
+    spsolve per pair, nodal/equiv.py:31-61).  The first pair is a solve of its own (it sets the hierarchy up); the
+    others go sixteen at a time through the block iteration (csrc/sagg_multi.h), stopped on the functional."""
+    import numpy as np
+    from nodal_amd import _ffi
+    from nodal_amd import generators as gen
+    table = gen.grid_table(1000)
+    rng = np.random.RandomState(3)
+    ia = rng.randint(0, table.K, size=npairs).astype(np.int32)
+    ib = rng.randint(-1, table.K, size=npairs).astype(np.int32)
+    ib[ib == ia] = -1
+    h = _ffi.Handle(device)
+    h.upload(table)
+    h.assemble_symbolic()
+    h.assemble_numeric()
+    secs = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        res, info = h.solve_pairs(ia, ib, False)
+        secs.append(time.perf_counter() - t0)
+    h.close()
+    return {"workload": f"cfg3's network (grid(1000), 1e6 nodes), {npairs} random pairs, nodal_solve_pairs(dense = 0)",
+            "first_s": secs[0], "repeated_s": secs[1], "ms_per_pair": secs[1] / npairs * 1e3, "info": int(info),
+            "note": "first_s includes the hierarchy setup and the growth of the block iteration's buffers; parity of "
+                    "the block iteration with one solve per pair and with a sparse LU: tests/test_gpu_parity.py::"
+                    "test_block_iteration_matches_one_solve_per_pair"}
+
+
 def make_workload(name, rank, world, device, dist, per_step, force_collective=False):
     if name == "cfg4":
         return BatchShard(rank, world, per_step, device, dist, force_collective)
@@ -738,6 +768,7 @@ def main():
                 also[other]["reuse_symbolic"] = {k: r3[k] for k in ("circuits_per_sec", "ms_per_solve", "phase_ms", "solver",
                                                                      "scaled_residual")}
         also["sparse_direct"] = direct_route_times(local)
+        also["resistance_sweep"] = resistance_sweep_times(local)
         out["also"] = also
     if rank == 0:
         print(json.dumps(out))
