@@ -28,7 +28,7 @@ constexpr int MK = 16;        // columns of a block
 using cyc_t = float;
 constexpr int MK_SHIFT = 4;
 constexpr int MSC = 32;       // scalars per column: the single-vector block's F_COUNT words + the functional's (below)
-enum { M_SUM = 16, M_INC = 17 /* .. 20: the last increments alpha_j r_j.z_j, a ring */, M_RING = 4, M_WINDOW = 2, M_FDONE = 21 };
+enum { M_SUM = 16, M_INC = 17 /* .. 20: the last increments alpha_j r_j.z_j, a ring */, M_RING = 4, M_FDONE = 21 };
 constexpr int MPARTS = 1024;  // workgroups that leave dot partials (grid cap of the level-0 kernels that do)
 
 // per-column sum over the workgroup of NQ quantities; result written to part[(q * nblocks_cap + block) * MK + y]
@@ -276,12 +276,12 @@ __global__ __launch_bounds__(TB) void m_coarsest(int64_t n, const double *__rest
 // so b.x_k + x_k.r_k is R up to the SQUARE of the energy-norm error, whatever the preconditioner (in exact CG the
 // term x_k.r_k vanishes; the flexible iteration keeps one old direction only, so it does not: leaving it out costs
 // first order, 1e-9 measured at the point where the rule below stops).  Each step is an exact line minimisation, so
-// |e_k|_A^2 - |e_{k+1}|_A^2 = alpha_k r_k.z_k (Hestenes-Stiefel; Strakos & Tichy for the preconditioned form): the
-// last M_WINDOW of those decrements are |e|_A^2 of M_WINDOW iterations ago (less the little that is left now), and
-// their running sum is R.  A column is done when the window is below 1e-10 of the sum; the multigrid-preconditioned
-// iteration contracts |e|_A^2 eightfold per step, so what (*) leaves out is then below 1e-11 R: the 1e-9 bar of
-// SURVEY 8f N1 with two orders to spare, in half the iterations the residual rule |r| <= 1e-13 |b| needs (that
-// rule stays: NODAL_PAIRS_FUNCTIONAL=0).
+// d_k = |e_k|_A^2 - |e_{k+1}|_A^2 = alpha_k r_k.z_k (Hestenes-Stiefel; Strakos & Tichy for the preconditioned form):
+// the running sum of the decrements is R, and what is left after step k is the tail d_{k+1} + d_{k+2} + ...,
+// estimated as a geometric one with the worse of the last two ratios q = max(d_k / d_{k-1}, d_{k-1} / d_{k-2}).  A
+// column is done when d_k q / (1 - q) <= 1e-11 of the sum (q < 0.9; a slower iteration is left to the residual
+// rule): the 1e-9 bar of SURVEY 8f N1 with two orders to spare, in under half the iterations the residual rule
+// |r| <= 1e-13 |b| needs (that rule stays: NODAL_PAIRS_FUNCTIONAL=0).
 
 __global__ void m_set_scalars(double *__restrict__ sc, double tol2) {
     const int y = threadIdx.x;
@@ -386,13 +386,20 @@ __global__ __launch_bounds__(TB) void m_update(double *__restrict__ x, double *_
     if (blockIdx.x == 0 && threadIdx.x < MK && !done) {
         sc[F_ALPHA + cur] = alpha;
         if (bad) sc[F_FLAG] = 1.0;
-        const double inc = alpha * rz;  // |x - x_k|_A^2 - |x - x_{k+1}|_A^2
+        const double inc = alpha * rz;  // d_k = |x - x_k|_A^2 - |x - x_{k+1}|_A^2
         const double sum = sc[M_SUM] + inc;
-        double window = inc;  // the decrements of the last M_WINDOW iterations, this one included
-        for (int k = 1; k < M_WINDOW; ++k) window += sc[M_INC + ((itno - k) & (M_RING - 1))];
+        const double d2 = sc[M_INC + ((itno - 1) & (M_RING - 1))], d3 = sc[M_INC + ((itno - 2) & (M_RING - 1))];
         sc[M_SUM] = sum;
         sc[M_INC + (itno & (M_RING - 1))] = inc;
-        if (functional && itno >= 6 && window <= 1e-10 * sum) {
+        // what is left, |x - x_{k+1}|_A^2 = d_{k+1} + d_{k+2} + ..., as a geometric tail with the worse of the last
+        // two ratios (CG converges superlinearly: the ratios fall, the estimate errs on the safe side); an iteration
+        // that contracts by less than 0.9 per step is left to the residual rule
+        bool fdone = false;
+        if (functional && itno >= 4 && d2 > 0.0 && d3 > 0.0) {
+            const double q = fmax(inc / d2, d2 / d3);
+            fdone = q < 0.9 && inc * q <= 1e-11 * sum * (1.0 - q);
+        }
+        if (fdone) {
             sc[M_FDONE] = 1.0;  // x and r of this column are final after this launch: m_direction stops it next time
             sc[F_ITERS] = (double)itno;
         }

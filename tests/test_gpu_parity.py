@@ -710,6 +710,38 @@ def test_block_iteration_matches_one_solve_per_pair(monkeypatch):
     assert np.abs(res - out["0"]).max() <= 1e-11 * np.abs(out["0"]).max()
 
 
+def test_block_iteration_on_a_network_of_uneven_resistors():
+    """The functional's stopping rule (csrc/sagg_multi.h) on a grid whose resistances spread over a decade (the
+    smoothed-aggregation hierarchy still takes it; the iteration contracts more slowly than on the uniform grid):
+    every pair within 1e-9 of a sparse LU of the oracle's matrix."""
+    import scipy.sparse.linalg as spla
+    N = 120
+    rng = np.random.RandomState(21)
+    values = 10.0 ** rng.uniform(0.0, 1.0, size=gen.grid_resistor_count(N))
+    table = gen.grid_table(N, values)
+    ia = rng.randint(0, table.K, size=33).astype(np.int32)
+    ib = rng.randint(-1, table.K, size=33).astype(np.int32)
+    ib[ib == ia] = -1
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    res, info = h.solve_pairs(ia, ib, dense=False)
+    h.close()
+    assert info == 0
+    G, _ = oracle.assemble_fast(table)
+    lu = spla.splu(G.tocsc())
+    want = np.zeros(len(ia))
+    for q in range(len(ia)):
+        b = np.zeros(G.shape[0])
+        b[ia[q]] = 1.0
+        if ib[q] >= 0:
+            b[ib[q]] = -1.0
+        want[q] = b @ lu.solve(b)
+    assert np.abs(res - want).max() <= 1e-9 * np.abs(want).max()
+    assert np.all(np.abs(res - want) <= 1e-9 * np.abs(want))  # (per pair: the bar is relative to the pair's own R)
+
+
 def test_reference_resistance_tests_exact():
     """reference tests.py:24-29 asserts exact equality for resistive_{1,2,3}."""
     want = {"doc/resistive_1": 2.0, "doc/resistive_2": 1.0, "doc/resistive_3": 1.0}
