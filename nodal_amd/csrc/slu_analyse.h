@@ -3,16 +3,37 @@
 // which runs the numeric phase on the host with the same structures and compares with SuperLU.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <future>
+#include <thread>
 #include <vector>
 
 namespace slu {
 
 constexpr int LEAF = 32;          // pieces of at most this many vertices are not dissected further
+
+// f(lo, hi) over [0, n) in contiguous chunks on up to 16 host threads (the calling one included); chunks of at
+// least `min_chunk` items, one chunk = a plain call.  The loops handed to it write disjoint ranges.
+template <class F>
+inline void parallel_chunks(int64_t n, int64_t min_chunk, F f) {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char *e = getenv("NODAL_HOST_THREADS")) hw = (unsigned)std::max(1, atoi(e));
+    const int64_t T = std::max<int64_t>(1, std::min<int64_t>({(int64_t)(hw ? hw : 1), 16, n / std::max<int64_t>(1, min_chunk)}));
+    if (T <= 1) {
+        f((int64_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve((size_t)T - 1);
+    for (int64_t c = 1; c < T; ++c) th.emplace_back(f, n * c / T, n * (c + 1) / T);
+    f((int64_t)0, n / T);
+    for (auto &t : th) t.join();
+}
 
 
 // rmatch[j] = row matched to column j (a perfect matching on the non-zero entries), false if none exists
@@ -121,158 +142,212 @@ inline void symmetrised_graph(int64_t n, const int32_t *indptr, const int32_t *i
             raw[(size_t)fill[(size_t)l]++] = p;
         }
     }
+    // each vertex's list sorted and made unique in place (independent: threads), then packed
     g.ptr.assign((size_t)n + 1, 0);
-    g.adj.clear();
-    g.adj.reserve(raw.size());
-    for (int64_t v = 0; v < n; ++v) {
-        auto b = raw.begin() + cnt[(size_t)v], e = raw.begin() + cnt[(size_t)v + 1];
-        std::sort(b, e);
-        e = std::unique(b, e);
-        g.adj.insert(g.adj.end(), b, e);
-        g.ptr[(size_t)v + 1] = (int64_t)g.adj.size();
-    }
+    parallel_chunks(n, 50000, [&](int64_t lo, int64_t hi) {
+        for (int64_t v = lo; v < hi; ++v) {
+            auto b = raw.begin() + cnt[(size_t)v], e = raw.begin() + cnt[(size_t)v + 1];
+            std::sort(b, e);
+            g.ptr[(size_t)v + 1] = (int64_t)(std::unique(b, e) - b);
+        }
+    });
+    for (int64_t v = 0; v < n; ++v) g.ptr[(size_t)v + 1] += g.ptr[(size_t)v];
+    g.adj.resize((size_t)g.ptr[(size_t)n]);
+    parallel_chunks(n, 50000, [&](int64_t lo, int64_t hi) {
+        for (int64_t v = lo; v < hi; ++v)
+            std::copy(raw.begin() + cnt[(size_t)v], raw.begin() + cnt[(size_t)v] + (g.ptr[(size_t)v + 1] - g.ptr[(size_t)v]),
+                      g.adj.begin() + g.ptr[(size_t)v]);
+    });
 }
 
 // Nested dissection by level structures.  order: vertices in elimination order; sn_start: supernode
 // boundaries in that order.
+//
+// A piece is split into its connected components; a connected piece of more than LEAF vertices gets a
+// pseudo-peripheral root (two sweeps), a level structure from it, and the level that balances best becomes the
+// separator S between A (the levels below, plus the separator's vertices without a neighbour above) and B; the
+// order is order(A), order(B), S.  The halves are independent: above nd_par_min() vertices the first one goes to another
+// thread (a few levels deep: 16 threads at most), the result is the sequential one's whatever the schedule --
+// every piece owns its vertices' `tag` and `lvl` words, and a piece's level marks start above every mark its
+// ancestors left on those vertices.
+inline int64_t nd_par_min() {  // pieces below this are not worth a thread (NODAL_ND_PAR: the tests thread small graphs)
+    static const int64_t m = getenv("NODAL_ND_PAR") ? atoll(getenv("NODAL_ND_PAR")) : 20000;
+    return m;
+}
+inline int nd_par_depth() { static const int d = getenv("NODAL_ND_DEPTH") ? atoi(getenv("NODAL_ND_DEPTH")) : 4; return d; }
+//
+// In place: a piece is a span [lo, hi) of ONE permutation array, its breadth-first queue the same span of ONE
+// scratch array; the split writes A, B, S back into the span in that order, so the finished array IS the
+// elimination order and a supernode boundary is a flag at its first position.  (A vector per piece and level --
+// 45 n words at 1e6 vertices -- cost more in page faults than the searches did on a cold process.)
+
+struct NdState {
+    const Graph &g;
+    // (relaxed atomics: a piece reads the tags of its vertices' neighbours, which another thread may be re-tagging
+    // for its own piece -- with an id that is never this piece's, old or new)
+    std::vector<std::atomic<int32_t>> tag;  // piece a vertex currently belongs to (-2: hub / separator / done)
+    std::vector<int32_t> lvl, perm, scratch;
+    std::vector<uint8_t> cls, snflag;
+    std::atomic<int32_t> next_id{0};
+    NdState(const Graph &gr, int64_t n)
+        : g(gr), tag((size_t)n), lvl((size_t)n, -1), perm((size_t)n), scratch((size_t)n), cls((size_t)n), snflag((size_t)n + 1, 0) {}
+};
+
+// levels lvl[v] = mark_base + depth over the piece `id` from `root`; the visited vertices go to q[0 ..) in
+// breadth-first order; returns their number
+inline int64_t nd_bfs(NdState &st, int32_t id, int32_t root, int32_t mark_base, int32_t *q) {
+    const Graph &g = st.g;
+    int64_t head = 0, tail = 0;
+    q[tail++] = root;
+    st.lvl[(size_t)root] = mark_base;
+    while (head < tail) {
+        const int32_t v = q[head++];
+        for (int64_t e = g.ptr[(size_t)v]; e < g.ptr[(size_t)v + 1]; ++e) {
+            const int32_t u = g.adj[(size_t)e];
+            if (st.tag[(size_t)u].load(std::memory_order_relaxed) != id || st.lvl[(size_t)u] >= mark_base) continue;
+            st.lvl[(size_t)u] = st.lvl[(size_t)v] + 1;
+            q[tail++] = u;
+        }
+    }
+    return tail;
+}
+
+// `base`: above every mark on the piece's vertices.  `connected`: known to be one component.
+inline void nd_dissect(NdState &st, int64_t lo, int64_t hi, bool connected, int32_t base, int depth) {
+    if (hi <= lo) return;
+    const Graph &g = st.g;
+    const int64_t m = hi - lo;
+    int32_t *vs = st.perm.data() + lo, *q = st.scratch.data() + lo;
+    const int32_t id = st.next_id.fetch_add(1, std::memory_order_relaxed);
+    for (int64_t k = 0; k < m; ++k) st.tag[(size_t)vs[k]].store(id, std::memory_order_relaxed);
+    const int32_t span = (int32_t)m + 2;
+    // The first sweep (from the piece's first vertex) doubles as the connectivity test: if it reaches every vertex
+    // the piece is one component and the sweep is the first of the pseudo-peripheral search.
+    bool swept = false;
+    if (!connected) {
+        swept = nd_bfs(st, id, vs[0], base, q) == m;
+        base += span;
+        connected = swept;
+    }
+    if (!connected) {
+        const int32_t b0 = base;
+        base += span;
+        std::vector<int64_t> starts;  // of the components inside q, in the order they were found
+        int64_t filled = 0;
+        for (int64_t k = 0; k < m; ++k) {
+            if (st.lvl[(size_t)vs[k]] >= b0) continue;
+            starts.push_back(filled);
+            filled += nd_bfs(st, id, vs[k], b0, q + filled);
+        }
+        // (the order of the sequential, stack-driven form this one replaced: the component found last comes
+        // first; each in breadth-first order)
+        starts.push_back(filled);
+        int64_t at = 0;
+        std::vector<int64_t> bounds(1, 0);
+        for (size_t c = starts.size() - 1; c-- > 0;) {
+            std::copy(q + starts[c], q + starts[c + 1], vs + at);
+            at += starts[c + 1] - starts[c];
+            bounds.push_back(at);
+        }
+        for (size_t c = 0; c + 1 < bounds.size(); ++c) nd_dissect(st, lo + bounds[c], lo + bounds[c + 1], true, base, depth);
+        return;
+    }
+    if (m <= LEAF) {
+        st.snflag[(size_t)lo] = 1;
+        return;
+    }
+    // pseudo-peripheral vertex: two sweeps
+    if (!swept) {
+        (void)nd_bfs(st, id, vs[0], base, q);
+        base += span;
+    }
+    (void)nd_bfs(st, id, q[m - 1], base, q);
+    base += span;
+    const int32_t b2 = base;
+    (void)nd_bfs(st, id, q[m - 1], b2, q);
+    base += span;
+    const int32_t nlev = st.lvl[(size_t)q[m - 1]] - b2 + 1;
+    if (nlev < 3) {  // a clique-like piece: one dense supernode
+        st.snflag[(size_t)lo] = 1;
+        return;
+    }
+    std::vector<int64_t> count((size_t)nlev, 0);
+    for (int64_t k = 0; k < m; ++k) ++count[(size_t)(st.lvl[(size_t)q[k]] - b2)];
+    int32_t best = -1;
+    double best_cost = 1e300;
+    int64_t below = count[0];
+    for (int32_t l = 1; l + 1 < nlev; ++l) {
+        const double frac = (double)below / (double)m;
+        // small separator, balanced halves: size * (1 + penalty for imbalance)
+        const double imb = std::fabs(frac + 0.5 * (double)count[(size_t)l] / (double)m - 0.5);
+        const double cost = (double)count[(size_t)l] * (1.0 + 8.0 * imb * imb * 4.0) + (imb > 0.3 ? 1e9 * imb : 0.0);
+        if (cost < best_cost) { best_cost = cost; best = l; }
+        below += count[(size_t)l];
+    }
+    // classes: 0 = A (the levels below the separator's, and its vertices without a neighbour above), 1 = B, 2 = S
+    uint8_t *cls = st.cls.data() + lo;
+    int64_t nA = 0, nB = 0, nS = 0;
+    for (int64_t k = 0; k < m; ++k) {
+        const int32_t v = q[k];
+        const int32_t l = st.lvl[(size_t)v] - b2;
+        uint8_t c = 0;
+        if (l > best) c = 1;
+        else if (l == best) {
+            bool up = false;
+            for (int64_t e = g.ptr[(size_t)v]; e < g.ptr[(size_t)v + 1] && !up; ++e) {
+                const int32_t u = g.adj[(size_t)e];
+                up = st.tag[(size_t)u].load(std::memory_order_relaxed) == id && st.lvl[(size_t)u] - b2 == best + 1;
+            }
+            c = up ? 2 : 0;
+        }
+        cls[k] = c;
+        nA += c == 0;
+        nB += c == 1;
+        nS += c == 2;
+    }
+    if (nS == 0 || nA == 0 || nB == 0) {  // (cannot happen on a connected piece with >= 3 levels)
+        st.snflag[(size_t)lo] = 1;
+        return;
+    }
+    int64_t at[3] = {0, nA, nA + nB};
+    for (int64_t k = 0; k < m; ++k) vs[at[cls[k]]++] = q[k];  // (each class in breadth-first order)
+    for (int64_t k = nA + nB; k < m; ++k) st.tag[(size_t)vs[k]].store(-2, std::memory_order_relaxed);
+    st.snflag[(size_t)(lo + nA + nB)] = 1;  // the separator: one supernode, after both halves
+    if (depth < nd_par_depth() && nA >= nd_par_min() && nB >= nd_par_min()) {
+        auto fa = std::async(std::launch::async, [&st, lo, nA, base, depth]() { nd_dissect(st, lo, lo + nA, false, base, depth + 1); });
+        nd_dissect(st, lo + nA, lo + nA + nB, false, base, depth + 1);
+        fa.get();
+    } else {
+        nd_dissect(st, lo, lo + nA, false, base, depth + 1);
+        nd_dissect(st, lo + nA, lo + nA + nB, false, base, depth + 1);
+    }
+}
+
 inline void nested_dissection(int64_t n, const Graph &g, std::vector<int32_t> &order, std::vector<int32_t> &sn_start) {
-    order.clear();
-    order.reserve((size_t)n);
-    sn_start.assign(1, 0);
-    auto emit = [&](const std::vector<int32_t> &vs) {
-        if (vs.empty()) return;
-        order.insert(order.end(), vs.begin(), vs.end());
-        sn_start.push_back((int32_t)order.size());
-    };
     // hubs: set aside, eliminated last
     const double avg = n > 0 ? (double)g.adj.size() / (double)n : 0.0;
     const int64_t hub_bar = std::max<int64_t>(64, (int64_t)(20.0 * avg));
-    std::vector<int32_t> hubs, rest;
-    std::vector<int32_t> tag((size_t)n, -1);  // task a vertex currently belongs to (-2: hub / done)
-    for (int64_t v = 0; v < n; ++v) {
+    NdState st(g, n);
+    int64_t nrest = 0, nhubs = 0;
+    for (int64_t v = 0; v < n; ++v) {  // perm: the rest in front (ascending), the hubs behind them (ascending)
         if (g.ptr[(size_t)v + 1] - g.ptr[(size_t)v] > hub_bar) {
-            hubs.push_back((int32_t)v);
-            tag[(size_t)v] = -2;
+            st.scratch[(size_t)nhubs++] = (int32_t)v;
+            st.tag[(size_t)v].store(-2, std::memory_order_relaxed);
         } else {
-            rest.push_back((int32_t)v);
+            st.perm[(size_t)nrest++] = (int32_t)v;
+            st.tag[(size_t)v].store(-1, std::memory_order_relaxed);
         }
     }
-    struct Task {
-        std::vector<int32_t> vs;
-        bool separator;   // emit as it is
-        bool connected;   // known to be one component
-    };
-    std::vector<Task> stack;
-    stack.push_back(Task{std::move(rest), false, false});
-    std::vector<int32_t> lvl((size_t)n, -1), queue;
-    int32_t next_id = 0;
-    int32_t base = 0;  // (levels are made unique per search by a growing base: no clearing pass)
-    while (!stack.empty()) {
-        Task t = std::move(stack.back());
-        stack.pop_back();
-        if (t.vs.empty()) continue;
-        if (t.separator) {
-            emit(t.vs);
-            continue;
-        }
-        const int32_t id = next_id++;
-        for (int32_t v : t.vs) tag[(size_t)v] = id;
-        auto bfs = [&](int32_t root, int32_t mark_base) -> int32_t {  // levels lvl[v] = mark_base + depth; returns last vertex
-            queue.clear();
-            queue.push_back(root);
-            lvl[(size_t)root] = mark_base;
-            size_t head = 0;
-            while (head < queue.size()) {
-                const int32_t v = queue[head++];
-                for (int64_t e = g.ptr[(size_t)v]; e < g.ptr[(size_t)v + 1]; ++e) {
-                    const int32_t u = g.adj[(size_t)e];
-                    if (tag[(size_t)u] != id || lvl[(size_t)u] >= mark_base) continue;
-                    lvl[(size_t)u] = lvl[(size_t)v] + 1;
-                    queue.push_back(u);
-                }
-            }
-            return queue.back();
-        };
-        if (base > (1 << 30)) {
-            std::fill(lvl.begin(), lvl.end(), -1);
-            base = 0;
-        }
-        if (!t.connected) {
-            // split into connected components first
-            const int32_t b0 = base;
-            base += (int32_t)t.vs.size() + 2;
-            std::vector<Task> comps;
-            for (int32_t v : t.vs) {
-                if (lvl[(size_t)v] >= b0) continue;
-                (void)bfs(v, b0);
-                comps.push_back(Task{queue, false, true});
-            }
-            if (comps.size() > 1) {
-                for (auto &c : comps) stack.push_back(std::move(c));
-                continue;
-            }
-        }
-        if ((int64_t)t.vs.size() <= LEAF) {
-            emit(t.vs);
-            continue;
-        }
-        // pseudo-peripheral vertex: two sweeps
-        int32_t b1 = base;
-        base += (int32_t)t.vs.size() + 2;
-        int32_t far = bfs(t.vs[0], b1);
-        b1 = base;
-        base += (int32_t)t.vs.size() + 2;
-        far = bfs(far, b1);
-        const int32_t b2 = base;
-        base += (int32_t)t.vs.size() + 2;
-        (void)bfs(far, b2);
-        const int32_t nlev = lvl[(size_t)queue.back()] - b2 + 1;
-        if (nlev < 3) {  // a clique-like piece: one dense supernode
-            emit(t.vs);
-            continue;
-        }
-        std::vector<int64_t> count((size_t)nlev, 0);
-        for (int32_t v : queue) ++count[(size_t)(lvl[(size_t)v] - b2)];
-        const int64_t total = (int64_t)queue.size();
-        int32_t best = -1;
-        double best_cost = 1e300;
-        int64_t below = count[0];
-        for (int32_t m = 1; m + 1 < nlev; ++m) {
-            const double frac = (double)below / (double)total;
-            // small separator, balanced halves: size * (1 + penalty for imbalance)
-            const double imb = std::fabs(frac + 0.5 * (double)count[(size_t)m] / (double)total - 0.5);
-            const double cost = (double)count[(size_t)m] * (1.0 + 8.0 * imb * imb * 4.0) + (imb > 0.3 ? 1e9 * imb : 0.0);
-            if (cost < best_cost) { best_cost = cost; best = m; }
-            below += count[(size_t)m];
-        }
-        Task A{{}, false, false}, B{{}, false, false}, S{{}, true, true};
-        for (int32_t v : queue) {
-            const int32_t l = lvl[(size_t)v] - b2;
-            if (l < best) A.vs.push_back(v);
-            else if (l > best) B.vs.push_back(v);
-            else {
-                bool up = false;
-                for (int64_t e = g.ptr[(size_t)v]; e < g.ptr[(size_t)v + 1] && !up; ++e) {
-                    const int32_t u = g.adj[(size_t)e];
-                    up = tag[(size_t)u] == id && lvl[(size_t)u] - b2 == best + 1;
-                }
-                (up ? S.vs : A.vs).push_back(v);
-            }
-        }
-        if (S.vs.empty() || A.vs.empty() || B.vs.empty()) {  // (cannot happen on a connected piece with >= 3 levels)
-            emit(t.vs);
-            continue;
-        }
-        for (int32_t v : S.vs) tag[(size_t)v] = -2;
-        stack.push_back(std::move(S));
-        stack.push_back(std::move(B));
-        stack.push_back(std::move(A));
-    }
+    std::copy(st.scratch.begin(), st.scratch.begin() + nhubs, st.perm.begin() + nrest);
+    nd_dissect(st, 0, nrest, false, 0, 0);
     // a hub supernode of thousands of vertices would be one huge dense pivot block: chunks of 256 instead
-    for (size_t k = 0; k < hubs.size(); k += 256) {
-        std::vector<int32_t> part(hubs.begin() + (long)k, hubs.begin() + (long)std::min(hubs.size(), k + 256));
-        emit(part);
-    }
+    for (int64_t k = nrest; k < n; k += 256) st.snflag[(size_t)k] = 1;
+    order = std::move(st.perm);
+    sn_start.clear();
+    for (int64_t k = 0; k < n; ++k)
+        if (st.snflag[(size_t)k]) sn_start.push_back((int32_t)k);
+    sn_start.push_back((int32_t)n);
+    if (n == 0) sn_start.assign(1, 0);
 }
 
 struct Symbolic {
@@ -355,6 +430,7 @@ inline bool analyse(int64_t n, const int32_t *indptr, const int32_t *indices, co
             last_child[(size_t)p] = t;
         }
     }
+    const double t_sf = ms_since(t0);
     // fronts, vectors, levels
     S.front_off.assign((size_t)nsn + 1, 0);
     S.vec_off.assign((size_t)nsn + 1, 0);
@@ -400,33 +476,45 @@ inline bool analyse(int64_t n, const int32_t *indptr, const int32_t *indices, co
         const auto it = std::lower_bound(b, e, p);
         return (it != e && *it == p) ? (end - start) + (int32_t)(it - b) : -1;
     };
+    const double t_lv = ms_since(t0);
     S.cmap.assign(S.struct_idx.size(), -1);
-    for (int32_t c = 0; c < nsn; ++c) {
-        const int32_t p = S.parent[(size_t)c];
-        if (p < 0) continue;
-        for (int64_t q = S.struct_ptr[(size_t)c]; q < S.struct_ptr[(size_t)c + 1]; ++q)
-            S.cmap[(size_t)q] = local_in(p, S.struct_idx[(size_t)q]);
-    }
+    parallel_chunks(nsn, 2000, [&](int64_t lo, int64_t hi) {
+        for (int64_t c = lo; c < hi; ++c) {
+            const int32_t p = S.parent[(size_t)c];
+            if (p < 0) continue;
+            for (int64_t q = S.struct_ptr[(size_t)c]; q < S.struct_ptr[(size_t)c + 1]; ++q)
+                S.cmap[(size_t)q] = local_in(p, S.struct_idx[(size_t)q]);
+        }
+    });
+    const double t_cm = ms_since(t0);
     // destination of every CSR entry
     const int64_t nnz = indptr[n];
     S.dest.assign((size_t)nnz, -1);
-    for (int64_t i = 0; i < n; ++i) {
-        const int32_t kr = S.newrow[(size_t)i];
-        for (int32_t e = indptr[i]; e < indptr[i + 1]; ++e) {
-            const int32_t kc = newpos[(size_t)indices[e]];
-            const int32_t t = sn_of[(size_t)std::min(kr, kc)];
-            const int32_t lr = local_in(t, kr), lc = local_in(t, kc);
-            if (lr < 0 || lc < 0) return false;  // (cannot happen: every entry is an edge of the graph)
-            const int64_t dim = (S.sn_start[(size_t)t + 1] - S.sn_start[(size_t)t]) +
-                                (S.struct_ptr[(size_t)t + 1] - S.struct_ptr[(size_t)t]);
-            S.dest[(size_t)e] = S.front_off[(size_t)t] + lr + (int64_t)lc * dim;
+    std::atomic<bool> misplaced{false};
+    parallel_chunks(n, 50000, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const int32_t kr = S.newrow[(size_t)i];
+            for (int32_t e = indptr[i]; e < indptr[i + 1]; ++e) {
+                const int32_t kc = newpos[(size_t)indices[e]];
+                const int32_t t = sn_of[(size_t)std::min(kr, kc)];
+                const int32_t lr = local_in(t, kr), lc = local_in(t, kc);
+                if (lr < 0 || lc < 0) {  // (cannot happen: every entry is an edge of the graph)
+                    misplaced.store(true, std::memory_order_relaxed);
+                    continue;
+                }
+                const int64_t dim = (S.sn_start[(size_t)t + 1] - S.sn_start[(size_t)t]) +
+                                    (S.struct_ptr[(size_t)t + 1] - S.struct_ptr[(size_t)t]);
+                S.dest[(size_t)e] = S.front_off[(size_t)t] + lr + (int64_t)lc * dim;
+            }
         }
-    }
+    });
+    if (misplaced.load()) return false;
     if (trace)
         fprintf(stderr,
-                "[direct] analysis: matching %.1f ms, graph %.1f, dissection %.1f, symbolic %.1f; %d supernodes, "
-                "%d levels, largest front %d, fronts %.3f GB\n",
-                t_match, t_graph - t_match, t_nd - t_graph, ms_since(t0) - t_nd, nsn, nlev, S.max_dim,
+                "[direct] analysis: matching %.1f ms, graph %.1f, dissection %.1f, symbolic %.1f (structures %.1f, "
+                "levels %.1f, child maps %.1f, entry map %.1f); %d supernodes, %d levels, largest front %d, fronts %.3f GB\n",
+                t_match, t_graph - t_match, t_nd - t_graph, ms_since(t0) - t_nd, t_sf - t_nd, t_lv - t_sf, t_cm - t_lv,
+                ms_since(t0) - t_cm, nsn, nlev, S.max_dim,
                 (double)S.front_off[(size_t)nsn] * 8e-9);
     return true;
 }

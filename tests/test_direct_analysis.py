@@ -71,3 +71,30 @@ def test_structurally_singular_matrix_is_reported(checker, tmp_path):
     rows = list(gen.grid_rows(8)) + [["e0", "E", "1", "g", "g"]]
     r, *_ = _run(checker, tmp_path, lower(n.Netlist.from_rows(rows)))
     assert r.returncode == 3 and "structurally singular" in r.stderr
+
+
+def test_threaded_in_place_dissection_equals_the_sequential_form(tmp_path):
+    """csrc/slu_analyse.h dissects in place and hands independent halves to other threads; the elimination order
+    and the supernode boundaries must be those of the sequential, stack-driven form it replaced
+    (tools/nd_reference.h), whatever the schedule: random graphs with several components, chords and hubs, a
+    grid and config 5's topology, with the threading threshold lowered so that small pieces take threads too."""
+    if shutil.which("g++") is None:
+        pytest.skip("no host C++ compiler")
+    exe = str(tmp_path / "nd_compare")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-o", exe, os.path.join(ROOT, "tools", "nd_compare.cpp")])
+    files = []
+    for name, table in (("grid", gen.grid_table(90)), ("cfg5", gen.cfg5_table(60))):
+        G, _ = oracle.assemble_fast(table)
+        G = G.tocsr()
+        G.sort_indices()
+        path = str(tmp_path / (name + ".bin"))
+        with open(path, "wb") as f:
+            np.array([G.shape[0], G.nnz], dtype=np.int64).tofile(f)
+            G.indptr.astype(np.int32).tofile(f)
+            G.indices.astype(np.int32).tofile(f)
+            G.data.astype(np.float64).tofile(f)
+        files.append(path)
+    for env in ({}, {"NODAL_ND_PAR": "40", "NODAL_ND_DEPTH": "6"}, {"NODAL_ND_DEPTH": "0"}):
+        r = subprocess.run([exe, "random"] + files, capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert "DIFFERENT" not in r.stdout and r.stdout.count("identical") == 14
