@@ -580,7 +580,8 @@ int nodal_solve_pairs(nodal_handle h, int32_t dense, int32_t npairs, const int32
     }
     if (reduced) {
         // results are in `res`
-    } else if (dense || n <= 64 || !(h->B == 0 && h->passive_network)) {
+    } else if (dense || n <= 64 || (!(h->B == 0 && h->passive_network) && n <= 8192)) {
+        // (a non-passive network above 8192 unknowns on the sparse switch: one sparse LU, sparse_solve_pairs)
         // one LU for up to CHUNK pairs: they are extra right-hand-side columns
         const int32_t CHUNK = 512;
         for (int32_t q0 = 0; q0 < npairs; q0 += CHUNK) {

@@ -677,7 +677,11 @@ int sparse_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const in
     double *b = h->ps_buf.as<double>();
     *info = 0;
     bool direct = false;  // the multigrid CG broke down on this network: one sparse LU serves every pair from then on
-    if (getenv("NODAL_PAIRS_DIRECT")) {  // (testing: the fallback from the first pair on)
+    // A network with a non-positive resistance (the only non-passive kind a resistance sweep meets: reference
+    // nodal/equiv.py:31-37 admits resistors only) is no M-matrix: one sparse LU serves every pair, as SuperLU
+    // serves the reference.
+    const bool indefinite = !(h->B == 0 && h->passive_network);
+    if (indefinite || getenv("NODAL_PAIRS_DIRECT")) {  // (NODAL_PAIRS_DIRECT, testing: the fallback from the first pair on)
         int32_t inf = 0;
         NODAL_TRY(slu_factor(h, &inf));
         if (inf > 0) {

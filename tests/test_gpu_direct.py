@@ -259,3 +259,35 @@ def test_matrix_only_context_left_by_the_low_degree_elimination_takes_the_direct
     assert "[lowdeg]" in err and "[direct] analysis" in err, err[-600:]
     assert normwise(h.download_x(), xo) <= TOL and h.residual() <= 1e-13
     h.close()
+
+
+def test_resistance_sweep_on_a_large_network_with_a_negative_resistor():
+    """A resistive network with a non-positive resistance is admitted by the reference's sweep (nodal/equiv.py:
+    31-37 checks the component types only) and is no M-matrix: above the dense route's size the sparse switch
+    factors it once with the sparse LU and serves every pair from the factors."""
+    import scipy.sparse.linalg as spla
+    N = 130
+    rng = np.random.RandomState(5)
+    values = rng.uniform(0.5, 2.0, size=gen.grid_resistor_count(N))
+    values[rng.randint(0, len(values), size=40)] *= -1.0
+    table = gen.grid_table(N, values)
+    ia = rng.randint(0, table.K, size=9).astype(np.int32)
+    ib = rng.randint(-1, table.K, size=9).astype(np.int32)
+    ib[ib == ia] = -1
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    assert h.n > 8192
+    res, info = h.solve_pairs(ia, ib, dense=False)
+    h.close()
+    assert info == 0
+    G, _ = oracle.assemble_fast(table)
+    lu = spla.splu(G.tocsc())
+    for q in range(len(ia)):
+        b = np.zeros(G.shape[0])
+        b[ia[q]] = 1.0
+        if ib[q] >= 0:
+            b[ib[q]] = -1.0
+        want = b @ lu.solve(b)
+        assert abs(res[q] - want) <= 1e-9 * max(abs(want), np.abs(lu.solve(b)).max())
