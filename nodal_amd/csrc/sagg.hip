@@ -58,6 +58,12 @@ constexpr int DOT_BLOCKS = 1024;   // partial sums per dot product of the K-cycl
 #endif
 constexpr double OMEGA = NODAL_SA_OMEGA;      // damped-Jacobi smoother
 constexpr double OMEGA_P = 2.0 / 3.0;         // prolongator smoothing (rho(D^-1 A) <= 2 for an M-matrix)
+// Vectors inside the cycle (the preconditioner: residuals, corrections and smoothing iterates of every level outside
+// the tail, the start iterate w D^-1 r and the result z) are kept in f32 like the cycle's copies of A, P and R: the
+// outer iterations are flexible ones and their own vectors (x, r, p, Ap; the Krylov basis of the general path) and
+// every dot product stay f64.  A level-0 pass of the single-vector cycle moves 56 instead of 64 bytes per row (the
+// matrix is most of it), one of the sixteen-column block iteration (sagg_multi.h) 64 instead of 128 per column.
+using cyc_t = float;
 
 inline unsigned grid_for(int64_t n, unsigned cap = 8192) {  // (caps are multiples of 8: see xcd_block)
     int64_t g = (n + TB - 1) / TB;
@@ -110,7 +116,8 @@ struct SLevel {
         e.valf = avalf.as<float>();
         return e;
     }
-    double *v(int which) const { return vec.as<double>() + (int64_t)which * ld; }
+    // (slots of ld doubles; a cyc_t vector uses the front of its slot)
+    template <typename T = double> T *v(int which) const { return reinterpret_cast<T *>(vec.as<double>() + (int64_t)which * ld); }
 };
 enum { V_X = 0, V_R = 1, V_XP = 2, V_RC = 3, V_C1 = 4, V_C2 = 5, V_V1 = 6, V_V2 = 7, V_R2 = 8, V_X1 = 9, V_T = 10,
        V_COUNT = 11 };
@@ -1107,7 +1114,8 @@ SHierarchy *hierarchy_of(nodal_ctx *h) {
 }
 
 struct SolveBufs {
-    double *r, *z, *p, *Ap, *x0, *part_rz, *part_zap, *part_rr, *part_pap, *sc;
+    double *r, *p, *Ap, *part_rz, *part_zap, *part_rr, *part_pap, *sc;
+    cyc_t *z, *x0;
     int g0;  // grid of the level-0 kernels that produce / consume dot partials
 };
 
@@ -1633,7 +1641,8 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
     }
     // (The cycle is a preconditioner: its sweeps read f32 copies of A, P, R -- a third less traffic, the
     // iteration count does not move -- which csr_to_ell, build_P, r_to_ell and the Galerkin kernel wrote
-    // beside the f64 values; the vectors, the outer SpMV and the residual stay f64.)
+    // beside the f64 values; so are its vectors (cyc_t, above); the outer iteration's vectors, the outer SpMV and
+    // the residual recurrence stay f64.)
     if (trace) {
         fprintf(stderr, "[sagg] levels (rows/entries/longest row/padded width):");
         for (int k = 0; k < H->nlev; ++k)
@@ -1664,7 +1673,8 @@ namespace {
 
 // out ~= A_l^-1 b.  At level 0 the post-smoothing kernel also leaves the partial dot products
 // out.b and out.Ap of the outer iteration (sb != nullptr).
-int cycle(nodal_ctx *h, SHierarchy *H, int l, const double *b, const double *x0, double *out, const SolveBufs *sb) {
+// the levels that end the recursion: the tail (one workgroup, sagg_cycle.h) or the coarsest level; f64 in and out
+int last_level(nodal_ctx *h, SHierarchy *H, int l, const double *b, double *out) {
     hipStream_t st = h->stream;
     SLevel *L = H->pool[l];
     const int64_t n = L->n;
@@ -1672,77 +1682,94 @@ int cycle(nodal_ctx *h, SHierarchy *H, int l, const double *b, const double *x0,
         if (H->td.slots <= 8) k_tail<8><<<1, 1024, (size_t)H->td.lds_bytes, st>>>(H->td, H->tail_image.as<char>(), b, out, 1);
         else if (H->td.slots <= 16) k_tail<16><<<1, 1024, (size_t)H->td.lds_bytes, st>>>(H->td, H->tail_image.as<char>(), b, out, 1);
         else k_tail<32><<<1, 1024, (size_t)H->td.lds_bytes, st>>>(H->td, H->tail_image.as<char>(), b, out, 1);
-        NODAL_HIP_TRY(h, hipGetLastError());
-        return NODAL_OK;
-    }
-    if (l == H->nlev - 1) {
+    } else {
         k_coarsest<<<grid_for(n), TB, 0, st>>>(n, H->dense_coarsest ? H->coarse_inv.as<double>() : nullptr,
                                                L->dinv.as<double>(), b, out);
-        NODAL_HIP_TRY(h, hipGetLastError());
-        return NODAL_OK;
     }
+    NODAL_HIP_TRY(h, hipGetLastError());
+    return NODAL_OK;
+}
+
+// One cycle of level l (never a last level: the hierarchy has two levels at least and the tail starts at level 1
+// or below).  TBV: type of the right-hand side (f64 from the outer iteration at level 0, cyc_t inside); TOUT: of the
+// result (cyc_t; f64 when the general path's FGMRES takes it as a Krylov vector).
+template <typename TBV, typename TOUT>
+int cycle(nodal_ctx *h, SHierarchy *H, int l, const TBV *b, const cyc_t *x0, TOUT *out, const SolveBufs *sb) {
+    hipStream_t st = h->stream;
+    SLevel *L = H->pool[l];
+    const int64_t n = L->n;
     SLevel *C = H->pool[l + 1];
     const int64_t nc = C->n;
     const Ell A = L->A();
     const double *dinv = L->dinv.as<double>();
-    const double *x = x0;  // the pre-smoothed iterate w D^-1 b, from the producer of b
-    double *r = L->v(V_R), *xp = L->v(V_XP);
-    double *rc = C->v(V_RC), *c1 = C->v(V_C1), *c2 = C->v(V_C2);
+    const cyc_t *x = x0;  // the pre-smoothed iterate w D^-1 b, from the producer of b
+    cyc_t *r = L->v<cyc_t>(V_R), *xp = L->v<cyc_t>(V_XP);
     const unsigned g = sb ? (unsigned)sb->g0 : grid_for(n);
     const unsigned tb = L->wfix ? TB : TB * LPR_RAGGED;  // (ragged rows: LPR_RAGGED lanes each, same rows per workgroup)
     const int nu = H->nu[l < 2 ? l : 2];
     if (nu >= 2) {  // second pre-smoothing sweep: x1 = x0 + w D^-1 (b - A x0)
-        double *x1 = L->v(V_X1);
-        SAGG_DISPATCH_W(L->wfix, (k_post<W, false><<<g, tb, 0, st>>>(A, dinv, b, x0, x1, nullptr, nullptr, nullptr)));
+        cyc_t *x1 = L->v<cyc_t>(V_X1);
+        SAGG_DISPATCH_W(L->wfix, (k_post<W, false, TBV, cyc_t><<<g, tb, 0, st>>>(A, dinv, b, x0, x1, nullptr, nullptr, nullptr)));
         x = x1;
     }
-    SAGG_DISPATCH_W(L->wfix, (k_smooth_residual<W><<<g, tb, 0, st>>>(A, b, x, r)));
-    double *x0c = C->v(V_X);
-    k_restrict<<<grid_for(nc * RL), TB, 0, st>>>(nc, L->rld, L->rcol.as<int32_t>(), L->rvalf.as<float>(),
-                                                L->rlen.as<int32_t>(), r, rc, C->dinv.as<double>(), x0c);
-    NODAL_HIP_TRY(h, hipGetLastError());
-    int nparts = 0;
-    // K-cycle (two flexible-CG steps on the coarse problem) at the first coarse level only, when
-    // that level is large enough to be outside the tail; plain V hand-over everywhere else
-    const bool kcycle = l < H->klevels && H->kcycle && l + 1 != H->tail && l + 1 != H->nlev - 1;
-    if (kcycle) {
-        double *v1 = C->v(V_V1), *v2 = C->v(V_V2), *r2 = C->v(V_R2);
-        double *part = C->part.as<double>();
-        const Ell Ac = C->A();
-        const unsigned gd = grid_for(nc, DOT_BLOCKS);  // (grid-stride beyond DOT_BLOCKS x TB rows)
-        const unsigned tbc = C->wfix ? TB : TB * LPR_RAGGED;
-        nparts = (int)gd;
-        NODAL_TRY(cycle(h, H, l + 1, rc, x0c, c1, nullptr));
-        SAGG_DISPATCH_W(C->wfix, (k_spmv_dots<W><<<gd, tbc, 0, st>>>(Ac, c1, v1, rc, nullptr, part + 0 * DOT_BLOCKS,
-                                                                    part + 1 * DOT_BLOCKS, nullptr)));
-        k_second_residual<<<grid_for(nc), TB, 0, st>>>(nc, rc, v1, part, nparts, r2, C->dinv.as<double>(), x0c);
-        NODAL_HIP_TRY(h, hipGetLastError());
-        NODAL_TRY(cycle(h, H, l + 1, r2, x0c, c2, nullptr));
-        SAGG_DISPATCH_W(C->wfix, (k_spmv_dots<W><<<gd, tbc, 0, st>>>(Ac, c2, v2, v1, r2, part + 3 * DOT_BLOCKS,
-                                                                    part + 2 * DOT_BLOCKS, part + 4 * DOT_BLOCKS)));
-        NODAL_HIP_TRY(h, hipGetLastError());
-    } else {
-        NODAL_TRY(cycle(h, H, l + 1, rc, x0c, c1, nullptr));
-    }
+    SAGG_DISPATCH_W(L->wfix, (k_smooth_residual<W, TBV><<<g, tb, 0, st>>>(A, b, x, r)));
+    const bool last = l + 1 == H->tail || l + 1 == H->nlev - 1;
     const double *coef = nullptr;
-    if (nparts) {  // s1, s2 once, instead of five reductions in every workgroup of the prolongation
-        double *cf = C->part.as<double>() + 5 * DOT_BLOCKS;
-        k_kcoef<<<1, 320, 0, st>>>(C->part.as<double>(), nparts, cf);
-        coef = cf;
+    if (last) {
+        double *rc = C->v<double>(V_RC), *c1 = C->v<double>(V_C1);
+        k_restrict<double><<<grid_for(nc * RL), TB, 0, st>>>(nc, L->rld, L->rcol.as<int32_t>(), L->rvalf.as<float>(),
+                                                            L->rlen.as<int32_t>(), r, rc, C->dinv.as<double>(), nullptr);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        NODAL_TRY(last_level(h, H, l + 1, rc, c1));
+        k_prolong<double><<<grid_for(n), TB, 0, st>>>(n, L->ld, L->pcol.as<int32_t>(), L->pvalf.as<float>(), x, c1,
+                                                     (const double *)nullptr, nullptr, xp);
+    } else {
+        cyc_t *rc = C->v<cyc_t>(V_RC), *c1 = C->v<cyc_t>(V_C1), *c2 = C->v<cyc_t>(V_C2), *x0c = C->v<cyc_t>(V_X);
+        k_restrict<cyc_t><<<grid_for(nc * RL), TB, 0, st>>>(nc, L->rld, L->rcol.as<int32_t>(), L->rvalf.as<float>(),
+                                                           L->rlen.as<int32_t>(), r, rc, C->dinv.as<double>(), x0c);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        int nparts = 0;
+        // K-cycle (two flexible-CG steps on the coarse problem) at the first coarse level only, when
+        // that level is large enough to be outside the tail; plain V hand-over everywhere else
+        const bool kcycle = l < H->klevels && H->kcycle;
+        if (kcycle) {
+            cyc_t *v1 = C->v<cyc_t>(V_V1), *v2 = C->v<cyc_t>(V_V2), *r2 = C->v<cyc_t>(V_R2);
+            double *part = C->part.as<double>();
+            const Ell Ac = C->A();
+            const unsigned gd = grid_for(nc, DOT_BLOCKS);  // (grid-stride beyond DOT_BLOCKS x TB rows)
+            const unsigned tbc = C->wfix ? TB : TB * LPR_RAGGED;
+            nparts = (int)gd;
+            NODAL_TRY((cycle<cyc_t, cyc_t>(h, H, l + 1, rc, x0c, c1, nullptr)));
+            SAGG_DISPATCH_W(C->wfix, (k_spmv_dots<W><<<gd, tbc, 0, st>>>(Ac, c1, v1, rc, nullptr, part + 0 * DOT_BLOCKS,
+                                                                        part + 1 * DOT_BLOCKS, nullptr)));
+            k_second_residual<<<grid_for(nc), TB, 0, st>>>(nc, rc, v1, part, nparts, r2, C->dinv.as<double>(), x0c);
+            NODAL_HIP_TRY(h, hipGetLastError());
+            NODAL_TRY((cycle<cyc_t, cyc_t>(h, H, l + 1, r2, x0c, c2, nullptr)));
+            SAGG_DISPATCH_W(C->wfix, (k_spmv_dots<W><<<gd, tbc, 0, st>>>(Ac, c2, v2, v1, r2, part + 3 * DOT_BLOCKS,
+                                                                        part + 2 * DOT_BLOCKS, part + 4 * DOT_BLOCKS)));
+            NODAL_HIP_TRY(h, hipGetLastError());
+        } else {
+            NODAL_TRY((cycle<cyc_t, cyc_t>(h, H, l + 1, rc, x0c, c1, nullptr)));
+        }
+        if (nparts) {  // s1, s2 once, instead of five reductions in every workgroup of the prolongation
+            double *cf = C->part.as<double>() + 5 * DOT_BLOCKS;
+            k_kcoef<<<1, 320, 0, st>>>(C->part.as<double>(), nparts, cf);
+            coef = cf;
+        }
+        k_prolong<cyc_t><<<grid_for(n), TB, 0, st>>>(n, L->ld, L->pcol.as<int32_t>(), L->pvalf.as<float>(), x, c1, c2, coef,
+                                                    xp);
     }
-    k_prolong<<<grid_for(n), TB, 0, st>>>(n, L->ld, L->pcol.as<int32_t>(), L->pvalf.as<float>(), x, c1, c2, coef,
-                                         xp);
-    const double *cur = xp;
+    const cyc_t *cur = xp;
     if (nu >= 2) {  // first of two post-smoothing sweeps
-        double *mid = L->v(V_T);
-        SAGG_DISPATCH_W(L->wfix, (k_post<W, false><<<g, tb, 0, st>>>(A, dinv, b, cur, mid, nullptr, nullptr, nullptr)));
+        cyc_t *mid = L->v<cyc_t>(V_T);
+        SAGG_DISPATCH_W(L->wfix, (k_post<W, false, TBV, cyc_t><<<g, tb, 0, st>>>(A, dinv, b, cur, mid, nullptr, nullptr, nullptr)));
         cur = mid;
     }
     if (sb) {
-        SAGG_DISPATCH_W(L->wfix, (k_post<W, true><<<g, tb, 0, st>>>(A, dinv, b, cur, out, sb->Ap, sb->part_rz,
-                                                                    sb->part_zap)));
+        SAGG_DISPATCH_W(L->wfix, (k_post<W, true, TBV, TOUT><<<g, tb, 0, st>>>(A, dinv, b, cur, out, sb->Ap, sb->part_rz,
+                                                                              sb->part_zap)));
     } else {
-        SAGG_DISPATCH_W(L->wfix, (k_post<W, false><<<g, tb, 0, st>>>(A, dinv, b, cur, out, nullptr, nullptr, nullptr)));
+        SAGG_DISPATCH_W(L->wfix, (k_post<W, false, TBV, TOUT><<<g, tb, 0, st>>>(A, dinv, b, cur, out, nullptr, nullptr, nullptr)));
     }
     NODAL_HIP_TRY(h, hipGetLastError());
     return NODAL_OK;
@@ -1760,9 +1787,9 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 // z ~= A^-1 r with one cycle of the hierarchy built by sagg_setup_csr (the preconditioner of the
 // general path's FGMRES, sparse_general.hip)
 __global__ __launch_bounds__(TB) void k_x0(int64_t n, const double *__restrict__ dinv, const double *__restrict__ r,
-                                           double *__restrict__ x0) {
+                                           cyc_t *__restrict__ x0) {
     for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
-        x0[i] = OMEGA * dinv[i] * r[i];
+        x0[i] = (cyc_t)(OMEGA * dinv[i] * r[i]);
 }
 bool sagg_ready(nodal_ctx *h, int64_t n) {
     SHierarchy *H = static_cast<SHierarchy *>(h->sagg);
@@ -1776,10 +1803,10 @@ int sagg_apply(nodal_ctx *h, const double *r, double *z) {
     SHierarchy *H = static_cast<SHierarchy *>(h->sagg);
     if (!H || !H->ready) return nodal_fail(h, NODAL_E_INVALID, "sagg_setup_csr not called");
     SLevel *L0 = H->pool[0];
-    double *x0 = L0->v(V_X);
+    cyc_t *x0 = L0->v<cyc_t>(V_X);
     k_x0<<<grid_for(L0->n), TB, 0, h->stream>>>(L0->n, L0->dinv.as<double>(), r, x0);
     NODAL_HIP_TRY(h, hipGetLastError());
-    return cycle(h, H, 0, r, x0, z, nullptr);
+    return cycle<double, double>(h, H, 0, r, x0, z, nullptr);
 }
 
 // y = A x with the level-0 ELL copy of the matrix the hierarchy was built on
@@ -1834,10 +1861,10 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     char *base = h->solver.as<char>();
     SolveBufs sb;
     sb.r = reinterpret_cast<double *>(base);
-    sb.z = reinterpret_cast<double *>(base + vec);
+    sb.z = reinterpret_cast<cyc_t *>(base + vec);
     sb.p = reinterpret_cast<double *>(base + 2 * vec);
     sb.Ap = reinterpret_cast<double *>(base + 3 * vec);
-    sb.x0 = reinterpret_cast<double *>(base + 4 * vec);
+    sb.x0 = reinterpret_cast<cyc_t *>(base + 4 * vec);
     sb.part_rz = reinterpret_cast<double *>(base + 5 * vec);
     sb.part_zap = sb.part_rz + MAX_PARTIALS;
     sb.part_rr = sb.part_zap + MAX_PARTIALS;
@@ -1874,7 +1901,7 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     int polls = 0;
     // one outer iteration (the kernels take its parity only: see f_direction)
     auto iteration = [&](int it, bool timed) -> int {
-        NODAL_TRY(cycle(h, H, 0, sb.r, sb.x0, sb.z, &sb));
+        NODAL_TRY((cycle<double, cyc_t>(h, H, 0, sb.r, sb.x0, sb.z, &sb)));
         f_direction<<<sb.g0, TB, 0, st>>>(sb.z, sb.p, sb.part_rz, sb.part_zap, sb.part_rr, sb.g0, sb.sc, it & 1, n);
         // one launch per poll batch is timed: start / stop events tied to the dispatch itself
         // (hipExtLaunchKernelGGL), i.e. the kernel's own duration as rocprofv3 reports it -- a pair

@@ -131,15 +131,15 @@ __device__ __forceinline__ void reduce_partials3(const double *__restrict__ pa, 
 // r = b - A x0, where x0 = w D^-1 b is the pre-smoothed iterate from a zero guess.  x0 comes from
 // whoever produced b (f_init / f_update, k_restrict, k_second_residual): the row sum then gathers
 // one vector, not D^-1 and b.
-template <int W>
-__global__ __launch_bounds__(TB * RowLanes<W>::value) void k_smooth_residual(Ell A, const double *__restrict__ b,
-                                                        const double *__restrict__ x0, double *__restrict__ r) {
+template <int W, typename TBV>
+__global__ __launch_bounds__(TB * RowLanes<W>::value) void k_smooth_residual(Ell A, const TBV *__restrict__ b,
+                                                        const cyc_t *__restrict__ x0, cyc_t *__restrict__ r) {
     constexpr int LPR = RowLanes<W>::value, NT = TB * LPR;  // (the workgroup still covers TB rows)
     const int sub = threadIdx.x & (LPR - 1);
     for (int64_t t = (int64_t)xcd_block() * NT + threadIdx.x; t / LPR < A.n; t += (int64_t)gridDim.x * NT) {
         const int64_t i = t / LPR;
-        const double s = ell_row_w<W>(A, A.valf, i, sub, [&](int32_t j) { return x0[j]; });
-        if (sub == 0) r[i] = b[i] - s;
+        const double s = ell_row_w<W>(A, A.valf, i, sub, [&](int32_t j) { return (double)x0[j]; });
+        if (sub == 0) r[i] = (cyc_t)((double)b[i] - s);
     }
 }
 
@@ -148,10 +148,11 @@ __global__ __launch_bounds__(TB * RowLanes<W>::value) void k_smooth_residual(Ell
 // wavefront eight consecutive rows = 64 contiguous entries.  (One thread per row walked its
 // 17-40 entries alone: 10-20 dependent round trips, 15-20 us whatever the level's size.)
 constexpr int RL = 8;
+template <typename TO>
 __global__ __launch_bounds__(TB) void k_restrict(int64_t nc, int64_t rld, const int32_t *__restrict__ rcol,
                                                  const float *__restrict__ rval, const int32_t *__restrict__ rlen,
-                                                 const double *__restrict__ r, double *__restrict__ rc,
-                                                 const double *__restrict__ cdinv, double *__restrict__ x0c) {
+                                                 const cyc_t *__restrict__ r, TO *__restrict__ rc,
+                                                 const double *__restrict__ cdinv, cyc_t *__restrict__ x0c) {
     const int sub = threadIdx.x & (RL - 1);
     const int64_t rows_per_pass = (int64_t)gridDim.x * (TB / RL);
     for (int64_t I0 = (int64_t)xcd_block() * (TB / RL); I0 < nc; I0 += rows_per_pass) {
@@ -173,14 +174,14 @@ __global__ __launch_bounds__(TB) void k_restrict(int64_t nc, int64_t rld, const 
                     v[u] = ok ? (double)loaded : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < RU; ++u) s = fma(v[u], r[c[u]], s);
+                for (int u = 0; u < RU; ++u) s = fma(v[u], (double)r[c[u]], s);
             }
         }
 #pragma unroll
         for (int off = RL >> 1; off > 0; off >>= 1) s += __shfl_down(s, off, RL);
         if (I < nc && sub == 0) {
-            rc[I] = s;
-            if (x0c) x0c[I] = OMEGA * cdinv[I] * s;  // pre-smoothed iterate of the coarse visit
+            rc[I] = (TO)s;
+            if (x0c) x0c[I] = (cyc_t)(OMEGA * cdinv[I] * s);  // pre-smoothed iterate of the coarse visit
         }
     }
 }
@@ -227,10 +228,11 @@ __global__ __launch_bounds__(320) void k_kcoef(const double *__restrict__ part, 
 }
 
 // xp = x + P (s1 c1 + s2 c2)   (coef == nullptr: plain V hand-over, xp = x + P c1)
+template <typename TC>
 __global__ __launch_bounds__(TB) void k_prolong(int64_t n, int64_t ld, const int32_t *__restrict__ pcol,
-                                                const float *__restrict__ pval, const double *__restrict__ x,
-                                                const double *__restrict__ c1, const double *__restrict__ c2,
-                                                const double *__restrict__ coef, double *__restrict__ xp) {
+                                                const float *__restrict__ pval, const cyc_t *__restrict__ x,
+                                                const TC *__restrict__ c1, const TC *__restrict__ c2,
+                                                const double *__restrict__ coef, cyc_t *__restrict__ xp) {
     const bool two = coef != nullptr;
     const double s1 = two ? coef[0] : 1.0, s2 = two ? coef[1] : 0.0;
     for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
@@ -243,21 +245,21 @@ __global__ __launch_bounds__(TB) void k_prolong(int64_t n, int64_t ld, const int
             J[q] = pcol[(int64_t)q * ld + i];
             w[q] = (double)pval[(int64_t)q * ld + i];
         }
-        double s = x[i];
+        double s = (double)x[i];
 #pragma unroll
         for (int q = 0; q < PW; ++q) {
             const int32_t j = J[q] < 0 ? 0 : J[q];
-            const double e = two ? s1 * c1[j] + s2 * c2[j] : c1[j];
+            const double e = two ? s1 * (double)c1[j] + s2 * (double)c2[j] : (double)c1[j];
             s = fma(J[q] < 0 ? 0.0 : w[q], e, s);
         }
-        xp[i] = s;
+        xp[i] = (cyc_t)s;
     }
 }
 
 // out = xp + w D^-1 (b - A xp); DOTS: partial sums of out.b and out.u (the outer iteration's z.r, z.Ap)
-template <int W, bool DOTS>
-__global__ __launch_bounds__(TB * RowLanes<W>::value) void k_post(Ell A, const double *__restrict__ dinv, const double *__restrict__ b,
-                                             const double *__restrict__ xp, double *__restrict__ out,
+template <int W, bool DOTS, typename TBV, typename TOUT>
+__global__ __launch_bounds__(TB * RowLanes<W>::value) void k_post(Ell A, const double *__restrict__ dinv, const TBV *__restrict__ b,
+                                             const cyc_t *__restrict__ xp, TOUT *__restrict__ out,
                                              const double *__restrict__ u, double *__restrict__ p_ob,
                                              double *__restrict__ p_ou) {
     double a0 = 0.0, a1 = 0.0;
@@ -265,11 +267,13 @@ __global__ __launch_bounds__(TB * RowLanes<W>::value) void k_post(Ell A, const d
     const int sub = threadIdx.x & (LPR - 1);
     for (int64_t t = (int64_t)xcd_block() * NT + threadIdx.x; t / LPR < A.n; t += (int64_t)gridDim.x * NT) {
         const int64_t i = t / LPR;
-        const double s = ell_row_w<W>(A, A.valf, i, sub, [&](int32_t j) { return xp[j]; });
+        const double s = ell_row_w<W>(A, A.valf, i, sub, [&](int32_t j) { return (double)xp[j]; });
         if (sub != 0) continue;
-        const double bi = b[i];
-        const double o = fma(OMEGA * dinv[i], bi - s, xp[i]);
-        out[i] = o;
+        const double bi = (double)b[i];
+        // (the dots take the value as stored: z.r and z.Ap are those of the z the direction is built from)
+        const TOUT os = (TOUT)fma(OMEGA * dinv[i], bi - s, (double)xp[i]);
+        const double o = (double)os;
+        out[i] = os;
         if (DOTS) {
             a0 = fma(o, bi, a0);
             a1 = fma(o, u[i], a1);
@@ -287,8 +291,8 @@ __global__ __launch_bounds__(TB * RowLanes<W>::value) void k_post(Ell A, const d
 
 // v = A c and the partial dot products c.v, c.u1 (and c.u2 when given)
 template <int W>
-__global__ __launch_bounds__(TB * RowLanes<W>::value) void k_spmv_dots(Ell A, const double *__restrict__ c, double *__restrict__ v,
-                                                  const double *__restrict__ u1, const double *__restrict__ u2,
+__global__ __launch_bounds__(TB * RowLanes<W>::value) void k_spmv_dots(Ell A, const cyc_t *__restrict__ c, cyc_t *__restrict__ v,
+                                                  const cyc_t *__restrict__ u1, const cyc_t *__restrict__ u2,
                                                   double *__restrict__ p_cv, double *__restrict__ p_cu1,
                                                   double *__restrict__ p_cu2) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -296,13 +300,14 @@ __global__ __launch_bounds__(TB * RowLanes<W>::value) void k_spmv_dots(Ell A, co
     const int sub = threadIdx.x & (LPR - 1);
     for (int64_t t = (int64_t)xcd_block() * NT + threadIdx.x; t / LPR < A.n; t += (int64_t)gridDim.x * NT) {
         const int64_t i = t / LPR;
-        const double s = ell_row_w<W>(A, A.valf, i, sub, [&](int32_t j) { return c[j]; });
+        const double sd = ell_row_w<W>(A, A.valf, i, sub, [&](int32_t j) { return (double)c[j]; });
         if (sub != 0) continue;
-        v[i] = s;
-        const double ci = c[i];
+        const cyc_t vs = (cyc_t)sd;
+        v[i] = vs;
+        const double s = (double)vs, ci = (double)c[i];
         a0 = fma(ci, s, a0);
-        a1 = fma(ci, u1[i], a1);
-        if (u2) a2 = fma(ci, u2[i], a2);
+        a1 = fma(ci, (double)u1[i], a1);
+        if (u2) a2 = fma(ci, (double)u2[i], a2);
     }
     a0 = block_sum<NT>(a0);
     a1 = block_sum<NT>(a1);
@@ -315,19 +320,19 @@ __global__ __launch_bounds__(TB * RowLanes<W>::value) void k_spmv_dots(Ell A, co
 }
 
 // r2 = rc - (alpha1 / rho1) v1
-__global__ __launch_bounds__(TB) void k_second_residual(int64_t n, const double *__restrict__ rc,
-                                                        const double *__restrict__ v1,
+__global__ __launch_bounds__(TB) void k_second_residual(int64_t n, const cyc_t *__restrict__ rc,
+                                                        const cyc_t *__restrict__ v1,
                                                         const double *__restrict__ part, int nparts,
-                                                        double *__restrict__ r2, const double *__restrict__ dinv,
-                                                        double *__restrict__ x0) {
+                                                        cyc_t *__restrict__ r2, const double *__restrict__ dinv,
+                                                        cyc_t *__restrict__ x0) {
     double rho1, alpha1, unused;
     reduce_partials3(part + 0 * DOT_BLOCKS, part + 1 * DOT_BLOCKS, nullptr, nparts, rho1, alpha1, unused);
     const double t = rho1 > 0.0 ? alpha1 / rho1 : 0.0;
     for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
     {
-        const double v = fma(-t, v1[i], rc[i]);
-        r2[i] = v;
-        x0[i] = OMEGA * dinv[i] * v;
+        const double v = fma(-t, (double)v1[i], (double)rc[i]);
+        r2[i] = (cyc_t)v;
+        x0[i] = (cyc_t)(OMEGA * dinv[i] * v);
     }
 }
 
@@ -626,14 +631,14 @@ constexpr int MAX_PARTIALS = 1024;
 
 __global__ __launch_bounds__(TB) void f_init(const double *__restrict__ b, double *__restrict__ x,
                                              double *__restrict__ r, double *__restrict__ Ap,
-                                             const double *__restrict__ dinv, double *__restrict__ x0,
+                                             const double *__restrict__ dinv, cyc_t *__restrict__ x0,
                                              double *__restrict__ part_rr, int64_t n) {
     double srr = 0.0;
     for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
         const double ri = b[i];
         x[i] = 0.0;
         r[i] = ri;
-        x0[i] = OMEGA * dinv[i] * ri;
+        x0[i] = (cyc_t)(OMEGA * dinv[i] * ri);
         Ap[i] = 0.0;
         srr = fma(ri, ri, srr);
     }
@@ -646,7 +651,7 @@ __global__ __launch_bounds__(TB) void f_init(const double *__restrict__ b, doubl
 // f_direction(parity cur) reads ITNO[prev] -- written by the previous iteration's f_direction, so no
 // workgroup of this launch can see it change -- and leaves ITNO[cur] = that + 1.  A pair of iterations
 // (parities 0, 1) therefore has fixed kernel arguments and can be replayed as a hipGraph.
-__global__ __launch_bounds__(TB) void f_direction(const double *__restrict__ z, double *__restrict__ p,
+__global__ __launch_bounds__(TB) void f_direction(const cyc_t *__restrict__ z, double *__restrict__ p,
                                                   const double *__restrict__ part_rz,
                                                   const double *__restrict__ part_zap,
                                                   const double *__restrict__ part_rr, int nparts,
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(TB) void f_direction(const double *__restrict__ z, 
     }
     if (converged) return;  // uniform over the grid: every workgroup reduces the same partials
     for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
-        p[i] = iter > 0 ? fma(beta, p[i], z[i]) : z[i];
+        p[i] = iter > 0 ? fma(beta, p[i], (double)z[i]) : (double)z[i];
 }
 
 // y = A x on the level-0 matrix (fp64 values): the Krylov SpMV of the general path when the hierarchy's
@@ -716,7 +721,7 @@ __global__ __launch_bounds__(TB * RowLanes<W>::value) void f_spmv(Ell A, const d
 __global__ __launch_bounds__(TB) void f_update(double *__restrict__ x, double *__restrict__ r,
                                                const double *__restrict__ p, const double *__restrict__ Ap,
                                                const double *__restrict__ part_pap, int nparts,
-                                               const double *__restrict__ dinv, double *__restrict__ x0,
+                                               const double *__restrict__ dinv, cyc_t *__restrict__ x0,
                                                double *__restrict__ part_rr, double *__restrict__ sc, int iter,
                                                int64_t n) {
     const int cur = iter & 1;
@@ -734,7 +739,7 @@ __global__ __launch_bounds__(TB) void f_update(double *__restrict__ x, double *_
         x[i] = fma(alpha, p[i], x[i]);
         const double ri = fma(-alpha, Ap[i], r[i]);
         r[i] = ri;
-        x0[i] = OMEGA * dinv[i] * ri;  // the next cycle's pre-smoothed iterate
+        x0[i] = (cyc_t)(OMEGA * dinv[i] * ri);  // the next cycle's pre-smoothed iterate
         srr = fma(ri, ri, srr);
     }
     srr = block_sum(srr);

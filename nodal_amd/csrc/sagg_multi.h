@@ -21,11 +21,7 @@
 namespace {
 
 constexpr int MK = 16;        // columns of a block
-// Vectors inside the cycle (the preconditioner: residuals, corrections and smoothing iterates of every level outside
-// the tail, the start iterate w D^-1 r and the result z) are kept in f32 like the cycle's copies of A, P and R: the
-// outer iteration is a flexible one and its own vectors (x, r, p, Ap) and every dot product stay f64.  Level-0 passes
-// move 64 B per row and vector instead of 128.
-using cyc_t = float;
+// (cyc_t, the type of the vectors inside the cycle: sagg.hip)
 constexpr int MK_SHIFT = 4;
 constexpr int MSC = 32;       // scalars per column: the single-vector block's F_COUNT words + the functional's (below)
 enum { M_SUM = 16, M_INC = 17 /* .. 20: the last increments alpha_j r_j.z_j, a ring */, M_RING = 4, M_FDONE = 21 };

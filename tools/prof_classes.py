@@ -28,16 +28,17 @@ def classify(path, workload, n, nnz, verbose=False):
     W = 5  # padded ELL width of the grid's level 0
     f32row = W * 8          # col i32 + val f32 per slot
     f64row = W * 12
-    # bytes per level-0 row of each pass (reads + writes, vectors f64)
+    # bytes per level-0 row of each pass (reads + writes; the outer iteration's vectors x, r, p, Ap are f64, the
+    # vectors inside the cycle -- x0, the cycle's residual, xp, z -- f32 since round 4: csrc/sagg.hip, cyc_t)
     level0_bytes = {
-        "k_smooth_residual": f32row + 8 + 8 + 8,            # A, x0 gather, b, r
-        "k_restrict": 4 * 8 + 8 + 8 / 7.0,                  # R entries (col + f32 val) of the 4 P slots per fine row, r, rc
-        "k_prolong": 4 * 8 + 8 + 8 + 8 / 7.0,               # P (col + f32 val) x 4, x, xp, coarse gathers
-        "k_post": f32row + 8 + 8 + 8 + 8 + 8 + 8,           # A, xp gather + own, b, dinv, out, u
+        "k_smooth_residual": f32row + 8 + 4 + 4,            # A, b (f64: the outer residual), x0 gather, r
+        "k_restrict": 4 * 8 + 4 + 8 / 7.0,                  # R entries (col + f32 val) of the 4 P slots per fine row, r, rc
+        "k_prolong": 4 * 8 + 4 + 4 + 8 / 7.0,               # P (col + f32 val) x 4, x, xp, coarse gathers
+        "k_post": f32row + 8 + 4 + 4 + 4 + 8 + 8,           # A, b (f64), xp gather + own, out (z), u (Ap, f64), dinv
         "f_spmv": f64row + 8 + 8 + 8,                       # A (f64), p gather + own, Ap
-        "f_direction": 8 + 8 + 8,                           # z, p, p
-        "f_update": 8 * 4 + 8 * 3 + 8,                      # x r p Ap in, x r x0 out, dinv
-        "f_init": 8 * 2 + 8 * 4,
+        "f_direction": 4 + 8 + 8,                           # z, p, p
+        "f_update": 8 * 4 + 8 * 2 + 4 + 8,                  # x r p Ap in, x r out, x0 out, dinv
+        "f_init": 8 * 2 + 8 * 3 + 4,
     }
     setup_names = ("mis_", "assign_", "build_P", "r_count", "r_fill", "r_sort", "r_to_ell", "r_refresh", "ap_rows",
                    "galerkin", "coarsest_inverse", "flags_up", "last_level", "any_unflagged", "k_tail_pack", "row_stats",
