@@ -323,13 +323,20 @@ inline void nd_dissect(NdState &st, int64_t lo, int64_t hi, bool connected, int3
     }
 }
 
-inline void nested_dissection(int64_t n, const Graph &g, std::vector<int32_t> &order, std::vector<int32_t> &sn_start) {
+// `skip` (optional): vertices that are not part of the graph any more (peel_low_degree below has ordered them);
+// `order` then holds the others only.
+inline void nested_dissection(int64_t n, const Graph &g, std::vector<int32_t> &order, std::vector<int32_t> &sn_start,
+                              const std::vector<uint8_t> *skip = nullptr) {
     // hubs: set aside, eliminated last
     const double avg = n > 0 ? (double)g.adj.size() / (double)n : 0.0;
     const int64_t hub_bar = std::max<int64_t>(64, (int64_t)(20.0 * avg));
     NdState st(g, n);
     int64_t nrest = 0, nhubs = 0;
     for (int64_t v = 0; v < n; ++v) {  // perm: the rest in front (ascending), the hubs behind them (ascending)
+        if (skip && (*skip)[(size_t)v]) {
+            st.tag[(size_t)v].store(-2, std::memory_order_relaxed);
+            continue;
+        }
         if (g.ptr[(size_t)v + 1] - g.ptr[(size_t)v] > hub_bar) {
             st.scratch[(size_t)nhubs++] = (int32_t)v;
             st.tag[(size_t)v].store(-2, std::memory_order_relaxed);
@@ -339,15 +346,127 @@ inline void nested_dissection(int64_t n, const Graph &g, std::vector<int32_t> &o
         }
     }
     std::copy(st.scratch.begin(), st.scratch.begin() + nhubs, st.perm.begin() + nrest);
+    const int64_t m = nrest + nhubs;  // (= n without a skip list)
     nd_dissect(st, 0, nrest, false, 0, 0);
     // a hub supernode of thousands of vertices would be one huge dense pivot block: chunks of 256 instead
-    for (int64_t k = nrest; k < n; k += 256) st.snflag[(size_t)k] = 1;
+    for (int64_t k = nrest; k < m; k += 256) st.snflag[(size_t)k] = 1;
     order = std::move(st.perm);
+    order.resize((size_t)m);
     sn_start.clear();
-    for (int64_t k = 0; k < n; ++k)
+    for (int64_t k = 0; k < m; ++k)
         if (st.snflag[(size_t)k]) sn_start.push_back((int32_t)k);
-    sn_start.push_back((int32_t)n);
-    if (n == 0) sn_start.assign(1, 0);
+    sn_start.push_back((int32_t)m);
+    if (m == 0) sn_start.assign(1, 0);
+}
+
+// Tree-like parts first.  Level structures dissect a branching tree badly (half of its vertices sit in the last
+// level: a 2944-wide front for a binary tree of 20 000 nodes), while eliminating vertices with at most two
+// neighbours costs no fill to speak of: a leaf none, a vertex of a chain one edge between its neighbours.  Rounds
+// of INDEPENDENT such vertices (no two adjacent: a round is one level of the assembly tree, fronts of dimension
+// <= 3; the highest hash wins among adjacent candidates) are ordered first, as lowdeg.hip eliminates them
+// numerically on passive networks; what is left -- with the fill edges -- goes to the dissection.  Only when the first
+// round takes a sixteenth of the graph (trees, chains, wires; a grid has its four corners); rounds go on while they
+// take half a percent of what is left.
+inline uint32_t peel_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+inline void peel_low_degree(int64_t n, const Graph &g, std::vector<int32_t> &peeled, std::vector<uint8_t> &gone,
+                            Graph &core) {
+    peeled.clear();
+    {   // (cheap way out: fewer than a sixteenth of the vertices have two neighbours or fewer to begin with)
+        int64_t low = 0;
+        for (int64_t v = 0; v < n; ++v) low += g.ptr[(size_t)v + 1] - g.ptr[(size_t)v] <= 2;
+        if (low * 16 < n) return;
+    }
+    gone.assign((size_t)n, 0);
+    std::vector<std::vector<int32_t>> extra((size_t)n);  // fill edges (both directions)
+    std::vector<int32_t> nb;                              // scratch: current neighbours of a vertex
+    auto neighbours = [&](int32_t u, std::vector<int32_t> &out) {  // remaining neighbours, each once, at most 3 wanted
+        out.clear();
+        auto take = [&](int32_t w) {
+            if (gone[(size_t)w] || w == u) return;
+            for (int32_t x : out)
+                if (x == w) return;
+            out.push_back(w);
+        };
+        for (int64_t e = g.ptr[(size_t)u]; e < g.ptr[(size_t)u + 1] && out.size() < 3; ++e) take(g.adj[(size_t)e]);
+        for (size_t e = 0; e < extra[(size_t)u].size() && out.size() < 3; ++e) take(extra[(size_t)u][e]);
+    };
+    std::vector<int32_t> cand, next_cand, chosen;
+    std::vector<uint8_t> is_cand((size_t)n, 0), queued((size_t)n, 0);
+    for (int64_t v = 0; v < n; ++v) {
+        neighbours((int32_t)v, nb);
+        if (nb.size() <= 2) { cand.push_back((int32_t)v); is_cand[(size_t)v] = 1; }
+    }
+    int64_t remaining = n;
+    for (int round = 0; round < 64 && !cand.empty(); ++round) {
+        // independent set among the candidates: the highest (hash, id) among adjacent candidates
+        chosen.clear();
+        for (int32_t v : cand) {
+            neighbours(v, nb);
+            if (nb.size() > 2) { is_cand[(size_t)v] = 0; continue; }  // (its degree grew: a fill edge)
+            const uint64_t pv = ((uint64_t)peel_hash((uint32_t)v) << 32) | (uint32_t)v;
+            bool best = true;
+            for (int32_t w : nb)
+                if (is_cand[(size_t)w] && (((uint64_t)peel_hash((uint32_t)w) << 32) | (uint32_t)w) > pv) best = false;
+            if (best) chosen.push_back(v);
+        }
+        if (round == 0 && (int64_t)chosen.size() * 16 < n) break;
+        if ((int64_t)chosen.size() * 200 < remaining) break;
+        next_cand.clear();
+        for (int32_t v : cand)
+            if (is_cand[(size_t)v]) queued[(size_t)v] = 0;
+        for (int32_t v : chosen) {
+            neighbours(v, nb);
+            gone[(size_t)v] = 1;
+            is_cand[(size_t)v] = 0;
+            peeled.push_back(v);
+            if (nb.size() == 2) {  // the fill edge, unless it is there already
+                const int32_t a = nb[0], b = nb[1];
+                bool have = false;
+                for (int64_t e = g.ptr[(size_t)a]; e < g.ptr[(size_t)a + 1] && !have; ++e) have = g.adj[(size_t)e] == b;
+                for (size_t e = 0; e < extra[(size_t)a].size() && !have; ++e) have = extra[(size_t)a][e] == b;
+                if (!have) {
+                    extra[(size_t)a].push_back(b);
+                    extra[(size_t)b].push_back(a);
+                }
+            }
+            for (int32_t w : nb)
+                if (!queued[(size_t)w]) { queued[(size_t)w] = 1; next_cand.push_back(w); }
+        }
+        remaining -= (int64_t)chosen.size();
+        // candidates of the next round: the old ones that were not chosen, and the neighbours of the chosen ones
+        for (int32_t v : cand)
+            if (is_cand[(size_t)v] && !gone[(size_t)v] && !queued[(size_t)v]) { queued[(size_t)v] = 1; next_cand.push_back(v); }
+        cand.clear();
+        for (int32_t v : next_cand) {
+            queued[(size_t)v] = 0;
+            if (gone[(size_t)v]) continue;
+            neighbours(v, nb);
+            is_cand[(size_t)v] = nb.size() <= 2;
+            if (is_cand[(size_t)v]) cand.push_back(v);
+        }
+        std::sort(cand.begin(), cand.end());  // (a fixed order whatever the history)
+    }
+    if (peeled.empty()) return;
+    // what is left, with the fill edges
+    core.ptr.assign((size_t)n + 1, 0);
+    core.adj.clear();
+    std::vector<int32_t> list;
+    for (int64_t u = 0; u < n; ++u) {
+        if (!gone[(size_t)u]) {
+            list.clear();
+            for (int64_t e = g.ptr[(size_t)u]; e < g.ptr[(size_t)u + 1]; ++e)
+                if (!gone[(size_t)g.adj[(size_t)e]]) list.push_back(g.adj[(size_t)e]);
+            for (int32_t w : extra[(size_t)u])
+                if (!gone[(size_t)w]) list.push_back(w);
+            std::sort(list.begin(), list.end());
+            list.erase(std::unique(list.begin(), list.end()), list.end());
+            core.adj.insert(core.adj.end(), list.begin(), list.end());
+        }
+        core.ptr[(size_t)u + 1] = (int64_t)core.adj.size();
+    }
 }
 
 struct Symbolic {
@@ -375,7 +494,27 @@ inline bool analyse(int64_t n, const int32_t *indptr, const int32_t *indices, co
     symmetrised_graph(n, indptr, indices, rmatch, g);
     const double t_graph = ms_since(t0);
     std::vector<int32_t> order;
-    nested_dissection(n, g, order, S.sn_start);
+    {
+        std::vector<int32_t> peeled;
+        std::vector<uint8_t> gone;
+        Graph core;
+        static const bool peel = !(getenv("NODAL_DIRECT_PEEL") && atoi(getenv("NODAL_DIRECT_PEEL")) == 0);
+        if (peel) peel_low_degree(n, g, peeled, gone, core);
+        if (peeled.empty()) {
+            nested_dissection(n, g, order, S.sn_start);
+        } else {
+            std::vector<int32_t> rest_order, rest_sn;
+            nested_dissection(n, core, rest_order, rest_sn, &gone);
+            order = peeled;  // every peeled vertex a supernode of its own
+            order.insert(order.end(), rest_order.begin(), rest_order.end());
+            S.sn_start.resize(peeled.size());
+            for (size_t k = 0; k < peeled.size(); ++k) S.sn_start[k] = (int32_t)k;
+            for (int32_t b : rest_sn) S.sn_start.push_back((int32_t)peeled.size() + b);
+            if (trace)
+                fprintf(stderr, "[direct] %zu of %lld vertices with at most two neighbours ordered first\n", peeled.size(),
+                        (long long)n);
+        }
+    }
     const double t_nd = ms_since(t0);
     const int32_t nsn = (int32_t)S.sn_start.size() - 1;
     std::vector<int32_t> newpos((size_t)n), sn_of((size_t)n);

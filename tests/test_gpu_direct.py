@@ -291,3 +291,22 @@ def test_resistance_sweep_on_a_large_network_with_a_negative_resistor():
             b[ib[q]] = -1.0
         want = b @ lu.solve(b)
         assert abs(res[q] - want) <= 1e-9 * max(abs(want), np.abs(lu.solve(b)).max())
+
+
+def test_direct_route_orders_tree_like_parts_first():
+    """A branching tree defeats the level-structure dissection (half of its vertices sit in the last level: fronts
+    of 223 GB for a binary tree of 1e6 nodes); csrc/slu_analyse.h orders rounds of independent vertices with at most
+    two neighbours first, which leaves fronts of dimension 3.  The direct route, forced, against the default route
+    (the low-degree elimination of lowdeg.hip) on a tree the dense rescue could not hold."""
+    table = gen.binary_tree_table(300000)
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    x_default, info, _, _ = h.solve_sparse()
+    assert info == 0
+    x_direct, info, iters, _ = h.solve_sparse(method=_ffi.SPARSE_DIRECT)
+    assert info == 0 and iters <= 3
+    assert h.residual() < 1e-13
+    h.close()
+    assert np.abs(x_direct - x_default).max() <= 1e-9 * np.abs(x_default).max()
