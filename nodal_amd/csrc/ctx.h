@@ -296,6 +296,7 @@ void sagg_destroy(nodal_ctx *h);
 int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, int32_t *iters, double *resid);
 bool sagg_ready(nodal_ctx *h, int64_t n);  // a hierarchy for n unknowns is set up
 // up to 16 probe pairs per iteration on that hierarchy (sagg_multi.h); -1: breakdown / no convergence
+int sagg_pairs_block_width();  // pairs the block iteration takes per call (sagg_multi.h: MK)
 int sagg_fcg_solve_pairs_block(nodal_ctx *h, int32_t count, const int32_t *ia_host, const int32_t *ib_host,
                                double *res_dev, int32_t *iters);
 void sagg_invalidate(nodal_ctx *h);  // the hierarchy is not to be used again until the next setup

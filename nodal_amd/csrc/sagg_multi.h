@@ -20,9 +20,12 @@
 
 namespace {
 
-constexpr int MK = 16;        // columns of a block
+#ifndef NODAL_MK_SHIFT
+#define NODAL_MK_SHIFT 4
+#endif
+constexpr int MK = 1 << NODAL_MK_SHIFT;  // columns of a block (16; 32 / 64 measured: tools/experiments/README.md)
 // (cyc_t, the type of the vectors inside the cycle: sagg.hip)
-constexpr int MK_SHIFT = 4;
+constexpr int MK_SHIFT = NODAL_MK_SHIFT;
 constexpr int MSC = 32;       // scalars per column: the single-vector block's F_COUNT words + the functional's (below)
 enum { M_SUM = 16, M_INC = 17 /* .. 20: the last increments alpha_j r_j.z_j, a ring */, M_RING = 4, M_FDONE = 21 };
 constexpr int MPARTS = 1024;  // workgroups that leave dot partials (grid cap of the level-0 kernels that do)
@@ -35,8 +38,8 @@ __device__ __forceinline__ void column_partials(double (&a)[NQ], double *__restr
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         double v = a[q];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
+#pragma unroll
+        for (int off = MK; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);  // (lanes MK apart hold the same column)
         if (lane < MK) ws[q][wave][lane] = v;
     }
     __syncthreads();
@@ -70,8 +73,8 @@ __global__ __launch_bounds__(MR) void m_reduce_kernel(const double *__restrict__
         s0 += v0, s1 += v1, s2 += v2, s3 += v3;
     }
     double s = (s0 + s1) + (s2 + s3);
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
+#pragma unroll
+    for (int off = MK; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
     if ((threadIdx.x & 63) < MK) ws[threadIdx.x >> 6][y] = s;
     __syncthreads();
     if (threadIdx.x < MK) {
@@ -548,6 +551,8 @@ int m_cycle(nodal_ctx *h, SHierarchy *H, const MBufs &M, int l, const TBV *b, co
 }
 
 }  // namespace
+
+int sagg_pairs_block_width() { return MK; }
 
 // Pairs [0, count), count <= MK, on the hierarchy of the last setup: res_dev[q] = e(ia[q]) - e(ib[q]) for a
 // 1 A probe.  Return NODAL_OK (all columns converged), -1 breakdown / no convergence (the caller falls back

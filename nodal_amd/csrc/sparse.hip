@@ -696,7 +696,8 @@ int sparse_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const in
         // through the block iteration (sagg_multi.h: one launch sequence and one pass over every matrix per block
         // instead of per pair).  A block that breaks down is redone pair by pair below.
         if (!direct && block_allowed && q > 0 && sagg_ready(h, n) && npairs - q >= 2) {
-            const int32_t cnt = npairs - q < 16 ? npairs - q : 16;
+            const int32_t bw = sagg_pairs_block_width();
+            const int32_t cnt = npairs - q < bw ? npairs - q : bw;
             int32_t it = 0;
             const int s = sagg_fcg_solve_pairs_block(h, cnt, ia + q, ib + q, res_dev + q, &it);
             if (s == NODAL_OK) {
