@@ -1545,3 +1545,25 @@ def test_stream_fold_matches_the_per_entry_fold(kind, monkeypatch):
     else:
         a, b = got["1"][2], got["0"][2]
         assert all(np.array_equal(x, y) for x, y in zip(a, b))  # indptr, indices, data, rhs: bit for bit
+
+
+@pytest.mark.parametrize("source", [1e-60, 1e-36, 1e-25, 1e30, 1e39, 1e60])
+def test_sparse_solution_is_linear_in_the_source_at_any_scale(source):
+    """The multigrid cycle keeps its vectors in f32 (csrc/sagg.hip, cyc_t); a right-hand side far outside the f32
+    range must still give the f64 answer (the reference's spsolve is scale-free): the iteration then breaks down or
+    crawls and what stands behind it takes over.  Linearity: x(s A) = s x(1 A) to 1e-9."""
+    N = 150
+    out = []
+    for s in (1.0, source):
+        table = gen.grid_table(N)
+        table.value[-1] = s
+        h = _ffi.Handle(0)
+        h.upload(table)
+        h.assemble_symbolic()
+        assert h.assemble_numeric()[0] == _ffi.OK
+        x, info, _, _ = h.solve_sparse()
+        assert info == 0 and np.isfinite(x).all()
+        assert h.residual() < 1e-12
+        out.append(x / s)
+        h.close()
+    assert np.abs(out[1] - out[0]).max() <= 1e-9 * np.abs(out[0]).max()
