@@ -199,6 +199,9 @@ struct nodal_ctx {
 
     void *amg = nullptr;  // multigrid hierarchy (amg.hip)
     void *sagg = nullptr; // smoothed-aggregation hierarchy (sagg.hip)
+    int64_t sym_low_rows = -1;           // ... of the table grouped last (kept with sym_sizes)
+    int64_t low_rows = -1;               // rows of two or three entries of the matrix pattern (upper bound; group.h), -1 unknown
+    unsigned long long low_rows_epoch = ~0ull;  // struct_epoch it belongs to
     void *slu = nullptr;  // multifrontal LU of the direct route (sparse_direct.hip)
     bool slu_strict = false;  // refinement judged by |r| / |b| alone (the direct route's second opinion)
     int32_t last_iterations = 0;

@@ -158,6 +158,11 @@ __global__ __launch_bounds__(TB) void row_heads_short(const uint32_t *__restrict
                                                       int32_t *__restrict__ medium_list,
                                                       int32_t *__restrict__ long_list,
                                                       uint32_t *__restrict__ list_counts) {
+    // list_counts[5]: rows of two or three entries (a diagonal and one or two neighbours: what lowdeg.hip can
+    // eliminate; rows handed to the longer sorts are counted too, their entries are not known here) -- an upper bound
+    // the solver reads with the sizes, so that a network without such nodes does not pay a launch and a round trip to
+    // learn that there is nothing to eliminate
+    uint32_t low = 0;
     for (int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x; r <= nrows;
          r += (int64_t)gridDim.x * TB) {
         if (r == nrows) {  // (the scan runs over nrows + 1 slots: the last one receives the number of entries)
@@ -166,13 +171,23 @@ __global__ __launch_bounds__(TB) void row_heads_short(const uint32_t *__restrict
         }
         const uint32_t s = rowstart[r];
         const int len = (int)(rowstart[r + 1] - s);
-        if (len < 2) rowheads[r] = (uint32_t)len;
-        else if (len <= 4) rowheads[r] = short_row_heads<4>(skey + s, len);
-        else if (len <= 8) rowheads[r] = short_row_heads<8>(skey + s, len);
-        else if (len <= SHORT_MAX) rowheads[r] = short_row_heads<16>(skey + s, len);
+        uint32_t heads = 2;
+        if (len < 2) rowheads[r] = heads = (uint32_t)len;
+        else if (len <= 4) rowheads[r] = heads = short_row_heads<4>(skey + s, len);
+        else if (len <= 8) rowheads[r] = heads = short_row_heads<8>(skey + s, len);
+        else if (len <= SHORT_MAX) rowheads[r] = heads = short_row_heads<16>(skey + s, len);
         else if (len <= MEDIUM_MAX) medium_list[atomicAdd(&list_counts[0], 1u)] = (int32_t)r;
         else long_list[atomicAdd(&list_counts[1], 1u)] = (int32_t)r;
+        low += (heads == 2 || heads == 3) ? 1u : 0u;
     }
+    __shared__ uint32_t low_total;
+    if (threadIdx.x == 0) low_total = 0;
+    __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) low += __shfl_down(low, off, 64);
+    if ((threadIdx.x & 63) == 0 && low) atomicAdd(&low_total, low);
+    __syncthreads();
+    if (threadIdx.x == 0 && low_total) atomicAdd(&list_counts[5], low_total);
 }
 
 // one workgroup per listed row, bitonic sort in LDS (len <= MEDIUM_MAX)
@@ -400,7 +415,10 @@ struct emits_exactly<E, std::void_t<decltype(E::EXACT)>> : std::bool_constant<E:
 template <class E>
 int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int64_t *ncon_out,
                 DevBuf &indices, DevBuf &rowidx, DevBuf &cptr, DevBuf &contrib, DevBuf *indptr,
-                DevBuf *diag_pos, int64_t known_nent = -1, int64_t known_C = -1, int *long_rows = nullptr) {
+                DevBuf *diag_pos, int64_t known_nent = -1, int64_t known_C = -1, int *long_rows = nullptr,
+                int64_t *low_rows = nullptr) {
+    // low_rows (optional, out): rows of two or three entries, an upper bound (row_heads_short); written only when this
+    // grouping reads its sizes back
     // long_rows (optional): in, 0 = the caller knows that no row has more than SHORT_MAX tuples (the same
     // items grouped before): the two sorts of longer rows are not launched; out, what this grouping found
     // (only when it reads the number of entries back anyway), -1 otherwise.
@@ -490,9 +508,10 @@ int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int
     NODAL_TRY(scan_exclusive_u32(h, rowheads, eptr, nrows + 1, &counts[3], w2 + o_scan2));
     int64_t nent = known_nent;
     if (nent < 0) {
-        uint32_t back[4] = {0, 0, 0, 0};  // medium rows, long rows, contributions, entries
-        NODAL_TRY(nodal_read_words(h, back, counts, 16));
+        uint32_t back[6] = {0, 0, 0, 0, 0, 0};  // medium rows, long rows, contributions, entries, -, rows of 2-3 entries
+        NODAL_TRY(nodal_read_words(h, back, counts, 24));
         nent = back[3];
+        if (low_rows) *low_rows = back[5];
         if (long_rows && !no_long_rows) *long_rows = (back[0] | back[1]) ? 1 : 0;
     }
     *nent_out = nent;

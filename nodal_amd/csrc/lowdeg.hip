@@ -360,6 +360,16 @@ int lowdeg_solve(nodal_ctx *h, int min_share, bool *done, int32_t *info, int32_t
     int32_t *newidx = h->ld_newidx.as<int32_t>();
     bool slow = false;
     int64_t nk = build ? 0 : h->lowdeg->n;
+    if (build && h->low_rows >= 0 && h->low_rows_epoch == h->struct_epoch) {
+        // the grouping that built this matrix counted its rows of two or three entries (an upper bound of what the
+        // selection below can find): too few for a round to pay -- no launch, no round trip
+        const int bar = h->ld_rounds == 0 && min_share > 64 ? 64 : min_share;
+        if (h->low_rows * bar < n) {
+            h->ld_state = 0;
+            remember(1);
+            return NODAL_OK;
+        }
+    }
     if (build) {
         h->ld_state = 0;
         NODAL_HIP_TRY(h, hipMemsetAsync(count, 0, 8, st));
@@ -427,8 +437,11 @@ int lowdeg_solve(nodal_ctx *h, int min_share, bool *done, int32_t *info, int32_t
         en.newidx = newidx;
         int64_t ncon = 0;
         // (grouping scratch in the child's work buffers: the parent's may hold live data of the caller)
+        int64_t low = -1;
         const int bs = grp::build_lists(c, en, nk, &nent, &ncon, c->indices, c->rowidx, c->cptr, c->contrib,
-                                        &c->indptr, &c->diag_pos);
+                                        &c->indptr, &c->diag_pos, -1, -1, nullptr, &low);
+        c->low_rows = low;  // (what the next round can take at most: it looks before it launches its selection)
+        c->low_rows_epoch = c->struct_epoch;
         if (bs != NODAL_OK) {
             h->err = c->err;
             return bs;

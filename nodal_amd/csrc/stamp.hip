@@ -338,8 +338,12 @@ int stamp_symbolic(nodal_ctx *h) {
     int long_rows = known ? h->sym_long_rows : -1;  // (0: no node with more than 16 stamps in a row last time)
     NODAL_TRY(grp::build_lists(h, MatrixStamps{tb, tb.ncomp}, n, &h->nnz, &h->ncontrib, h->indices,
                                h->rowidx, h->cptr, h->contrib, &h->indptr, &h->diag_pos,
-                               known ? h->sym_sizes[0] : -1, known ? h->sym_sizes[1] : -1, &long_rows));
+                               known ? h->sym_sizes[0] : -1, known ? h->sym_sizes[1] : -1, &long_rows, &h->sym_low_rows));
     if (!known || long_rows >= 0) h->sym_long_rows = long_rows;
+    // (rows a low-degree elimination could take, an upper bound: read back with the sizes, kept with them for a
+    // repeated grouping of the same table)
+    h->low_rows = h->sym_low_rows;
+    h->low_rows_epoch = h->struct_epoch;
     // (rhs entries have no column index: the column list lands in a scratch buffer the context keeps --
     // a local one meant a hipMalloc and a hipFree, which waits for the whole device, per symbolic phase)
     // A handful of sources (the usual netlist; the bound is the last grouping's count or twice the number of
