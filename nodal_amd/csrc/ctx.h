@@ -307,7 +307,13 @@ void sagg_invalidate(nodal_ctx *h);  // the hierarchy is not to be used again un
 // of either sign, not symmetric); sagg_apply: z ~= A^-1 r with one cycle
 int sagg_setup_csr(nodal_ctx *h, int64_t n, int64_t nnz, const int32_t *indptr, const int32_t *indices,
                    const double *data, bool general, bool check_floating, bool *accepted, int32_t *floating);
-int sagg_apply(nodal_ctx *h, const double *r, double *z);
+typedef float nodal_cyc_t;  // vectors inside the multigrid cycle (csrc/sagg.hip: cyc_t)
+// x0_ready: the caller's last kernel already left the cycle's start iterate w D^-1 r (sagg_x0_slot) -- the launch that
+// computes it is skipped
+int sagg_apply(nodal_ctx *h, const double *r, double *z, bool x0_ready = false);
+// where a producer of r can leave the start iterate of the next sagg_apply: x0[i] = (nodal_cyc_t)(omega * dinv[i] * r[i]),
+// i < n0.  false: no hierarchy.
+bool sagg_x0_slot(nodal_ctx *h, const double **dinv, nodal_cyc_t **x0, int64_t *n0, double *omega);
 int sagg_levels(nodal_ctx *h);
 int sagg_spmv(nodal_ctx *h, const double *x, double *y, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);  // y = A x on the hierarchy's own (level-0, ELL) matrix
 int amg_has_floating_component(nodal_ctx *h, const uint8_t *grounded0, int32_t *floating);

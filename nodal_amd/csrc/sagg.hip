@@ -63,7 +63,7 @@ constexpr double OMEGA_P = 2.0 / 3.0;         // prolongator smoothing (rho(D^-1
 // outer iterations are flexible ones and their own vectors (x, r, p, Ap; the Krylov basis of the general path) and
 // every dot product stay f64.  A level-0 pass of the single-vector cycle moves 56 instead of 64 bytes per row (the
 // matrix is most of it), one of the sixteen-column block iteration (sagg_multi.h) 64 instead of 128 per column.
-using cyc_t = float;
+using cyc_t = nodal_cyc_t;  // float (ctx.h)
 
 inline unsigned grid_for(int64_t n, unsigned cap = 8192) {  // (caps are multiples of 8: see xcd_block)
     int64_t g = (n + TB - 1) / TB;
@@ -1799,12 +1799,22 @@ void sagg_invalidate(nodal_ctx *h) {
     if (h->sagg) static_cast<SHierarchy *>(h->sagg)->ready = false;
 }
 int sagg_levels(nodal_ctx *h) { return h->sagg ? static_cast<SHierarchy *>(h->sagg)->nlev : 0; }
-int sagg_apply(nodal_ctx *h, const double *r, double *z) {
+bool sagg_x0_slot(nodal_ctx *h, const double **dinv, nodal_cyc_t **x0, int64_t *n0, double *omega) {
+    SHierarchy *H = static_cast<SHierarchy *>(h->sagg);
+    if (!H || !H->ready) return false;
+    SLevel *L0 = H->pool[0];
+    *dinv = L0->dinv.as<double>();
+    *x0 = L0->v<cyc_t>(V_X);
+    *n0 = L0->n;
+    *omega = OMEGA;
+    return true;
+}
+int sagg_apply(nodal_ctx *h, const double *r, double *z, bool x0_ready) {
     SHierarchy *H = static_cast<SHierarchy *>(h->sagg);
     if (!H || !H->ready) return nodal_fail(h, NODAL_E_INVALID, "sagg_setup_csr not called");
     SLevel *L0 = H->pool[0];
     cyc_t *x0 = L0->v<cyc_t>(V_X);
-    k_x0<<<grid_for(L0->n), TB, 0, h->stream>>>(L0->n, L0->dinv.as<double>(), r, x0);
+    if (!x0_ready) k_x0<<<grid_for(L0->n), TB, 0, h->stream>>>(L0->n, L0->dinv.as<double>(), r, x0);
     NODAL_HIP_TRY(h, hipGetLastError());
     return cycle<double, double>(h, H, 0, r, x0, z, nullptr);
 }

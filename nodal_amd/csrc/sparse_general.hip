@@ -384,12 +384,19 @@ __global__ __launch_bounds__(TB) void gs_finish(const double *__restrict__ h1, c
 }
 
 // v_{j+1} = w / h_{j+1,j}
+// (x0 != nullptr: also the start iterate w D^-1 v of the multigrid cycle that preconditions v_{j+1} next, rows < n0:
+// the launch sagg_apply would spend on it)
 __global__ __launch_bounds__(TB) void scale_by_device(const double *__restrict__ src, const double *__restrict__ gst,
-                                                      double *__restrict__ dst, int64_t n) {
+                                                      double *__restrict__ dst, int64_t n,
+                                                      const double *__restrict__ dinv, nodal_cyc_t *__restrict__ x0,
+                                                      int64_t n0, double omega) {
     if (gst[G_DONE] != 0.0) return;
     const double scale = gst[G_INV_H];
-    for (int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x; r < n; r += (int64_t)gridDim.x * TB)
-        dst[r] = src[r] * scale;
+    for (int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x; r < n; r += (int64_t)gridDim.x * TB) {
+        const double v = src[r] * scale;
+        dst[r] = v;
+        if (x0 && r < n0) x0[r] = (nodal_cyc_t)(omega * dinv[r] * v);
+    }
 }
 
 // y = H^-1 g over the G_COUNT columns of the cycle (zero beyond)
@@ -625,6 +632,12 @@ int general_impl(nodal_ctx *h, const double *b, double *x, int32_t *info, int32_
         const int window = (cyc == 0 || window_env) ? window_first : RESTART + 1;
         scale_to<<<gv, TB, 0, st>>>(r, 1.0 / rnorm, V, n);
         gst_begin<<<1, 64, 0, st>>>(gst, rnorm, tol * bnorm);
+        // the kernel that normalises v_{j+1} also leaves the start iterate of the cycle that preconditions it
+        const double *x0_dinv = nullptr;
+        nodal_cyc_t *x0_slot = nullptr;
+        int64_t x0_n = 0;
+        double x0_omega = 0.0;
+        if (use_sa && !direct && !sagg_x0_slot(h, &x0_dinv, &x0_slot, &x0_n, &x0_omega)) x0_slot = nullptr;
         // Iterations are enqueued in batches; between batches the host reads the estimate and
         // sizes the next batch from the convergence rate seen so far (three quarters of what is
         // still missing, at least two).  A batch that overshoots costs idle launches only: every
@@ -641,7 +654,7 @@ int general_impl(nodal_ctx *h, const double *b, double *x, int32_t *info, int32_
                 // z_j = M^-1 v_j
                 if (j == 0) nodal_nan_probe(h, vj, n, "fgmres v0");
                 if (direct) NODAL_TRY(slu_apply(h, vj, zj));
-                else if (use_sa) NODAL_TRY(sagg_apply(h, vj, zj));
+                else if (use_sa) NODAL_TRY(sagg_apply(h, vj, zj, j > 0 && x0_slot != nullptr));
                 else NODAL_TRY(amg_apply(h, vj, zj));
                 if (j == 0) nodal_nan_probe(h, zj, K, "fgmres z0 (node block)");
                 if (n > K) {
@@ -671,7 +684,7 @@ int general_impl(nodal_ctx *h, const double *b, double *x, int32_t *info, int32_
                 gs_reduce<<<nv, TB, 0, st>>>(partial, (int)gd, nv, hdev2 + s0, nullptr, 0);
                 DISPATCH_NV(nv, (gs_update<NV><<<gd, TB, 0, st>>>(Vw, ld, nv, hdev2 + s0, w, n, partial2)));
                 gs_finish<<<1, TB, 0, st>>>(hdev, hdev2, partial2, (int)gd, j, s0, gst);
-                scale_by_device<<<gv, TB, 0, st>>>(w, gst, V + (int64_t)(j + 1) * ld, n);
+                scale_by_device<<<gv, TB, 0, st>>>(w, gst, V + (int64_t)(j + 1) * ld, n, x0_dinv, x0_slot, x0_n, x0_omega);
                 NODAL_HIP_TRY(h, hipGetLastError());
             }
             NODAL_TRY(nodal_read_words(h, hst, gst + G_INV_H, sizeof hst));
