@@ -423,7 +423,12 @@ inline void peel_low_degree(int64_t n, const Graph &g, std::vector<int32_t> &pee
             is_cand[(size_t)v] = 0;
             peeled.push_back(v);
             if (nb.size() == 2) {  // the fill edge, unless it is there already
-                const int32_t a = nb[0], b = nb[1];
+                int32_t a = nb[0], b = nb[1];
+                // (look the edge up from the end with the shorter lists: a hub collecting thousands of chains would
+                // otherwise be walked once per chain)
+                if ((g.ptr[(size_t)a + 1] - g.ptr[(size_t)a]) + (int64_t)extra[(size_t)a].size() >
+                    (g.ptr[(size_t)b + 1] - g.ptr[(size_t)b]) + (int64_t)extra[(size_t)b].size())
+                    std::swap(a, b);
                 bool have = false;
                 for (int64_t e = g.ptr[(size_t)a]; e < g.ptr[(size_t)a + 1] && !have; ++e) have = g.adj[(size_t)e] == b;
                 for (size_t e = 0; e < extra[(size_t)a].size() && !have; ++e) have = extra[(size_t)a][e] == b;
