@@ -349,6 +349,128 @@ __global__ __launch_bounds__(1024) void panel_factor(double *__restrict__ F, int
     }
 }
 
+// The same panel with its rows IN REGISTERS: thread t keeps rows k0 + t, k0 + t + 256, ... (RPT of them) of the
+// panel's PNB columns, loaded once and stored once; a column step is a block arg-max (shuffles + one LDS round), the
+// pivot row and row k through LDS, and the rank-1 update in registers -- no global memory inside the loop, where the
+// version above streams the shrinking panel through ONE compute unit twice per column (79 us per 16 columns of a
+// 1489-row front).  Same pivots (largest magnitude among the fully summed rows, the smallest row on ties, the
+// diagonal kept within a factor 4, the static replacement), the same operations on every entry in the same order:
+// bit-identical factors.  Panels of at most RPT * 256 rows (RPT <= 6: 96 values per thread).
+constexpr int PNB = 16;
+template <int RPT>
+__global__ __launch_bounds__(256) void panel_factor_regs(double *__restrict__ F, int dim, int s, int k0, int nb,
+                                                          int32_t *__restrict__ piv, double tiny, double repl,
+                                                          unsigned long long *__restrict__ stats) {
+    constexpr int BS = 256, NW = BS / 64;  // (256 threads: a budget of 256 registers each; 512 / 1024 threads leave 128 / 64 and spill)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ double red_v[NW];
+    __shared__ int red_i[NW];
+    __shared__ int piv_row;
+    __shared__ double prow[PNB], krow[PNB];
+    __shared__ double pivot_value;
+    double a[RPT][PNB];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int i = k0 + tid + r * BS;
+#pragma unroll
+        for (int c = 0; c < PNB; ++c) a[r][c] = (i < dim && c < nb) ? F[i + (int64_t)(k0 + c) * dim] : 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < PNB; ++c) {  // (fully unrolled: every index into a[][] is a constant -- registers, not scratch)
+        if (c < nb) {                // (uniform over the workgroup)
+        const int k = k0 + c;
+        double best = -1.0;
+        int bi = k;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int i = k0 + tid + r * BS;
+            const double v = fabs(a[r][c]);
+            if (i >= k && i < s && v > best) { best = v; bi = i; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_down(best, off, 64);
+            const int oi = __shfl_down(bi, off, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { red_v[wave] = best; red_i[wave] = bi; }
+        // row k of the panel for whoever needs it (the diagonal for the pivot rule, the row for the interchange)
+        if (tid == c) {  // (row k = k0 + c is thread c's first row)
+#pragma unroll
+            for (int j = 0; j < PNB; ++j) krow[j] = a[0][j];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double bv = red_v[0];
+            int br = red_i[0];
+            for (int w = 1; w < NW; ++w)
+                if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < br)) { bv = red_v[w]; br = red_i[w]; }
+            const double d = krow[c];
+            double pv = 0.0;  // 0: the pivot is whatever row br holds
+            if (!(bv >= tiny)) {
+                pv = d < 0.0 ? -repl : repl;
+                br = k;
+                atomicAdd(stats, 1ull);
+            } else if (fabs(d) >= 0.25 * bv) {
+                br = k;
+            }
+            piv_row = br;
+            pivot_value = pv;
+            piv[c] = br;
+        }
+        __syncthreads();
+        const int p = piv_row;
+        const double forced = pivot_value;
+        // the owner of row p publishes it
+        {
+            const int off = p - k0 - tid;  // row p is mine iff off = r * BS for some r < RPT
+#pragma unroll
+            for (int r = 0; r < RPT; ++r)
+                if (off == r * BS) {
+                    if (forced != 0.0) a[r][c] = forced;  // (then p == k: the replaced diagonal)
+#pragma unroll
+                    for (int j = 0; j < PNB; ++j) prow[j] = a[r][j];
+                }
+        }
+        __syncthreads();
+        if (p != k) {  // interchange rows k and p inside the panel
+            if (tid == c) {
+#pragma unroll
+                for (int j = 0; j < PNB; ++j) a[0][j] = prow[j];
+            }
+            const int off = p - k0 - tid;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r)
+                if (off == r * BS) {
+#pragma unroll
+                    for (int j = 0; j < PNB; ++j) a[r][j] = krow[j];
+                }
+        }
+        // (the pivot row -- row k after the interchange -- is read from LDS: broadcast reads, no registers)
+        const double rp = 1.0 / prow[c];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int i = k0 + tid + r * BS;
+            if (i > k && i < dim) {
+                const double l = a[r][c] * rp;
+                a[r][c] = l;
+#pragma unroll
+                for (int j = 0; j < PNB; ++j)
+                    if (j > c) a[r][j] = fma(-l, prow[j], a[r][j]);
+            }
+        }
+        __syncthreads();  // (prow / krow are rewritten by the next column)
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int i = k0 + tid + r * BS;
+#pragma unroll
+        for (int c = 0; c < PNB; ++c)
+            if (i < dim && c < nb) F[i + (int64_t)(k0 + c) * dim] = a[r][c];
+    }
+}
+
 // the panel's interchanges on the columns outside it (one thread per column, the nb swaps in order), and on
 // the front's row permutation (one extra thread)
 __global__ __launch_bounds__(256) void apply_swaps(double *__restrict__ F, int dim, int k0, int nb,
@@ -708,6 +830,7 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
         const int v = atoi(e);
         if (v == 16 || v == 32 || v == 48 || v == 64) panel_nb = v;
     }
+    const bool panel_regs = !(getenv("NODAL_DIRECT_PANEL_REGS") && atoi(getenv("NODAL_DIRECT_PANEL_REGS")) == 0);
     int64_t big_fronts = 0;
     for (int32_t l = 0; l < S->nlev; ++l) {
         const int32_t cnt = S->lvl_ptr[(size_t)l + 1] - S->lvl_ptr[(size_t)l];
@@ -737,7 +860,13 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
             iota_i32<<<(unsigned)((sz + 255) / 256), 256, 0, st>>>(perm, sz);
             for (int k0 = 0; k0 < sz; k0 += panel_nb) {
                 const int nb = sz - k0 < panel_nb ? sz - k0 : panel_nb;
-                panel_factor<<<1, 1024, 0, st>>>(F, dim, sz, k0, nb, piv, tiny, repl, S->stats.as<unsigned long long>());
+                // (the panel in registers when its rows fit: NODAL_DIRECT_PANEL_REGS=0 keeps the streaming kernel)
+                const int prows = dim - k0;
+                unsigned long long *pst = S->stats.as<unsigned long long>();
+                if (panel_regs && nb <= PNB && prows <= 512) panel_factor_regs<2><<<1, 256, 0, st>>>(F, dim, sz, k0, nb, piv, tiny, repl, pst);
+                else if (panel_regs && nb <= PNB && prows <= 1024) panel_factor_regs<4><<<1, 256, 0, st>>>(F, dim, sz, k0, nb, piv, tiny, repl, pst);
+                else if (panel_regs && nb <= PNB && prows <= 1536) panel_factor_regs<6><<<1, 256, 0, st>>>(F, dim, sz, k0, nb, piv, tiny, repl, pst);
+                else panel_factor<<<1, 1024, 0, st>>>(F, dim, sz, k0, nb, piv, tiny, repl, pst);
                 apply_swaps<<<(unsigned)((dim - nb + 1 + 255) / 256), 256, 0, st>>>(F, dim, k0, nb, piv, perm);
                 const int rest = dim - k0 - nb;
                 if (rest > 0) {
