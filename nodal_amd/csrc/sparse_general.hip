@@ -642,7 +642,9 @@ int general_impl(nodal_ctx *h, const double *b, double *x, int32_t *info, int32_
         // sizes the next batch from the convergence rate seen so far (three quarters of what is
         // still missing, at least two).  A batch that overshoots costs idle launches only: every
         // kernel that touches the small problem returns once G_DONE is up.
-        int enq = 0, batch = 6;
+        // (behind the direct factorisation an iteration is a 10-ms pair of triangular sweeps and one or two of them
+        // converge: the host looks after every one -- a batch of six ran four sweeps for nothing)
+        int enq = 0, batch = direct ? 1 : 6;
         double est_prev = rnorm;
         int at_prev = 0;
         bool done = false;
@@ -703,6 +705,7 @@ int general_impl(nodal_ctx *h, const double *b, double *x, int32_t *info, int32_
             batch = (int)std::floor(0.75 * need);
             if (batch < 2) batch = 2;
             if (batch > enq) batch = enq;  // (at most doubling)
+            if (direct) batch = 1;
             est_prev = est;
             at_prev = enq;
         }
