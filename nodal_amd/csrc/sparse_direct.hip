@@ -160,14 +160,23 @@ __global__ __launch_bounds__(BS) void extend_add(Tree T, const int32_t *__restri
 // Blocked right-looking partial LU of the s leading columns of a front (column-major, ld = dim), partial
 // pivoting restricted to the s fully summed rows; lperm[k] = local row that ended at position k.
 constexpr int NB = 16;
-template <int BS>
+// INLDS: the whole front is copied to LDS, factored there and copied back (levels whose widest front fits: the leaves
+// and the small separators, i.e. most fronts; every column step is four barriers around memory operations, at LDS
+// latency instead of a round trip to L2 each).  Same operations in the same order: the same factors.
+template <int BS, bool INLDS = false>
 __global__ __launch_bounds__(BS) void factor_fronts(Tree T, const int32_t *__restrict__ sns, double *__restrict__ fronts,
                                                     int32_t *__restrict__ lperm, double tiny, double repl,
                                                     unsigned long long *__restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) double front_lds[];
     const int32_t t = sns[blockIdx.x];
     const int s = T.sn_start[t + 1] - T.sn_start[t];
     const int dim = s + (int)(T.struct_ptr[t + 1] - T.struct_ptr[t]);
-    double *F = fronts + T.front_off[t];
+    double *Fg = fronts + T.front_off[t];
+    double *F = INLDS ? front_lds : Fg;
+    if constexpr (INLDS) {
+        for (int e = threadIdx.x; e < dim * dim; e += BS) front_lds[e] = Fg[e];
+        __syncthreads();
+    }
     int32_t *perm = lperm + T.sn_start[t];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = BS / 64;
@@ -270,6 +279,10 @@ __global__ __launch_bounds__(BS) void factor_fronts(Tree T, const int32_t *__res
             }
         }
         __syncthreads();
+    }
+    if constexpr (INLDS) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < dim * dim; e += BS) Fg[e] = front_lds[e];
     }
 }
 
@@ -830,6 +843,7 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
         const int v = atoi(e);
         if (v == 16 || v == 32 || v == 48 || v == 64) panel_nb = v;
     }
+    const bool fronts_in_lds = !(getenv("NODAL_DIRECT_FRONT_LDS") && atoi(getenv("NODAL_DIRECT_FRONT_LDS")) == 0);
     const bool panel_regs = !(getenv("NODAL_DIRECT_PANEL_REGS") && atoi(getenv("NODAL_DIRECT_PANEL_REGS")) == 0);
     int64_t big_fronts = 0;
     for (int32_t l = 0; l < S->nlev; ++l) {
@@ -847,6 +861,9 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
         if (nsmall > 0) {
             if (wide) factor_fronts<1024><<<nsmall, 1024, 0, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl,
                                                                   S->stats.as<unsigned long long>());
+            else if (fronts_in_lds && (size_t)S->lvl_maxdim[(size_t)l] * S->lvl_maxdim[(size_t)l] * 8 <= 56 * 1024)
+                factor_fronts<256, true><<<nsmall, 256, (size_t)S->lvl_maxdim[(size_t)l] * S->lvl_maxdim[(size_t)l] * 8, st>>>(
+                    T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl, S->stats.as<unsigned long long>());
             else factor_fronts<256><<<nsmall, 256, 0, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl,
                                                             S->stats.as<unsigned long long>());
         }
