@@ -834,7 +834,7 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
     const Tree T = tree_of(S);
     // after the equilibration every row and column has max-norm <= 1: the static-pivot bound is sqrt(eps)
     const double tiny = 1.4901161193847656e-08, repl = tiny * tiny_factor;
-    NODAL_HIP_TRY(h, S->bigpiv.reserve(NBB * 4 + 64));
+    NODAL_HIP_TRY(h, S->bigpiv.reserve(3 * NBB * 4 + 64));  // (one set of panel pivots per lane of wide fronts)
     // columns per panel of the wide fronts: 16 measured best (config 5 at 1e6 unknowns, analysis kept: 210 / 230 /
     // 270 / 260 ms for 16 / 32 / 48 / 64 -- the single-workgroup panel kernel is what a wider panel makes longer);
     // NODAL_DIRECT_NB = 16 / 32 / 48 / 64
@@ -843,6 +843,9 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
         const int v = atoi(e);
         if (v == 16 || v == 32 || v == 48 || v == 64) panel_nb = v;
     }
+    // (NODAL_DIRECT_LANES=0: the wide fronts of a level one after the other on the main stream)
+    const bool lanes_ok = !(getenv("NODAL_DIRECT_LANES") && atoi(getenv("NODAL_DIRECT_LANES")) == 0) &&
+                          nodal_ensure_aux_streams(h) == NODAL_OK && h->stream2 && h->stream3 && h->ev_bi[0] && h->ev_bi[2];
     const bool fronts_in_lds = !(getenv("NODAL_DIRECT_FRONT_LDS") && atoi(getenv("NODAL_DIRECT_FRONT_LDS")) == 0);
     const bool panel_regs = !(getenv("NODAL_DIRECT_PANEL_REGS") && atoi(getenv("NODAL_DIRECT_PANEL_REGS")) == 0);
     int64_t big_fronts = 0;
@@ -868,12 +871,23 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
                                                             S->stats.as<unsigned long long>());
         }
         NODAL_HIP_TRY(h, hipGetLastError());
+        // The wide fronts of a level are independent and each one's chain is a sequence of small launches (a
+        // one-workgroup panel, its interchanges, a triangular solve, a thin GEMM): up to three of them run side by
+        // side on the context's three streams, forked and joined by events around the level.
+        hipStream_t main_st = st;
+        const int nl = (lanes_ok && nbig > 1) ? (nbig < 3 ? nbig : 3) : 1;
+        if (nl > 1) {
+            NODAL_HIP_TRY(h, hipEventRecord(h->ev_bi[0], main_st));
+            for (int k = 1; k < nl; ++k) NODAL_HIP_TRY(h, hipStreamWaitEvent(k == 1 ? h->stream2 : h->stream3, h->ev_bi[0], 0));
+        }
         for (int32_t q = 0; q < nbig; ++q) {  // wide fronts: panel by panel (see big-front kernels above)
+            const int lane_no = q % nl;
+            hipStream_t st = lane_no == 0 ? main_st : (lane_no == 1 ? h->stream2 : h->stream3);  // (shadows the main stream)
             const int32_t t = S->h_lvl_sn[(size_t)S->lvl_ptr[(size_t)l] + nsmall + q];
             const int dim = S->h_dim[(size_t)t], start = S->h_start[(size_t)t], sz = S->h_start[(size_t)t + 1] - start;
             double *F = S->fronts.as<double>() + S->h_front_off[(size_t)t];
             int32_t *perm = S->lperm.as<int32_t>() + start;
-            int32_t *piv = S->bigpiv.as<int32_t>();
+            int32_t *piv = S->bigpiv.as<int32_t>() + lane_no * NBB;
             iota_i32<<<(unsigned)((sz + 255) / 256), 256, 0, st>>>(perm, sz);
             for (int k0 = 0; k0 < sz; k0 += panel_nb) {
                 const int nb = sz - k0 < panel_nb ? sz - k0 : panel_nb;
@@ -896,6 +910,10 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
             }
             NODAL_HIP_TRY(h, hipGetLastError());
             ++big_fronts;
+        }
+        for (int k = 1; k < nl; ++k) {
+            NODAL_HIP_TRY(h, hipEventRecord(h->ev_bi[k], k == 1 ? h->stream2 : h->stream3));
+            NODAL_HIP_TRY(h, hipStreamWaitEvent(main_st, h->ev_bi[k], 0));
         }
     }
     unsigned long long pert = 0;
