@@ -64,7 +64,11 @@ struct SluState {
     std::vector<int32_t> lvl_small, lvl_maxchildren, lvl_maxdim_all;
     std::vector<int32_t> h_lvl_sn, h_start, h_dim;   // host copies: level lists, first pivot column, front width
     std::vector<int64_t> h_front_off;
-    DevBuf bigpiv;                                     // pivot rows of the panel in flight
+    DevBuf bigpiv;                                     // pivot rows of the panels in flight (one set per lane)
+    static constexpr int LANES = 6;                    // wide fronts of a level factored side by side
+    hipStream_t lane_st[LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [0]: the context's stream (not owned)
+    hipEvent_t lane_ev[LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [0]: fork, [k]: lane k done
+    int lanes = 1;
     // device copies of the symbolic part
     DevBuf rowof, colof, newrow;   // permuted position -> original row / column; original row -> position
     DevBuf sn_start, struct_ptr, struct_idx, front_off, vec_off, lvl_sn, child_ptr, child_idx, cmap, dest;
@@ -709,6 +713,10 @@ void slu_destroy(nodal_ctx *h) {
                       &S->vec_off, &S->lvl_sn, &S->child_ptr, &S->child_idx, &S->cmap, &S->dest, &S->fronts,
                       &S->vec, &S->lperm, &S->rs, &S->cs, &S->xb, &S->stats, &S->bigpiv};
     for (DevBuf *b : bufs) b->release();
+    for (int k = 1; k < SluState::LANES; ++k)
+        if (S->lane_st[k]) (void)hipStreamDestroy(S->lane_st[k]);
+    for (int k = 0; k < SluState::LANES; ++k)
+        if (S->lane_ev[k]) (void)hipEventDestroy(S->lane_ev[k]);
     delete S;
     h->slu = nullptr;
 }
@@ -834,7 +842,7 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
     const Tree T = tree_of(S);
     // after the equilibration every row and column has max-norm <= 1: the static-pivot bound is sqrt(eps)
     const double tiny = 1.4901161193847656e-08, repl = tiny * tiny_factor;
-    NODAL_HIP_TRY(h, S->bigpiv.reserve(3 * NBB * 4 + 64));  // (one set of panel pivots per lane of wide fronts)
+    NODAL_HIP_TRY(h, S->bigpiv.reserve(SluState::LANES * NBB * 4 + 64));  // (one set of panel pivots per lane of wide fronts)
     // columns per panel of the wide fronts: 16 measured best (config 5 at 1e6 unknowns, analysis kept: 210 / 230 /
     // 270 / 260 ms for 16 / 32 / 48 / 64 -- the single-workgroup panel kernel is what a wider panel makes longer);
     // NODAL_DIRECT_NB = 16 / 32 / 48 / 64
@@ -843,9 +851,25 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
         const int v = atoi(e);
         if (v == 16 || v == 32 || v == 48 || v == 64) panel_nb = v;
     }
-    // (NODAL_DIRECT_LANES=0: the wide fronts of a level one after the other on the main stream)
-    const bool lanes_ok = !(getenv("NODAL_DIRECT_LANES") && atoi(getenv("NODAL_DIRECT_LANES")) == 0) &&
-                          nodal_ensure_aux_streams(h) == NODAL_OK && h->stream2 && h->stream3 && h->ev_bi[0] && h->ev_bi[2];
+    // (NODAL_DIRECT_LANES=1: the wide fronts of a level one after the other on the main stream)
+    int want_lanes = 4;  // (config 5's factorisation with 1 / 2 / 3 / 4 / 6 lanes: 93 / 73 / 67 / 65 / 83 ms)
+    if (const char *e = getenv("NODAL_DIRECT_LANES")) want_lanes = atoi(e) < 1 ? 1 : (atoi(e) > SluState::LANES ? SluState::LANES : atoi(e));
+    S->lane_st[0] = st;
+    if (S->lanes < want_lanes) {  // streams and events of the lanes: once per context (a failure leaves fewer lanes)
+        if (!S->lane_ev[0] && hipEventCreateWithFlags(&S->lane_ev[0], hipEventDisableTiming) != hipSuccess) S->lane_ev[0] = nullptr;
+        for (int k = S->lanes; k < want_lanes && S->lane_ev[0]; ++k) {
+            if (hipStreamCreateWithFlags(&S->lane_st[k], hipStreamNonBlocking) != hipSuccess) { S->lane_st[k] = nullptr; break; }
+            if (hipEventCreateWithFlags(&S->lane_ev[k], hipEventDisableTiming) != hipSuccess) {
+                (void)hipStreamDestroy(S->lane_st[k]);
+                S->lane_st[k] = nullptr;
+                S->lane_ev[k] = nullptr;
+                break;
+            }
+            S->lanes = k + 1;
+        }
+        (void)hipGetLastError();
+    }
+    const int max_lanes = S->lanes < want_lanes ? S->lanes : want_lanes;
     const bool fronts_in_lds = !(getenv("NODAL_DIRECT_FRONT_LDS") && atoi(getenv("NODAL_DIRECT_FRONT_LDS")) == 0);
     const bool panel_regs = !(getenv("NODAL_DIRECT_PANEL_REGS") && atoi(getenv("NODAL_DIRECT_PANEL_REGS")) == 0);
     int64_t big_fronts = 0;
@@ -873,16 +897,16 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
         NODAL_HIP_TRY(h, hipGetLastError());
         // The wide fronts of a level are independent and each one's chain is a sequence of small launches (a
         // one-workgroup panel, its interchanges, a triangular solve, a thin GEMM): up to three of them run side by
-        // side on the context's three streams, forked and joined by events around the level.
+        // side on streams of the factorisation's own (NODAL_DIRECT_LANES, four), forked and joined by events around the level.
         hipStream_t main_st = st;
-        const int nl = (lanes_ok && nbig > 1) ? (nbig < 3 ? nbig : 3) : 1;
+        const int nl = nbig < max_lanes ? (nbig > 0 ? nbig : 1) : max_lanes;
         if (nl > 1) {
-            NODAL_HIP_TRY(h, hipEventRecord(h->ev_bi[0], main_st));
-            for (int k = 1; k < nl; ++k) NODAL_HIP_TRY(h, hipStreamWaitEvent(k == 1 ? h->stream2 : h->stream3, h->ev_bi[0], 0));
+            NODAL_HIP_TRY(h, hipEventRecord(S->lane_ev[0], main_st));
+            for (int k = 1; k < nl; ++k) NODAL_HIP_TRY(h, hipStreamWaitEvent(S->lane_st[k], S->lane_ev[0], 0));
         }
         for (int32_t q = 0; q < nbig; ++q) {  // wide fronts: panel by panel (see big-front kernels above)
             const int lane_no = q % nl;
-            hipStream_t st = lane_no == 0 ? main_st : (lane_no == 1 ? h->stream2 : h->stream3);  // (shadows the main stream)
+            hipStream_t st = lane_no == 0 ? main_st : S->lane_st[lane_no];  // (shadows the main stream)
             const int32_t t = S->h_lvl_sn[(size_t)S->lvl_ptr[(size_t)l] + nsmall + q];
             const int dim = S->h_dim[(size_t)t], start = S->h_start[(size_t)t], sz = S->h_start[(size_t)t + 1] - start;
             double *F = S->fronts.as<double>() + S->h_front_off[(size_t)t];
@@ -912,8 +936,8 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
             ++big_fronts;
         }
         for (int k = 1; k < nl; ++k) {
-            NODAL_HIP_TRY(h, hipEventRecord(h->ev_bi[k], k == 1 ? h->stream2 : h->stream3));
-            NODAL_HIP_TRY(h, hipStreamWaitEvent(main_st, h->ev_bi[k], 0));
+            NODAL_HIP_TRY(h, hipEventRecord(S->lane_ev[k], S->lane_st[k]));
+            NODAL_HIP_TRY(h, hipStreamWaitEvent(main_st, S->lane_ev[k], 0));
         }
     }
     unsigned long long pert = 0;
