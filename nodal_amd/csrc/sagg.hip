@@ -157,6 +157,11 @@ struct SHierarchy {
     DevBuf tail_stamps, tail_image, apcol, apval, aplen, bstat;
     DevBuf mvec;  // vectors, partials and scalars of the block iteration (sagg_multi.h)
     hipEvent_t ev_copy = nullptr;  // behind the statistics read-back of a level (build_level)
+    // R = P^T (count, scan, fill, two sorts, blocked layout: seven latency-bound launches) and A P (one long one) need
+    // P only, not each other: R is built on a stream of the hierarchy's own while the main one computes A P
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool aux_tried = false;
     DevBuf stats, coarse_inv, mis_t, mis_m, mis_flag, mis_id, agg1, keys, rstart, cursor, lists;
     TailDesc td;
     uint64_t *host_stats = nullptr;  // pinned
@@ -199,6 +204,9 @@ struct SHierarchy {
     ~SHierarchy() {
         drop_graph();
         if (ev_copy) (void)hipEventDestroy(ev_copy);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (aux) (void)hipStreamDestroy(aux);
         for (SLevel *l : pool) {
             DevBuf *b[] = {&l->acol, &l->aval, &l->alen, &l->dinv, &l->agg, &l->pcol, &l->pval, &l->rcol,
                            &l->rval, &l->rlen, &l->vec, &l->part, &l->gflag, &l->avalf, &l->pvalf, &l->rvalf};
@@ -1121,8 +1129,10 @@ struct SolveBufs {
 
 // A_c = R (A P) of level l into level l + 1: AP = A P (one thread per fine row), then one
 // wavefront per coarse row.  NUMERIC: the pattern of A_c is already there (see SHierarchy::sym_valid).
+// phase 1: A P only; phase 2: the sums only (after r_ready, the event behind R's construction on the hierarchy's other
+// stream); 0: both
 template <bool NUMERIC>
-int galerkin_product(nodal_ctx *h, SHierarchy *H, int l) {
+int galerkin_product(nodal_ctx *h, SHierarchy *H, int l, hipEvent_t r_ready = nullptr, int phase = 0) {
     hipStream_t st = h->stream;
     SLevel *L = H->level(l), *C = H->level(l + 1);
     const int64_t n = L->n, ld = L->ld, nc = C->n;
@@ -1138,14 +1148,17 @@ int galerkin_product(nodal_ctx *h, SHierarchy *H, int l) {
     double *apval = H->apval.as<double>();
     unsigned long long *lst = dstats + (size_t)l * ST_COUNT;
     const unsigned g = grid_for(n);
-    switch (apw) {
-    case 16: ap_rows<16><<<g, TB, 0, st>>>(A, L->pcol.as<int32_t>(), L->pval.as<double>(), apcol, apval, aplen, lst); break;
-    default: {
-        const unsigned gl = (unsigned)((n + 63) / 64 < 4096 ? (n + 63) / 64 : 4096);
-        ap_rows_lds<64><<<gl, 64, 0, st>>>(A, L->pcol.as<int32_t>(), L->pval.as<double>(), apcol, apval, aplen, lst);
-    } break;
+    if (phase != 2) {
+        switch (apw) {
+        case 16: ap_rows<16><<<g, TB, 0, st>>>(A, L->pcol.as<int32_t>(), L->pval.as<double>(), apcol, apval, aplen, lst); break;
+        default: {
+            const unsigned gl = (unsigned)((n + 63) / 64 < 4096 ? (n + 63) / 64 : 4096);
+            ap_rows_lds<64><<<gl, 64, 0, st>>>(A, L->pcol.as<int32_t>(), L->pval.as<double>(), apcol, apval, aplen, lst);
+        } break;
+        }
+        NODAL_HIP_TRY(h, hipGetLastError());
     }
-    NODAL_HIP_TRY(h, hipGetLastError());
+    if (phase == 1) return NODAL_OK;
     // R entries per group: G * apw products (12 bytes each) in the LDS list
     int G = 1024 / apw;
     G = (G < 8 ? 8 : (G > 64 ? 64 : G));
@@ -1161,6 +1174,7 @@ int galerkin_product(nodal_ctx *h, SHierarchy *H, int l) {
     static const int64_t gcap = getenv("NODAL_SA_GCAP") ? atoll(getenv("NODAL_SA_GCAP")) : 16384;
     static const int maxseg = getenv("NODAL_SA_GSEG") ? atoi(getenv("NODAL_SA_GSEG")) : 4;
     const unsigned gg = (unsigned)(nc < gcap ? nc : (gcap < BSTAT_MAX ? gcap : BSTAT_MAX));
+    if (r_ready) NODAL_HIP_TRY(h, hipStreamWaitEvent(st, r_ready, 0));  // (R was built on the hierarchy's other stream)
     galerkin<NUMERIC><<<gg, 64, lds, st>>>(
         ld, apcol, apval, aplen, nc, L->rld, L->rcol.as<int32_t>(), L->rval.as<double>(), L->rlen.as<int32_t>(),
         C->ld, C->acol.as<int32_t>(), C->aval.as<double>(), C->avalf.as<float>(), C->alen.as<int32_t>(),
@@ -1263,11 +1277,62 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     }
     L->nc = nc;
 
-    // R = P^T by coarse row
+    // R = P^T by coarse row -- on the hierarchy's other stream when there is one (see SHierarchy::aux): every
+    // launch of this section, the scans included, goes where h->stream points
+    static const bool fork_allowed = !(getenv("NODAL_SA_FORK") && atoi(getenv("NODAL_SA_FORK")) == 0);
+    if (fork_allowed && !H->aux_tried) {
+        H->aux_tried = true;
+        if (hipStreamCreateWithFlags(&H->aux, hipStreamNonBlocking) != hipSuccess) H->aux = nullptr;
+        if (H->aux && (hipEventCreateWithFlags(&H->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                       hipEventCreateWithFlags(&H->ev_join, hipEventDisableTiming) != hipSuccess)) {
+            (void)hipStreamDestroy(H->aux);
+            H->aux = nullptr;
+        }
+        (void)hipGetLastError();
+    }
+    const bool forked = fork_allowed && H->aux != nullptr;
+    // every buffer the section writes is reserved BEFORE the fork: a buffer that grows is filled on the context's
+    // own stream (DevBuf::reserve), which the other stream does not wait for after the fork
     const size_t a4 = (((size_t)(nc + 1) * 4) + 255) & ~(size_t)255;
     const size_t scan2 = (scan_tmp_bytes(nc + 1) + 255) & ~(size_t)255;
     NODAL_HIP_TRY(h, H->rstart.reserve(a4 + 256 + scan2 + (size_t)PW * ld * 4 + 64));
     NODAL_HIP_TRY(h, H->keys.reserve((size_t)PW * n * 8 + 64));
+    SLevel *C = H->level(l + 1);
+    C->n = nc;
+    C->ld = pad64(nc);
+    C->width = ACAP;
+    C->nc = 0;
+    L->rld = C->ld;
+    const int rcap = rcap_for(nc);
+    NODAL_HIP_TRY(h, L->rcol.reserve((size_t)rcap * C->ld * 4 + 64));
+    NODAL_HIP_TRY(h, L->rval.reserve((size_t)rcap * C->ld * 8 + 64));
+    NODAL_HIP_TRY(h, L->rvalf.reserve((size_t)rcap * C->ld * 4 + 64));
+    NODAL_HIP_TRY(h, L->rlen.reserve((size_t)C->ld * 4 + 64));
+    // (and the ones the Galerkin product fills on the main stream meanwhile)
+    NODAL_HIP_TRY(h, C->acol.reserve((size_t)ACAP * C->ld * 4 + 64));
+    NODAL_HIP_TRY(h, C->aval.reserve((size_t)ACAP * C->ld * 8 + 64));
+    NODAL_HIP_TRY(h, C->avalf.reserve((size_t)ACAP * C->ld * 4 + 64));
+    NODAL_HIP_TRY(h, C->alen.reserve((size_t)C->ld * 4 + 64));
+    NODAL_HIP_TRY(h, C->dinv.reserve((size_t)C->ld * 8 + 64));
+    {
+        const int apw = L->maxlen <= 6 ? 16 : 64;  // (as galerkin_product sizes them)
+        NODAL_HIP_TRY(h, H->apcol.reserve((size_t)apw * ld * 4 + 64));
+        NODAL_HIP_TRY(h, H->apval.reserve((size_t)apw * ld * 8 + 64));
+        NODAL_HIP_TRY(h, H->aplen.reserve((size_t)ld * 4 + 64));
+    }
+    hipStream_t main_st = h->stream;
+    struct StreamGuard {  // (whatever way this function is left, the context gets its stream back)
+        nodal_ctx *h;
+        hipStream_t keep;
+        ~StreamGuard() { h->stream = keep; }
+    } guard{h, main_st};
+    if (forked) {
+        NODAL_HIP_TRY(h, hipEventRecord(H->ev_fork, main_st));
+        NODAL_HIP_TRY(h, hipStreamWaitEvent(H->aux, H->ev_fork, 0));
+        NODAL_TRY(galerkin_product<false>(h, H, l, nullptr, 1));  // A P first: the long launch of the pair
+        h->stream = H->aux;
+        st = H->aux;
+    }
     char *rs = H->rstart.as<char>();
     uint32_t *rstart = reinterpret_cast<uint32_t *>(rs);
     void *scan_tmp2 = rs + a4 + 256;
@@ -1282,17 +1347,6 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     r_sort_medium<<<(unsigned)(nc < 8192 ? nc : 8192), 64, 0, st>>>(rstart, keys, nc);
     NODAL_HIP_TRY(h, hipGetLastError());
 
-    SLevel *C = H->level(l + 1);
-    C->n = nc;
-    C->ld = pad64(nc);
-    C->width = ACAP;
-    C->nc = 0;
-    L->rld = C->ld;
-    const int rcap = rcap_for(nc);
-    NODAL_HIP_TRY(h, L->rcol.reserve((size_t)rcap * C->ld * 4 + 64));
-    NODAL_HIP_TRY(h, L->rval.reserve((size_t)rcap * C->ld * 8 + 64));
-    NODAL_HIP_TRY(h, L->rvalf.reserve((size_t)rcap * C->ld * 4 + 64));
-    NODAL_HIP_TRY(h, L->rlen.reserve((size_t)C->ld * 4 + 64));
     {
         const unsigned gr = grid_for(nc * 8);
         r_to_ell<<<gr, TB, 0, st>>>(nc, L->rld, rstart, keys, ld, L->pval.as<double>(), L->rcol.as<int32_t>(),
@@ -1300,12 +1354,13 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
                                    dstats + (size_t)l * ST_COUNT, H->bstat.as<uint32_t>(), (uint32_t)rcap);
         reduce_bstat<<<1, 1024, 0, st>>>((int)gr, H->bstat.as<uint32_t>(), dstats + (size_t)l * ST_COUNT, ST_MAXR, -1);
     }
-    NODAL_HIP_TRY(h, C->acol.reserve((size_t)ACAP * C->ld * 4 + 64));
-    NODAL_HIP_TRY(h, C->aval.reserve((size_t)ACAP * C->ld * 8 + 64));
-    NODAL_HIP_TRY(h, C->avalf.reserve((size_t)ACAP * C->ld * 4 + 64));
-    NODAL_HIP_TRY(h, C->alen.reserve((size_t)C->ld * 4 + 64));
-    NODAL_HIP_TRY(h, C->dinv.reserve((size_t)C->ld * 8 + 64));
-    NODAL_TRY(galerkin_product<false>(h, H, l));
+    if (forked) {
+        NODAL_HIP_TRY(h, hipGetLastError());
+        NODAL_HIP_TRY(h, hipEventRecord(H->ev_join, H->aux));
+        h->stream = main_st;
+        st = main_st;
+    }
+    NODAL_TRY(galerkin_product<false>(h, H, l, forked ? H->ev_join : nullptr, forked ? 2 : 0));
     return NODAL_OK;
 }
 
