@@ -160,8 +160,12 @@ struct SHierarchy {
     // R = P^T (count, scan, fill, two sorts, blocked layout: seven latency-bound launches) and A P (one long one) need
     // P only, not each other: R is built on a stream of the hierarchy's own while the main one computes A P
     hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_flags = nullptr;
     bool aux_tried = false;
+    // the "touches ground" flags go up the aggregate maps on that stream too, level by level behind R (they need the
+    // aggregates only): flags_levels = how many levels' flags_up have been enqueued there in this setup
+    bool want_flags = false;
+    int flags_levels = 0;
     DevBuf stats, coarse_inv, mis_t, mis_m, mis_flag, mis_id, agg1, keys, rstart, cursor, lists;
     TailDesc td;
     uint64_t *host_stats = nullptr;  // pinned
@@ -206,6 +210,7 @@ struct SHierarchy {
         if (ev_copy) (void)hipEventDestroy(ev_copy);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_flags) (void)hipEventDestroy(ev_flags);
         if (aux) (void)hipStreamDestroy(aux);
         for (SLevel *l : pool) {
             DevBuf *b[] = {&l->acol, &l->aval, &l->alen, &l->dinv, &l->agg, &l->pcol, &l->pval, &l->rcol,
@@ -1284,7 +1289,8 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
         H->aux_tried = true;
         if (hipStreamCreateWithFlags(&H->aux, hipStreamNonBlocking) != hipSuccess) H->aux = nullptr;
         if (H->aux && (hipEventCreateWithFlags(&H->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                       hipEventCreateWithFlags(&H->ev_join, hipEventDisableTiming) != hipSuccess)) {
+                       hipEventCreateWithFlags(&H->ev_join, hipEventDisableTiming) != hipSuccess ||
+                       hipEventCreateWithFlags(&H->ev_flags, hipEventDisableTiming) != hipSuccess)) {
             (void)hipStreamDestroy(H->aux);
             H->aux = nullptr;
         }
@@ -1314,6 +1320,10 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     NODAL_HIP_TRY(h, C->avalf.reserve((size_t)ACAP * C->ld * 4 + 64));
     NODAL_HIP_TRY(h, C->alen.reserve((size_t)C->ld * 4 + 64));
     NODAL_HIP_TRY(h, C->dinv.reserve((size_t)C->ld * 8 + 64));
+    if (forked && H->want_flags) {
+        if (l == 0) NODAL_HIP_TRY(h, L->gflag.reserve((size_t)n + 64));
+        NODAL_HIP_TRY(h, C->gflag.reserve((size_t)C->n + 64));
+    }
     {
         const int apw = L->maxlen <= 6 ? 16 : 64;  // (as galerkin_product sizes them)
         NODAL_HIP_TRY(h, H->apcol.reserve((size_t)apw * ld * 4 + 64));
@@ -1357,6 +1367,14 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     if (forked) {
         NODAL_HIP_TRY(h, hipGetLastError());
         NODAL_HIP_TRY(h, hipEventRecord(H->ev_join, H->aux));
+        if (H->want_flags && H->flags_levels == l) {  // behind R, while the main stream sums the Galerkin products
+            if (l == 0) NODAL_TRY(grounded_flags(h, L->gflag.as<uint8_t>()));  // (on h->stream = the other stream)
+            NODAL_HIP_TRY(h, hipMemsetAsync(C->gflag.p, 0, ((size_t)C->n + 63) & ~(size_t)63, st));
+            flags_up<<<grid_for(n), TB, 0, st>>>(n, L->agg.as<int32_t>(), L->gflag.as<uint8_t>(), C->gflag.as<uint8_t>());
+            NODAL_HIP_TRY(h, hipGetLastError());
+            NODAL_HIP_TRY(h, hipEventRecord(H->ev_flags, H->aux));
+            H->flags_levels = l + 1;
+        }
         h->stream = main_st;
         st = main_st;
     }
@@ -1549,6 +1567,8 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
     }
     H->sym_valid = false;
     H->refreshed = false;
+    H->want_flags = check_floating;
+    H->flags_levels = 0;
     H->last_iters = 0;
     H->drop_graph();
     NODAL_HIP_TRY(h, H->stats.reserve((size_t)MAX_LEVELS * ST_COUNT * 8 + 64));
@@ -1634,9 +1654,14 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
     if (check_floating) {
         // (round 4) the "touches ground" flags go up the aggregate maps while the host waits for that copy: they
         // need the aggregates of every level, which are all there, and nothing the copy brings
-        NODAL_HIP_TRY(h, H->level(0)->gflag.reserve((size_t)n0 + 64));
-        NODAL_TRY(grounded_flags(h, H->level(0)->gflag.as<uint8_t>()));
-        for (int k = 0; k + 1 < H->nlev; ++k) {
+        // (the levels whose flags went up on the hierarchy's other stream behind their R are done: build_level)
+        if (H->flags_levels == 0) {
+            NODAL_HIP_TRY(h, H->level(0)->gflag.reserve((size_t)n0 + 64));
+            NODAL_TRY(grounded_flags(h, H->level(0)->gflag.as<uint8_t>()));
+        } else {
+            NODAL_HIP_TRY(h, hipStreamWaitEvent(st, H->ev_flags, 0));
+        }
+        for (int k = H->flags_levels; k + 1 < H->nlev; ++k) {
             SLevel *L = H->pool[k], *C = H->pool[k + 1];
             NODAL_HIP_TRY(h, C->gflag.reserve((size_t)C->n + 64));
             NODAL_HIP_TRY(h, hipMemsetAsync(C->gflag.p, 0, ((size_t)C->n + 63) & ~(size_t)63, st));  // (one fill kernel)
