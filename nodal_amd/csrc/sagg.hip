@@ -1499,11 +1499,21 @@ int sagg_refresh(nodal_ctx *h, SHierarchy *H, const int32_t *indptr0, const int3
         A.width = L->maxlen;
         build_P<<<grid_for(L->n), TB, 0, st>>>(A, L->dinv.as<double>(), L->agg.as<int32_t>(), L->pcol.as<int32_t>(),
                                               L->pval.as<double>(), L->pvalf.as<float>());
-        r_refresh<<<grid_for(C->n * 8), TB, 0, st>>>(C->n, L->rld, L->rlen.as<int32_t>(), L->rcol.as<int32_t>(), L->ld,
-                                                    L->pcol.as<int32_t>(), L->pval.as<double>(), L->rval.as<double>(),
-                                                    L->rvalf.as<float>());
+        // (R's values on the hierarchy's other stream while this one computes A P: see build_level)
+        const bool forked = H->aux != nullptr && !(getenv("NODAL_SA_FORK") && atoi(getenv("NODAL_SA_FORK")) == 0);
+        hipStream_t rst = st;
+        if (forked) {
+            NODAL_HIP_TRY(h, hipEventRecord(H->ev_fork, st));
+            NODAL_HIP_TRY(h, hipStreamWaitEvent(H->aux, H->ev_fork, 0));
+            NODAL_TRY(galerkin_product<true>(h, H, l, nullptr, 1));
+            rst = H->aux;
+        }
+        r_refresh<<<grid_for(C->n * 8), TB, 0, rst>>>(C->n, L->rld, L->rlen.as<int32_t>(), L->rcol.as<int32_t>(), L->ld,
+                                                     L->pcol.as<int32_t>(), L->pval.as<double>(), L->rval.as<double>(),
+                                                     L->rvalf.as<float>());
         NODAL_HIP_TRY(h, hipGetLastError());
-        NODAL_TRY(galerkin_product<true>(h, H, l));
+        if (forked) NODAL_HIP_TRY(h, hipEventRecord(H->ev_join, H->aux));
+        NODAL_TRY(galerkin_product<true>(h, H, l, forked ? H->ev_join : nullptr, forked ? 2 : 0));
     }
     const int last = H->nlev - 1;
     if (H->dense_coarsest)
