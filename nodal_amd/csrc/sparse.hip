@@ -876,7 +876,10 @@ int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, do
     }
     const int64_t densify_max = 4096;
     const int64_t dense_rescue_max = 8192;  // a general system the iteration gives up on is decided by the dense LU up to here, by the sparse direct solve beyond
-    const int64_t lowdeg_min = 1024;  // below this a direct solve costs less than an elimination round
+    // below this a direct solve costs less than an elimination round.  (1024 until round 4: true of a round that is
+    // being BUILT, 0.2-0.4 ms; repeated on kept lists it is two 5-us launches, and the dense solve of the 780 unknowns
+    // seven rounds leave of a 1e5-section ladder was 0.75 of that solve's 0.91 ms.  NODAL_LOWDEG_MIN to compare.)
+    static const int64_t lowdeg_min = getenv("NODAL_LOWDEG_MIN") ? atoll(getenv("NODAL_LOWDEG_MIN")) : 32;
     bool auto_passive = false;
     // NODAL_SPARSE_FORCE_DIRECT=1 (testing): every automatic sparse solve through the direct route
     if (method == NODAL_SPARSE_AUTO && getenv("NODAL_SPARSE_FORCE_DIRECT")) method = NODAL_SPARSE_DIRECT;
