@@ -204,6 +204,7 @@ void nodal_free_buffers(nodal_ctx *h) {
     amg_destroy(h);
     sagg_destroy(h);
     slu_destroy(h);
+    presolve_free_plan(h);
     nodal_free_block_child(h);
     if (h->reduced) {
         nodal_free_buffers(h->reduced);
@@ -221,7 +222,7 @@ void nodal_free_buffers(nodal_ctx *h) {
                       &h->data, &h->rhs, &h->status, &h->x, &h->dense, &h->piv, &h->work,
                       &h->work2, &h->work3, &h->solver, &h->krylov, &h->gn_indptr, &h->gn_indices,
                       &h->gn_rowidx, &h->gn_data, &h->gn_diag, &h->schur, &h->ps_buf, &h->ps_newidx,
-                      &h->ps_hits, &h->grounded, &h->ld_newidx, &h->ld_work, &h->batch_scale, &h->rhs_none};
+                      &h->ps_hits, &h->ps_stage, &h->grounded, &h->ld_newidx, &h->ld_work, &h->batch_scale, &h->rhs_none};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
     h->evpool.clear();

@@ -129,7 +129,7 @@ struct nodal_ctx {
     size_t arena_bytes = 0;
     bool use_presolve = true;
     bool use_graphs = false;       // hipGraph replay of the FCG iteration: measured no gain (kernels are not host-bound)
-    DevBuf ps_buf, ps_newidx, ps_hits;
+    DevBuf ps_buf, ps_newidx, ps_hits, ps_stage;
     // exact elimination of nodes with <= 2 neighbours (lowdeg.hip): the reduced network is a
     // matrix-only context (no component table) that inherits the grounded-node flags
     nodal_ctx *lowdeg = nullptr;
@@ -203,6 +203,7 @@ struct nodal_ctx {
     int64_t low_rows = -1;               // rows of two or three entries of the matrix pattern (upper bound; group.h), -1 unknown
     unsigned long long low_rows_epoch = ~0ull;  // struct_epoch it belongs to
     void *slu = nullptr;  // multifrontal LU of the direct route (sparse_direct.hip)
+    void *ps_plan = nullptr;  // the presolve's plan, made ahead of the solve (presolve.hip: presolve_plan_ahead)
     bool slu_strict = false;  // refinement judged by |r| / |b| alone (the direct route's second opinion)
     int32_t last_iterations = 0;
     double last_relres = 0;
@@ -333,6 +334,8 @@ int lowdeg_solve(nodal_ctx *h, int min_share, bool *done, int32_t *info, int32_t
 int sparse_solve(nodal_ctx *h, int32_t method, int32_t *info, int32_t *iters, double *resid);
 int sparse_residual(nodal_ctx *h, double *scaled);
 // dense_child: solve the reduced system by the dense block elimination (only if it is passive)
+void presolve_plan_ahead(nodal_ctx *h);  // host-only; called by stamp_numeric while its kernels run
+void presolve_free_plan(nodal_ctx *h);
 int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, double *resid,
                    bool dense_child = false);
 // ---- sparse direct route (sparse_direct.hip): multifrontal LU + FGMRES refinement ----

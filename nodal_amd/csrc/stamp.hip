@@ -402,6 +402,8 @@ int stamp_numeric(nodal_ctx *h, int32_t member, int64_t *bad_component) {
                                                   h->rhs.as<double>(), h->nrhs);
         NODAL_HIP_TRY(h, hipGetLastError());
     }
+    // (host work that needs nothing from the device goes here, between the launches and the wait for their status)
+    if (h->B > 0 && !h->csr_only) presolve_plan_ahead(h);
     unsigned long long st_host[3];
     NODAL_TRY(nodal_read_words(h, st_host, status, 24));
     h->have_numeric = true;
