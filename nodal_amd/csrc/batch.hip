@@ -149,6 +149,12 @@ int replicate_symbolic(nodal_ctx *h, nodal_ctx *c, int32_t count) {
     if (nnz * count >= (1ll << 31) - 2 || C * count >= (1ll << 31) - 2)
         return nodal_fail(h, NODAL_E_UNSUPPORTED, "run_batch: shard too large for 32-bit indices; split it");
     ++c->struct_epoch;
+    // (rows a low-degree elimination could take: the member's count, times the members -- lowdeg.hip looks before it
+    // launches its selection)
+    if (h->low_rows >= 0 && h->low_rows_epoch == h->struct_epoch) {
+        c->low_rows = h->low_rows * count;
+        c->low_rows_epoch = c->struct_epoch;
+    }
     c->nnz = nnz * count;
     c->ncontrib = C * count;
     c->nrhs = nr * count;
