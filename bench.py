@@ -149,6 +149,7 @@ class SingleCircuits:
             self.table = gen.cfg5_table(1000)
             self.desc = "grid(1000) + 1% E + CCCS/VCVS (non-symmetric MNA), sparse path"
         self.h = _ffi.Handle(device)
+        self.h.set_option(_ffi.OPT_EXTRA_STREAMS, 1)  # one handle, one call at a time: it may use streams of its own
         t0 = time.perf_counter()
         self.h.upload(self.table)
         self.h.synchronize()
@@ -208,6 +209,7 @@ class BatchShard:
     def __init__(self, rank, world, per_gpu, device, dist, force_collective=False):
         import numpy as np
         from nodal_amd import generators as gen
+        from nodal_amd import _ffi
         from nodal_amd.batch import ShardedBatch
         self.name, self.per_step, self.dist, self.world = "cfg4", per_gpu, dist, world
         self.dense = False
@@ -222,6 +224,7 @@ class BatchShard:
         for i in range(per_gpu):
             vals[i, :-1] = gen.cfg4_values(rank * per_gpu + i, 100)
         h = self.shard.session.h
+        h.set_option(_ffi.OPT_EXTRA_STREAMS, 1)  # one handle per rank, one call at a time
         self.h2d_first_ms = None
         h.assemble_symbolic()  # per-member n, nnz for the byte counts (untimed)
         self.n, self.nnz = h.n, h.nnz
@@ -346,6 +349,7 @@ def direct_route_times(device):
     from nodal_amd import generators as gen
     table = gen.cfg5_table(1000)
     h = _ffi.Handle(device)
+    h.set_option(_ffi.OPT_EXTRA_STREAMS, 1)
     h.upload(table)
     h.assemble_symbolic()
     h.assemble_numeric()
@@ -378,6 +382,7 @@ def resistance_sweep_times(device, npairs=192):
     ib = rng.randint(-1, table.K, size=npairs).astype(np.int32)
     ib[ib == ia] = -1
     h = _ffi.Handle(device)
+    h.set_option(_ffi.OPT_EXTRA_STREAMS, 1)
     h.upload(table)
     h.assemble_symbolic()
     h.assemble_numeric()

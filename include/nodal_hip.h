@@ -190,8 +190,13 @@ int nodal_synchronize(nodal_handle h);
  * NODAL_OPT_FORCE_PIVOTING (0/1): dense LU always searches pivots, even on
  *   passive networks (column diagonally dominant G) where it provably never swaps.
  * NODAL_OPT_GEPP_PANEL (0/1, default 1): partial pivoting factors a 32-column panel in one launch
- *   (registers) instead of two launches per column; both forms give the same bits (cross-check). */
-enum { NODAL_OPT_FORCE_PIVOTING = 1, NODAL_OPT_GEPP_PANEL = 2 };
+ *   (registers) instead of two launches per column; both forms give the same bits (cross-check).
+ * NODAL_OPT_EXTRA_STREAMS (0/1, default 0; environment NODAL_EXTRA_STREAMS): a handle that is used ALONE -- one
+ *   handle in the process, one call at a time -- may spread independent pieces of a solve over streams of its own
+ *   (the multigrid setup builds R beside A P, the direct factorisation runs the wide fronts of a level side by
+ *   side).  Same kernels, same results.  Off by default: the runtime maps a process's streams onto a handful of
+ *   hardware queues, and a second stream per handle makes the main streams of several handles share them. */
+enum { NODAL_OPT_FORCE_PIVOTING = 1, NODAL_OPT_GEPP_PANEL = 2, NODAL_OPT_EXTRA_STREAMS = 3 };
 int nodal_set_option(nodal_handle h, int32_t option, int32_t value);
 
 /* ---- testing hooks (not part of the reference-facing surface) -------------

@@ -20,6 +20,7 @@ OK, E_INVALID, E_HIP, E_ZERO_RESISTANCE, E_STAMP_COLLISION, E_SINGULAR, E_NOMEM,
 SPARSE_AUTO, SPARSE_PCG, SPARSE_DENSIFY, SPARSE_LU, SPARSE_DIRECT = range(5)
 OPT_FORCE_PIVOTING = 1
 OPT_GEPP_PANEL = 2
+OPT_EXTRA_STREAMS = 3
 
 _p = C.POINTER
 _i32p, _i64p, _f64p, _u8p = _p(C.c_int32), _p(C.c_int64), _p(C.c_double), _p(C.c_uint8)

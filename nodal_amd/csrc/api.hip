@@ -3,12 +3,32 @@
 #include <string.h>
 
 #include "ctx.h"
+#include <atomic>
 
 int dense_prepare(nodal_ctx *h);  // sparse.hip
 int pair_read_host(nodal_ctx *h, const double *x, int32_t ia, int32_t ib, double *out);  // sparse.hip
 int nodal_upload_internal(nodal_ctx *h, int64_t ncomp, const uint8_t *type, const double *value,
                           const int32_t *a, const int32_t *b, const int32_t *c, const int32_t *d,
                           const int32_t *drv, const int32_t *k, int32_t K, int32_t B);
+
+// Host threads inside an API call right now, process-wide (nested calls of one thread count once).  A solve that
+// has the device to itself spreads independent pieces over streams of its own (the multigrid setup's second stream,
+// the direct route's lanes); with several solves in flight -- one context and host thread each -- the extra queues
+// only get in each other's way (four contexts with two streams each: 232 -> 178 circuits/s), and the solves overlap
+// anyway.
+static std::atomic<int> g_calls_in_flight{0};
+static thread_local int t_call_depth = 0;
+int nodal_calls_in_flight() { return g_calls_in_flight.load(std::memory_order_relaxed); }
+// Handles alive in the process.  (The runtime spreads a process's streams over a handful of hardware queues: a second
+// stream per handle makes the main streams of four handles share queues -- four solves in flight, symbolic phases
+// kept: 232 -> 181 circuits/s even with the extra streams idle, and a stream created while another handle's extra
+// stream exists keeps its shared queue after that one is gone.  Hence extra streams are an OPTION of the handle.)
+static std::atomic<int> g_live_handles{0};
+int nodal_live_handles() { return g_live_handles.load(std::memory_order_relaxed); }
+bool nodal_extra_streams_ok(const nodal_ctx *ctx) {  // the handle was told it is alone (NODAL_OPT_EXTRA_STREAMS) and no other call runs
+    const nodal_ctx *h = ctx->stream_owner ? ctx->stream_owner : ctx;
+    return h->extra_streams && nodal_calls_in_flight() <= 1;
+}
 
 namespace {
 
@@ -18,12 +38,14 @@ struct DeviceGuard {
     int prev = -1;
     FillStreamScope fill;
     explicit DeviceGuard(nodal_ctx *h) : fill(h->stream) {
+        if (t_call_depth++ == 0) g_calls_in_flight.fetch_add(1, std::memory_order_relaxed);
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != h->device) (void)hipSetDevice(h->device);
         else prev = -1;
     }
     ~DeviceGuard() {
         if (prev >= 0) (void)hipSetDevice(prev);
+        if (--t_call_depth == 0) g_calls_in_flight.fetch_sub(1, std::memory_order_relaxed);
     }
     DeviceGuard(const DeviceGuard &) = delete;
     DeviceGuard &operator=(const DeviceGuard &) = delete;
@@ -112,6 +134,8 @@ int nodal_create(int device_id, nodal_handle *out) {
     if (const char *e = getenv("NODAL_GJ_SCALAR")) h->gj_scalar = atoi(e);
     if (const char *e = getenv("NODAL_GEPP_PANEL")) h->gepp_panel = atoi(e) != 0;
     if (const char *e = getenv("NODAL_PRESOLVE")) h->use_presolve = atoi(e) != 0;  // 0: branch equations stay in the system
+    if (const char *e = getenv("NODAL_EXTRA_STREAMS")) h->extra_streams = atoi(e) != 0;
+    g_live_handles.fetch_add(1, std::memory_order_relaxed);
     *out = h;
     return NODAL_OK;
 }
@@ -283,6 +307,7 @@ int nodal_destroy(nodal_handle h) {
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->arena) (void)hipHostFree(h->arena);
     delete h;
+    g_live_handles.fetch_sub(1, std::memory_order_relaxed);
     return NODAL_OK;
 }
 
@@ -676,6 +701,10 @@ int nodal_set_option(nodal_handle h, int32_t option, int32_t value) {
     }
     if (option == NODAL_OPT_GEPP_PANEL) {
         h->gepp_panel = value != 0;
+        return NODAL_OK;
+    }
+    if (option == NODAL_OPT_EXTRA_STREAMS) {
+        h->extra_streams = value != 0;
         return NODAL_OK;
     }
     return nodal_fail(h, NODAL_E_INVALID, "unknown option");

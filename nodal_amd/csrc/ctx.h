@@ -202,6 +202,7 @@ struct nodal_ctx {
     int64_t sym_low_rows = -1;           // ... of the table grouped last (kept with sym_sizes)
     int64_t low_rows = -1;               // rows of two or three entries of the matrix pattern (upper bound; group.h), -1 unknown
     unsigned long long low_rows_epoch = ~0ull;  // struct_epoch it belongs to
+    bool extra_streams = false;  // NODAL_OPT_EXTRA_STREAMS: the handle is used alone and may use streams of its own
     void *slu = nullptr;  // multifrontal LU of the direct route (sparse_direct.hip)
     void *ps_plan = nullptr;  // the presolve's plan, made ahead of the solve (presolve.hip: presolve_plan_ahead)
     bool slu_strict = false;  // refinement judged by |r| / |b| alone (the direct route's second opinion)
@@ -354,6 +355,9 @@ void nodal_nan_probe(nodal_ctx *h, const double *dev, int64_t n, const char *tag
 // that only ever solves sparse systems holds ONE hardware queue, so that four of them in flight still
 // get a queue each (the runtime multiplexes streams beyond its hardware queues: erratic throughput).
 int nodal_ensure_aux_streams(nodal_ctx *h);  // api.hip
+int nodal_calls_in_flight();  // host threads inside an API call right now, process-wide (api.hip)
+int nodal_live_handles();     // handles alive in the process (api.hip)
+bool nodal_extra_streams_ok(const nodal_ctx *h);  // NODAL_OPT_EXTRA_STREAMS is set and no other call is in flight (api.hip)
 // NODAL_PINNED_BYTES of page-locked host memory of the handle (child contexts use their parent's): the
 // destination of every read-back of a few words -- a copy to a stack variable is staged by the runtime
 // through its own pinned buffer and costs 15-20 us more.  One API call at a time per handle, and every use is

@@ -1285,18 +1285,24 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     // R = P^T by coarse row -- on the hierarchy's other stream when there is one (see SHierarchy::aux): every
     // launch of this section, the scans included, goes where h->stream points
     static const bool fork_allowed = !(getenv("NODAL_SA_FORK") && atoi(getenv("NODAL_SA_FORK")) == 0);
-    if (fork_allowed && !H->aux_tried) {
+    if (H->aux && !nodal_extra_streams_ok(h) && nodal_calls_in_flight() <= 1) {  // (the option was taken back: so is the stream's hardware queue)
+        (void)hipStreamSynchronize(H->aux);
+        (void)hipStreamDestroy(H->aux);
+        H->aux = nullptr;
+        H->aux_tried = false;
+    }
+    if (fork_allowed && !H->aux_tried && nodal_extra_streams_ok(h)) {
         H->aux_tried = true;
         if (hipStreamCreateWithFlags(&H->aux, hipStreamNonBlocking) != hipSuccess) H->aux = nullptr;
-        if (H->aux && (hipEventCreateWithFlags(&H->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                       hipEventCreateWithFlags(&H->ev_join, hipEventDisableTiming) != hipSuccess ||
-                       hipEventCreateWithFlags(&H->ev_flags, hipEventDisableTiming) != hipSuccess)) {
+        if (H->aux && ((!H->ev_fork && hipEventCreateWithFlags(&H->ev_fork, hipEventDisableTiming) != hipSuccess) ||
+                       (!H->ev_join && hipEventCreateWithFlags(&H->ev_join, hipEventDisableTiming) != hipSuccess) ||
+                       (!H->ev_flags && hipEventCreateWithFlags(&H->ev_flags, hipEventDisableTiming) != hipSuccess))) {
             (void)hipStreamDestroy(H->aux);
             H->aux = nullptr;
         }
         (void)hipGetLastError();
     }
-    const bool forked = fork_allowed && H->aux != nullptr;
+    const bool forked = fork_allowed && H->aux != nullptr && nodal_extra_streams_ok(h);  // (see api.hip)
     // every buffer the section writes is reserved BEFORE the fork: a buffer that grows is filled on the context's
     // own stream (DevBuf::reserve), which the other stream does not wait for after the fork
     const size_t a4 = (((size_t)(nc + 1) * 4) + 255) & ~(size_t)255;
@@ -1500,7 +1506,8 @@ int sagg_refresh(nodal_ctx *h, SHierarchy *H, const int32_t *indptr0, const int3
         build_P<<<grid_for(L->n), TB, 0, st>>>(A, L->dinv.as<double>(), L->agg.as<int32_t>(), L->pcol.as<int32_t>(),
                                               L->pval.as<double>(), L->pvalf.as<float>());
         // (R's values on the hierarchy's other stream while this one computes A P: see build_level)
-        const bool forked = H->aux != nullptr && !(getenv("NODAL_SA_FORK") && atoi(getenv("NODAL_SA_FORK")) == 0);
+        const bool forked = H->aux != nullptr && nodal_extra_streams_ok(h) &&
+                            !(getenv("NODAL_SA_FORK") && atoi(getenv("NODAL_SA_FORK")) == 0);
         hipStream_t rst = st;
         if (forked) {
             NODAL_HIP_TRY(h, hipEventRecord(H->ev_fork, st));

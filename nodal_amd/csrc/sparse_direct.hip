@@ -855,7 +855,7 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
     int want_lanes = 4;  // (config 5's factorisation with 1 / 2 / 3 / 4 / 6 lanes: 93 / 73 / 67 / 65 / 83 ms)
     if (const char *e = getenv("NODAL_DIRECT_LANES")) want_lanes = atoi(e) < 1 ? 1 : (atoi(e) > SluState::LANES ? SluState::LANES : atoi(e));
     S->lane_st[0] = st;
-    if (S->lanes < want_lanes) {  // streams and events of the lanes: once per context (a failure leaves fewer lanes)
+    if (S->lanes < want_lanes && nodal_extra_streams_ok(h)) {  // streams and events of the lanes: once per context (a failure leaves fewer lanes)
         if (!S->lane_ev[0] && hipEventCreateWithFlags(&S->lane_ev[0], hipEventDisableTiming) != hipSuccess) S->lane_ev[0] = nullptr;
         for (int k = S->lanes; k < want_lanes && S->lane_ev[0]; ++k) {
             if (hipStreamCreateWithFlags(&S->lane_st[k], hipStreamNonBlocking) != hipSuccess) { S->lane_st[k] = nullptr; break; }
@@ -869,7 +869,7 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
         }
         (void)hipGetLastError();
     }
-    const int max_lanes = S->lanes < want_lanes ? S->lanes : want_lanes;
+    const int max_lanes = !nodal_extra_streams_ok(h) ? 1 : (S->lanes < want_lanes ? S->lanes : want_lanes);  // (see api.hip)
     const bool fronts_in_lds = !(getenv("NODAL_DIRECT_FRONT_LDS") && atoi(getenv("NODAL_DIRECT_FRONT_LDS")) == 0);
     const bool panel_regs = !(getenv("NODAL_DIRECT_PANEL_REGS") && atoi(getenv("NODAL_DIRECT_PANEL_REGS")) == 0);
     int64_t big_fronts = 0;

@@ -1567,3 +1567,25 @@ def test_sparse_solution_is_linear_in_the_source_at_any_scale(source):
         out.append(x / s)
         h.close()
     assert np.abs(out[1] - out[0]).max() <= 1e-9 * np.abs(out[0]).max()
+
+
+def test_extra_streams_option_changes_nothing_but_the_schedule():
+    """NODAL_OPT_EXTRA_STREAMS: the multigrid setup builds R on a second stream beside A P and sends the grounded flags
+    up there; the direct factorisation runs the wide fronts of a level side by side.  Same kernels on the same data:
+    bit-identical solutions, fresh and with the symbolic phases kept, and through the direct route."""
+    table = gen.grid_table(260)
+    out = {}
+    for opt in (0, 1):
+        h = _ffi.Handle(0)
+        h.set_option(_ffi.OPT_EXTRA_STREAMS, opt)
+        h.upload(table)
+        assert h.run(False) == 0
+        x_fresh = h.download_x()
+        assert h.run(False, 0, True) == 0  # symbolic phases kept: the values-only refresh
+        x_kept = h.download_x()
+        x_direct, info, _, _ = h.solve_sparse(method=_ffi.SPARSE_DIRECT)
+        assert info == 0
+        out[opt] = (x_fresh, x_kept, x_direct)
+        h.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
