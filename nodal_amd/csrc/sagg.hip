@@ -2003,6 +2003,7 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
         if (batch > 32) batch = 32;
     }
     int status = 0;  // 0 running, 1 converged, 2 breakdown, 3 maxit
+    const bool poll_partials = !(getenv("NODAL_FCG_HOST_SUM") && atoi(getenv("NODAL_FCG_HOST_SUM")) == 0);
     double rr_prev = -1.0;
     int64_t it_prev = 0;
     int polls = 0;
@@ -2080,17 +2081,44 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
                 ++enqueued;
             }
         }
-        NODAL_TRY(nodal_read_words(h, hs, sb.sc, F_COUNT * 8));
+        // The look brings the scalars AND the partial sums of |r|^2 that the last f_update left (they lie in front of
+        // the scalars: one copy).  The device learns that iteration k has converged in f_direction of iteration k + 1,
+        // behind that iteration's multigrid cycle -- 0.3 ms for nothing at the end of every solve; the host adds the
+        // partials up itself (a fixed order) and stops the moment the residual is there.
+        double rr_now = -1.0;
+        {
+            const size_t bytes = (size_t)(2 * MAX_PARTIALS + F_COUNT) * 8;  // part_rr | part_pap | sc
+            double *stage = poll_partials ? static_cast<double *>(nodal_pinned_arena(h, bytes)) : nullptr;
+            if (stage) {
+                NODAL_HIP_TRY(h, hipMemcpyAsync(stage, sb.part_rr, bytes, hipMemcpyDeviceToHost, st));
+                NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+                memcpy(hs, stage + 2 * MAX_PARTIALS, F_COUNT * 8);
+                double acc = 0.0;
+                for (int k = 0; k < sb.g0; ++k) acc += stage[k];
+                rr_now = acc;
+            } else {
+                NODAL_TRY(nodal_read_words(h, hs, sb.sc, F_COUNT * 8));
+            }
+        }
         ++polls;
-        const bool conv = hs[F_CONV + ((enqueued - 1) & 1)] != 0.0;
+        bool conv = hs[F_CONV + ((enqueued - 1) & 1)] != 0.0;
+        bool host_conv = false;
+        if (!conv && rr_now >= 0.0 && hs[F_FLAG] == 0.0 && hs[F_BB] > 0.0 && rr_now <= tol * tol * hs[F_BB]) {
+            // (the residual after the iteration enqueued last; the device's own flag would follow one cycle later)
+            host_conv = true;
+            hs[F_RR] = rr_now;
+            hs[F_ITERS] = (double)enqueued;
+        } else if (!conv && rr_now >= 0.0) {
+            hs[F_RR] = rr_now;  // (one iteration fresher than the device's word: the rate below is the better for it)
+        }
         float ms = 0;
         // (the timed launch did its work unless the iteration had converged before it)
-        if (!(conv && hs[F_ITERS] <= (double)(enqueued - batch)) && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+        if (!(conv && !host_conv && hs[F_ITERS] <= (double)(enqueued - batch)) && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
             h->kern_ms += ms;
             h->kern_launches += 1;
         }
         if (hs[F_FLAG] != 0.0 || !(hs[F_RR] == hs[F_RR])) status = 2;
-        else if (conv) status = 1;
+        else if (conv || host_conv) status = 1;
         else if (enqueued >= maxit) status = 3;
         else {
             // remaining iterations from the observed reduction per iteration; three quarters of the
