@@ -542,7 +542,9 @@ int amg_fcg_solve_ex(nodal_ctx *h, const double *b, bool do_setup, int32_t *info
     const double tol = 1e-13;
     // chain-like networks need ~1000 iterations; beyond the cap: Jacobi-CG fallback
     const int64_t maxit = getenv("NODAL_FCG_MAXIT") ? atoll(getenv("NODAL_FCG_MAXIT")) : 5000;
-    const int check = 4;
+    int check = 6;  // iterations before the next look at the residual (first: six; then from the rate seen so far)
+    double rr_prev = -1.0;
+    int64_t it_prev = 0;
     double hs[F_COUNT];
     int64_t it = 0;
     int status = 0;  // 0 running, 1 converged, 2 breakdown, 3 maxit
@@ -584,16 +586,47 @@ int amg_fcg_solve_ex(nodal_ctx *h, const double *b, bool do_setup, int32_t *info
             if (exec && !timed) NODAL_HIP_TRY(h, hipGraphLaunch(exec, st));
             else NODAL_TRY(iteration(timed));
         }
-        NODAL_TRY(nodal_read_words(h, hs, sc, F_COUNT * 8));
+        // The look brings the scalars and the partial sums of |r|^2 the last fcg_update left (one copy: they lie in
+        // front of the scalars); the host adds them up in a fixed order -- the residual AFTER the last iteration,
+        // where sc[F_RR] is the one before it -- and sizes the next batch from the reduction per iteration seen so
+        // far (three quarters of what is still missing), as sagg_fcg_solve does.  (Until round 4: a look every
+        // four iterations -- eight of them and two iterations too many on a 32-iteration solve.)
+        {
+            const size_t bytes = (size_t)(3 * MAX_PARTIALS + F_COUNT) * 8;  // part_rr | part_pap | part_zap | sc
+            double *stage = static_cast<double *>(nodal_pinned_arena(h, bytes));
+            if (stage) {
+                NODAL_HIP_TRY(h, hipMemcpyAsync(stage, part_rr, bytes, hipMemcpyDeviceToHost, st));
+                NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+                memcpy(hs, stage + 3 * MAX_PARTIALS, F_COUNT * 8);
+                double acc = 0.0;
+                for (unsigned k = 0; k < gv; ++k) acc += stage[k];
+                if (acc == acc && hs[F_FLAG] == 0.0) hs[F_RR] = acc;
+            } else {
+                NODAL_TRY(nodal_read_words(h, hs, sc, F_COUNT * 8));
+            }
+        }
         float ms = 0;
         if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
             h->kern_ms += ms;
             h->kern_launches += 1;
         }
-        // sc[F_RR] is |r|^2 as of the direction kernel of the last iteration
         if (hs[F_FLAG] != 0.0 || !(hs[F_RR] == hs[F_RR])) status = 2;
         else if (hs[F_BB] == 0.0 || hs[F_RR] <= tol * tol * hs[F_BB]) status = 1;
         else if (it >= maxit) status = 3;
+        else {
+            int next = 2;
+            const double target = tol * tol * hs[F_BB];
+            const double rr_ref = rr_prev > 0.0 ? rr_prev : hs[F_BB];
+            const int64_t it_ref = rr_prev > 0.0 ? it_prev : 0;
+            if (hs[F_RR] > 0.0 && hs[F_RR] < rr_ref && it > it_ref) {
+                const double rate = log(hs[F_RR] / rr_ref) / (double)(it - it_ref);  // < 0
+                next = (int)floor(0.75 * log(target / hs[F_RR]) / rate);
+            }
+            if (next > it) next = (int)it;  // (at most doubling: early rates are pessimistic)
+            check = next < 1 ? 1 : (next > 32 ? 32 : next);
+            rr_prev = hs[F_RR];
+            it_prev = it;
+        }
     }
     if (exec) (void)hipGraphExecDestroy(exec);
     if (graph) (void)hipGraphDestroy(graph);
