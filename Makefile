@@ -1,5 +1,7 @@
 # Builds the HIP C-ABI library in-tree (travels to the GPU box with the snapshot).
 # One object per source so that `make -j` rebuilds only what changed.
+# --wrap: every kernel launch of the library passes through the launch log of csrc/wait.hip (the diagnostics of a
+# host wait that times out name the last kernel enqueued on the stream).
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 SRC   := $(wildcard nodal_amd/csrc/*.hip)
@@ -17,7 +19,7 @@ $(OBJDIR)/%.o: nodal_amd/csrc/%.hip $(HDR)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 $(LIB): $(OBJ)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--wrap=hipLaunchKernel -Wl,--wrap=hipExtLaunchKernel -o $@ $(OBJ)
 
 # host-side netlist tokenizer (front-end, optional: fastparse.py falls back to pandas without it)
 $(CSVLIB): nodal_amd/csrc/fastcsv.cpp

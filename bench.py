@@ -9,17 +9,22 @@ circuit symbolic + numeric assembly + solve, the equivalent of the reference's
 uploaded before the timed region; nothing is cached between circuits or steps.
 
 Workloads (BASELINE.json `configs`):
-    cfg3  1000x1000 resistor grid (1e6 nodes), sparse CSR path        default at N = 1
+    cfg3  1000x1000 resistor grid (1e6 nodes), sparse CSR path        the headline at EVERY N
           (the configuration north_star's ">= 50x scipy.sparse" target is quoted on)
     cfg4  batch of 100x100 grids with per-member values, 128 members per GPU, solved as
-          one block-diagonal system per rank and gathered over RCCL   default at N > 1
+          one block-diagonal system per rank and gathered over RCCL   (`also`, at every N)
     cfg2  100x100 resistor grid, dense G, fp64 block elimination / LU
     cfg5  1000x1000 grid + 1% E + CCCS/VCVS, sparse path
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N rank processes itself
 (fresh children, before this process touches the GPU); under torchrun (WORLD_SIZE set) it
-is a rank.  cfg4 is the path that shards (weak scaling: 128 members per GPU); cfg2 / cfg3 /
-cfg5 are single-GPU problems and run as independent replicas when asked for with N > 1.
+is a rank.  ONE workload at every N (round 5): each rank solves its own independent cfg3
+circuits (north_star: "partition independent netlists ... across the 8 GPUs"), the solution of
+every finished circuit is all-gathered over RCCL inside the timed region (8 MB per circuit and
+rank, overlapped with the next solve: nodal_amd.batch.ShardedCircuits), `value` = circuits all
+ranks solved / the slowest rank's time -- weak scaling in the number of circuits.  At N = 1
+there is no process group: the line is BENCH's.  cfg4, the value sweep that shards as one
+block system per rank, is measured in `also` at every N.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel of the workload,
 timed with HIP events on the library's stream, plus the end-to-end figure of SURVEY.md
@@ -133,7 +138,7 @@ class SingleCircuits:
     """cfg2 / cfg3 / cfg5: `per_step` independent circuits per step, one after the other on
     one handle; every circuit runs symbolic + numeric + solve."""
 
-    def __init__(self, name, rank, per_step, device):
+    def __init__(self, name, rank, per_step, device, dist=None, force_collective=False):
         import numpy as np
         from nodal_amd import _ffi
         from nodal_amd import generators as gen
@@ -148,12 +153,16 @@ class SingleCircuits:
         else:
             self.table = gen.cfg5_table(1000)
             self.desc = "grid(1000) + 1% E + CCCS/VCVS (non-symmetric MNA), sparse path"
-        self.h = _ffi.Handle(device)
-        self.h.set_option(_ffi.OPT_EXTRA_STREAMS, 1)  # one handle, one call at a time: it may use streams of its own
-        t0 = time.perf_counter()
-        self.h.upload(self.table)
-        self.h.synchronize()
-        self.h2d_first_ms = (time.perf_counter() - t0) * 1e3  # (device buffers allocated and zero-filled here)
+        # N > 1 (or --force-collective): the rank's circuits through nodal_amd.batch.ShardedCircuits, which shares
+        # every finished circuit's x with all ranks (all_gather over RCCL, overlapped with the next solve); at
+        # N = 1 there is no group and ShardedCircuits.solve_next is the bare nodal_run below
+        from nodal_amd.batch import ShardedCircuits
+        self.sc = ShardedCircuits(self.table, dist, device, force_collective=force_collective, dense=self.dense)
+        self.h = self.sc.h
+        if self.sc.collective:
+            self.desc += (f"; every circuit's x all_gathered over {'RCCL' if self.sc.backend == 'nccl' else self.sc.backend}"
+                          f" ({self.table.n * 8 / 1e6:.1f} MB per rank and circuit, overlapped with the next solve)")
+        self.h2d_first_ms = self.sc.upload_first_ms  # (device buffers allocated and zero-filled there)
         t0 = time.perf_counter()
         self.h.upload(self.table)
         self.h.synchronize()
@@ -167,7 +176,7 @@ class SingleCircuits:
     def step(self):
         h = self.h
         for _ in range(self.per_step):
-            info = h.run(self.dense, member=0, reuse_symbolic=self.reuse)
+            info = self.sc.solve_next(reuse_symbolic=self.reuse)
             if info != 0:
                 raise RuntimeError(f"solver reported info={info}")
             ms, launches, alg = h.kernel_stats()
@@ -176,26 +185,39 @@ class SingleCircuits:
             self.kern_alg = alg
             self.phase += h.timings()
             self.circuits_done += 1
+        self.sc.drain()  # (the last gathers of the step: inside the timed region)
+
+    @property
+    def gather_ms(self):
+        return self.sc.gather_ms
 
     def reset_stats(self):
         self.phase[:] = 0
         self.kern_ms = self.kern_n = 0
         self.circuits_done = 0
+        self.sc.gather_ms = 0.0
 
     def finish(self):
         import numpy as np
         h = self.h
+        gathered_ok = None
+        if self.sc.collective:  # every rank must hold every rank's last solution (identical circuits: identical x)
+            g = self.sc.latest()
+            gathered_ok = bool(g.shape[0] == self.sc.world and np.isfinite(g).all() and
+                               all(np.array_equal(g[r], g[self.sc.rank]) for r in range(g.shape[0])))
         t0 = time.perf_counter()
         x = h.download_x()
         d2h_ms = (time.perf_counter() - t0) * 1e3
+        if gathered_ok:
+            gathered_ok = bool(np.array_equal(self.sc.latest()[self.sc.rank], x))
         iterations, levels, _ = h.solve_info()
         out = dict(resid=h.residual(), x0=float(x[0]), n=h.n, nnz=h.nnz, iterations=iterations,
                    amg_levels=levels, d2h_ms=d2h_ms, h2d_ms=self.h2d_ms, h2d_first_ms=self.h2d_first_ms,
                    h2d_bytes=int(sum(np.asarray(getattr(self.table, f)).nbytes for f in
                                      (("type", "value", "a", "b") if self.table.B == 0 else
                                       ("type", "value", "a", "b", "c", "d", "drv", "k")))),
-                   d2h_bytes=int(x.nbytes))
-        h.close()
+                   d2h_bytes=int(x.nbytes), gathered_ok=gathered_ok)
+        self.sc.close()
         return out
 
 
@@ -402,7 +424,7 @@ def resistance_sweep_times(device, npairs=192):
 def make_workload(name, rank, world, device, dist, per_step, force_collective=False):
     if name == "cfg4":
         return BatchShard(rank, world, per_step, device, dist, force_collective)
-    return SingleCircuits(name, rank, per_step, device)
+    return SingleCircuits(name, rank, per_step, device, dist, force_collective)
 
 
 def time_workload(name, rank, world, device, dist, steps, warmup, per_step, force_collective=False, reuse=False):
@@ -591,8 +613,8 @@ def summary(st, world, with_cpu):
         out["pcie_inclusive"] = {"circuits_per_sec": world * 1e3 / per, "ms_per_circuit": per,
                                  "h2d_GB_per_s": st["h2d_bytes"] / st["h2d_ms"] / 1e6 if st["h2d_ms"] > 0 else None,
                                  "h2d_first_ms": st.get("h2d_first_ms")}
-    if st["name"] == "cfg4":
-        out["gather_ms_per_step"] = st["gather_ms"]
+    if st.get("gathered_ok") is not None:
+        out["gather_ms_per_step"] = st["gather_ms"]  # cfg4: the gather; cfg3: what the overlap left the host waiting for
         out["gathered_ok"] = st["gathered_ok"]
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(st["name"], st["table"])
@@ -701,7 +723,9 @@ def main():
             dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local))
         dist = dist_mod
 
-    name = args.workload or ("cfg3" if world == 1 and not args.force_collective else "cfg4")
+    # ONE headline workload at every N: config 3 (BASELINE.json's metric is "circuits/sec ... N-node resistor grid,
+    # 1/2/4/8" -- one workload); --force-collective keeps config 4 as its default (the block gather on one GPU)
+    name = args.workload or ("cfg4" if args.force_collective else "cfg3")
     per_step = args.per_step or CIRCUITS_PER_STEP[name]
     st = time_workload(name, rank, world, local, dist, args.steps, args.warmup, per_step, args.force_collective)
     head = summary(st, world, with_cpu=(rank == 0 and world == 1 and not args.no_cpu))
@@ -718,7 +742,11 @@ def main():
         "ms_per_step": st["elapsed"] / args.steps * 1e3,
         "ms_per_solve": head["ms_per_solve"],
         "higher_is_better": True,
+        # what is scaled: the number of independent circuits (per-GPU work fixed: `circuits_per_gpu_per_step` each)
         "scaling": "weak",
+        "scaling_what": ("single GPU: nothing is sharded" if world == 1 and dist is None else
+                         ("the members of a value sweep: 128 per GPU as one block system" if name == "cfg4" else
+                          "the number of independent circuits: every rank solves its own, x of each all_gathered")),
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -726,7 +754,8 @@ def main():
                    "n": st["n"], "nnz": st["nnz"],
                    "parallelism": ("batch members sharded over ranks, all_gather of x"
                                    if name == "cfg4" and (world > 1 or args.force_collective)
-                                   else f"independent circuits x{world}")},
+                                   else (f"independent circuits x{world}, every x all_gathered" if dist is not None
+                                         else "one GPU"))},
     }
     for key in ("phase_ms", "h2d_ms", "d2h_ms", "h2d_bytes", "d2h_bytes", "scaled_residual", "solver",
                 "roofline", "assembly", "pcie_inclusive", "h2d_note", "cpu_baseline", "speedup_vs_cpu_baseline",
@@ -752,6 +781,13 @@ def main():
                                     for c in conc]
     if rank == 0 and world == 1 and name == "cfg3" and not args.no_also:
         out["print_1e6_s"] = print_solution_seconds(local)
+    if world > 1 and name != "cfg4" and not args.no_also:
+        # config 4 -- the value sweep that shards as one block system per rank, 128 members per GPU, gathered over
+        # RCCL -- measured at every N beside the headline (every rank takes part; rank 0 reports)
+        s4 = time_workload("cfg4", rank, world, local, dist, 6, 1, 128, False)
+        r4 = summary(s4, world, with_cpu=False)
+        out["also"] = {"cfg4": {k: r4[k] for k in ("workload", "circuits_per_sec", "ms_per_solve", "phase_ms", "solver",
+                                                    "scaled_residual", "gather_ms_per_step", "gathered_ok") if k in r4}}
     if rank == 0 and world == 1 and not args.no_also and not args.force_collective:
         also = {}
         for other in ("cfg4", "cfg5", "cfg2"):

@@ -170,6 +170,11 @@ int nodal_run_batch(nodal_handle h, int32_t first, int32_t count, int32_t reuse_
 /* copy the count x n results of the last nodal_run_batch into DEVICE memory of the handle's
  * GPU (e.g. the send buffer of a collective); capacity_bytes is the size of that buffer */
 int nodal_batch_x_device(nodal_handle h, void *device_dst, int64_t capacity_bytes);
+/* the same for the n unknowns of the last single-circuit solve (nodal_solve_dense / nodal_solve_sparse /
+ * nodal_run): x of an independent circuit into the send buffer of the all_gather that shares the ranks'
+ * solutions (nodal_amd/batch.py ShardedCircuits; the D2D counterpart of nodal_download_x, which replaces the
+ * host array the reference's Circuit.solve returns, reference nodal/nodal.py:336).  Returns when the copy is done. */
+int nodal_x_device(nodal_handle h, void *device_dst, int64_t capacity_bytes);
 
 /* ---- timing of the last call, measured with HIP events on the handle's
  *      stream: milliseconds spent in [symbolic, numeric, factor/solve] ----- */

@@ -49,6 +49,7 @@ SIGNATURES = {
     "nodal_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _i32p]),
     "nodal_run_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p, _i32p]),
     "nodal_batch_x_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "nodal_x_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "nodal_last_timings": (C.c_int, [C.c_void_p, _f64p]),
     "nodal_last_kernel_stats": (C.c_int, [C.c_void_p, _f64p, _i64p, _f64p]),
     "nodal_last_solve_info": (C.c_int, [C.c_void_p, _i32p, _i32p, _f64p]),
@@ -292,6 +293,10 @@ class Handle:
     def batch_x_to_device(self, data_ptr, capacity_bytes):
         """Copy the last run_batch's results into device memory (a torch tensor's data_ptr())."""
         self._check(self.lib.nodal_batch_x_device(self._h, C.c_void_p(data_ptr), capacity_bytes))
+
+    def x_to_device(self, data_ptr, capacity_bytes):
+        """Copy the last single-circuit solution into device memory (a torch tensor's data_ptr())."""
+        self._check(self.lib.nodal_x_device(self._h, C.c_void_p(data_ptr), capacity_bytes))
 
     def timings(self):
         ms = (C.c_double * 3)()

@@ -201,10 +201,13 @@ class ShardedBatch:
         self.dev = torch.device("cuda", dev_index) if needs_gpu else torch.device("cpu")
         self._own_session = on_gpu and session is None
         self.session = (session if session is not None else BatchSolver(table, dev_index)) if on_gpu else None
-        # short shards are padded with NaN rows (written once: a step only rewrites the members)
-        self.block = torch.full((self.width, table.n), float("nan"), dtype=torch.float64, device=self.dev)
+        # short shards are padded with NaN rows (written once: a step only rewrites the members); one more row
+        # travels with the block: its first word says whether this rank's shard raised (step)
+        self.rows = self.width + 1
+        self.block = torch.full((self.rows, max(table.n, 1)), float("nan"), dtype=torch.float64, device=self.dev)
+        self.block[self.width, 0] = 0.0
         collective = grouped and (self.world > 1 or force_collective)
-        self.gathered = (torch.empty((self.world * self.width, table.n), dtype=torch.float64, device=self.dev)
+        self.gathered = (torch.empty((self.world * self.rows, max(table.n, 1)), dtype=torch.float64, device=self.dev)
                          if collective else None)
         self._sync_torch()
         self.values = None
@@ -236,22 +239,45 @@ class ShardedBatch:
         if self.session is not None and values.shape[0]:
             self.session.upload_values(values)
 
+    def _solve_shard(self, reuse_symbolic):
+        import torch
+        if self.session is not None and self.sparse:
+            self.session.run(sparse=True, reuse_symbolic=reuse_symbolic, download=False)
+            self._sync_torch()
+            self.session.copy_to_device(self.block)  # returns once the copy has finished
+        elif self.session is not None:  # dense members: one factorisation each, this rank's shard only
+            mine = self.session.run(sparse=False)
+            self._sync_torch()
+            self.block[: self.hi - self.lo] = torch.from_numpy(np.ascontiguousarray(mine)).to(self.dev)
+        else:
+            mine = self.solver(self.table, self.values, self.sparse)
+            self.block[: self.hi - self.lo] = torch.from_numpy(np.ascontiguousarray(mine)).to(self.dev)
+
     def step(self, reuse_symbolic=False):
         import time
         import torch
+        # A member that raises on ITS rank (a singular dense member: LinAlgError; a zero resistance: ValueError; a
+        # stamp collision: AssertionError -- what Circuit(netlist) raises for it) must not leave the other ranks
+        # waiting inside the collective: the rank keeps the exception, fills its block with NaNs, goes through the
+        # gather like everybody else, and every rank raises afterwards (the owner its own exception, the others
+        # the same class with the owner's rank in the message).
+        failure = None
         if self.hi > self.lo:
-            if self.session is not None and self.sparse:
-                self.session.run(sparse=True, reuse_symbolic=reuse_symbolic, download=False)
-                self._sync_torch()
-                self.session.copy_to_device(self.block)  # returns once the copy has finished
-            elif self.session is not None:  # dense members: one factorisation each, this rank's shard only
-                mine = self.session.run(sparse=False)
-                self._sync_torch()
-                self.block[: self.hi - self.lo] = torch.from_numpy(np.ascontiguousarray(mine)).to(self.dev)
+            if self.gathered is None:
+                self._solve_shard(reuse_symbolic)
             else:
-                mine = self.solver(self.table, self.values, self.sparse)
-                self.block[: self.hi - self.lo] = torch.from_numpy(np.ascontiguousarray(mine)).to(self.dev)
+                try:
+                    self._solve_shard(reuse_symbolic)
+                except (np.linalg.LinAlgError, ValueError, AssertionError) as e:
+                    failure = e
+                    self._sync_torch()
+                    self.block[: self.hi - self.lo] = float("nan")
         if self.gathered is not None:
+            code = 0 if failure is None else next(i for i, c in enumerate(self._FAILURES)
+                                                  if c is not None and isinstance(failure, c))
+            if code or self._flagged:
+                self.block[self.width, 0] = float(code)
+                self._flagged = bool(code)
             t0 = time.perf_counter()
             if self.backend == "nccl" or self.dev.type == "cpu":
                 self.dist.all_gather_into_tensor(self.gathered, self.block)
@@ -261,10 +287,24 @@ class ShardedBatch:
                 self.gathered.copy_(g)
             self._sync_torch()
             self.gather_ms += (time.perf_counter() - t0) * 1e3
+            self._raise_together(failure)
+
+    _FAILURES = (None, np.linalg.LinAlgError, ValueError, AssertionError)
+    _flagged = False
+
+    def _raise_together(self, failure):
+        """Every rank reads the status words that travelled with the blocks and all raise alike."""
+        codes = self.gathered[self.width::self.rows, 0].cpu().tolist()
+        if failure is not None:
+            raise failure
+        for r, c in enumerate(codes):
+            if c:
+                cls = self._FAILURES[int(c)]
+                raise cls(f"a member of rank {r}'s shard failed there with {cls.__name__}")
 
     def own_block(self):
         """[hi - lo, n] results of this rank's members (host copy)."""
-        return self.block[: self.hi - self.lo].cpu().numpy()
+        return self.block[: self.hi - self.lo, : self.table.n].cpu().numpy()
 
     def result(self):
         """[total, n]: every member, on every rank (after a step with the gather)."""
@@ -274,8 +314,118 @@ class ShardedBatch:
         out = np.empty((self.total, self.table.n))
         for r in range(self.world):
             rlo, rhi = shard_range(self.total, r, self.world)
-            out[rlo:rhi] = flat[r * self.width: r * self.width + (rhi - rlo)]
+            out[rlo:rhi] = flat[r * self.rows: r * self.rows + (rhi - rlo), : self.table.n]
         return out
+
+
+class ShardedCircuits:
+    """Independent circuits over the ranks of one node (north_star: "partition independent netlists ... across
+    the 8 GPUs"): every rank solves ITS OWN circuits, one after the other on its GPU -- symbolic + numeric assembly
+    + solve, the equivalent of the reference's `Circuit(netlist, sparse)` + `.solve()` per circuit (reference
+    nodal/nodal.py:306-336) -- and the solution of each finished circuit is shared with every rank by
+    `all_gather_into_tensor` (RCCL over xGMI with backend "nccl": n x 8 bytes per rank and circuit, straight from
+    device memory, no reduction).  The gather of circuit i runs on torch's stream WHILE the library's stream solves
+    circuit i + 1: x is copied device-to-device into one of two send buffers (`nodal_x_device`), the collective is
+    started asynchronously, and a slot is only reused after its collective has finished.
+
+    `bench.py --gpus N` times this for config 3 at every N (the N = 1 line has no process group: no copy, no
+    gather -- the plain sequence of `nodal_run` calls).  `solver(table) -> x` replaces the HIP path in the CPU
+    tests (gloo); with a GPU handle and a gloo group (the one-GPU rehearsal) x travels through host memory.
+    All ranks' tables must have the same number of unknowns."""
+
+    def __init__(self, table, dist=None, device=None, solver=None, force_collective=False, dense=False):
+        import torch
+        self.table, self.dist, self.solver, self.dense = table, dist, solver, dense
+        grouped = dist is not None and dist.is_initialized()
+        self.rank = dist.get_rank() if grouped else 0
+        self.world = dist.get_world_size() if grouped else 1
+        self.backend = dist.get_backend() if grouped else None
+        on_gpu = solver is None
+        needs_gpu = on_gpu or self.backend == "nccl"
+        dev_index = device if device is not None else (local_device_index(self.rank) if needs_gpu else 0)
+        self.h = None
+        self.upload_first_ms = None
+        if on_gpu:
+            from . import _ffi
+            self.h = _ffi.Handle(dev_index)
+            self.h.set_option(_ffi.OPT_EXTRA_STREAMS, 1)  # one handle per rank, one call at a time
+            import time
+            t0 = time.perf_counter()
+            self.h.upload(table)
+            self.h.synchronize()
+            self.upload_first_ms = (time.perf_counter() - t0) * 1e3
+        self.collective = grouped and (self.world > 1 or force_collective)
+        # the gather runs where the group lives: device memory for RCCL, host memory for gloo
+        self.dev = torch.device("cuda", dev_index) if (self.backend == "nccl") else torch.device("cpu")
+        n = table.n
+        self.send = self.recv = None
+        if self.collective:
+            self.send = [torch.empty(n, dtype=torch.float64, device=self.dev) for _ in range(2)]
+            self.recv = [torch.empty(self.world * n, dtype=torch.float64, device=self.dev) for _ in range(2)]
+            if self.dev.type == "cuda":
+                torch.cuda.current_stream(self.dev).synchronize()
+        self.work = [None, None]
+        self.count = 0          # circuits this rank has solved
+        self.gather_ms = 0.0    # host time spent waiting for collectives (what the overlap did not hide)
+        self.last_x = None
+
+    def close(self):
+        self.drain()
+        if self.h is not None:
+            self.h.close()
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _finish(self, slot):
+        import time
+        w = self.work[slot]
+        if w is not None:
+            t0 = time.perf_counter()
+            w.wait()
+            if self.dev.type == "cuda":
+                import torch
+                torch.cuda.current_stream(self.dev).synchronize()
+            self.gather_ms += (time.perf_counter() - t0) * 1e3
+            self.work[slot] = None
+
+    def solve_next(self, reuse_symbolic=False):
+        """One circuit on this rank; its x goes into the gather (when there is a group).  Returns the solver's info."""
+        import torch
+        info = 0
+        if self.h is not None:
+            info = self.h.run(self.dense, member=0, reuse_symbolic=reuse_symbolic)
+        else:
+            self.last_x = np.ascontiguousarray(self.solver(self.table), dtype=np.float64)
+        if self.collective:
+            slot = self.count & 1
+            self._finish(slot)  # (the collective that used this slot two circuits ago: long finished)
+            if self.h is not None and self.dev.type == "cuda":
+                self.h.x_to_device(self.send[slot].data_ptr(), self.send[slot].numel() * 8)  # returns when copied
+            elif self.h is not None:  # rehearsal: a GPU solve gathered over gloo, through host memory
+                self.send[slot].copy_(torch.from_numpy(self.h.download_x()))
+            else:
+                self.send[slot].copy_(torch.from_numpy(self.last_x).to(self.dev))
+            self.work[slot] = self.dist.all_gather_into_tensor(self.recv[slot], self.send[slot], async_op=True)
+        self.count += 1
+        return info
+
+    def drain(self):
+        """Wait for the collectives still in flight (the end of a timed region, before reading `latest`)."""
+        for slot in (0, 1):
+            self._finish(slot)
+
+    def latest(self):
+        """[world, n] host array: the last circuit's solution of every rank (own solution without a group)."""
+        self.drain()
+        if not self.collective:
+            x = self.h.download_x() if self.h is not None else self.last_x
+            return np.asarray(x, dtype=np.float64)[None, :]
+        return self.recv[(self.count - 1) & 1].cpu().numpy().reshape(self.world, -1)
 
 
 def solve_batch_distributed(table, values, sparse=True, device=None, solver=None, dist=None,

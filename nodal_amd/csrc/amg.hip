@@ -993,7 +993,7 @@ int matching_pass(nodal_ctx *h, const Csr &A, double match_theta, int32_t *agg, 
     NODAL_HIP_TRY(h, hipGetLastError());
     uint32_t total = 0;
     NODAL_HIP_TRY(h, hipMemcpyAsync(&total, lead + n, 4, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    NODAL_WAIT_STREAM(h, st);
     *nagg = total;
     return NODAL_OK;
 }
@@ -1033,7 +1033,7 @@ int build_blocks(nodal_ctx *h, Level *L, double *flag) {
     NODAL_TRY(scan_exclusive_u32(h, boff, boff, nc + 1, total_dev, h->work.as<char>() + 256));
     uint32_t total = 0;
     NODAL_HIP_TRY(h, hipMemcpyAsync(&total, total_dev, 4, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    NODAL_WAIT_STREAM(h, st);
     NODAL_HIP_TRY(h, L->binv.reserve((size_t)total * 8 + 64));
     block_build_reg<16, 0><<<grid_for(nc * 16), TB, 0, st>>>(L->A, nc, L->agg.as<int32_t>(),
                                                             L->memptr.as<int32_t>(), L->mem.as<int32_t>(), boff,
@@ -1052,7 +1052,7 @@ int build_blocks(nodal_ctx *h, Level *L, double *flag) {
         block_stats<<<grid_for(nc), TB, 0, st>>>(nc, L->memptr.as<int32_t>(), st3);
         uint32_t hs3[3];
         NODAL_HIP_TRY(h, hipMemcpyAsync(hs3, st3, 12, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_WAIT_STREAM(h, st);
         fprintf(stderr, "[amg] blocks: %lld aggregates, %u larger than 16, %u larger than 32, largest %u, %u doubles\n",
                 (long long)nc, hs3[0], hs3[1], hs3[2], total);
     }
@@ -1100,7 +1100,7 @@ int build_tail(nodal_ctx *h, Hierarchy *H) {
                     H->levels[t]->A.n, H->levels[t]->A.indptr, dev + t);
         NODAL_HIP_TRY(h, hipGetLastError());
         NODAL_HIP_TRY(h, hipMemcpyAsync(longest, dev, MAX_LEVELS * 4, hipMemcpyDeviceToHost, h->stream));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+        NODAL_WAIT_STREAM(h, h->stream);
     }
     for (int t = 1; t < L; ++t) {  // level 0 and the coarsest alone never form a tail
         if (L - t + 1 > TAIL_MAX_LEVELS) continue;
@@ -1235,7 +1235,7 @@ int amg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr,
         NODAL_HIP_TRY(h, hipGetLastError());
         uint32_t dominated = 0;
         NODAL_HIP_TRY(h, hipMemcpyAsync(&dominated, cnt, 4, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_WAIT_STREAM(h, st);
         // (a count, not a share: every such node is a near-null mode the Krylov iteration has to
         // find by itself -- 100 near-shorts in a 90 000-node grid cost point Jacobi 880 iterations)
         const int64_t bar = n0 / 100 < 32 ? (n0 / 100 > 0 ? n0 / 100 : 1) : 32;
@@ -1517,7 +1517,7 @@ int amg_has_floating_component(nodal_ctx *h, const uint8_t *grounded0, int32_t *
         NODAL_TRY(csr_floating_check_small(h, nl, last->A.indptr, last->A.indices, cur,
                                            reinterpret_cast<uint32_t *>(flags + 1)));
         NODAL_HIP_TRY(h, hipMemcpyAsync(floating, flags + 1, 4, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_WAIT_STREAM(h, st);
         return NODAL_OK;
     }
     cc_init<<<grid_for(nl), TB, 0, st>>>(nl, label);
@@ -1527,7 +1527,7 @@ int amg_has_floating_component(nodal_ctx *h, const uint8_t *grounded0, int32_t *
         cc_jump<<<grid_for(nl), TB, 0, st>>>(nl, label);
         int32_t changed = 0;
         NODAL_HIP_TRY(h, hipMemcpyAsync(&changed, flags, 4, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_WAIT_STREAM(h, st);
         if (!changed) break;
     }
     NODAL_HIP_TRY(h, hipMemsetAsync(root_ok, 0, (size_t)nl * 4, st));
@@ -1536,7 +1536,7 @@ int amg_has_floating_component(nodal_ctx *h, const uint8_t *grounded0, int32_t *
     cc_verdict<<<grid_for(nl), TB, 0, st>>>(nl, label, root_ok, flags + 1);
     NODAL_HIP_TRY(h, hipGetLastError());
     NODAL_HIP_TRY(h, hipMemcpyAsync(floating, flags + 1, 4, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    NODAL_WAIT_STREAM(h, st);
     return NODAL_OK;
 }
 
@@ -1565,7 +1565,7 @@ int csr_has_floating_component(nodal_ctx *h, const uint8_t *grounded, int32_t *f
         cc_jump<<<grid_for(n), TB, 0, st>>>(n, label);
         int32_t changed = 0;
         NODAL_HIP_TRY(h, hipMemcpyAsync(&changed, flags, 4, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_WAIT_STREAM(h, st);
         if (!changed) break;
     }
     NODAL_HIP_TRY(h, hipMemsetAsync(root_ok, 0, (size_t)n * 4, st));
@@ -1574,6 +1574,6 @@ int csr_has_floating_component(nodal_ctx *h, const uint8_t *grounded, int32_t *f
     cc_verdict<<<grid_for(n), TB, 0, st>>>(n, label, root_ok, flags + 1);
     NODAL_HIP_TRY(h, hipGetLastError());
     NODAL_HIP_TRY(h, hipMemcpyAsync(floating, flags + 1, 4, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    NODAL_WAIT_STREAM(h, st);
     return NODAL_OK;
 }

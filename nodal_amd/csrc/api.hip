@@ -171,7 +171,7 @@ void *nodal_pinned_arena(nodal_ctx *ctx, size_t bytes) {
 int nodal_read_words(nodal_ctx *h, void *dst, const void *dev_src, size_t bytes) {
     void *pin = bytes <= NODAL_PINNED_BYTES ? nodal_pinned(h) : nullptr;
     NODAL_HIP_TRY(h, hipMemcpyAsync(pin ? pin : dst, dev_src, bytes, hipMemcpyDeviceToHost, h->stream));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    NODAL_WAIT_STREAM(h, h->stream);
     if (pin) memcpy(dst, pin, bytes);
     return NODAL_OK;
 }
@@ -271,8 +271,9 @@ void nodal_nan_probe(nodal_ctx *h, const double *dev, int64_t n, const char *tag
     static const bool on = getenv("NODAL_NANCHECK") != nullptr;
     if (!on || !dev || n <= 0) return;
     std::vector<double> host((size_t)n);
-    if (hipStreamSynchronize(h->stream) != hipSuccess ||
-        hipMemcpy(host.data(), dev, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+    if (nodal_wait_stream(h, h->stream, NODAL_SITE) != NODAL_OK ||
+        hipMemcpyAsync(host.data(), dev, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        nodal_wait_stream(h, h->stream, NODAL_SITE) != NODAL_OK) {
         fprintf(stderr, "[nancheck] %s: copy failed\n", tag);
         return;
     }
@@ -291,9 +292,16 @@ extern "C" {
 int nodal_destroy(nodal_handle h) {
     if (!h) return NODAL_OK;
     DeviceGuard g(h);
-    (void)hipStreamSynchronize(h->stream);
-    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
-    if (h->stream3) (void)hipStreamSynchronize(h->stream3);
+    // (bounded like every other wait: a handle whose device work never ends is leaked, not freed under running kernels)
+    bool drained = !h->hung && nodal_wait_stream(h, h->stream, NODAL_SITE) == NODAL_OK;
+    if (drained && h->stream2) drained = nodal_wait_stream(h, h->stream2, NODAL_SITE) == NODAL_OK;
+    if (drained && h->stream3) drained = nodal_wait_stream(h, h->stream3, NODAL_SITE) == NODAL_OK;
+    if (!drained) {
+        fprintf(stderr, "[nodal] nodal_destroy: the handle's streams did not drain (%s): its device memory is leaked\n",
+                h->err.c_str());
+        g_live_handles.fetch_sub(1, std::memory_order_relaxed);
+        return NODAL_E_HIP;
+    }
     nodal_free_buffers(h);
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -332,6 +340,7 @@ int nodal_upload_internal(nodal_ctx *h, int64_t ncomp, const uint8_t *type, cons
     if (ncomp > 0 && (!type || !value || !a || !b || (!plain && (!c || !d || !drv || !k)) || (plain && B != 0)))
         return nodal_fail(h, NODAL_E_INVALID, "null component column");
     DeviceGuard g(h);
+    if (h->hung) return NODAL_E_HIP;  // (a wait timed out earlier: nodal_last_error still says where)
     const int64_t n = (int64_t)K + B;
     h->have_table = h->have_symbolic = h->have_numeric = h->have_x = false;
     ++h->table_epoch;
@@ -343,7 +352,7 @@ int nodal_upload_internal(nodal_ctx *h, int64_t ncomp, const uint8_t *type, cons
     h->batch = 0;
     // (an early return must not leave DMA from the caller's columns in flight: the caller may free them)
     auto fail_synced = [&](int status) {
-        (void)hipStreamSynchronize(h->stream);
+        (void)nodal_wait_stream(h, h->stream, NODAL_SITE);
         return status;
     };
 #define UPLOAD_TRY(expr)                             \
@@ -415,8 +424,9 @@ extern "C" {
 int nodal_upload_values(nodal_handle h, int32_t batch, const double *values) {
     if (!h || !h->have_table || batch < 1 || !values) return NODAL_E_INVALID;
     DeviceGuard g(h);
+    if (h->hung) return NODAL_E_HIP;  // (a wait timed out earlier: nodal_last_error still says where)
     NODAL_TRY(upload(h, h->values_batch, values, (int64_t)batch * h->ncomp));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    NODAL_WAIT_STREAM(h, h->stream);
     if (h->keep_host_table && h->B > 0)
         h->host.values_batch.assign(values, values + (size_t)batch * h->ncomp);
     h->batch = batch;
@@ -427,10 +437,11 @@ int nodal_upload_values(nodal_handle h, int32_t batch, const double *values) {
 int nodal_assemble_symbolic(nodal_handle h) {
     if (!h) return NODAL_E_INVALID;
     DeviceGuard g(h);
+    if (h->hung) return NODAL_E_HIP;  // (a wait timed out earlier: nodal_last_error still says where)
     NODAL_HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
     int s = stamp_symbolic(h);
     NODAL_HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
-    NODAL_HIP_TRY(h, hipEventSynchronize(h->ev[1]));
+    NODAL_WAIT_EVENT(h, h->ev[1], h->stream);
     h->ms[0] = elapsed(h, 0, 1);
     return s;
 }
@@ -438,10 +449,11 @@ int nodal_assemble_symbolic(nodal_handle h) {
 int nodal_assemble_numeric(nodal_handle h, int32_t member, int64_t *bad_component) {
     if (!h) return NODAL_E_INVALID;
     DeviceGuard g(h);
+    if (h->hung) return NODAL_E_HIP;  // (a wait timed out earlier: nodal_last_error still says where)
     NODAL_HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
     int s = stamp_numeric(h, member, bad_component);
     NODAL_HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
-    NODAL_HIP_TRY(h, hipEventSynchronize(h->ev[1]));
+    NODAL_WAIT_EVENT(h, h->ev[1], h->stream);
     h->ms[1] = elapsed(h, 0, 1);
     return s;
 }
@@ -458,6 +470,7 @@ int nodal_export_csr(nodal_handle h, int32_t *indptr, int32_t *indices, double *
                      double *rhs) {
     if (!h || !h->have_symbolic) return NODAL_E_INVALID;
     DeviceGuard g(h);
+    if (h->hung) return NODAL_E_HIP;  // (a wait timed out earlier: nodal_last_error still says where)
     hipStream_t st = h->stream;
     if (indptr)
         NODAL_HIP_TRY(h, hipMemcpyAsync(indptr, h->indptr.p, (size_t)(h->n + 1) * 4,
@@ -474,13 +487,14 @@ int nodal_export_csr(nodal_handle h, int32_t *indptr, int32_t *indices, double *
             NODAL_HIP_TRY(h, hipMemcpyAsync(rhs, h->rhs.p, (size_t)h->n * 8,
                                             hipMemcpyDeviceToHost, st));
     }
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    NODAL_WAIT_STREAM(h, st);
     return NODAL_OK;
 }
 
 int nodal_export_dense(nodal_handle h, double *G, double *rhs) {
     if (!h || !h->have_numeric) return NODAL_E_INVALID;
     DeviceGuard g(h);
+    if (h->hung) return NODAL_E_HIP;  // (a wait timed out earlier: nodal_last_error still says where)
     const int64_t n = h->n;
     if (G && n) {
         NODAL_HIP_TRY(h, h->dense.reserve((size_t)dense_lda(n) * (size_t)(n + 1) * 8 + 64));
@@ -491,17 +505,18 @@ int nodal_export_dense(nodal_handle h, double *G, double *rhs) {
     if (rhs && n)
         NODAL_HIP_TRY(h, hipMemcpyAsync(rhs, h->rhs.p, (size_t)n * 8, hipMemcpyDeviceToHost,
                                         h->stream));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    NODAL_WAIT_STREAM(h, h->stream);
     return NODAL_OK;
 }
 
 int nodal_download_x(nodal_handle h, double *x) {
     if (!h || !h->have_x || !x) return NODAL_E_INVALID;
     DeviceGuard g(h);
+    if (h->hung) return NODAL_E_HIP;  // (a wait timed out earlier: nodal_last_error still says where)
     if (h->n)
         NODAL_HIP_TRY(h, hipMemcpyAsync(x, h->x.p, (size_t)h->n * 8, hipMemcpyDeviceToHost,
                                         h->stream));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    NODAL_WAIT_STREAM(h, h->stream);
     return NODAL_OK;
 }
 
@@ -509,6 +524,7 @@ int nodal_solve_dense(nodal_handle h, double *x, int32_t *info) {
     if (!h || !info) return NODAL_E_INVALID;
     if (!h->have_numeric) return nodal_fail(h, NODAL_E_INVALID, "assemble_numeric not called");
     DeviceGuard g(h);
+    if (h->hung) return NODAL_E_HIP;  // (a wait timed out earlier: nodal_last_error still says where)
     nodal_poison_scratch(h);
     *info = 0;
     h->have_x = false;
@@ -543,7 +559,7 @@ int nodal_solve_dense(nodal_handle h, double *x, int32_t *info) {
         }
     }
     NODAL_HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
-    NODAL_HIP_TRY(h, hipEventSynchronize(h->ev[1]));
+    NODAL_WAIT_EVENT(h, h->ev[1], h->stream);
     h->ms[2] = elapsed(h, 0, 1);
     if (*info > 0) return nodal_fail(h, NODAL_E_SINGULAR, "singular matrix: a zero pivot or a floating sub-network");
     h->have_x = true;
@@ -555,6 +571,7 @@ int nodal_solve_sparse(nodal_handle h, int32_t method, double *x, int32_t *info,
                        double *resid) {
     if (!h || !info) return NODAL_E_INVALID;
     DeviceGuard g(h);
+    if (h->hung) return NODAL_E_HIP;  // (a wait timed out earlier: nodal_last_error still says where)
     nodal_poison_scratch(h);
     int32_t it = 0;
     double rs = 0;
@@ -565,7 +582,7 @@ int nodal_solve_sparse(nodal_handle h, int32_t method, double *x, int32_t *info,
     h->last_iterations = it;
     h->last_relres = rs;
     NODAL_HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
-    NODAL_HIP_TRY(h, hipEventSynchronize(h->ev[1]));
+    NODAL_WAIT_EVENT(h, h->ev[1], h->stream);
     h->ms[2] = elapsed(h, 0, 1);
     if (iters) *iters = it;
     if (resid) *resid = rs;
@@ -580,6 +597,7 @@ int nodal_solve_pairs(nodal_handle h, int32_t dense, int32_t npairs, const int32
         return NODAL_E_INVALID;
     if (!h->have_numeric) return nodal_fail(h, NODAL_E_INVALID, "assemble_numeric not called");
     DeviceGuard g(h);
+    if (h->hung) return NODAL_E_HIP;  // (a wait timed out earlier: nodal_last_error still says where)
     nodal_poison_scratch(h);
     *info = 0;
     const int64_t n = h->n;
@@ -633,13 +651,14 @@ int nodal_solve_pairs(nodal_handle h, int32_t dense, int32_t npairs, const int32
     }
     NODAL_HIP_TRY(h, hipMemcpyAsync(resistance, res, (size_t)npairs * 8, hipMemcpyDeviceToHost,
                                     h->stream));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    NODAL_WAIT_STREAM(h, h->stream);
     return NODAL_OK;
 }
 
 int nodal_residual(nodal_handle h, double *scaled_residual) {
     if (!h || !scaled_residual) return NODAL_E_INVALID;
     DeviceGuard g(h);
+    if (h->hung) return NODAL_E_HIP;  // (a wait timed out earlier: nodal_last_error still says where)
     if (h->last_batch_block && h->blocksys) {  // whole block-diagonal system of the last nodal_run_batch
         const int s = sparse_residual(h->blocksys, scaled_residual);
         if (s != NODAL_OK) h->err = h->blocksys->err;
@@ -652,6 +671,7 @@ int nodal_run(nodal_handle h, int32_t dense, int32_t member, int32_t reuse_symbo
               int32_t *info) {
     if (!h || !info) return NODAL_E_INVALID;
     DeviceGuard g(h);
+    if (h->hung) return NODAL_E_HIP;  // (a wait timed out earlier: nodal_last_error still says where)
     // symbolic + numeric back to back: the symbolic phase's timer is read AFTER the numeric phase has waited for its
     // status words anyway (waiting for it in between left the GPU idle for ~30 us per circuit)
     hipEvent_t ev_s0 = h->ev[2], ev_s1 = h->ev[3];  // (free until the solve records them around its dominant kernel)
@@ -664,7 +684,7 @@ int nodal_run(nodal_handle h, int32_t dense, int32_t member, int32_t reuse_symbo
     NODAL_HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
     const int sn = stamp_numeric(h, member, nullptr);
     NODAL_HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
-    NODAL_HIP_TRY(h, hipEventSynchronize(h->ev[1]));
+    NODAL_WAIT_EVENT(h, h->ev[1], h->stream);
     h->ms[1] = elapsed(h, 0, 1);
     h->ms[0] = 0.0;  // (kept: nothing ran)
     if (do_symbolic) {
@@ -714,6 +734,7 @@ int nodal_debug_gemm(nodal_handle h, int32_t M, int32_t N, int32_t K, const doub
                      const double *B, double *C) {
     if (!h || M < 1 || N < 1 || K < 1 || !A || !B || !C) return NODAL_E_INVALID;
     DeviceGuard g(h);
+    if (h->hung) return NODAL_E_HIP;  // (a wait timed out earlier: nodal_last_error still says where)
     const size_t sa = (size_t)M * K * 8, sb = (size_t)K * N * 8, sc = (size_t)M * N * 8;
     NODAL_HIP_TRY(h, h->work.reserve(sa + sb + sc + 768));
     char *w = h->work.as<char>();
@@ -725,7 +746,7 @@ int nodal_debug_gemm(nodal_handle h, int32_t M, int32_t N, int32_t K, const doub
     NODAL_HIP_TRY(h, hipMemcpyAsync(dC, C, sc, hipMemcpyHostToDevice, h->stream));
     NODAL_TRY(gemm_sub_f64(h, h->stream, dC, M, dA, M, dB, K, M, N, K));
     NODAL_HIP_TRY(h, hipMemcpyAsync(C, dC, sc, hipMemcpyDeviceToHost, h->stream));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    NODAL_WAIT_STREAM(h, h->stream);
     return NODAL_OK;
 }
 
@@ -741,7 +762,8 @@ int nodal_last_solve_info(nodal_handle h, int32_t *iterations, int32_t *amg_leve
 int nodal_synchronize(nodal_handle h) {
     if (!h) return NODAL_E_INVALID;
     DeviceGuard g(h);
-    NODAL_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->hung) return NODAL_E_HIP;  // (a wait timed out earlier: nodal_last_error still says where)
+    NODAL_WAIT_STREAM(h, h->stream);
     return NODAL_OK;
 }
 

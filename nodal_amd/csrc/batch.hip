@@ -330,6 +330,7 @@ int nodal_run_batch(nodal_handle h, int32_t first, int32_t count, int32_t reuse_
     (void)hipSetDevice(h->device);
     struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
     FillStreamScope fill(h->stream);
+    if (h->hung) return NODAL_E_HIP;
     nodal_poison_scratch(h);
     hipStream_t st = h->stream;
     const int64_t n = h->n, ncomp = h->ncomp;
@@ -365,7 +366,7 @@ int nodal_run_batch(nodal_handle h, int32_t first, int32_t count, int32_t reuse_
         if (source_scaled) {
             source_scales(h, first, count, sc_host);
             NODAL_HIP_TRY(h, hipMemcpyAsync(scale, sc_host.data(), (size_t)count * 8, hipMemcpyHostToDevice, st));
-            NODAL_HIP_TRY(h, hipStreamSynchronize(st));  // (pageable source: gone when this scope is left early)
+            NODAL_WAIT_STREAM(h, st);  // (pageable source: gone when this scope is left early)
         }
         replicate_rows<<<grid_for(total), TB, 0, st>>>(
             ncomp, count, first, h->K, h->B, h->type.as<uint8_t>(), h->values_batch.as<double>(),
@@ -432,7 +433,7 @@ int nodal_run_batch(nodal_handle h, int32_t first, int32_t count, int32_t reuse_
             h->err = c->err;
             return s;
         }
-        NODAL_HIP_TRY(h, hipEventSynchronize(ev[3]));
+        NODAL_WAIT_EVENT(h, ev[3], st);
         h->ms[0] = elapsed(ev[0], ev[1]);
         h->ms[1] = elapsed(ev[1], ev[2]);
         h->ms[2] = elapsed(ev[2], ev[3]);
@@ -441,7 +442,7 @@ int nodal_run_batch(nodal_handle h, int32_t first, int32_t count, int32_t reuse_
     h->batch_count = count;
     if (x_out && n > 0)
         NODAL_HIP_TRY(h, hipMemcpyAsync(x_out, out, (size_t)n * count * 8, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    NODAL_WAIT_STREAM(h, st);
     return NODAL_OK;
 }
 
@@ -455,10 +456,26 @@ int nodal_batch_x_device(nodal_handle h, void *device_dst, int64_t capacity_byte
     (void)hipSetDevice(h->device);
     hipError_t e = bytes ? hipMemcpyAsync(device_dst, h->batch_x.p, bytes, hipMemcpyDeviceToDevice, h->stream)
                          : hipSuccess;
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    const int ws = e == hipSuccess ? nodal_wait_stream(h, h->stream, NODAL_SITE) : NODAL_OK;
     (void)hipSetDevice(prev);
     NODAL_HIP_TRY(h, e);
-    return NODAL_OK;
+    return ws;
+}
+
+int nodal_x_device(nodal_handle h, void *device_dst, int64_t capacity_bytes) {
+    if (!h || !device_dst) return NODAL_E_INVALID;
+    if (h->hung) return NODAL_E_HIP;
+    if (!h->have_x) return nodal_fail(h, NODAL_E_INVALID, "x_device: no solution on the handle");
+    const size_t bytes = (size_t)h->n * 8;
+    if ((size_t)capacity_bytes < bytes) return nodal_fail(h, NODAL_E_INVALID, "x_device: destination too small");
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(h->device);
+    hipError_t e = bytes ? hipMemcpyAsync(device_dst, h->x.p, bytes, hipMemcpyDeviceToDevice, h->stream) : hipSuccess;
+    const int ws = e == hipSuccess ? nodal_wait_stream(h, h->stream, NODAL_SITE) : NODAL_OK;
+    (void)hipSetDevice(prev);
+    NODAL_HIP_TRY(h, e);
+    return ws;
 }
 
 }  // extern "C"

@@ -621,6 +621,9 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
         return e < ncols ? e : ncols;
     };
 
+    StreamJoinGuard join(sp);  // (a failed call below must not leave the bulk / strip streams running unjoined)
+    join.add(sg, ev_done);
+    join.add(s3, ev_strip);
     NODAL_HIP_TRY(h, hipEventRecord(ev_start, sp));  // the matrix was prepared on the main stream
     NODAL_HIP_TRY(h, hipStreamWaitEvent(sg, ev_start, 0));
     NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_start, 0));
@@ -690,6 +693,7 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
     NODAL_HIP_TRY(h, hipEventRecord(ev_done, sg));
     NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_done, 0));
     NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_wrest, 0));
+    join.disarm();
     return NODAL_OK;
 }
 
@@ -739,7 +743,7 @@ int dense_block_elimination(nodal_ctx *h, double *A, int64_t n, int64_t lda, int
         asymmetry<<<1024, 256, 0, st>>>(A, lda, n, o);
         double host[2];
         NODAL_HIP_TRY(h, hipMemcpyAsync(host, o, 16, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_WAIT_STREAM(h, st);
         fprintf(stderr, "[dense] symmetric block elimination, n %lld: max |a_ij - a_ji| = %.3e, max |a_ij| = %.3e\n",
                 (long long)n, host[0], host[1]);
     }

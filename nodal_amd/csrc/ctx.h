@@ -95,6 +95,7 @@ struct nodal_ctx {
     hipEvent_t ev_bi[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t gt_used = 0;              // GemmTimer (dense_common.h): timed launches, their flops
     double gt_flops = 0.0;
+    bool hung = false;               // a bounded wait ran out (wait.hip): nothing more may run on this handle
     bool optimistic_nopivot = false; // dense: block elimination although not passive (caller verifies the answer)
     int gj_scalar = 0;               // NODAL_GJ_SCALAR=1: scalar Gauss-Jordan, 2: rank-4 MFMA steps; default rank-16
     bool dense_blockinv = true;      // passive dense systems: block elimination (NODAL_DENSE_BLOCKINV=0: LU)
@@ -224,11 +225,52 @@ struct nodal_ctx {
         }                                                                        \
     } while (0)
 
+// ---- bounded host waits (wait.hip) ----
+// Every host wait of the library: polls hipStreamQuery / hipEventQuery against NODAL_WAIT_TIMEOUT_S (default 60 s;
+// 0: the runtime's blocking wait).  On a timeout: NODAL_E_HIP, nodal_last_error = the wait site + the last kernel
+// enqueued on that stream, the handle marked hung.  `site` is a string literal ("file:line").
+struct nodal_ctx;
+int nodal_wait_stream(nodal_ctx *h, hipStream_t st, const char *site);
+int nodal_wait_event(nodal_ctx *h, hipEvent_t ev, hipStream_t recorded_on, const char *site);
+unsigned long long nodal_launches_noted();  // launches this thread has sent through the library's launch log
+#define NODAL_STR2(x) #x
+#define NODAL_STR(x) NODAL_STR2(x)
+#define NODAL_SITE __FILE__ ":" NODAL_STR(__LINE__)
+#define NODAL_WAIT_STREAM(h, st) NODAL_TRY(nodal_wait_stream((h), (st), NODAL_SITE))
+#define NODAL_WAIT_EVENT(h, ev, st) NODAL_TRY(nodal_wait_event((h), (ev), (st), NODAL_SITE))
+
 #define NODAL_TRY(expr)                  \
     do {                                 \
         int _s = (expr);                 \
         if (_s != NODAL_OK) return _s;   \
     } while (0)
+
+// A section that spreads work over side streams joins them at its end; this makes the main stream wait for them on
+// every OTHER way out as well (a failed call in the middle), so that no side stream keeps writing a handle's buffers
+// behind the back of whatever the main stream does next.  disarm() on the normal way out, after the section's own join.
+struct StreamJoinGuard {
+    hipStream_t main;
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int count = 0;
+    bool armed = true;
+    explicit StreamJoinGuard(hipStream_t m) : main(m) {}
+    void add(hipStream_t s, hipEvent_t e) {
+        if (s && e && s != main && count < 4) {
+            side[count] = s;
+            ev[count++] = e;
+        }
+    }
+    void disarm() { armed = false; }
+    ~StreamJoinGuard() {
+        if (!armed) return;
+        for (int i = 0; i < count; ++i)
+            if (hipEventRecord(ev[i], side[i]) == hipSuccess) (void)hipStreamWaitEvent(main, ev[i], 0);
+        (void)hipGetLastError();
+    }
+    StreamJoinGuard(const StreamJoinGuard &) = delete;
+    StreamJoinGuard &operator=(const StreamJoinGuard &) = delete;
+};
 
 static inline int nodal_fail(nodal_ctx *h, int code, const char *msg) {
     h->err = msg;

@@ -882,7 +882,7 @@ int factor_gepp(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncols, 
     if (probe) {
         long long host[8];
         NODAL_HIP_TRY(h, hipMemcpyAsync(host, probe, 64, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_WAIT_STREAM(h, st);
         if (host[5] > 0)
             fprintf(stderr, "[gepp] n %lld: %lld panels, cycles per panel: search %lld, publish + barrier %lld, winner %lld, "
                             "elimination %lld, write-back %lld\n", (long long)n, host[5], host[0] / host[5], host[1] / host[5],
@@ -908,6 +908,8 @@ int factor_tournament(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t n
                        reinterpret_cast<double *>(wbase + 2 * idx_bytes + val_bytes)};
     double *lu11 = reinterpret_cast<double *>(wbase + 2 * (idx_bytes + val_bytes));
     bool trail_pending = false;
+    StreamJoinGuard join(st);  // (a failed call below must not leave the trailing-update stream running unjoined)
+    join.add(h->stream2, h->ev_la[1]);
 
     for (int64_t J0 = 0; J0 < n; J0 += W) {
         const int64_t J1 = J0 + W < n ? J0 + W : n;
@@ -960,6 +962,7 @@ int factor_tournament(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t n
         NODAL_TRY(trailing_update(h, A, n, lda, ncols, J0, J1, piv, tm, trail_pending));
     }
     if (trail_pending) NODAL_HIP_TRY(h, hipStreamWaitEvent(st, h->ev_la[1], 0));
+    join.disarm();
     return NODAL_OK;
 }
 
@@ -970,6 +973,8 @@ int factor_nopivot(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncol
     NODAL_HIP_TRY(h, h->work.reserve(NB * NB * 8 + 256));
     double *lu11 = h->work.as<double>();
     bool trail_pending = false;
+    StreamJoinGuard join(st);  // (a failed call below must not leave the trailing-update stream running unjoined)
+    join.add(h->stream2, h->ev_la[1]);
     for (int64_t J0 = 0; J0 < n; J0 += W) {
         const int64_t J1 = J0 + W < n ? J0 + W : n;
         for (int64_t c0 = J0; c0 < J1; c0 += NB) {
@@ -993,6 +998,7 @@ int factor_nopivot(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t ncol
         NODAL_TRY(trailing_update(h, A, n, lda, ncols, J0, J1, nullptr, tm, trail_pending));
     }
     if (trail_pending) NODAL_HIP_TRY(h, hipStreamWaitEvent(st, h->ev_la[1], 0));
+    join.disarm();
     return NODAL_OK;
 }
 

@@ -482,7 +482,7 @@ int lowdeg_solve(nodal_ctx *h, int min_share, bool *done, int32_t *info, int32_t
         }
     }
     if (trace && build) {
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_WAIT_STREAM(h, st);
         fprintf(stderr, "[lowdeg] %lld -> %lld unknowns, %lld -> %lld entries (%.2f ms)\n", (long long)n,
                 (long long)nk, (long long)A.nnz, (long long)nent,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());

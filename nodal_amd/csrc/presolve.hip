@@ -731,7 +731,7 @@ static int presolve_build_reduced(nodal_ctx *h, nodal_ctx *r, const double *valu
     x.cap = cx;
     NODAL_HIP_TRY(h, h->ps_stage.reserve((size_t)cx * sizeof(ExtraRow) + 64));  // (before the wait: a growing buffer is filled)
     if (nhit) NODAL_HIP_TRY(h, hipMemcpyAsync(hits, h->ps_hits.p, (size_t)nhit * 4, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    NODAL_WAIT_STREAM(h, st);
     lap("components compacted, hits on the host");
     if (!rewrite_hits(h, value_host, plan, hits, nhit, x)) return NODAL_OK;  // not expressible: fall back
     const int64_t nx = x.n;
@@ -761,7 +761,7 @@ static int presolve_build_reduced(nodal_ctx *h, nodal_ctx *r, const double *valu
         mix((uint64_t)(uint32_t)e.c << 32 | (uint32_t)e.d);
         mix((uint64_t)(uint32_t)e.k);
     }
-    if (nx) NODAL_HIP_TRY(h, hipStreamSynchronize(st));  // (the arena is free again)
+    if (nx) NODAL_WAIT_STREAM(h, st);  // (the arena is free again)
     const int32_t nkept = (int32_t)plan.kept.size();
     const bool same_topology = r->have_symbolic && r->reduced_key == key && r->ncomp == nkeep + nx && r->K == plan.Kr &&
                                r->B == nkept;
@@ -830,7 +830,7 @@ static int presolve_recover(nodal_ctx *h, const PresolvePlan &plan, const double
                                                     h->indices.as<int32_t>(), h->data.as<double>(),
                                                     h->rhs.as<double>(), x);
     NODAL_HIP_TRY(h, hipGetLastError());
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));  // (the arena is free again)
+    NODAL_WAIT_STREAM(h, st);  // (the arena is free again)
     return NODAL_OK;
 }
 

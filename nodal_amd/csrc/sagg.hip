@@ -161,6 +161,8 @@ struct SHierarchy {
     // P only, not each other: R is built on a stream of the hierarchy's own while the main one computes A P
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_flags = nullptr;
+    bool aux_pending = false;  // work was enqueued on `aux` that the main stream has not been made to wait for yet
+                               // (sagg_setup_csr joins it on EVERY way out: declined, stopped, failed)
     bool aux_tried = false;
     // the "touches ground" flags go up the aggregate maps on that stream too, level by level behind R (they need the
     // aggregates only): flags_levels = how many levels' flags_up have been enqueued there in this setup
@@ -1252,7 +1254,7 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     build_P<<<g, TB, 0, st>>>(A, L->dinv.as<double>(), L->agg.as<int32_t>(), L->pcol.as<int32_t>(),
                              L->pval.as<double>(), L->pvalf.as<float>());
     NODAL_HIP_TRY(h, hipGetLastError());
-    NODAL_HIP_TRY(h, hipEventSynchronize(H->ev_copy));  // (the copies, not the three kernels behind them)
+    NODAL_WAIT_EVENT(h, H->ev_copy, st);  // (the copies, not the three kernels behind them)
     if (trace_mis) {
         fprintf(stderr, "[sagg] level %d: undecided after each MIS round:", l);
         for (int r = 1; r <= MIS_ROUNDS; ++r) fprintf(stderr, " %llu", hcnt[r]);
@@ -1286,7 +1288,7 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     // launch of this section, the scans included, goes where h->stream points
     static const bool fork_allowed = !(getenv("NODAL_SA_FORK") && atoi(getenv("NODAL_SA_FORK")) == 0);
     if (H->aux && !nodal_extra_streams_ok(h) && nodal_calls_in_flight() <= 1) {  // (the option was taken back: so is the stream's hardware queue)
-        (void)hipStreamSynchronize(H->aux);
+        NODAL_WAIT_STREAM(h, H->aux);
         (void)hipStreamDestroy(H->aux);
         H->aux = nullptr;
         H->aux_tried = false;
@@ -1345,6 +1347,7 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     if (forked) {
         NODAL_HIP_TRY(h, hipEventRecord(H->ev_fork, main_st));
         NODAL_HIP_TRY(h, hipStreamWaitEvent(H->aux, H->ev_fork, 0));
+        H->aux_pending = true;
         NODAL_TRY(galerkin_product<false>(h, H, l, nullptr, 1));  // A P first: the long launch of the pair
         h->stream = H->aux;
         st = H->aux;
@@ -1385,6 +1388,8 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
         st = main_st;
     }
     NODAL_TRY(galerkin_product<false>(h, H, l, forked ? H->ev_join : nullptr, forked ? 2 : 0));
+    // (the main stream now waits for R; flags that went up behind R are joined by sagg_setup_csr, through ev_flags)
+    if (forked && H->flags_levels != l + 1) H->aux_pending = false;
     return NODAL_OK;
 }
 
@@ -1512,6 +1517,7 @@ int sagg_refresh(nodal_ctx *h, SHierarchy *H, const int32_t *indptr0, const int3
         if (forked) {
             NODAL_HIP_TRY(h, hipEventRecord(H->ev_fork, st));
             NODAL_HIP_TRY(h, hipStreamWaitEvent(H->aux, H->ev_fork, 0));
+            H->aux_pending = true;
             NODAL_TRY(galerkin_product<true>(h, H, l, nullptr, 1));
             rst = H->aux;
         }
@@ -1521,6 +1527,7 @@ int sagg_refresh(nodal_ctx *h, SHierarchy *H, const int32_t *indptr0, const int3
         NODAL_HIP_TRY(h, hipGetLastError());
         if (forked) NODAL_HIP_TRY(h, hipEventRecord(H->ev_join, H->aux));
         NODAL_TRY(galerkin_product<true>(h, H, l, forked ? H->ev_join : nullptr, forked ? 2 : 0));
+        if (forked) H->aux_pending = false;
     }
     const int last = H->nlev - 1;
     if (H->dense_coarsest)
@@ -1528,7 +1535,7 @@ int sagg_refresh(nodal_ctx *h, SHierarchy *H, const int32_t *indptr0, const int3
     if (H->tail >= 0) k_tail_pack<<<1, 1024, 0, st>>>(H->td, H->tail_image.as<char>());
     NODAL_HIP_TRY(h, hipGetLastError());
     NODAL_HIP_TRY(h, hipMemcpyAsync(hs, dstats, (size_t)MAX_LEVELS * ST_COUNT * 8, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    NODAL_WAIT_STREAM(h, st);
     const int64_t bar = n0 / 100 < 32 ? (n0 / 100 > 0 ? n0 / 100 : 1) : 32;
     if (hs[ST_BADDIAG] || (int64_t)hs[ST_GRADED] >= bar) return NODAL_OK;
     for (int k = 1; k < H->nlev; ++k)
@@ -1554,8 +1561,26 @@ void sagg_destroy(nodal_ctx *h) {
 // FGMRES.  check_floating: the context's component table says which nodes a resistor joins to
 // ground (grounded_flags); a connected component of the matrix pattern without such a node is
 // reported in *floating.
+static int sagg_setup_csr_body(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr0, const int32_t *indices0,
+                               const double *data0, bool general, bool check_floating, bool *accepted, int32_t *floating);
+
 int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr0, const int32_t *indices0,
                    const double *data0, bool general, bool check_floating, bool *accepted, int32_t *floating) {
+    const int s = sagg_setup_csr_body(h, n0, nnz0, indptr0, indices0, data0, general, check_floating, accepted, floating);
+    // Whatever way the setup ended -- accepted, declined at some level, a failed call -- nothing stays in flight on
+    // the hierarchy's second stream behind the main stream's back (round 5: a declined hierarchy used to leave the
+    // last level's "touches ground" kernels running there while the caller went on to its other paths).
+    SHierarchy *H = static_cast<SHierarchy *>(h->sagg);
+    if (H && H->aux && H->aux_pending && H->ev_flags) {
+        if (hipEventRecord(H->ev_flags, H->aux) == hipSuccess) (void)hipStreamWaitEvent(h->stream, H->ev_flags, 0);
+        H->aux_pending = false;
+        (void)hipGetLastError();
+    }
+    return s;
+}
+
+static int sagg_setup_csr_body(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr0, const int32_t *indices0,
+                               const double *data0, bool general, bool check_floating, bool *accepted, int32_t *floating) {
     *accepted = false;
     *floating = 0;
     static const bool enabled = !(getenv("NODAL_SAGG") && atoi(getenv("NODAL_SAGG")) == 0);
@@ -1609,7 +1634,7 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
     }
     NODAL_HIP_TRY(h, hipGetLastError());
     NODAL_HIP_TRY(h, hipMemcpyAsync(hs, dstats, ST_COUNT * 8, hipMemcpyDeviceToHost, st));
-    NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    NODAL_WAIT_STREAM(h, st);
     const int64_t bar = n0 / 100 < 32 ? (n0 / 100 > 0 ? n0 / 100 : 1) : 32;  // amg.hip's contrast criterion
     if (hs[ST_MAXLEN] > (unsigned long long)W0_MAX || hs[ST_MAXLEN] == 0 || hs[ST_BADDIAG] ||
         (int64_t)hs[ST_GRADED] >= bar) {
@@ -1677,6 +1702,7 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
             NODAL_TRY(grounded_flags(h, H->level(0)->gflag.as<uint8_t>()));
         } else {
             NODAL_HIP_TRY(h, hipStreamWaitEvent(st, H->ev_flags, 0));
+            H->aux_pending = false;
         }
         for (int k = H->flags_levels; k + 1 < H->nlev; ++k) {
             SLevel *L = H->pool[k], *C = H->pool[k + 1];
@@ -1687,7 +1713,7 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
         }
         NODAL_HIP_TRY(h, hipGetLastError());
     }
-    NODAL_HIP_TRY(h, hipEventSynchronize(H->ev_copy));
+    NODAL_WAIT_EVENT(h, H->ev_copy, st);
     for (int k = 0; k < H->nlev; ++k) {
         const unsigned long long *s = hs + (size_t)k * ST_COUNT;
         if (k > 0) {
@@ -1719,7 +1745,7 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
     // structural singularity: OR the "touches ground" flags up, look at the last level
     if (!check_floating) {
         NODAL_HIP_TRY(h, hipMemcpyAsync(hs, dstats, (size_t)MAX_LEVELS * ST_COUNT * 8, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_WAIT_STREAM(h, st);
         if (hs[(size_t)l * ST_COUNT + ST_BADDIAG] & 2ull) return NODAL_OK;  // coarsest pivot not positive
     } else {
         // (the flags went up the hierarchy in front of the statistics read-back above)
@@ -1729,7 +1755,7 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n0, int64_t nnz0, const int32_t *indptr
         else any_unflagged<<<grid_for(last->n), TB, 0, st>>>(last->n, last->gflag.as<uint8_t>(), fl);
         NODAL_HIP_TRY(h, hipGetLastError());
         NODAL_HIP_TRY(h, hipMemcpyAsync(hs, dstats, (size_t)MAX_LEVELS * ST_COUNT * 8, hipMemcpyDeviceToHost, st));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_WAIT_STREAM(h, st);
         if (hs[(size_t)l * ST_COUNT + ST_BADDIAG] & 2ull) {  // coarsest pivot not positive
             if (trace) fprintf(stderr, "[sagg] declined: coarsest matrix not positive definite\n");
             return NODAL_OK;
@@ -2091,7 +2117,7 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
             double *stage = poll_partials ? static_cast<double *>(nodal_pinned_arena(h, bytes)) : nullptr;
             if (stage) {
                 NODAL_HIP_TRY(h, hipMemcpyAsync(stage, sb.part_rr, bytes, hipMemcpyDeviceToHost, st));
-                NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+                NODAL_WAIT_STREAM(h, st);
                 memcpy(hs, stage + 2 * MAX_PARTIALS, F_COUNT * 8);
                 double acc = 0.0;
                 for (int k = 0; k < sb.g0; ++k) acc += stage[k];

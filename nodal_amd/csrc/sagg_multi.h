@@ -608,7 +608,7 @@ int sagg_fcg_solve_pairs_block(nodal_ctx *h, int32_t count, const int32_t *ia_ho
     int32_t *pin = static_cast<int32_t *>(nodal_pinned(h));
     if (pin) memcpy(pin, pairs, sizeof pairs);
     NODAL_HIP_TRY(h, hipMemcpyAsync(M.ia, pin ? pin : pairs, sizeof pairs, hipMemcpyHostToDevice, st));
-    if (!pin) NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+    if (!pin) NODAL_WAIT_STREAM(h, st);
 
     const SLevel *L0 = H->pool[0];
     const Ell A0 = L0->A();

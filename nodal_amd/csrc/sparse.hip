@@ -513,7 +513,7 @@ int amg_fcg_solve_ex(nodal_ctx *h, const double *b, bool do_setup, int32_t *info
         NODAL_TRY(amg_setup(h, sc + F_FLAG));
         h->amg_levels = amg_num_levels(h);
         if (trace) {
-            NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+            NODAL_WAIT_STREAM(h, st);
             fprintf(stderr, "[amg] hierarchy %.2f ms\n",
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
         }
@@ -531,7 +531,7 @@ int amg_fcg_solve_ex(nodal_ctx *h, const double *b, bool do_setup, int32_t *info
         }
     }
     if (trace) {
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_WAIT_STREAM(h, st);
         fprintf(stderr, "[amg] setup + structural check %.2f ms (%d levels)\n",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(),
                 h->amg_levels);
@@ -596,7 +596,7 @@ int amg_fcg_solve_ex(nodal_ctx *h, const double *b, bool do_setup, int32_t *info
             double *stage = static_cast<double *>(nodal_pinned_arena(h, bytes));
             if (stage) {
                 NODAL_HIP_TRY(h, hipMemcpyAsync(stage, part_rr, bytes, hipMemcpyDeviceToHost, st));
-                NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+                NODAL_WAIT_STREAM(h, st);
                 memcpy(hs, stage + 3 * MAX_PARTIALS, F_COUNT * 8);
                 double acc = 0.0;
                 for (unsigned k = 0; k < gv; ++k) acc += stage[k];

@@ -745,7 +745,7 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
             NODAL_HIP_TRY(h, hipMemcpyAsync(indices.data(), h->indices.p, (size_t)nnz * 4, hipMemcpyDeviceToHost, st));
             NODAL_HIP_TRY(h, hipMemcpyAsync(data.data(), h->data.p, (size_t)nnz * 8, hipMemcpyDeviceToHost, st));
         }
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));
+        NODAL_WAIT_STREAM(h, st);
         Symbolic sym;
         if (!analyse(n, indptr.data(), indices.data(), data.data(), sym, trace)) {
             if (trace) fprintf(stderr, "[direct] no perfect matching: structurally singular\n");
@@ -808,7 +808,7 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
         NODAL_TRY(upload_vec(h, S->child_idx, sym.child_idx));
         NODAL_TRY(upload_vec(h, S->cmap, sym.cmap));
         NODAL_TRY(upload_vec(h, S->dest, sym.dest));
-        NODAL_HIP_TRY(h, hipStreamSynchronize(st));  // (the host vectors go out of scope)
+        NODAL_WAIT_STREAM(h, st);  // (the host vectors go out of scope)
         double amax = 0.0;
         for (double v : data) amax = std::max(amax, std::fabs(v));
         S->amax = amax;
@@ -900,9 +900,13 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
         // side on streams of the factorisation's own (NODAL_DIRECT_LANES, four), forked and joined by events around the level.
         hipStream_t main_st = st;
         const int nl = nbig < max_lanes ? (nbig > 0 ? nbig : 1) : max_lanes;
+        StreamJoinGuard join(main_st);  // (a failed call inside the level must not leave its lanes running unjoined)
         if (nl > 1) {
             NODAL_HIP_TRY(h, hipEventRecord(S->lane_ev[0], main_st));
-            for (int k = 1; k < nl; ++k) NODAL_HIP_TRY(h, hipStreamWaitEvent(S->lane_st[k], S->lane_ev[0], 0));
+            for (int k = 1; k < nl; ++k) {
+                NODAL_HIP_TRY(h, hipStreamWaitEvent(S->lane_st[k], S->lane_ev[0], 0));
+                join.add(S->lane_st[k], S->lane_ev[k]);
+            }
         }
         for (int32_t q = 0; q < nbig; ++q) {  // wide fronts: panel by panel (see big-front kernels above)
             const int lane_no = q % nl;
@@ -939,6 +943,7 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
             NODAL_HIP_TRY(h, hipEventRecord(S->lane_ev[k], S->lane_st[k]));
             NODAL_HIP_TRY(h, hipStreamWaitEvent(main_st, S->lane_ev[k], 0));
         }
+        join.disarm();
     }
     unsigned long long pert = 0;
     NODAL_TRY(nodal_read_words(h, &pert, S->stats.p, 8));

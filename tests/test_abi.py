@@ -44,3 +44,15 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(base, f)).read()
                 assert "oracle" not in text.replace("no CPU fallback", ""), f
+
+
+def test_every_launch_of_the_library_passes_through_the_launch_log():
+    """The diagnostics of a host wait that times out name the last kernel enqueued on the stream (csrc/wait.hip):
+    the link step wraps hipLaunchKernel / hipExtLaunchKernel, so the library defines the wrappers and still
+    imports the runtime's functions (called by the wrappers only)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", _ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    defined = {line.split()[-1].split("@")[0] for line in out.splitlines() if " T " in line}
+    undefined = {line.split()[-1].split("@")[0] for line in out.splitlines() if " U " in line}
+    assert {"__wrap_hipLaunchKernel", "__wrap_hipExtLaunchKernel"} <= defined
+    assert {"hipLaunchKernel", "hipExtLaunchKernel"} <= undefined

@@ -199,3 +199,133 @@ def test_rccl_single_rank_gather():
     assert out["backend"] == "nccl" and out["world_size"] == 1
     assert out["tensors_on_device"] and out["gathered_equals_block"] and out["finite"]
     assert out["member3_normwise_error"] <= 1e-9
+
+
+# ---- independent circuits over the ranks (bench.py --gpus N: config 3 at every N) ----
+
+def _single_circuit_oracle(table):
+    from oracle import nodal_oracle as oracle
+    G, A = oracle.assemble_fast(table)
+    return oracle.solve(G.tocsr(), A, True)[0]
+
+
+def _rank_table(rank, side=7):
+    """The rank's own circuit: the same grid topology (the gather needs equal n), its own resistances."""
+    table = gen.grid_table(side)
+    table.value[:-1] = gen.cfg4_values(100 + rank, side)
+    return table
+
+
+def _circuits_worker(rank, world, port, circuits, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    table = _rank_table(rank)
+    seen = []
+    with batch.ShardedCircuits(table, dist, solver=_single_circuit_oracle) as sc:
+        for i in range(circuits):
+            # every circuit of a rank differs from the last one: a stale send / receive slot would show
+            table.value[-1] = 1.0 + i
+            assert sc.solve_next() == 0
+            if i in (0, circuits - 1):
+                seen.append(sc.latest().copy())
+        q.put((rank, seen, sc.count))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("circuits", [1, 5])
+def test_two_rank_gloo_independent_circuits(circuits):
+    """ShardedCircuits (the N > 1 headline of bench.py): every rank solves its own circuits, x of each finished
+    circuit is all-gathered through two alternating slots with the collective left in flight -- every rank must
+    hold every rank's LATEST solution (reference: one Circuit(netlist).solve() per circuit, nodal/nodal.py:306-336)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_circuits_worker, args=(r, 2, port, circuits, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, seen, count in got:
+        assert count == circuits
+        for which, i in zip(seen, sorted({0, circuits - 1})):
+            assert which.shape[0] == 2
+            for r in (0, 1):
+                t = _rank_table(r)
+                t.value[-1] = 1.0 + i
+                assert np.array_equal(which[r], _single_circuit_oracle(t))
+
+
+def test_independent_circuits_without_a_group():
+    table = _rank_table(0)
+    with batch.ShardedCircuits(table, None, solver=_single_circuit_oracle) as sc:
+        assert sc.solve_next() == 0 and not sc.collective
+        assert np.array_equal(sc.latest(), _single_circuit_oracle(table)[None, :])
+
+
+# ---- a member that raises on one rank must not leave the others inside the collective ----
+
+def dense_oracle_solver(table, values, sparse):
+    from oracle import nodal_oracle as oracle
+    out = np.empty((values.shape[0], table.n))
+    for i, v in enumerate(values):
+        t = table.truncated(table.ncomp)
+        t.value[:] = v
+        G, A = oracle.assemble_fast(t)
+        out[i] = oracle.solve(G.toarray(), A, False)[0]  # np.linalg.solve: raises LinAlgError when singular
+    return out
+
+
+def _failing_member_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nodal_amd.netlist import Netlist
+    from nodal_amd.lowering import lower
+    # two voltage sources across the same node pair: singular whatever the values (SURVEY 8c: LinAlgError, dense)
+    rows = [["r1", "R", "1", "1", "g"], ["r2", "R", "1", "1", "2"], ["r3", "R", "1", "2", "g"],
+            ["e1", "E", "1", "2", "g"], ["e2", "E", "1", "2", "g"]]
+    table = lower(Netlist.from_rows(rows))
+    members = 4
+    vals = np.tile(table.value, (members, 1))
+
+    def solver(t, v, sparse):
+        if rank == 1:  # (only rank 1's members are singular: rank 0's stand-in drops the second source)
+            return dense_oracle_solver(t, v, sparse)
+        return np.zeros((v.shape[0], t.n))
+
+    outcome = "no exception"
+    try:
+        batch.solve_batch_distributed(table, vals, sparse=False, solver=solver, dist=dist)
+    except np.linalg.LinAlgError as e:
+        outcome = f"LinAlgError: {e}"
+    q.put((rank, outcome))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_singular_dense_member_raises_on_every_rank():
+    """Advisor's finding (round 4): BatchSolver.run(sparse=False) raises on the rank that owns the bad member
+    BEFORE the all_gather; the other ranks used to wait in the collective until its timeout.  Now the owner goes
+    through the gather with a NaN block and a status word, and every rank raises LinAlgError afterwards."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_member_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[1].startswith("LinAlgError") and "Singular" in got[1]
+    assert got[0].startswith("LinAlgError") and "rank 1" in got[0]

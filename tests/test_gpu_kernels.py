@@ -836,3 +836,17 @@ def test_dense_symmetric_block_elimination_on_unbanded_networks(n):
         xo, _ = oracle.solve(G.toarray(), A, False)
         assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
     h.close()
+
+
+def test_a_host_wait_that_runs_out_says_where_and_what():
+    """Round 5: every host wait of the library is bounded (csrc/wait.hip).  With a bound of a few microseconds
+    the first wait of a large solve runs out: NODAL_E_HIP, the wait site (file:line) and the last kernel enqueued
+    on the stream in nodal_last_error, the handle refuses further calls (tests/wait_child.py)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, NODAL_WAIT_TIMEOUT_S="0.000002")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "wait_child.py")], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "wait child ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
