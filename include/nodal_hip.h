@@ -72,7 +72,9 @@ const char *nodal_version(void);
  * The range check of the rows (nodes < K, drivers < ncomp, branch types <=> k >= 0)
  * runs on the device behind the copies; NODAL_E_INVALID as before for a bad row.
  * c, d, drv, k may be NULL -- all four together -- when B == 0 (resistors and current
- * sources read none of them): the columns then hold -1 on the device.
+ * sources read none of them): the columns then hold -1 on the device.  In a table WITH those columns they are
+ * read for the rows whose type uses them (E .. CCCS and the internal GM) and taken as -1 on resistor and current-source
+ * rows, whatever the caller's arrays hold there: only the dependent rows' entries travel (round 5).
  * Columns that live in pinned memory (nodal_host_alloc) are copied by DMA at link
  * rate; pageable memory goes through the runtime's staging copies. */
 int nodal_upload_components(nodal_handle h, int64_t ncomp,
@@ -200,8 +202,13 @@ int nodal_synchronize(nodal_handle h);
  *   handle in the process, one call at a time -- may spread independent pieces of a solve over streams of its own
  *   (the multigrid setup builds R beside A P, the direct factorisation runs the wide fronts of a level side by
  *   side).  Same kernels, same results.  Off by default: the runtime maps a process's streams onto a handful of
- *   hardware queues, and a second stream per handle makes the main streams of several handles share them. */
-enum { NODAL_OPT_FORCE_PIVOTING = 1, NODAL_OPT_GEPP_PANEL = 2, NODAL_OPT_EXTRA_STREAMS = 3 };
+ *   hardware queues, and a second stream per handle makes the main streams of several handles share them.
+ * NODAL_OPT_BORROW_TABLE (0/1, default 0): the caller promises that the columns it passes to
+ *   nodal_upload_components stay valid and unchanged until the next upload or nodal_destroy.  The library then reads
+ *   them in place where its host code needs the table (the presolve of systems with branch equations looks at the
+ *   branch rows and at the rows touching an eliminated node) instead of keeping a copy of its own: the upload of a
+ *   table with branches is DMA only.  nodal_amd/_ffi.py sets it (its Handle keeps the arrays alive). */
+enum { NODAL_OPT_FORCE_PIVOTING = 1, NODAL_OPT_GEPP_PANEL = 2, NODAL_OPT_EXTRA_STREAMS = 3, NODAL_OPT_BORROW_TABLE = 4 };
 int nodal_set_option(nodal_handle h, int32_t option, int32_t value);
 
 /* ---- testing hooks (not part of the reference-facing surface) -------------

@@ -21,6 +21,7 @@ SPARSE_AUTO, SPARSE_PCG, SPARSE_DENSIFY, SPARSE_LU, SPARSE_DIRECT = range(5)
 OPT_FORCE_PIVOTING = 1
 OPT_GEPP_PANEL = 2
 OPT_EXTRA_STREAMS = 3
+OPT_BORROW_TABLE = 4
 
 _p = C.POINTER
 _i32p, _i64p, _f64p, _u8p = _p(C.c_int32), _p(C.c_int64), _p(C.c_double), _p(C.c_uint8)
@@ -162,6 +163,8 @@ class Handle:
                 status, f"nodal_create(device={device}) failed: no usable MI355X "
                 "(HIP device) is visible; nodal_amd has no CPU fallback")
         self.n = self.nnz = self.ncontrib = 0
+        # upload() keeps the table's columns alive (self._keep) until the next upload: the library may read them in place
+        self.lib.nodal_set_option(self._h, OPT_BORROW_TABLE, 1)
         _live.add(self)
 
     def close(self):

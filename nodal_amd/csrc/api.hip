@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include "ctx.h"
+#include <algorithm>
 #include <atomic>
 
 int dense_prepare(nodal_ctx *h);  // sparse.hip
@@ -92,6 +93,20 @@ __global__ __launch_bounds__(256) void validate_table(int64_t ncomp, int32_t K, 
         const unsigned tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
         if (tot) atomicAdd(bad + 1, (unsigned long long)tot);
     }
+}
+
+// rec: (row, c, d, drv, k) of the rows that read those columns (packed by the host: nodal_upload_internal)
+__global__ __launch_bounds__(256) void place_dependent_rows(int64_t count, const int32_t *__restrict__ rec, int64_t ncomp,
+                                                            int32_t *__restrict__ c, int32_t *__restrict__ d,
+                                                            int32_t *__restrict__ drv, int32_t *__restrict__ k) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= count) return;
+    const int32_t row = rec[5 * q];
+    if (row < 0 || row >= ncomp) return;
+    c[row] = rec[5 * q + 1];
+    d[row] = rec[5 * q + 2];
+    drv[row] = rec[5 * q + 3];
+    k[row] = rec[5 * q + 4];
 }
 
 double elapsed(nodal_ctx *h, int a, int b) {
@@ -364,18 +379,54 @@ int nodal_upload_internal(nodal_ctx *h, int64_t ncomp, const uint8_t *type, cons
     UPLOAD_TRY(upload(h, h->value, value, ncomp));
     UPLOAD_TRY(upload(h, h->a, a, ncomp));
     UPLOAD_TRY(upload(h, h->b, b, ncomp));
-    if (plain) {
+    // c, d, drv, k: -1 everywhere, then (a table with branches) the entries of the rows that use them.  Those rows
+    // are few -- 3e4 of config 5's 2e6 -- and 16 of the 33 bytes per row are these four columns: the host lists the
+    // dependent rows while the first four columns are on their way (threads over chunks of the type column), packs
+    // their entries into the page-locked arena, one copy and one scatter kernel place them (config 5: 67 -> 35 MB up).
+    {
         DevBuf *cols[] = {&h->c, &h->d, &h->drv, &h->k};
         for (DevBuf *col : cols) {
             if (col->reserve((size_t)ncomp * 4 + 16) != hipSuccess ||
                 (ncomp > 0 && hipMemsetAsync(col->p, 0xFF, (size_t)ncomp * 4, h->stream) != hipSuccess))  // -1
                 return fail_synced(nodal_fail(h, NODAL_E_NOMEM, "upload: could not allocate a table column"));
         }
-    } else {
-        UPLOAD_TRY(upload(h, h->c, c, ncomp));
-        UPLOAD_TRY(upload(h, h->d, d, ncomp));
-        UPLOAD_TRY(upload(h, h->drv, drv, ncomp));
-        UPLOAD_TRY(upload(h, h->k, k, ncomp));
+    }
+    std::vector<int64_t> branch_rows;
+    if (!plain && ncomp > 0) {
+        // dependent rows by chunk of the type column, in file order
+        constexpr int CHUNKS = 8;
+        std::vector<int64_t> found[CHUNKS];
+        {
+            nodal_parallel_chunks(CHUNKS, 1, ncomp >= (1 << 18) ? CHUNKS : 1, [&](int64_t c0, int64_t c1) {
+                for (int64_t q = c0; q < c1; ++q) {
+                    std::vector<int64_t> &out = found[q];
+                    for (int64_t i = ncomp * q / CHUNKS, e = ncomp * (q + 1) / CHUNKS; i < e; ++i)
+                        if (type[i] >= NODAL_T_E) out.push_back(i);
+                }
+            });
+            int64_t total = 0;
+            for (int q = 0; q < CHUNKS; ++q) total += (int64_t)found[q].size();
+            struct DepRow { int32_t row, c, d, drv, k; };
+            DepRow *rec = total ? static_cast<DepRow *>(nodal_pinned_arena(h, (size_t)total * sizeof(DepRow))) : nullptr;
+            if (total && !rec) return fail_synced(nodal_fail(h, NODAL_E_NOMEM, "upload: no page-locked staging memory"));
+            int64_t at = 0;
+            branch_rows.reserve((size_t)total);
+            for (int q = 0; q < CHUNKS; ++q)
+                for (const int64_t i : found[q]) {
+                    rec[at++] = DepRow{(int32_t)i, c[i], d[i], drv[i], k[i]};
+                    if (type[i] <= NODAL_T_CCCS) branch_rows.push_back(i);
+                }
+            if (total) {
+                if (h->ps_stage.reserve((size_t)total * sizeof(DepRow) + 64) != hipSuccess)
+                    return fail_synced(nodal_fail(h, NODAL_E_NOMEM, "upload: dependent rows"));
+                if (hipMemcpyAsync(h->ps_stage.p, rec, (size_t)total * sizeof(DepRow), hipMemcpyHostToDevice, h->stream) != hipSuccess)
+                    return fail_synced(nodal_fail(h, NODAL_E_HIP, "upload: dependent rows"));
+                place_dependent_rows<<<(unsigned)((total + 255) / 256), 256, 0, h->stream>>>(
+                    total, reinterpret_cast<const int32_t *>(h->ps_stage.p), ncomp, h->c.as<int32_t>(), h->d.as<int32_t>(),
+                    h->drv.as<int32_t>(), h->k.as<int32_t>());
+                if (hipGetLastError() != hipSuccess) return fail_synced(nodal_fail(h, NODAL_E_HIP, "upload: dependent rows launch failed"));
+            }
+        }
     }
     // the range check runs on the device, behind the copies; its verdict is the one word that comes back
     if (h->status.reserve(64) != hipSuccess) return fail_synced(nodal_fail(h, NODAL_E_NOMEM, "upload: status words"));
@@ -389,31 +440,47 @@ int nodal_upload_internal(nodal_ctx *h, int64_t ncomp, const uint8_t *type, cons
             ncomp, K, B, h->type.as<uint8_t>(), h->a.as<int32_t>(), h->b.as<int32_t>(),
             plain ? nullptr : h->c.as<int32_t>(), plain ? nullptr : h->d.as<int32_t>(),
             plain ? nullptr : h->drv.as<int32_t>(), plain ? nullptr : h->k.as<int32_t>(), bad_dev);
+        // (the entries of the dependent rows only: a row number that is out of range was not placed and its k stays -1,
+        // which the branch-type test above reports)
         if (hipGetLastError() != hipSuccess) return fail_synced(nodal_fail(h, NODAL_E_HIP, "upload: range check launch failed"));
     }
 #undef UPLOAD_TRY
+    // the host's view of the table (only systems with branch equations are presolved), made while the copies run:
+    // the caller's columns in place when it has promised to keep them (NODAL_OPT_BORROW_TABLE), else copies (threads)
+    if (h->keep_host_table && B > 0) {
+        HostTable &t = h->host;
+        if (h->borrow_table) {
+            t.type.borrow(type, (size_t)ncomp);
+            t.value.borrow(value, (size_t)ncomp);
+            t.a.borrow(a, (size_t)ncomp);
+            t.b.borrow(b, (size_t)ncomp);
+            t.c.borrow(c, (size_t)ncomp);
+            t.d.borrow(d, (size_t)ncomp);
+            t.drv.borrow(drv, (size_t)ncomp);
+            t.k.borrow(k, (size_t)ncomp);
+        } else {
+            t.type.resize((size_t)ncomp);
+            t.value.resize((size_t)ncomp);
+            HostCol<int32_t> *ic[] = {&t.a, &t.b, &t.c, &t.d, &t.drv, &t.k};
+            const int32_t *src[] = {a, b, c, d, drv, k};
+            for (HostCol<int32_t> *col : ic) col->resize((size_t)ncomp);
+            nodal_parallel_chunks(ncomp, 1 << 16, 8, [&](int64_t lo, int64_t hi) {
+                memcpy(t.type.own.data() + lo, type + lo, (size_t)(hi - lo));
+                memcpy(t.value.own.data() + lo, value + lo, (size_t)(hi - lo) * 8);
+                for (int q = 0; q < 6; ++q) memcpy(ic[q]->own.data() + lo, src[q] + lo, (size_t)(hi - lo) * 4);
+            });
+        }
+        t.values_batch.clear();
+        t.branch_rows.swap(branch_rows);
+    } else {
+        h->host = HostTable();
+    }
     NODAL_TRY(nodal_read_words(h, bad, bad_dev, 16));
     h->rhs_items = (int64_t)bad[1];
     if (bad[0] != ~0ull) {
         h->ncomp = 0;  // (nothing may run on this table)
-        return nodal_fail(h, NODAL_E_INVALID, "component table row out of range");
-    }
-    if (h->keep_host_table && B > 0) {  // only systems with branch equations are presolved
-        HostTable &t = h->host;
-        t.type.assign(type, type + ncomp);
-        t.value.assign(value, value + ncomp);
-        t.a.assign(a, a + ncomp);
-        t.b.assign(b, b + ncomp);
-        t.c.assign(c, c + ncomp);
-        t.d.assign(d, d + ncomp);
-        t.drv.assign(drv, drv + ncomp);
-        t.k.assign(k, k + ncomp);
-        t.values_batch.clear();
-        t.branch_rows.clear();
-        for (int64_t i = 0; i < ncomp; ++i)
-            if (type[i] >= NODAL_T_E && type[i] <= NODAL_T_CCCS) t.branch_rows.push_back(i);
-    } else {
         h->host = HostTable();
+        return nodal_fail(h, NODAL_E_INVALID, "component table row out of range");
     }
     h->have_table = true;
     return NODAL_OK;
@@ -725,6 +792,10 @@ int nodal_set_option(nodal_handle h, int32_t option, int32_t value) {
     }
     if (option == NODAL_OPT_EXTRA_STREAMS) {
         h->extra_streams = value != 0;
+        return NODAL_OK;
+    }
+    if (option == NODAL_OPT_BORROW_TABLE) {
+        h->borrow_table = value != 0;
         return NODAL_OK;
     }
     return nodal_fail(h, NODAL_E_INVALID, "unknown option");

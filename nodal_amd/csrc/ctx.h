@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nodal_hip.h"
@@ -74,17 +75,72 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
-// host copy of the component table (the presolve of presolve.hip works on it)
+// A column of the host table: either a copy the library owns, or (NODAL_OPT_BORROW_TABLE) the caller's own column,
+// read in place.  The subset of std::vector's interface the readers use.
+template <class T>
+struct HostCol {
+    const T *p = nullptr;
+    size_t n = 0;
+    std::vector<T> own;
+    bool empty() const { return n == 0; }
+    size_t size() const { return n; }
+    const T *data() const { return p; }
+    const T &operator[](size_t i) const { return p[i]; }
+    T &operator[](size_t i) { return own[i]; }  // (writers: a column they resize()d themselves)
+    void assign(const T *first, const T *last) {
+        own.assign(first, last);
+        p = own.data();
+        n = own.size();
+    }
+    void borrow(const T *q, size_t count) {
+        std::vector<T>().swap(own);
+        p = q;
+        n = count;
+    }
+    void resize(size_t count) {
+        own.resize(count);
+        p = own.data();
+        n = count;
+    }
+    void clear() {
+        own.clear();
+        p = nullptr;
+        n = 0;
+    }
+};
+
+// host view of the component table (the presolve of presolve.hip works on it)
 struct HostTable {
-    std::vector<uint8_t> type;
-    std::vector<double> value;
-    std::vector<int32_t> a, b, c, d, drv, k;
+    HostCol<uint8_t> type;
+    HostCol<double> value;
+    HostCol<int32_t> a, b, c, d, drv, k;
     std::vector<double> values_batch;
     std::vector<int64_t> branch_rows;  // rows of the components that own a branch unknown (types E .. CCCS),
                                        // in file order: what the presolve's planning pass looks at
     mutable std::vector<int32_t> node_slot;  // K entries, all -1 between uses: the presolve's direct map from a
                                              // node to its place in a short list (lead nodes, pivots)
 };
+
+// f(lo, hi) over [0, n) in contiguous chunks on up to `max_threads` host threads (the calling one included); chunks
+// of at least `min_chunk` items, one chunk = a plain call.  The loops handed to it write disjoint ranges.
+template <class F>
+inline void nodal_parallel_chunks(int64_t n, int64_t min_chunk, int max_threads, F f) {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char *e = getenv("NODAL_HOST_THREADS")) hw = (unsigned)(atoi(e) > 1 ? atoi(e) : 1);
+    int64_t T = hw ? (int64_t)hw : 1;
+    if (T > max_threads) T = max_threads;
+    if (min_chunk < 1) min_chunk = 1;
+    if (T > n / min_chunk) T = n / min_chunk;
+    if (T <= 1) {
+        f((int64_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve((size_t)T - 1);
+    for (int64_t c = 1; c < T; ++c) th.emplace_back(f, n * c / T, n * (c + 1) / T);
+    f((int64_t)0, n / T);
+    for (auto &t : th) t.join();
+}
 
 struct nodal_ctx {
     int device = 0;
@@ -120,6 +176,7 @@ struct nodal_ctx {
     hipEvent_t ev_batch[4] = {nullptr, nullptr, nullptr, nullptr};  // phase timing of nodal_run_batch
     HostTable host;
     bool keep_host_table = true;
+    bool borrow_table = false;       // NODAL_OPT_BORROW_TABLE: the caller's columns stay valid until the next upload
     int32_t member = 0;            // batch member of the last numeric assembly
     nodal_ctx *reduced = nullptr;  // presolved (branch-free) system, see presolve.hip
     uint64_t reduced_key = 0;      // (on the reduced context) fingerprint of the topology its symbolic lists belong to
@@ -385,6 +442,7 @@ int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, doub
 // tiny_factor scales (and signs) the value that replaces an unusable pivot
 int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor = 1.0);
 int slu_apply(nodal_ctx *h, const double *r, double *z);
+int64_t slu_perturbed(nodal_ctx *h);  // pivots the last slu_factor replaced
 void slu_destroy(nodal_ctx *h);
 void slu_poison(nodal_ctx *h);
 int sparse_direct_solve(nodal_ctx *h, const double *b, double *x, int32_t *info, int32_t *iters, double *resid);

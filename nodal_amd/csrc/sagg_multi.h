@@ -630,7 +630,12 @@ int sagg_fcg_solve_pairs_block(nodal_ctx *h, int32_t count, const int32_t *ia_ho
         NODAL_HIP_TRY(h, hipGetLastError());
         return NODAL_OK;
     };
-    const int64_t maxit = getenv("NODAL_FCG_MAXIT") ? atoll(getenv("NODAL_FCG_MAXIT")) : 2000;
+    // (a block iteration costs 1.2 ms at 1e6 rows: the cap follows what the first pair's own solve took on this
+    // hierarchy -- four times that, at least 64 -- so that a slowly converging network costs a failing block tenths of
+    // a second, not 2000 iterations, before the sweep goes on pair by pair)
+    int64_t maxit = 2000;
+    if (H->last_iters > 0) maxit = std::max<int64_t>(64, 4 * (int64_t)H->last_iters);
+    if (getenv("NODAL_FCG_MAXIT")) maxit = atoll(getenv("NODAL_FCG_MAXIT"));
     double hs[MK * MSC];
     int64_t enqueued = 0;
     // A block iteration takes ~1.2 ms at 1e6 rows and a look at the scalars ~50 us: the host looks after one

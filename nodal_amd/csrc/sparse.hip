@@ -723,7 +723,9 @@ int sparse_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const in
         }
         direct = true;
     }
-    const bool block_allowed = !(getenv("NODAL_PAIRS_BLOCK") && atoi(getenv("NODAL_PAIRS_BLOCK")) == 0);
+    // (latched off by the first block that breaks down or does not converge: the pairs of that block and every later
+    // one go singly -- a second failing block would cost its iteration cap again for nothing)
+    bool block_allowed = !(getenv("NODAL_PAIRS_BLOCK") && atoi(getenv("NODAL_PAIRS_BLOCK")) == 0);
     for (int32_t q = 0; q < npairs;) {
         // Once the first pair has set the smoothed-aggregation hierarchy up, the others go sixteen at a time
         // through the block iteration (sagg_multi.h: one launch sequence and one pass over every matrix per block
@@ -739,6 +741,7 @@ int sparse_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const in
                 continue;
             }
             if (s > 0) return s;
+            block_allowed = false;
         }
         NODAL_HIP_TRY(h, hipMemsetAsync(b, 0, (size_t)n * 8, st));
         pair_rhs<<<1, 1, 0, st>>>(b, ia[q], ib[q]);

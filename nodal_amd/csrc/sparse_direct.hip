@@ -74,8 +74,8 @@ struct SluState {
     DevBuf sn_start, struct_ptr, struct_idx, front_off, vec_off, lvl_sn, child_ptr, child_idx, cmap, dest;
     // numeric part
     DevBuf fronts, vec, lperm, rs, cs, xb, stats;
-    double amax = 0.0;
     int64_t perturbed = 0;
+    bool analysis_kept = false;  // the last slu_factor reused an analysis (row matching!) made for EARLIER values
 };
 
 SluState *state_of(nodal_ctx *h) { return static_cast<SluState *>(h->slu); }
@@ -736,7 +736,8 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
     }
     const auto t0 = std::chrono::steady_clock::now();
     auto ms_since = [&](auto t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
-    if (!(S->have_symbolic && S->epoch == h->struct_epoch && S->n == n && S->nnz == nnz)) {
+    S->analysis_kept = S->have_symbolic && S->epoch == h->struct_epoch && S->n == n && S->nnz == nnz;
+    if (!S->analysis_kept) {
         S->have_symbolic = S->have_numeric = false;
         std::vector<int32_t> indptr((size_t)n + 1), indices((size_t)nnz);
         std::vector<double> data((size_t)nnz);
@@ -809,9 +810,6 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor) {
         NODAL_TRY(upload_vec(h, S->cmap, sym.cmap));
         NODAL_TRY(upload_vec(h, S->dest, sym.dest));
         NODAL_WAIT_STREAM(h, st);  // (the host vectors go out of scope)
-        double amax = 0.0;
-        for (double v : data) amax = std::max(amax, std::fabs(v));
-        S->amax = amax;
         S->epoch = h->struct_epoch;
         S->n = n;
         S->nnz = nnz;
@@ -990,7 +988,12 @@ int slu_apply(nodal_ctx *h, const double *r, double *z) {
 // G x = b by the multifrontal LU + flexible GMRES refinement.  *info > 0: singular (structurally, or the
 // refinement does not converge on the statically pivoted factors): the caller fills NaNs, as the
 // reference's spsolve does (reference nodal/nodal.py:323-336: NaNs + MatrixRankWarning, no exception).
-int sparse_direct_solve(nodal_ctx *h, const double *b, double *x, int32_t *info, int32_t *iters, double *resid) {
+int64_t slu_perturbed(nodal_ctx *h) {
+    SluState *S = state_of(h);
+    return S ? S->perturbed : 0;
+}
+
+static int sparse_direct_solve_once(nodal_ctx *h, const double *b, double *x, int32_t *info, int32_t *iters, double *resid) {
     *info = 0;
     *iters = 0;
     *resid = 0.0;
@@ -1024,4 +1027,24 @@ int sparse_direct_solve(nodal_ctx *h, const double *b, double *x, int32_t *info,
     if (info2 > 0) *info = 1;
     *iters += it2;
     return NODAL_OK;
+}
+
+// G x = b by the multifrontal LU + flexible GMRES refinement.  *info > 0: singular (structurally, or replaced pivots and
+// a refinement that stalls): the caller fills NaNs, as the reference's spsolve does (reference nodal/nodal.py:323-336:
+// NaNs + MatrixRankWarning, no exception).
+// The analysis is kept per sparsity pattern, but its row matching looked at VALUES (a diagonal is kept when it carries
+// weight, the largest entry of a free column otherwise): a value sweep, nodal_run(reuse_symbolic) or a pair sweep can
+// hand the kept matching entries that are tiny or zero now.  So a verdict that rests on a kept analysis -- singular, or
+// pivots were replaced -- is not final: the analysis is redone with the current values, once (advisor, round 4).
+int sparse_direct_solve(nodal_ctx *h, const double *b, double *x, int32_t *info, int32_t *iters, double *resid) {
+    for (int attempt = 0;; ++attempt) {
+        NODAL_TRY(sparse_direct_solve_once(h, b, x, info, iters, resid));
+        SluState *S = state_of(h);
+        const bool doubtful = *info > 0 || (S && S->perturbed > 0);
+        if (attempt > 0 || !S || !S->analysis_kept || !doubtful) return NODAL_OK;
+        if (getenv("NODAL_TRACE"))
+            fprintf(stderr, "[direct] %s on an analysis kept from earlier values: the analysis is redone with the current ones\n",
+                    *info > 0 ? "singular verdict" : "replaced pivots");
+        S->have_symbolic = S->have_numeric = false;
+    }
 }
