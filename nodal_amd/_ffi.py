@@ -239,7 +239,7 @@ class Handle:
     # -- solve ------------------------------------------------------------
     def solve_dense(self, download=True):
         """Returns (x or None, info).  info > 0: exact zero pivot (singular)."""
-        x = np.empty(self.n, dtype=np.float64) if download else None
+        x = host_empty(self.n, np.float64) if download else None  # (pinned when large: the copy down is plain DMA)
         info = C.c_int32(0)
         self._check(self.lib.nodal_solve_dense(
             self._h, _ptr(x, C.c_double) if download else None, C.byref(info)),
@@ -248,7 +248,7 @@ class Handle:
 
     def solve_sparse(self, method=SPARSE_AUTO, download=True):
         """Returns (x or None, info, iterations, relative residual)."""
-        x = np.empty(self.n, dtype=np.float64) if download else None
+        x = host_empty(self.n, np.float64) if download else None  # (pinned when large: the copy down is plain DMA)
         info, iters, resid = C.c_int32(0), C.c_int32(0), C.c_double(0)
         self._check(self.lib.nodal_solve_sparse(
             self._h, method, _ptr(x, C.c_double) if download else None,
@@ -267,7 +267,7 @@ class Handle:
         return out, info.value
 
     def download_x(self):
-        x = np.empty(self.n, dtype=np.float64)
+        x = host_empty(self.n, np.float64)
         self._check(self.lib.nodal_download_x(self._h, _ptr(x, C.c_double)))
         return x
 
