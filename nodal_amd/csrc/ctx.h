@@ -440,9 +440,12 @@ int presolve_solve(nodal_ctx *h, bool *done, int32_t *info, int32_t *iters, doub
                    bool dense_child = false);
 // ---- sparse direct route (sparse_direct.hip): multifrontal LU + FGMRES refinement ----
 // tiny_factor scales (and signs) the value that replaces an unusable pivot
-int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor = 1.0);
+int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor = 1.0, double tiny_threshold = 0.0);
 int slu_apply(nodal_ctx *h, const double *r, double *z);
 int64_t slu_perturbed(nodal_ctx *h);  // pivots the last slu_factor replaced
+constexpr int SLU_MULTI = 16;         // right-hand sides of slu_apply_multi (interleaved by row: element (i, c) at [i * 16 + c])
+int slu_apply_multi(nodal_ctx *h, const double *r, double *z);
+bool slu_analysis_kept(nodal_ctx *h); // an analysis for the context's present pattern is at hand (no host work to factor)
 void slu_destroy(nodal_ctx *h);
 void slu_poison(nodal_ctx *h);
 int sparse_direct_solve(nodal_ctx *h, const double *b, double *x, int32_t *info, int32_t *iters, double *resid);

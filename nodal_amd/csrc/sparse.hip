@@ -648,6 +648,39 @@ __global__ void pair_read(const double *__restrict__ x, int32_t ia, int32_t ib,
     *out = (ia >= 0 ? x[ia] : 0.0) - (ib >= 0 ? x[ib] : 0.0);
 }
 
+// ---- sixteen probe pairs at a time through the sparse LU (sparse_solve_pairs_direct below) ----
+// vectors interleaved by row: element (i, c) at [i * SLU_MULTI + c]; pair (-1, -1) = unused column
+struct PairBlock { int32_t ia[SLU_MULTI], ib[SLU_MULTI]; };
+__global__ __launch_bounds__(64) void pair_rhs_multi(double *__restrict__ b, PairBlock pb) {
+    const int c = threadIdx.x;
+    if (c >= SLU_MULTI) return;
+    if (pb.ia[c] >= 0) b[(int64_t)pb.ia[c] * SLU_MULTI + c] += 1.0;
+    if (pb.ib[c] >= 0) b[(int64_t)pb.ib[c] * SLU_MULTI + c] -= 1.0;
+}
+__global__ __launch_bounds__(64) void pair_read_multi(const double *__restrict__ x, PairBlock pb, int count,
+                                                      double *__restrict__ out) {
+    const int c = threadIdx.x;
+    if (c >= count) return;
+    out[c] = (pb.ia[c] >= 0 ? x[(int64_t)pb.ia[c] * SLU_MULTI + c] : 0.0) -
+             (pb.ib[c] >= 0 ? x[(int64_t)pb.ib[c] * SLU_MULTI + c] : 0.0);
+}
+// r = b - A x for the sixteen columns: the lanes of a row share every matrix entry and gather 128 contiguous bytes of x
+__global__ __launch_bounds__(TB) void csr_residual_multi(int64_t n, const int32_t *__restrict__ indptr,
+                                                         const int32_t *__restrict__ indices, const double *__restrict__ data,
+                                                         const double *__restrict__ x, const double *__restrict__ b,
+                                                         double *__restrict__ r) {
+    for (int64_t e = (int64_t)blockIdx.x * TB + threadIdx.x; e < n * SLU_MULTI; e += (int64_t)gridDim.x * TB) {
+        const int64_t i = e / SLU_MULTI;
+        const int c = (int)(e % SLU_MULTI);
+        double acc = b[e];
+        for (int32_t q = indptr[i]; q < indptr[i + 1]; ++q) acc = fma(-data[q], x[(int64_t)indices[q] * SLU_MULTI + c], acc);
+        r[e] = acc;
+    }
+}
+__global__ __launch_bounds__(TB) void add_into(int64_t count, const double *__restrict__ d, double *__restrict__ x) {
+    for (int64_t e = (int64_t)blockIdx.x * TB + threadIdx.x; e < count; e += (int64_t)gridDim.x * TB) x[e] += d[e];
+}
+
 __global__ __launch_bounds__(TB) void copy_rhs_column(const double *__restrict__ rhs,
                                                       double *__restrict__ col, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
@@ -702,6 +735,48 @@ int pair_read_host(nodal_ctx *h, const double *x, int32_t ia, int32_t ib, double
     return NODAL_OK;
 }
 
+// Factor once, substitute for sixteen pairs at a time (SURVEY 8f N1 in its own words: "one factorisation + batched
+// triangular solves"; reference nodal/equiv.py:31-61 rebuilds and re-solves per pair): X = A^-1 B by slu_apply_multi
+// and ONE step of refinement on the block (R = B - A X, X += A^-1 R: the factors are those of a statically pivoted LU).
+// *taken = false: pivots had to be replaced -- the caller's pair-by-pair route, which judges every answer, takes over.
+static int sparse_solve_pairs_direct(nodal_ctx *h, int32_t npairs, const int32_t *ia, const int32_t *ib, double *res_dev,
+                                     int32_t *info, bool *taken) {
+    *taken = false;
+    const int64_t n = h->n;
+    hipStream_t st = h->stream;
+    int32_t inf = 0;
+    NODAL_TRY(slu_factor(h, &inf));
+    if (inf > 0) {
+        *info = 1;
+        *taken = true;
+        return NODAL_OK;
+    }
+    if (slu_perturbed(h) > 0) return NODAL_OK;
+    const size_t vb = (size_t)n * SLU_MULTI * 8;
+    NODAL_HIP_TRY(h, h->krylov.reserve(3 * vb + 256));
+    double *B = h->krylov.as<double>(), *X = B + (size_t)n * SLU_MULTI, *R = X + (size_t)n * SLU_MULTI;
+    const unsigned gv = (unsigned)std::min<int64_t>((n * SLU_MULTI + TB - 1) / TB, 65536);
+    for (int32_t q = 0; q < npairs; q += SLU_MULTI) {
+        const int cnt = npairs - q < SLU_MULTI ? npairs - q : SLU_MULTI;
+        PairBlock pb;
+        for (int c = 0; c < SLU_MULTI; ++c) {
+            pb.ia[c] = c < cnt ? ia[q + c] : -1;
+            pb.ib[c] = c < cnt ? ib[q + c] : -1;
+        }
+        NODAL_HIP_TRY(h, hipMemsetAsync(B, 0, vb, st));
+        pair_rhs_multi<<<1, 64, 0, st>>>(B, pb);
+        NODAL_TRY(slu_apply_multi(h, B, X));
+        csr_residual_multi<<<gv, TB, 0, st>>>(n, h->indptr.as<int32_t>(), h->indices.as<int32_t>(), h->data.as<double>(), X, B, R);
+        NODAL_TRY(slu_apply_multi(h, R, B));  // (B is free: the correction lands there)
+        add_into<<<gv, TB, 0, st>>>(n * SLU_MULTI, B, X);
+        pair_read_multi<<<1, 64, 0, st>>>(X, pb, cnt, res_dev + q);
+        NODAL_HIP_TRY(h, hipGetLastError());
+    }
+    h->last_iterations = 1;
+    *taken = true;
+    return NODAL_OK;
+}
+
 int sparse_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const int32_t *ib,
                        double *res_dev, int32_t *info) {
     const int64_t n = h->n;
@@ -714,7 +789,22 @@ int sparse_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const in
     // nodal/equiv.py:31-37 admits resistors only) is no M-matrix: one sparse LU serves every pair, as SuperLU
     // serves the reference.
     const bool indefinite = !(h->B == 0 && h->passive_network);
-    if (indefinite || getenv("NODAL_PAIRS_DIRECT")) {  // (NODAL_PAIRS_DIRECT, testing: the fallback from the first pair on)
+    // The factor-once route.  A factorisation costs what ~70 block-iteration pairs cost (measured on the 1e6-node grid:
+    // DESIGN 3.5), its analysis -- host work, kept per sparsity pattern -- four times that; a substitution for sixteen
+    // pairs costs a fifth of their block iteration.  So: sweeps of at least PAIRS_DIRECT_MIN pairs when the analysis
+    // is at hand, four times as many when it has to be made; always where the multigrid has no business (indefinite).
+    // NODAL_PAIRS_DIRECT=1 forces it, =0 forbids it.
+    {
+        const int forced = getenv("NODAL_PAIRS_DIRECT") ? atoi(getenv("NODAL_PAIRS_DIRECT")) : -1;  // (per call: tests switch it)
+        const int64_t min_pairs = getenv("NODAL_PAIRS_DIRECT_MIN") ? atoll(getenv("NODAL_PAIRS_DIRECT_MIN")) : 96;
+        const bool worth = npairs >= (slu_analysis_kept(h) ? min_pairs : 4 * min_pairs);
+        if (forced != 0 && (forced == 1 || indefinite || worth)) {
+            bool taken = false;
+            NODAL_TRY(sparse_solve_pairs_direct(h, npairs, ia, ib, res_dev, info, &taken));
+            if (taken) return NODAL_OK;
+        }
+    }
+    if (indefinite || (getenv("NODAL_PAIRS_DIRECT") && atoi(getenv("NODAL_PAIRS_DIRECT")) == 1)) {  // (pair by pair on the factors)
         int32_t inf = 0;
         NODAL_TRY(slu_factor(h, &inf));
         if (inf > 0) {

@@ -370,3 +370,41 @@ def test_a_kept_analysis_is_redone_before_a_singular_verdict(monkeypatch, capfd)
         assert info == 0 and normwise(x, xo) <= 1e-7, (m, info)
         outs.append(x)
     h.close()
+
+
+@pytest.mark.parametrize("kind", ["grid", "grid over a decade", "wires"])
+def test_factor_once_route_of_a_pair_sweep_matches_the_oracle(kind, monkeypatch):
+    """SURVEY 8f N1 in its own words -- "one factorisation + batched triangular solves" -- on the sparse path
+    (reference nodal/equiv.py:31-61: deepcopy + rebuild + spsolve per pair): sparse_solve_pairs_direct factors G
+    once (multifrontal LU) and substitutes for sixteen probe pairs at a time (slu_apply_multi: the diagonal blocks'
+    inverses, sixteen interleaved right-hand sides), one refinement step on the block.  Every pair within 1e-9 of a
+    sparse LU of the oracle's matrix; 40 pairs = two full blocks and a ragged one."""
+    import scipy.sparse.linalg as spla
+    monkeypatch.setenv("NODAL_PAIRS_DIRECT", "1")
+    if kind == "grid":
+        table = gen.grid_table(150)
+    elif kind == "grid over a decade":
+        table = gen.grid_table(120, _graded(120, 1, 9))
+    else:
+        table = gen.grid_with_wires_table(70, 120)
+    rng = np.random.RandomState(11)
+    ia = rng.randint(0, table.K, size=40).astype(np.int32)
+    ib = rng.randint(-1, table.K, size=40).astype(np.int32)
+    ib[ib == ia] = -1
+    h = _ffi.Handle(0)
+    h.upload(table)
+    h.assemble_symbolic()
+    assert h.assemble_numeric()[0] == _ffi.OK
+    res, info = h.solve_pairs(ia, ib, dense=False)
+    again, info2 = h.solve_pairs(ia[:17], ib[:17], dense=False)  # (the analysis is kept; another ragged block)
+    h.close()
+    assert info == 0 and info2 == 0 and np.array_equal(again, res[:17])
+    G, _ = oracle.assemble_fast(table)
+    lu = spla.splu(G.tocsc())
+    for q in range(len(ia)):
+        b = np.zeros(G.shape[0])
+        b[ia[q]] = 1.0
+        if ib[q] >= 0:
+            b[ib[q]] = -1.0
+        want = b @ lu.solve(b)
+        assert abs(res[q] - want) <= TOL * abs(want), (q, res[q], want)

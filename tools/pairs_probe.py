@@ -27,7 +27,14 @@ if len(sys.argv) > 3:  # child: one mode
     np.save(f"/tmp/pairs_{sys.argv[3]}.npy", res)
     h.close()
 else:
-    for mode, env in (("block", {}), ("single", {"NODAL_PAIRS_BLOCK": "0"})):
+    modes = [("block", {"NODAL_PAIRS_DIRECT": "0"}), ("direct", {"NODAL_PAIRS_DIRECT": "1"})]
+    if npairs <= 64:
+        modes.append(("single", {"NODAL_PAIRS_BLOCK": "0", "NODAL_PAIRS_DIRECT": "0"}))
+    for mode, env in modes:
         subprocess.run([sys.executable, __file__, str(N), str(npairs), mode], env=dict(os.environ, **env), check=True)
-    a, b = np.load("/tmp/pairs_block.npy"), np.load("/tmp/pairs_single.npy")
-    print(f"  block vs single: max relative difference {np.abs(a - b).max() / np.abs(b).max():.2e}")
+    a, d = np.load("/tmp/pairs_block.npy"), np.load("/tmp/pairs_direct.npy")
+    print(f"  block vs factor-once (sparse LU, 16 columns per substitution): max relative difference "
+          f"{np.abs(a - d).max() / np.abs(d).max():.2e}")
+    if npairs <= 64:
+        b = np.load("/tmp/pairs_single.npy")
+        print(f"  block vs single: max relative difference {np.abs(a - b).max() / np.abs(b).max():.2e}")
