@@ -789,14 +789,16 @@ int sparse_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const in
     // nodal/equiv.py:31-37 admits resistors only) is no M-matrix: one sparse LU serves every pair, as SuperLU
     // serves the reference.
     const bool indefinite = !(h->B == 0 && h->passive_network);
-    // The factor-once route.  A factorisation costs what ~70 block-iteration pairs cost (measured on the 1e6-node grid:
-    // DESIGN 3.5), its analysis -- host work, kept per sparsity pattern -- four times that; a substitution for sixteen
-    // pairs costs a fifth of their block iteration.  So: sweeps of at least PAIRS_DIRECT_MIN pairs when the analysis
-    // is at hand, four times as many when it has to be made; always where the multigrid has no business (indefinite).
-    // NODAL_PAIRS_DIRECT=1 forces it, =0 forbids it.
+    // The factor-once route.  Measured on the 1e6-node grid (round 5): a factorisation 65 ms (its analysis --
+    // host work, kept per sparsity pattern -- 0.2 s more), a substitution for sixteen pairs 9.4 ms, i.e. 1.6 ms per pair
+    // with the refinement step against 0.93 ms per pair of the block iteration: on the networks the multigrid takes,
+    // the block iteration stays the default, and this route serves the ones it has no business with (indefinite:
+    // a non-positive resistance) -- sixteen pairs per substitution instead of one.  NODAL_PAIRS_DIRECT=1 forces it,
+    // =0 forbids it; NODAL_PAIRS_DIRECT_MIN=k takes it for sweeps of at least k pairs (4 k when the analysis is not
+    // at hand yet).
     {
         const int forced = getenv("NODAL_PAIRS_DIRECT") ? atoi(getenv("NODAL_PAIRS_DIRECT")) : -1;  // (per call: tests switch it)
-        const int64_t min_pairs = getenv("NODAL_PAIRS_DIRECT_MIN") ? atoll(getenv("NODAL_PAIRS_DIRECT_MIN")) : 96;
+        const int64_t min_pairs = getenv("NODAL_PAIRS_DIRECT_MIN") ? atoll(getenv("NODAL_PAIRS_DIRECT_MIN")) : (int64_t)1 << 40;
         const bool worth = npairs >= (slu_analysis_kept(h) ? min_pairs : 4 * min_pairs);
         if (forced != 0 && (forced == 1 || indefinite || worth)) {
             bool taken = false;

@@ -668,6 +668,26 @@ __global__ __launch_bounds__(64) void invert_diag_blocks(Tree T, int64_t nblocks
 
 template <int NR> struct ColGroup { static constexpr int CW = NR >= 4 ? 4 : NR; static constexpr int CG = NR / CW; };
 
+// acc[0 .. CW) -= sum_k F[i + (c0 + k) dim] * Y[k][col0 ..]: the nb (<= DB) entries of row i in the column chunk c0,
+// ALL requested before the first is used -- one round trip to memory per chunk, not one per entry (a loop that
+// loads, multiplies and loads again took 1.1 ms per sweep of a 1489-row front).  Y: the chunk's vector rows, in LDS.
+template <int NR, int CW>
+__device__ __forceinline__ void chunk_update(const double *__restrict__ Frow, int64_t dim, int nb, const double (*Y)[NR],
+                                             int col0, double (&acc)[CW]) {
+    double l[DB];
+    if (nb == DB) {
+#pragma unroll
+        for (int k = 0; k < DB; ++k) l[k] = Frow[(int64_t)k * dim];
+    } else {
+#pragma unroll
+        for (int k = 0; k < DB; ++k) l[k] = k < nb ? Frow[(int64_t)k * dim] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < DB; ++k)
+#pragma unroll
+        for (int jj = 0; jj < CW; ++jj) acc[jj] = fma(-l[k], Y[k][col0 + jj], acc[jj]);
+}
+
 // forward substitution of one level: v = [b'_S ; 0] + children's contributions, rows permuted like the
 // factorisation's, y_S = L11^-1 v_S, v_B -= L21 y_S.  y_S stays in v[0:s), the contribution in v[s:dim).
 template <int BS, int NR>
@@ -676,7 +696,9 @@ __global__ __launch_bounds__(BS) void forward_level(Tree T, const int32_t *__res
                                                     const int32_t *__restrict__ lperm, const double *__restrict__ xb,
                                                     double *__restrict__ vec) {
     constexpr int CW = ColGroup<NR>::CW, CG = ColGroup<NR>::CG;
-    __shared__ double Y[DB][NR];
+    __shared__ double Y[DB][NR];       // the block's solved rows (zero rows behind a short last block)
+    __shared__ double Vb[DB][NR];      // ... before the multiplication by inv(L_bb)
+    __shared__ double Li[DB][DB + 1];  // inv(L_bb)
     const int32_t t = sns[blockIdx.x];
     const int start = T.sn_start[t];
     const int s = T.sn_start[t + 1] - start;
@@ -704,25 +726,29 @@ __global__ __launch_bounds__(BS) void forward_level(Tree T, const int32_t *__res
     __syncthreads();
     for (int b0 = 0; b0 < s; b0 += DB) {
         const int nb = s - b0 < DB ? s - b0 : DB;
-        for (int e = tid; e < nb * NR; e += BS) {  // y_b = inv(L_bb) v_b (unit diagonal)
+        // the block and its rows of v into LDS (coalesced), the product from there
+        for (int e = tid; e < DB * DB; e += BS) {
+            const int r = e % DB, k = e / DB;
+            Li[r][k] = (r < nb && k < r) ? F[(b0 + r) + (int64_t)(b0 + k) * dim] : 0.0;
+        }
+        for (int e = tid; e < DB * NR; e += BS) Vb[e / NR][e % NR] = e < nb * NR ? v[(int64_t)b0 * NR + e] : 0.0;
+        __syncthreads();
+        for (int e = tid; e < DB * NR; e += BS) {  // y_b = inv(L_bb) v_b (unit diagonal)
             const int r = e / NR, c = e % NR;
-            double acc = v[(int64_t)(b0 + r) * NR + c];
-            for (int k = 0; k < r; ++k) acc = fma(F[(b0 + r) + (int64_t)(b0 + k) * dim], v[(int64_t)(b0 + k) * NR + c], acc);
+            double acc = Vb[r][c];
+#pragma unroll
+            for (int k = 0; k < DB; ++k) acc = fma(Li[r][k], Vb[k][c], acc);
             Y[r][c] = acc;
+            if (r < nb) v[(int64_t)(b0 + r) * NR + c] = acc;
         }
         __syncthreads();
-        for (int e = tid; e < nb * NR; e += BS) v[(int64_t)b0 * NR + e] = Y[e / NR][e % NR];
         const int below = b0 + nb, rows = dim - below;
         for (int e = tid; e < rows * CG; e += BS) {
             const int i = below + e % rows, g = e / rows;
             double acc[CW];
 #pragma unroll
             for (int jj = 0; jj < CW; ++jj) acc[jj] = v[(int64_t)i * NR + g * CW + jj];
-            for (int k = 0; k < nb; ++k) {
-                const double l = F[i + (int64_t)(b0 + k) * dim];
-#pragma unroll
-                for (int jj = 0; jj < CW; ++jj) acc[jj] = fma(-l, Y[k][g * CW + jj], acc[jj]);
-            }
+            chunk_update<NR, CW>(F + i + (int64_t)b0 * dim, dim, nb, Y, g * CW, acc);
 #pragma unroll
             for (int jj = 0; jj < CW; ++jj) v[(int64_t)i * NR + g * CW + jj] = acc[jj];
         }
@@ -737,6 +763,8 @@ __global__ __launch_bounds__(BS) void backward_level(Tree T, const int32_t *__re
                                                      double *__restrict__ vec) {
     constexpr int CW = ColGroup<NR>::CW, CG = ColGroup<NR>::CG;
     __shared__ double Y[DB][NR];
+    __shared__ double Vb[DB][NR];
+    __shared__ double Ui[DB][DB + 1];
     const int32_t t = sns[blockIdx.x];
     const int start = T.sn_start[t];
     const int s = T.sn_start[t + 1] - start;
@@ -745,43 +773,47 @@ __global__ __launch_bounds__(BS) void backward_level(Tree T, const int32_t *__re
     double *v = vec + T.vec_off[t] * NR;
     const int32_t *bidx = T.struct_idx + T.struct_ptr[t];
     const int tid = threadIdx.x;
-    for (int e = s * NR + tid; e < dim * NR; e += BS) v[e] = xb[(int64_t)bidx[e / NR - s] * NR + e % NR];
-    __syncthreads();
-    // v_S -= U12 x_B: rows over the threads (column-major: coalesced), the boundary's columns in sequence
-    for (int e = tid; e < s * CG; e += BS) {
-        const int i = e % s, g = e / s;
-        double acc[CW];
+    // v_S -= U12 x_B, the boundary's columns in chunks of DB: the chunk of x_B goes to LDS straight from the ancestors'
+    // solution, every thread then takes its row's entries of the chunk in one round trip
+    for (int c0 = s; c0 < dim; c0 += DB) {
+        const int nb = dim - c0 < DB ? dim - c0 : DB;
+        for (int e = tid; e < DB * NR; e += BS)
+            Y[e / NR][e % NR] = e < nb * NR ? xb[(int64_t)bidx[c0 - s + e / NR] * NR + e % NR] : 0.0;
+        __syncthreads();
+        for (int e = tid; e < s * CG; e += BS) {
+            const int i = e % s, g = e / s;
+            double acc[CW];
 #pragma unroll
-        for (int jj = 0; jj < CW; ++jj) acc[jj] = v[(int64_t)i * NR + g * CW + jj];
-        for (int j = s; j < dim; ++j) {
-            const double u = F[i + (int64_t)j * dim];
+            for (int jj = 0; jj < CW; ++jj) acc[jj] = v[(int64_t)i * NR + g * CW + jj];
+            chunk_update<NR, CW>(F + i + (int64_t)c0 * dim, dim, nb, Y, g * CW, acc);
 #pragma unroll
-            for (int jj = 0; jj < CW; ++jj) acc[jj] = fma(-u, v[(int64_t)j * NR + g * CW + jj], acc[jj]);
-        }
-#pragma unroll
-        for (int jj = 0; jj < CW; ++jj) v[(int64_t)i * NR + g * CW + jj] = acc[jj];
-    }
-    __syncthreads();
-    for (int b0 = ((s - 1) / DB) * DB; b0 >= 0; b0 -= DB) {
-        const int nb = s - b0 < DB ? s - b0 : DB;
-        for (int e = tid; e < nb * NR; e += BS) {  // x_b = inv(U_bb) v_b
-            const int r = e / NR, c = e % NR;
-            double acc = 0.0;
-            for (int k = r; k < nb; ++k) acc = fma(F[(b0 + r) + (int64_t)(b0 + k) * dim], v[(int64_t)(b0 + k) * NR + c], acc);
-            Y[r][c] = acc;
+            for (int jj = 0; jj < CW; ++jj) v[(int64_t)i * NR + g * CW + jj] = acc[jj];
         }
         __syncthreads();
-        for (int e = tid; e < nb * NR; e += BS) v[(int64_t)b0 * NR + e] = Y[e / NR][e % NR];
+    }
+    for (int b0 = ((s - 1) / DB) * DB; b0 >= 0; b0 -= DB) {
+        const int nb = s - b0 < DB ? s - b0 : DB;
+        for (int e = tid; e < DB * DB; e += BS) {
+            const int r = e % DB, k = e / DB;
+            Ui[r][k] = (k < nb && r <= k) ? F[(b0 + r) + (int64_t)(b0 + k) * dim] : 0.0;
+        }
+        for (int e = tid; e < DB * NR; e += BS) Vb[e / NR][e % NR] = e < nb * NR ? v[(int64_t)b0 * NR + e] : 0.0;
+        __syncthreads();
+        for (int e = tid; e < DB * NR; e += BS) {  // x_b = inv(U_bb) v_b
+            const int r = e / NR, c = e % NR;
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < DB; ++k) acc = fma(Ui[r][k], Vb[k][c], acc);
+            Y[r][c] = acc;
+            if (r < nb) v[(int64_t)(b0 + r) * NR + c] = acc;
+        }
+        __syncthreads();
         for (int e = tid; e < b0 * CG; e += BS) {  // the rows above
             const int i = e % b0, g = e / b0;
             double acc[CW];
 #pragma unroll
             for (int jj = 0; jj < CW; ++jj) acc[jj] = v[(int64_t)i * NR + g * CW + jj];
-            for (int k = 0; k < nb; ++k) {
-                const double u = F[i + (int64_t)(b0 + k) * dim];
-#pragma unroll
-                for (int jj = 0; jj < CW; ++jj) acc[jj] = fma(-u, Y[k][g * CW + jj], acc[jj]);
-            }
+            chunk_update<NR, CW>(F + i + (int64_t)b0 * dim, dim, nb, Y, g * CW, acc);
 #pragma unroll
             for (int jj = 0; jj < CW; ++jj) v[(int64_t)i * NR + g * CW + jj] = acc[jj];
         }
