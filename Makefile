@@ -23,7 +23,7 @@ $(LIB): $(OBJ)
 
 # host-side netlist tokenizer (front-end, optional: fastparse.py falls back to pandas without it)
 $(CSVLIB): nodal_amd/csrc/fastcsv.cpp
-	g++ -O2 -std=c++17 -fPIC -shared -Wall -o $@ $<
+	g++ -O2 -std=c++17 -fPIC -shared -pthread -Wall -o $@ $<
 
 oracle:
 	$(MAKE) -C oracle

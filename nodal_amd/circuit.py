@@ -116,6 +116,8 @@ class Circuit:
             raise exc
         self._assemble(table)
         if getattr(nl, "_fast", False):
+            if not nl._is_anom.any():  # (no branch unknowns: the names are not even looked at)
+                return []
             return nl._name[nl._is_anom].tolist()
         comps = nl.components
         return [key for key in nl.component_keys if comps[key].type in c.NODE_TYPES_ANOM]
@@ -207,11 +209,20 @@ class Solution:
 
     def __init__(self, result, netlist, currents):
         self.result = result
-        self.nodenum = netlist.nodenum
+        self._netlist = netlist
         self.nums = netlist.nums
         self.currents = currents
         self.ground = netlist.ground
-        self.anomnum = netlist.anomnum
+
+    # (the netlist's own dicts, as in the reference -- nodal/nodal.py:416-420 aliases them -- but looked at only when
+    # somebody does: a natively read netlist builds them on first access)
+    @property
+    def nodenum(self):
+        return self._netlist.nodenum
+
+    @property
+    def anomnum(self):
+        return self._netlist.anomnum
 
     def __str__(self):
         # values as str(np.float64) prints them (shortest round-trip repr), names in

@@ -12,11 +12,14 @@
 // This is front-end plumbing (strings -> integers), not part of the GPU hot path; it is
 // built with g++ into nodal_amd/libnodal_csv.so and is optional (fastparse.py falls back to
 // the pandas reader without it).
+#include <atomic>
 #include <cerrno>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <string_view>
+#include <thread>
+#include <utility>
 #include <vector>
 
 extern "C" {
@@ -167,58 +170,44 @@ static bool parse_plain_decimal(std::string_view v, double *out) {
     return true;
 }
 
-template <class T>
-static T *dup(const std::vector<T> &v) {
-    T *p = static_cast<T *>(malloc(v.size() * sizeof(T) + 8));
-    if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
-    return p;
-}
-
-extern "C" {
-
-int nodal_csv_parse(const char *buf, int64_t len, nodal_csv_result *out) {
-    memset(out, 0, sizeof *out);
-    std::vector<int64_t> line_off;
-    std::vector<int32_t> line_len, acode, bcode;
+// ---- one chunk of the file (whole lines), tokenized on its own thread --------------------------------------------
+// Round 5: the file is cut at newlines into one chunk per host thread.  A chunk splits its lines, checks them and
+// numbers ITS node labels in order of first appearance in a table of its own; afterwards the chunks' label lists are
+// merged in file order -- a label is new to the file in the first chunk that holds it, and inside a chunk the new
+// labels keep their local order, which is exactly the order of first appearance in the file (anode before bnode,
+// rows in file order: the dict insertion order the reference's numbering depends on, nodal/nodal.py:222-257).
+// Both merges -- labels, and the uniqueness of the component names -- run on the same threads, split by hash bucket.
+struct Chunk {
+    int64_t begin = 0, end = 0;   // byte range [begin, end): whole lines
+    int64_t nlines = 0;           // physical lines read (all of them unless the chunk stopped at an irregular line)
+    int status = CSV_OK;          // the chunk's first irregular line, if any (it stops there)
+    int64_t bad_local = 0;
+    std::vector<int64_t> line_off, row_line;  // per component row: offset of its line; local physical line number
+    std::vector<int32_t> line_len, la, lb;    // ...: length of its line; LOCAL ids of its two lead labels
     std::vector<uint8_t> type_idx, nfields;
     std::vector<double> value;
-    const size_t guess = (size_t)(len / 24 + 16);
-    line_off.reserve(guess); line_len.reserve(guess); acode.reserve(guess); bcode.reserve(guess);
-    type_idx.reserve(guess); nfields.reserve(guess); value.reserve(guess);
-    StringIds name_ids(guess), node_ids(guess / 2);
+    std::vector<std::string_view> name;
+    std::vector<uint64_t> hname;
+    StringIds labels{64};
+    // filled by the merge
+    std::vector<int32_t> gid;                 // local label id -> id in the file's first-appearance order
+    std::vector<uint8_t> is_new;              // the label appears in no earlier chunk
+    std::vector<std::pair<int32_t, int32_t>> canon;  // (chunk, local id) of its first appearance otherwise
+    int64_t line_base = 0, row_base = 0, new_base = 0, new_count = 0, name_bytes = 0, label_bytes = 0;
+};
+
+static void tokenize_chunk(const char *buf, Chunk &ck) {
+    const int64_t len = ck.end;
+    const size_t guess = (size_t)((ck.end - ck.begin) / 24 + 16);
+    ck.line_off.reserve(guess); ck.row_line.reserve(guess); ck.line_len.reserve(guess); ck.la.reserve(guess);
+    ck.lb.reserve(guess); ck.type_idx.reserve(guess); ck.nfields.reserve(guess); ck.value.reserve(guess);
+    ck.name.reserve(guess); ck.hname.reserve(guess);
+    ck.labels = StringIds(guess / 2);
     auto fail = [&](int status, int64_t line) {
-        out->status = status;
-        out->bad_line = line;
-        return status;
+        ck.status = status;
+        ck.bad_local = line;
     };
-
-    // Two phases per block of rows: tokenize BLOCK rows, hashing their name and lead labels and
-    // requesting the table slots; then run the table operations in file order (first-appearance ids,
-    // first duplicate reported).  Errors found while tokenizing a later row of the block are only
-    // returned after the earlier rows' table operations, so the FIRST irregular line is reported.
-    constexpr int BLOCK = 16;
-    struct Staged { std::string_view name, a, b; uint64_t hn, ha, hb; int64_t line; };
-    Staged block[BLOCK];
-    int staged = 0;
-    auto flush = [&]() -> int {
-        for (int q = 0; q < staged; ++q) {
-            const Staged &st = block[q];
-            bool fresh = false;
-            name_ids.get(st.name, st.hn, &fresh);
-            if (!fresh) return fail(CSV_DUPLICATE_NAME, st.line);
-            acode.push_back(node_ids.get(st.a, st.ha, &fresh));  // first-appearance ids
-            bcode.push_back(node_ids.get(st.b, st.hb, &fresh));
-        }
-        staged = 0;
-        return CSV_OK;
-    };
-    // (an irregular row stops the file: the rows staged before it are checked for duplicates first)
-    auto fail_after_flush = [&](int status, int64_t line) {
-        const int st_ = flush();
-        return st_ != CSV_OK ? st_ : fail(status, line);
-    };
-
-    int64_t pos = 0, lineno = 0;
+    int64_t pos = ck.begin, lineno = 0;
     char numbuf[64];
     while (pos < len) {
         const char *nl = static_cast<const char *>(memchr(buf + pos, '\n', (size_t)(len - pos)));
@@ -227,16 +216,17 @@ int nodal_csv_parse(const char *buf, int64_t len, nodal_csv_result *out) {
         const int64_t start = pos;
         pos = next;
         const int64_t this_line = lineno++;
+        ck.nlines = lineno;
         if (end > start && buf[end - 1] == '\r') --end;
         if (end == start) continue;  // empty line: csv.reader yields [] and the reference skips it
         bool blank = true;
         for (int64_t i = start; i < end; ++i) {
             const char ch = buf[i];
-            if (ch == '"') return fail_after_flush(CSV_QUOTES, this_line);
-            if (ch == '\r') return fail_after_flush(CSV_NEWLINE_IN_FIELD, this_line);
+            if (ch == '"') return fail(CSV_QUOTES, this_line);
+            if (ch == '\r') return fail(CSV_NEWLINE_IN_FIELD, this_line);
             if (ch != ' ' && ch != '\t') blank = false;
         }
-        if (blank) return fail_after_flush(CSV_BLANK_WITH_SPACES, this_line);  // the reference raises IndexError there
+        if (blank) return fail(CSV_BLANK_WITH_SPACES, this_line);  // the reference raises IndexError there
         // split (skipinitialspace: blanks right after a delimiter / at the start are dropped)
         std::string_view f[9];
         int nf = 0;
@@ -254,24 +244,24 @@ int nodal_csv_parse(const char *buf, int64_t len, nodal_csv_result *out) {
                 break;
             }
         }
-        if (f[0].empty()) return fail_after_flush(CSV_EMPTY_FIRST_FIELD, this_line);
+        if (f[0].empty()) return fail(CSV_EMPTY_FIRST_FIELD, this_line);
         if (f[0][0] == '#') continue;  // comment row
-        if (nf > 8) return fail_after_flush(CSV_TOO_MANY_FIELDS, this_line);
-        if (nf < 2) return fail_after_flush(CSV_FIELD_COUNT, this_line);
+        if (nf > 8) return fail(CSV_TOO_MANY_FIELDS, this_line);
+        if (nf < 2) return fail(CSV_FIELD_COUNT, this_line);
         const int ti = type_index(f[1]);
-        if (ti < 0) return fail_after_flush(CSV_UNKNOWN_TYPE, this_line);
-        if (nf != TYPE_FIELDS[ti]) return fail_after_flush(CSV_FIELD_COUNT, this_line);
+        if (ti < 0) return fail(CSV_UNKNOWN_TYPE, this_line);
+        if (nf != TYPE_FIELDS[ti]) return fail(CSV_FIELD_COUNT, this_line);
         // value: plain decimal spellings only; everything float() accepts beyond that
         // ("1_0", " 1 ", "nan", "inf") goes to the exact parser
         const std::string_view v = f[2];
-        if (v.empty() || v.size() >= sizeof numbuf) return fail_after_flush(CSV_BAD_VALUE, this_line);
+        if (v.empty() || v.size() >= sizeof numbuf) return fail(CSV_BAD_VALUE, this_line);
         bool digit = false;
         for (char ch : v) {
             if (ch >= '0' && ch <= '9') digit = true;
             else if (ch != '+' && ch != '-' && ch != '.' && ch != 'e' && ch != 'E')
-                return fail_after_flush(CSV_BAD_VALUE, this_line);
+                return fail(CSV_BAD_VALUE, this_line);
         }
-        if (!digit) return fail_after_flush(CSV_BAD_VALUE, this_line);
+        if (!digit) return fail(CSV_BAD_VALUE, this_line);
         double val;
         if (!parse_plain_decimal(v, &val)) {  // exponent forms, long mantissas: strtod (correctly rounded too)
             memcpy(numbuf, v.data(), v.size());
@@ -279,63 +269,247 @@ int nodal_csv_parse(const char *buf, int64_t len, nodal_csv_result *out) {
             char *endp = nullptr;
             errno = 0;
             val = strtod(numbuf, &endp);
-            if (endp != numbuf + v.size()) return fail_after_flush(CSV_BAD_VALUE, this_line);
+            if (endp != numbuf + v.size()) return fail(CSV_BAD_VALUE, this_line);
         }
-        Staged &st = block[staged++];
-        st.name = f[0]; st.a = f[3]; st.b = f[4];
-        st.hn = StringIds::hash(f[0]); st.ha = StringIds::hash(f[3]); st.hb = StringIds::hash(f[4]);
-        st.line = this_line;
-        name_ids.prefetch(st.hn);
-        node_ids.prefetch(st.ha);
-        node_ids.prefetch(st.hb);
-        line_off.push_back(start);
-        line_len.push_back((int32_t)(end - start));
-        type_idx.push_back((uint8_t)ti);
-        nfields.push_back((uint8_t)nf);
-        value.push_back(val);
-        if (staged == BLOCK) {
-            const int st_ = flush();
-            if (st_ != CSV_OK) return st_;
+        bool fresh = false;
+        ck.la.push_back(ck.labels.get(f[3], StringIds::hash(f[3]), &fresh));  // anode before bnode
+        ck.lb.push_back(ck.labels.get(f[4], StringIds::hash(f[4]), &fresh));
+        ck.name.push_back(f[0]);
+        ck.hname.push_back(StringIds::hash(f[0]));
+        ck.row_line.push_back(this_line);
+        ck.line_off.push_back(start);
+        ck.line_len.push_back((int32_t)(end - start));
+        ck.type_idx.push_back((uint8_t)ti);
+        ck.nfields.push_back((uint8_t)nf);
+        ck.value.push_back(val);
+    }
+}
+
+// f(k) for k in [0, count) on up to `threads` host threads (the calling one included)
+template <class F>
+static void parallel_for(int count, int threads, F f) {
+    if (threads <= 1 || count <= 1) {
+        for (int k = 0; k < count; ++k) f(k);
+        return;
+    }
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (int k = next.fetch_add(1); k < count; k = next.fetch_add(1)) f(k);
+    };
+    std::vector<std::thread> th;
+    const int extra = (threads < count ? threads : count) - 1;
+    for (int t = 0; t < extra; ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+}
+
+extern "C" {
+
+int nodal_csv_parse(const char *buf, int64_t len, nodal_csv_result *out) {
+    memset(out, 0, sizeof *out);
+    auto fail = [&](int status, int64_t line) {
+        out->status = status;
+        out->bad_line = line;
+        return status;
+    };
+    // ---- chunks ----
+    int threads = (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("NODAL_HOST_THREADS")) threads = atoi(e);
+    if (threads < 1) threads = 1;
+    if (threads > 32) threads = 32;
+    // (four chunks per thread: the threads stay level, and a chunk's label table stays in the L2 cache)
+    int nchunks = threads > 1 ? 4 * threads : 1;
+    if (const char *e = getenv("NODAL_CSV_CHUNKS")) nchunks = atoi(e);  // (testing: more chunks than a small file deserves)
+    else if (len < (int64_t)nchunks * (1 << 18)) nchunks = (int)(len >> 18);
+    if (nchunks < 1) nchunks = 1;
+    if (nchunks > 256) nchunks = 256;
+    std::vector<Chunk> chunks((size_t)nchunks);
+    {
+        int64_t at = 0;
+        for (int c = 0; c < nchunks; ++c) {
+            chunks[(size_t)c].begin = at;
+            int64_t stop = c + 1 == nchunks ? len : len * (c + 1) / nchunks;
+            if (stop < at) stop = at;
+            if (c + 1 < nchunks && stop < len) {  // to the end of the line the cut falls into
+                const char *nl = static_cast<const char *>(memchr(buf + stop, '\n', (size_t)(len - stop)));
+                stop = nl ? (nl - buf) + 1 : len;
+            }
+            chunks[(size_t)c].end = stop;
+            at = stop;
         }
+    }
+    parallel_for(nchunks, threads, [&](int c) { tokenize_chunk(buf, chunks[(size_t)c]); });
+    // physical line numbers, row numbers; the first irregular line among the chunks (later ones do not count)
+    int first_bad = -1;
+    {
+        int64_t lines = 0, rows = 0;
+        for (int c = 0; c < nchunks; ++c) {
+            Chunk &ck = chunks[(size_t)c];
+            ck.line_base = lines;
+            ck.row_base = rows;
+            lines += ck.nlines;
+            rows += (int64_t)ck.name.size();
+            if (ck.status != CSV_OK) {
+                first_bad = c;
+                break;
+            }
+        }
+    }
+    const int live = first_bad >= 0 ? first_bad + 1 : nchunks;  // chunks whose rows count
+    // ---- component names must be unique: the rows by hash bucket, every bucket in file order on one thread ----
+    constexpr int BUCKETS = 32;
+    auto bucket_of = [](uint64_t h) { return (int)(h >> 59); };  // (the table slots use the low bits)
+    int64_t dup_line[BUCKETS];
+    {
+        int64_t total_rows = 0;
+        for (int c = 0; c < live; ++c) total_rows += (int64_t)chunks[(size_t)c].name.size();
+        parallel_for(BUCKETS, threads, [&](int b) {
+            dup_line[b] = -1;
+            StringIds seen((size_t)(total_rows / BUCKETS + total_rows / (4 * BUCKETS) + 16));
+            for (int c = 0; c < live && dup_line[b] < 0; ++c) {
+                const Chunk &ck = chunks[(size_t)c];
+                const size_t nrow = ck.name.size();
+                for (size_t r = 0; r < nrow; ++r) {
+                    if (bucket_of(ck.hname[r]) != b) continue;
+                    bool fresh = false;
+                    seen.get(ck.name[r], ck.hname[r], &fresh);
+                    if (!fresh) {
+                        dup_line[b] = ck.line_base + ck.row_line[r];
+                        break;
+                    }
+                }
+            }
+        });
     }
     {
-        const int st_ = flush();
-        if (st_ != CSV_OK) return st_;
-    }
-    const std::vector<std::string_view> &names = name_ids.items, &labels = node_ids.items;
-    if (names.empty()) return fail(CSV_NO_COMPONENTS, 0);
-
-    auto join = [](const std::vector<std::string_view> &v, int64_t *bytes) -> char * {
-        size_t total = 0;
-        for (const auto &s : v) total += s.size() + 1;
-        char *p = static_cast<char *>(malloc(total + 8));
-        if (!p) return nullptr;
-        size_t o = 0;
-        for (const auto &s : v) {
-            memcpy(p + o, s.data(), s.size());
-            o += s.size();
-            p[o++] = '\n';
+        // the FIRST irregular line of the file: the smallest of the chunks' own and the first repeated name
+        int64_t best_line = -1;
+        int best_status = CSV_OK;
+        if (first_bad >= 0) {
+            best_line = chunks[(size_t)first_bad].line_base + chunks[(size_t)first_bad].bad_local;
+            best_status = chunks[(size_t)first_bad].status;
         }
-        *bytes = (int64_t)(total ? total - 1 : 0);  // without the last separator
-        return p;
-    };
-    out->nrows = (int64_t)names.size();
-    out->nnodes = (int64_t)labels.size();
-    out->line_off = dup(line_off);
-    out->line_len = dup(line_len);
-    out->type_idx = dup(type_idx);
-    out->nfields = dup(nfields);
-    out->value = dup(value);
-    out->acode = dup(acode);
-    out->bcode = dup(bcode);
-    out->names_blob = join(names, &out->names_bytes);
-    out->labels_blob = join(labels, &out->labels_bytes);
+        for (int b = 0; b < BUCKETS; ++b)
+            if (dup_line[b] >= 0 && (best_line < 0 || dup_line[b] < best_line)) {
+                best_line = dup_line[b];
+                best_status = CSV_DUPLICATE_NAME;
+            }
+        if (best_status != CSV_OK) return fail(best_status, best_line);
+    }
+    int64_t nrows = 0;
+    for (const Chunk &ck : chunks) nrows += (int64_t)ck.name.size();
+    if (nrows == 0) return fail(CSV_NO_COMPONENTS, 0);
+    // ---- node labels: which chunk saw each one first ----
+    for (Chunk &ck : chunks) {
+        ck.is_new.assign(ck.labels.items.size(), 0);
+        ck.canon.assign(ck.labels.items.size(), {-1, -1});
+        ck.gid.assign(ck.labels.items.size(), -1);
+    }
+    {
+        int64_t total_labels = 0;
+        for (const Chunk &ck : chunks) total_labels += (int64_t)ck.labels.items.size();
+        parallel_for(BUCKETS, threads, [&](int b) {
+            // first[label] = (chunk, local id) of its first appearance, for the labels of this bucket
+            StringIds seen((size_t)(total_labels / BUCKETS + total_labels / (4 * BUCKETS) + 16));
+            std::vector<std::pair<int32_t, int32_t>> first;
+            for (int c = 0; c < nchunks; ++c) {
+                Chunk &ck = chunks[(size_t)c];
+                const size_t m = ck.labels.items.size();
+                for (size_t l = 0; l < m; ++l) {
+                    const uint64_t h = ck.labels.hashes[l];
+                    if (bucket_of(h) != b) continue;
+                    bool fresh = false;
+                    const int32_t e = seen.get(ck.labels.items[l], h, &fresh);
+                    if (fresh) {
+                        first.push_back({(int32_t)c, (int32_t)l});
+                        ck.is_new[l] = 1;
+                    } else {
+                        ck.canon[l] = first[(size_t)e];
+                    }
+                }
+            }
+        });
+    }
+    // ids in first-appearance order: chunk by chunk, the new labels of a chunk in its local order
+    {
+        int64_t base = 0;
+        for (Chunk &ck : chunks) {
+            ck.new_base = base;
+            int64_t k = 0, bytes = 0;
+            for (size_t l = 0; l < ck.is_new.size(); ++l)
+                if (ck.is_new[l]) {
+                    ck.gid[l] = (int32_t)(base + k++);
+                    bytes += (int64_t)ck.labels.items[l].size() + 1;
+                }
+            ck.new_count = k;
+            ck.label_bytes = bytes;
+            base += k;
+        }
+        out->nnodes = base;
+    }
+    parallel_for(nchunks, threads, [&](int c) {
+        Chunk &ck = chunks[(size_t)c];
+        for (size_t l = 0; l < ck.gid.size(); ++l)
+            if (!ck.is_new[l]) ck.gid[l] = chunks[(size_t)ck.canon[l].first].gid[(size_t)ck.canon[l].second];
+        int64_t bytes = 0;
+        for (const auto &nm : ck.name) bytes += (int64_t)nm.size() + 1;
+        ck.name_bytes = bytes;
+    });
+    // ---- output arrays ----
+    int64_t names_total = 0, labels_total = 0;
+    std::vector<int64_t> name_at((size_t)nchunks), label_at((size_t)nchunks);
+    for (int c = 0; c < nchunks; ++c) {
+        name_at[(size_t)c] = names_total;
+        label_at[(size_t)c] = labels_total;
+        names_total += chunks[(size_t)c].name_bytes;
+        labels_total += chunks[(size_t)c].label_bytes;
+    }
+    out->nrows = nrows;
+    out->line_off = static_cast<int64_t *>(malloc((size_t)nrows * 8 + 8));
+    out->line_len = static_cast<int32_t *>(malloc((size_t)nrows * 4 + 8));
+    out->type_idx = static_cast<uint8_t *>(malloc((size_t)nrows + 8));
+    out->nfields = static_cast<uint8_t *>(malloc((size_t)nrows + 8));
+    out->value = static_cast<double *>(malloc((size_t)nrows * 8 + 8));
+    out->acode = static_cast<int32_t *>(malloc((size_t)nrows * 4 + 8));
+    out->bcode = static_cast<int32_t *>(malloc((size_t)nrows * 4 + 8));
+    out->names_blob = static_cast<char *>(malloc((size_t)names_total + 8));
+    out->labels_blob = static_cast<char *>(malloc((size_t)labels_total + 8));
     if (!out->line_off || !out->line_len || !out->type_idx || !out->nfields || !out->value || !out->acode ||
         !out->bcode || !out->names_blob || !out->labels_blob) {
         nodal_csv_free(out);
         out->status = CSV_NO_MEMORY;
         return CSV_NO_MEMORY;
     }
+    parallel_for(nchunks, threads, [&](int c) {
+        const Chunk &ck = chunks[(size_t)c];
+        const size_t nrow = ck.name.size();
+        const int64_t r0 = ck.row_base;
+        if (nrow) {
+            memcpy(out->line_off + r0, ck.line_off.data(), nrow * 8);
+            memcpy(out->line_len + r0, ck.line_len.data(), nrow * 4);
+            memcpy(out->type_idx + r0, ck.type_idx.data(), nrow);
+            memcpy(out->nfields + r0, ck.nfields.data(), nrow);
+            memcpy(out->value + r0, ck.value.data(), nrow * 8);
+        }
+        char *np = out->names_blob + name_at[(size_t)c];
+        for (size_t r = 0; r < nrow; ++r) {
+            out->acode[r0 + (int64_t)r] = ck.gid[(size_t)ck.la[r]];
+            out->bcode[r0 + (int64_t)r] = ck.gid[(size_t)ck.lb[r]];
+            memcpy(np, ck.name[r].data(), ck.name[r].size());
+            np += ck.name[r].size();
+            *np++ = '\n';
+        }
+        char *lp = out->labels_blob + label_at[(size_t)c];
+        for (size_t l = 0; l < ck.is_new.size(); ++l)
+            if (ck.is_new[l]) {
+                const std::string_view &s = ck.labels.items[l];
+                memcpy(lp, s.data(), s.size());
+                lp += s.size();
+                *lp++ = '\n';
+            }
+    });
+    out->names_bytes = names_total ? names_total - 1 : 0;   // without the last separator
+    out->labels_bytes = labels_total ? labels_total - 1 : 0;
     return CSV_OK;
 }
 

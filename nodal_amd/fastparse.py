@@ -165,22 +165,106 @@ def _read_native(netlist, path, lib):
         value = arr(res.value, n)
         acode = arr(res.acode, n)
         bcode = arr(res.bcode, n)
-        try:
-            names = C.string_at(res.names_blob, res.names_bytes).decode().split("\n")
-            labels = C.string_at(res.labels_blob, res.labels_bytes).decode().split("\n")
+        names_blob = C.string_at(res.names_blob, res.names_bytes)
+        labels_blob = C.string_at(res.labels_blob, res.labels_bytes)
+        try:  # (validation only: the strings are made when somebody asks for them)
+            if not names_blob.isascii():
+                names_blob.decode()
+            if not labels_blob.isascii():
+                labels_blob.decode()
         except UnicodeDecodeError:
             raise Irregular("not UTF-8")
+        if names_blob.count(b"\n") + 1 != n or labels_blob.count(b"\n") + 1 != m:
+            raise Irregular("line structure")
     finally:
         lib.nodal_csv_free(C.byref(res))
-    if len(names) != n or len(labels) != m:
-        raise Irregular("line structure")
     nl = netlist
     nl._df = None
     nl._raw, nl._line_off, nl._line_len = raw, line_off, line_len
     nl._tidx = tidx
-    name = np.empty(n, dtype=object)
-    name[:] = names
-    return _finish_fast(nl, name, _TYPE_NAMES[tidx], value, nfields, acode, bcode, labels)
+    return _finish_native(nl, names_blob, labels_blob, n, m, value, nfields, acode, bcode)
+
+
+# ---- the public containers of a natively read netlist, built when somebody asks for them --------------------
+# Round 5: `Netlist(path)` of the 2e6-row grid(1000) file spent as long building Python objects -- two million name
+# strings, a million labels, the degrees and nodenum dicts -- as tokenizing the file, and `Circuit(netlist)` +
+# `.solve()` read none of them (the lowering works on the integer columns).  The native reader keeps the two string
+# blobs and the columns; `component_keys`, `degrees`, `nodenum`, `anomnum` (and the private name array) are made on
+# first access (Netlist.__getattr__), with exactly the contents the eager build had: same keys, same insertion
+# order, same values.  `ground`, `nums` and the integer columns are there at once.
+LAZY_ATTRIBUTES = ("component_keys", "degrees", "nodenum", "anomnum", "_name", "_labels", "_names_list")
+
+
+def _finish_native(nl, names_blob, labels_blob, n, m, value, nfields, acode, bcode):
+    deg = np.bincount(acode, minlength=m) + np.bincount(bcode, minlength=m)
+    nl._fast = True
+    nl._names_blob, nl._labels_blob = names_blob, labels_blob
+    nl._nrows_file, nl._nlabels = int(n), int(m)
+    nl._deg = deg
+    nl._type, nl._value = _TYPE_NAMES[nl._tidx], value
+    nl._nfields = nfields
+    nl._acode, nl._bcode = acode, bcode
+    for key in LAZY_ATTRIBUTES + ("_row_of",):
+        nl.__dict__.pop(key, None)
+    nl.components = LazyComponents(nl)
+    is_anom = nl._tidx >= 2  # everything after R, A owns a branch current
+    nl._is_anom = is_anom
+    nanom = int(np.count_nonzero(is_anom))
+    nl.nums["components"] = int(n)
+    nl.nums["anomalies"] = nanom
+    # ground: "g" if present, else the first node of maximal degree (labels are unique: one whole-label match at most)
+    lb = labels_blob
+    if lb == b"g" or lb.startswith(b"g\n"):
+        gcode = 0
+    else:
+        at = lb.find(b"\ng\n")
+        if at < 0 and lb.endswith(b"\ng"):
+            at = len(lb) - 2
+        gcode = lb.count(b"\n", 0, at + 1) if at >= 0 else -1
+    if gcode >= 0:
+        nl.ground = "g"
+    else:
+        gcode = int(np.argmax(deg))
+        nl.ground = nl._labels[gcode]
+    nl._gcode = gcode
+    node_index = np.arange(m, dtype=np.int64)
+    node_index[gcode + 1:] -= 1
+    node_index[gcode] = -1
+    nl._node_index = node_index  # label code -> nodenum index (-1 = ground)
+    nl.nums["kcl"] = m - 1
+    nl.nums["be"] = nanom
+    return nl
+
+
+def materialise(nl, name):
+    """One of LAZY_ATTRIBUTES of a natively read netlist (called by Netlist.__getattr__, once per attribute)."""
+    d = nl.__dict__
+    if name == "_names_list":
+        value = d["_names_blob"].decode().split("\n")
+    elif name == "_labels":
+        value = d["_labels_blob"].decode().split("\n")
+    elif name == "component_keys":
+        value = list(nl._names_list)
+    elif name == "_name":
+        value = np.empty(d["_nrows_file"], dtype=object)
+        value[:] = nl._names_list
+    elif name == "degrees":
+        value = dict(zip(nl._labels, d["_deg"].tolist()))
+    elif name == "nodenum":
+        labels, gcode = nl._labels, d["_gcode"]
+        order = labels[:gcode] + labels[gcode + 1:]
+        value = dict(zip(order, range(len(order))))
+    elif name == "anomnum":
+        rows = np.flatnonzero(d["_is_anom"][: d["_nrows_file"]])
+        if len(rows) == 0:
+            value = {}
+        else:
+            names = nl._names_list
+            value = {names[r]: k for k, r in enumerate(rows.tolist())}
+    else:
+        raise AttributeError(name)
+    d[name] = value
+    return value
 
 
 def read_fast(netlist, path):

@@ -144,6 +144,11 @@ class Netlist:
         self.opmodel_equivalents = []
 
     def __getattr__(self, name):
+        # natively read netlists build their public containers when somebody asks for them (fastparse.materialise)
+        if self.__dict__.get("_fast") and "_names_blob" in self.__dict__:
+            from . import fastparse
+            if name in fastparse.LAZY_ATTRIBUTES:
+                return fastparse.materialise(self, name)
         # vectorised netlists build their name -> row map only when somebody asks for it
         if name == "_row_of" and self.__dict__.get("_fast"):
             row_of = dict(zip(self.component_keys, range(len(self.component_keys))))
@@ -166,7 +171,8 @@ class Netlist:
         clone = self.__class__.__new__(self.__class__)
         memo[id(self)] = clone
         shared = {"_raw", "_line_off", "_line_len", "_tidx", "_df", "_name", "_type", "_value", "_nfields",
-                  "_acode", "_bcode", "_is_anom", "_node_index"}
+                  "_acode", "_bcode", "_is_anom", "_node_index", "_names_blob", "_labels_blob", "_deg",
+                  "_names_list", "_labels"}
         for key, value in self.__dict__.items():
             if key == "_row_of":
                 continue  # rebuilt on demand

