@@ -11,6 +11,49 @@ level-0 passes: rows x bytes per row of what the kernel reads and writes (DESIGN
 """
 import glob, json, sqlite3, sys
 
+W0 = 5  # padded ELL width of the grid's level 0
+_F32ROW = W0 * 8          # col i32 + val f32 per slot
+_F64ROW = W0 * 12
+# bytes per level-0 row of each pass (reads + writes; the outer iteration's vectors x, r, p, Ap are f64, the
+# vectors inside the cycle -- x0, the cycle's residual, xp, z -- f32 since round 4: csrc/sagg.hip, cyc_t)
+LEVEL0_BYTES = {
+    "k_smooth_residual": _F32ROW + 8 + 4 + 4,            # A, b (f64: the outer residual), x0 gather, r
+    "k_restrict": 4 * 8 + 4 + 8 / 7.0,                   # R entries (col + f32 val) of the 4 P slots per fine row, r, rc
+    "k_prolong": 4 * 8 + 4 + 4 + 8 / 7.0,                # P (col + f32 val) x 4, x, xp, coarse gathers
+    "k_post": _F32ROW + 8 + 4 + 4 + 4 + 8 + 8,           # A, b (f64), xp gather + own, out (z), u (Ap, f64), dinv
+    "f_spmv": _F64ROW + 8 + 8 + 8,                       # A (f64), p gather + own, Ap
+    "f_direction": 4 + 8 + 8,                            # z, p, p
+    "f_update": 8 * 4 + 8 * 2 + 4 + 8,                   # x r p Ap in, x r out, x0 out, dinv
+    "f_init": 8 * 2 + 8 * 3 + 4,
+}
+SETUP_NAMES = ("mis_", "assign_", "build_P", "r_count", "r_fill", "r_sort", "r_to_ell", "r_refresh", "ap_rows",
+               "galerkin", "coarsest_inverse", "flags_up", "last_level", "any_unflagged", "k_tail_pack", "row_stats",
+               "csr_to_ell", "reduce_bstat", "scan_", "grounded_flags", "select_nodes")
+STAMP_NAMES = ("grp::", "fold_matrix", "fold_rhs", "set_tail")
+
+
+def short(name):
+    nm = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return nm.split("(")[0]
+
+
+def class_of(nm, grid_threads, wg_threads, n):
+    """(class, base kernel name) of one dispatch: kernel name AND grid size (see the module docstring).  `nm` is the
+    short kernel name (no namespace, no argument list), the sizes are in threads."""
+    base = nm.split("<")[0]
+    wgs = (grid_threads / wg_threads) if (grid_threads and wg_threads) else 0
+    big = n / 256 * 0.9  # a grid that covers the level-0 rows (one thread per row, 256 per workgroup)
+    if any(base.startswith(p) or p in nm for p in STAMP_NAMES):
+        return "stamping", base
+    if any(base.startswith(p) for p in SETUP_NAMES):
+        return "hierarchy_setup", base
+    if base in LEVEL0_BYTES and (wgs >= big or nm.startswith(base + "<%d" % W0) or
+                                 base in ("f_spmv", "f_direction", "f_update", "f_init")):
+        return "level0_passes", base
+    if base.startswith("k_") or base.startswith("f_"):
+        return "coarse_levels", base
+    return "other", base
+
 
 def classify(path, workload, n, nnz, verbose=False):
     """Classes of kernels of one rocprofv3 --kernel-trace results.db (a directory is searched for it)."""
@@ -25,32 +68,10 @@ def classify(path, workload, n, nnz, verbose=False):
     wcol = next((x for x in ("workgroup_size_x", "workgroup_x", "workgroup_size") if x in cols), None)
     q = f"select name, start, end, {gcol or 0}, {wcol or 1} from {kt} order by start"
     rows = list(c.execute(q))
-    W = 5  # padded ELL width of the grid's level 0
-    f32row = W * 8          # col i32 + val f32 per slot
-    f64row = W * 12
-    # bytes per level-0 row of each pass (reads + writes; the outer iteration's vectors x, r, p, Ap are f64, the
-    # vectors inside the cycle -- x0, the cycle's residual, xp, z -- f32 since round 4: csrc/sagg.hip, cyc_t)
-    level0_bytes = {
-        "k_smooth_residual": f32row + 8 + 4 + 4,            # A, b (f64: the outer residual), x0 gather, r
-        "k_restrict": 4 * 8 + 4 + 8 / 7.0,                  # R entries (col + f32 val) of the 4 P slots per fine row, r, rc
-        "k_prolong": 4 * 8 + 4 + 4 + 8 / 7.0,               # P (col + f32 val) x 4, x, xp, coarse gathers
-        "k_post": f32row + 8 + 4 + 4 + 4 + 8 + 8,           # A, b (f64), xp gather + own, out (z), u (Ap, f64), dinv
-        "f_spmv": f64row + 8 + 8 + 8,                       # A (f64), p gather + own, Ap
-        "f_direction": 4 + 8 + 8,                           # z, p, p
-        "f_update": 8 * 4 + 8 * 2 + 4 + 8,                  # x r p Ap in, x r out, x0 out, dinv
-        "f_init": 8 * 2 + 8 * 3 + 4,
-    }
-    setup_names = ("mis_", "assign_", "build_P", "r_count", "r_fill", "r_sort", "r_to_ell", "r_refresh", "ap_rows",
-                   "galerkin", "coarsest_inverse", "flags_up", "last_level", "any_unflagged", "k_tail_pack", "row_stats",
-                   "csr_to_ell", "reduce_bstat", "scan_", "grounded_flags", "select_nodes")
-    stamp_names = ("grp::", "fold_matrix", "fold_rhs", "set_tail")
+
     classes = {}
     per_kernel = {}
     total = 0
-
-    def short(name):
-        nm = name.replace("(anonymous namespace)::", "").replace("void ", "")
-        return nm.split("(")[0]
 
     def add(cls, dur, nbytes=0.0):
         a = classes.setdefault(cls, {"us": 0.0, "launches": 0, "alg_bytes": 0.0})
@@ -58,7 +79,6 @@ def classify(path, workload, n, nnz, verbose=False):
         a["launches"] += 1
         a["alg_bytes"] += nbytes
 
-    big = n / 256 * 0.9  # a grid that covers the level-0 rows (one thread per row, 256 per workgroup)
     for name, start, end, grid, wg in rows:
         nm = short(name)
         dur = end - start
@@ -66,21 +86,16 @@ def classify(path, workload, n, nnz, verbose=False):
         pk = per_kernel.setdefault(nm, [0, 0])
         pk[0] += 1
         pk[1] += dur
-        wgs = (grid / wg) if (gcol and wcol and wg) else 0
-        base = nm.split("<")[0]
-        if any(base.startswith(p) or p in nm for p in stamp_names):
-            add("stamping", dur)
-        elif any(base.startswith(p) for p in setup_names):
-            add("hierarchy_setup", dur)
-        elif base in level0_bytes and (wgs >= big or nm.startswith(base + "<%d" % W) or
-                                       base in ("f_spmv", "f_direction", "f_update", "f_init")):
-            add("level0_passes", dur, level0_bytes[base] * n)
-        elif base.startswith("k_") or base.startswith("f_"):
+        cls, base = class_of(nm, grid if gcol else 0, wg if wcol else 0, n)
+        if cls == "level0_passes":
+            add(cls, dur, LEVEL0_BYTES[base] * n)
+        elif cls == "coarse_levels":
             # (a coarse level's row kernel: one thread per row; 64 B per row is what a 5-to-16-entry f32 ELL row plus
-            # its vectors comes to -- an estimate, the class is latency-bound whatever the bytes)
-            add("coarse_levels", dur, 64.0 * (grid if gcol else 0))
+            # its vectors comes to -- an ESTIMATE, the class is latency-bound whatever the bytes; the counter figure
+            # is in profiles/<round>_pmc_by_class.json, tools/pmc_by_class.py)
+            add(cls, dur, 64.0 * (grid if gcol else 0))
         else:
-            add("other", dur)
+            add(cls, dur)
     out_classes = {}
     for cls, a in classes.items():
         e = {"share_of_gpu_time": a["us"] * 1e3 / total, "us": a["us"], "launches": a["launches"]}
