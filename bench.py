@@ -53,7 +53,7 @@ FP64_MFMA_INSTR_TF = 36.2   # v_mfma_f64_16x16x4_f64, 138 cycles/instruction/wav
 FP64_VALU_FMA_TF = 59.3     # v_fma_f64
 
 CIRCUITS_PER_STEP = {"cfg3": 32, "cfg5": 16, "cfg2": 8, "cfg4": 128}
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def pmc_traffic(workload):
@@ -64,6 +64,22 @@ def pmc_traffic(workload):
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")) as f:
                 return json.load(f)["dominant"][workload]["hbm_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
+
+
+def pmc_by_class(workload):
+    """HBM bytes per dispatch of every class of kernel, from counters: the committed rocprofv3 --pmc passes of
+    `bench.py --workload W` summed per class by tools/pmc_by_class.py (profiles/<round>_pmc_by_class.json; the counters
+    cannot be collected inside the timed run).  None when that workload was not profiled."""
+    for rnd in (PROFILE_ROUND,):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_by_class.json")) as f:
+                got = json.load(f)
+            if got.get("workload") == workload:
+                got["file"] = f"profiles/{rnd}_pmc_by_class.json"
+                return got
         except Exception:
             continue
     return None
@@ -506,15 +522,31 @@ def roofline_of(st, circuits_per_sec_per_gpu):
                                      "per dependent launch whatever the rows)",
                     "level0_passes": "level-0 passes (smoother, transfer, Krylov kernels over the 1e6-row level)",
                     "hierarchy_setup": "multigrid setup kernels", "stamping": "stamping kernels"}.get(dom, dom)
+            # bytes from counters where a committed PMC pass has them (per dispatch of the class), else none; the
+            # algorithmic bytes of the coarse levels are an ESTIMATE (64 B x grid threads: tools/prof_classes.py) and say so
+            pmc = pmc_by_class(st["name"])
+            pmc_cls = (pmc or {}).get("by_class", {}).get(dom)
+            avg_us = d.get("us", 0.0) / launches
+            traffic = pmc_cls.get("hbm_bytes_per_dispatch") if pmc_cls else None
             out = {"bound": "hbm", "kernel": f"class `{dom}`: {what}", "achieved": gbs, "peak": HBM_PEAK_GBS,
                    "unit": "GB/s", "frac": (gbs / HBM_PEAK_GBS) if gbs else None,
-                   "traffic": None, "share_of_gpu_time": d.get("share_of_gpu_time"),
-                   "avg_launch_us": d.get("us", 0.0) / launches, "launches": d.get("launches"),
+                   "achieved_is": ("algorithmic bytes ESTIMATED as 64 B x grid threads / measured time" if dom == "coarse_levels"
+                                   else "algorithmic bytes (rows x bytes per row) / measured time"),
+                   "traffic": traffic,
+                   "traffic_source": (f"{pmc['file']}: FETCH_SIZE x 2 + WRITE_SIZE of every dispatch of the class, separate "
+                                      "--pmc passes (tools/pmc_by_class.py)") if traffic else None,
+                   "traffic_GB_per_s": (traffic / (avg_us * 1e-6) / 1e9) if traffic and avg_us else None,
+                   "traffic_frac_of_peak": (traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic and avg_us else None,
+                   "share_of_gpu_time": d.get("share_of_gpu_time"),
+                   "avg_launch_us": avg_us, "launches": d.get("launches"),
                    "alg_bytes_per_launch": (d.get("alg_bytes", 0.0) / launches) if d.get("alg_bytes") else None,
                    "how": "kernel durations of this run's rocprofv3 --kernel-trace child, summed per class; algorithmic "
                           "bytes per launch = rows x bytes per row of what the kernel reads and writes "
                           "(tools/prof_classes.py)",
                    "best_kernel": best}
+            if pmc:
+                out["hbm_bytes_per_circuit_by_class"] = {k: v.get("hbm_bytes_per_circuit") for k, v in pmc["by_class"].items()}
+                out["hbm_bytes_per_circuit"] = pmc.get("hbm_bytes_per_circuit")
             out["top_kernel_by_time"] = classes.get("top_kernel_by_time")
             out["by_class"] = by
             out["by_class_source"] = classes.get("source")
