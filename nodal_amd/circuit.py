@@ -41,27 +41,35 @@ def default_device():
 # Device contexts are expensive to create (four HIP streams, one of them CU-masked, a dozen
 # events: ~30 ms) and cheap to reuse (their buffers grow on demand), so a Circuit borrows one
 # from this pool and hands it back when it is garbage collected.
+# (The pool is touched from Circuit.__del__, i.e. from whatever thread the collector runs on, while the lanes of a
+# long resistance sweep build Circuits on threads of their own (equiv.py): one lock around every look at it.  A
+# re-entrant one: a collection triggered inside the locked region may run another Circuit's __del__ on this thread.)
+import threading
+
 _IDLE_HANDLES = {}
 _MAX_IDLE = 4
+_POOL_LOCK = threading.RLock()
 
 
 def _acquire_handle(device):
-    idle = _IDLE_HANDLES.get(device)
-    while idle:
-        h = idle.pop()
-        if not h.closed:
-            return h
+    with _POOL_LOCK:
+        idle = _IDLE_HANDLES.get(device)
+        while idle:
+            h = idle.pop()
+            if not h.closed:
+                return h
     return _ffi.Handle(device)
 
 
 def _release_handle(device, h):
     if h is None or h.closed:
         return
-    idle = _IDLE_HANDLES.setdefault(device, [])
-    if len(idle) < _MAX_IDLE:
-        idle.append(h)
-    else:
-        h.close()
+    with _POOL_LOCK:
+        idle = _IDLE_HANDLES.setdefault(device, [])
+        if len(idle) < _MAX_IDLE:
+            idle.append(h)
+            return
+    h.close()
 
 
 class Circuit:
