@@ -1048,9 +1048,21 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor, double tiny_thre
         if (nsmall > 0) {
             if (wide) factor_fronts<1024><<<nsmall, 1024, 0, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl,
                                                                   S->stats.as<unsigned long long>());
-            else if (fronts_in_lds && (size_t)S->lvl_maxdim[(size_t)l] * S->lvl_maxdim[(size_t)l] * 8 <= 56 * 1024)
-                factor_fronts<256, true><<<nsmall, 256, (size_t)S->lvl_maxdim[(size_t)l] * S->lvl_maxdim[(size_t)l] * 8, st>>>(
-                    T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl, S->stats.as<unsigned long long>());
+            else if (fronts_in_lds && (size_t)S->lvl_maxdim[(size_t)l] * S->lvl_maxdim[(size_t)l] * 8 <= 56 * 1024) {
+                // (NODAL_DIRECT_LDS_BS: threads per front of the in-LDS kernel -- one wavefront per front makes its four
+                // barriers per column step next to free; round 5)
+                static const int lds_bs = getenv("NODAL_DIRECT_LDS_BS") ? atoi(getenv("NODAL_DIRECT_LDS_BS")) : 64;
+                const size_t lds = (size_t)S->lvl_maxdim[(size_t)l] * S->lvl_maxdim[(size_t)l] * 8;
+                if (lds_bs == 64)
+                    factor_fronts<64, true><<<nsmall, 64, lds, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl,
+                                                                     S->stats.as<unsigned long long>());
+                else if (lds_bs == 128)
+                    factor_fronts<128, true><<<nsmall, 128, lds, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl,
+                                                                       S->stats.as<unsigned long long>());
+                else
+                    factor_fronts<256, true><<<nsmall, 256, lds, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl,
+                                                                       S->stats.as<unsigned long long>());
+            }
             else factor_fronts<256><<<nsmall, 256, 0, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl,
                                                             S->stats.as<unsigned long long>());
         }
