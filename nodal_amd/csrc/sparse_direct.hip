@@ -300,7 +300,7 @@ __global__ __launch_bounds__(BS) void factor_fronts(Tree T, const int32_t *__res
 // the rest of the front, the U block row by a triangular solve over the columns, and the trailing update
 // A22 -= L21 U12 by the fp64 MFMA GEMM of gemm_f64.hip -- the one place of the sparse path where the matrix cores
 // have work (north_star: MFMA where G is dense enough to be a panel factorisation).
-constexpr int BIG_DIM = 512;
+constexpr int BIG_DIM = 192;  // (512 until round 5: the fronts between are stepped with the wide ones now)
 constexpr int NBB = 64;  // (64: the panel kernel -- one CU's bandwidth -- 694 us and the triangular solve 375 us per panel, its 64 values per thread spilling)
 
 __global__ __launch_bounds__(256) void iota_i32(int32_t *__restrict__ p, int n) {
@@ -309,9 +309,9 @@ __global__ __launch_bounds__(256) void iota_i32(int32_t *__restrict__ p, int n) 
 
 // columns [k0, k0 + nb) of the front, rows k0 .. dim-1: right-looking within the panel, pivot rows among
 // k .. s-1 recorded in piv[0 .. nb) (rows are interchanged inside the panel only: apply_swaps does the rest)
-__global__ __launch_bounds__(1024) void panel_factor(double *__restrict__ F, int dim, int s, int k0, int nb,
-                                                     int32_t *__restrict__ piv, double tiny, double repl,
-                                                     unsigned long long *__restrict__ stats) {
+__device__ __forceinline__ void panel_factor_body(double *__restrict__ F, int dim, int s, int k0, int nb,
+                                                  int32_t *__restrict__ piv, double tiny, double repl,
+                                                  unsigned long long *__restrict__ stats) {
     constexpr int BS = 1024, NW = BS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ double red_v[NW];
@@ -369,6 +369,12 @@ __global__ __launch_bounds__(1024) void panel_factor(double *__restrict__ F, int
     }
 }
 
+__global__ __launch_bounds__(1024) void panel_factor(double *__restrict__ F, int dim, int s, int k0, int nb,
+                                                     int32_t *__restrict__ piv, double tiny, double repl,
+                                                     unsigned long long *__restrict__ stats) {
+    panel_factor_body(F, dim, s, k0, nb, piv, tiny, repl, stats);
+}
+
 // The same panel with its rows IN REGISTERS: thread t keeps rows k0 + t, k0 + t + 256, ... (RPT of them) of the
 // panel's PNB columns, loaded once and stored once; a column step is a block arg-max (shuffles + one LDS round), the
 // pivot row and row k through LDS, and the rank-1 update in registers -- no global memory inside the loop, where the
@@ -378,9 +384,9 @@ __global__ __launch_bounds__(1024) void panel_factor(double *__restrict__ F, int
 // bit-identical factors.  Panels of at most RPT * 256 rows (RPT <= 6: 96 values per thread).
 constexpr int PNB = 16;
 template <int RPT>
-__global__ __launch_bounds__(256) void panel_factor_regs(double *__restrict__ F, int dim, int s, int k0, int nb,
-                                                          int32_t *__restrict__ piv, double tiny, double repl,
-                                                          unsigned long long *__restrict__ stats) {
+__device__ __forceinline__ void panel_factor_regs_body(double *__restrict__ F, int dim, int s, int k0, int nb,
+                                                       int32_t *__restrict__ piv, double tiny, double repl,
+                                                       unsigned long long *__restrict__ stats) {
     constexpr int BS = 256, NW = BS / 64;  // (256 threads: a budget of 256 registers each; 512 / 1024 threads leave 128 / 64 and spill)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ double red_v[NW];
@@ -489,6 +495,158 @@ __global__ __launch_bounds__(256) void panel_factor_regs(double *__restrict__ F,
         for (int c = 0; c < PNB; ++c)
             if (i < dim && c < nb) F[i + (int64_t)(k0 + c) * dim] = a[r][c];
     }
+}
+
+template <int RPT>
+__global__ __launch_bounds__(256) void panel_factor_regs(double *__restrict__ F, int dim, int s, int k0, int nb,
+                                                          int32_t *__restrict__ piv, double tiny, double repl,
+                                                          unsigned long long *__restrict__ stats) {
+    panel_factor_regs_body<RPT>(F, dim, s, k0, nb, piv, tiny, repl, stats);
+}
+
+// ---- the same steps for ALL the wide fronts of a level at once (round 5) ------------------------------------------
+// Round 4 walked every wide front's panels from the host, front after front (four side by side on streams of their
+// own): a chain of one-workgroup panel kernels, 100 us per 16 columns per front.  The fronts of a level are independent
+// and their panels line up: step k0 of the level is ONE panel launch over its fronts (blockIdx = front; a front whose
+// pivot columns are exhausted returns at once), one launch for the interchanges, one for the U block rows, one for the
+// rank-16 updates of all trailing blocks (64 x 64 tiles, blockIdx.z = front).  A level costs 4 launches per 16 pivot
+// columns of its WIDEST front whatever the number of fronts, and the fronts between 192 and 512 rows -- one workgroup
+// each until now, their trailing blocks streamed through one compute unit -- take the same path.
+struct FrontRef { double *F; int dim, s; int32_t *perm; };
+__device__ __forceinline__ FrontRef front_ref(const Tree &T, const int32_t *__restrict__ sns, int which,
+                                              double *__restrict__ fronts, int32_t *__restrict__ lperm) {
+    const int32_t t = sns[which];
+    FrontRef f;
+    f.s = T.sn_start[t + 1] - T.sn_start[t];
+    f.dim = f.s + (int)(T.struct_ptr[t + 1] - T.struct_ptr[t]);
+    f.F = fronts + T.front_off[t];
+    f.perm = lperm + T.sn_start[t];
+    return f;
+}
+
+__global__ __launch_bounds__(256) void level_iota(Tree T, const int32_t *__restrict__ sns, double *__restrict__ fronts,
+                                                  int32_t *__restrict__ lperm) {
+    const FrontRef f = front_ref(T, sns, blockIdx.x, fronts, lperm);
+    for (int i = threadIdx.x; i < f.s; i += 256) f.perm[i] = i;
+}
+
+template <int RPT>
+__global__ __launch_bounds__(256) void level_panel_regs(Tree T, const int32_t *__restrict__ sns, double *__restrict__ fronts,
+                                                        int32_t *__restrict__ lperm, int k0, int32_t *__restrict__ pivs,
+                                                        double tiny, double repl, unsigned long long *__restrict__ stats) {
+    const FrontRef f = front_ref(T, sns, blockIdx.x, fronts, lperm);
+    if (k0 >= f.s) return;
+    const int nb = f.s - k0 < PNB ? f.s - k0 : PNB;
+    panel_factor_regs_body<RPT>(f.F, f.dim, f.s, k0, nb, pivs + (int64_t)blockIdx.x * NBB, tiny, repl, stats);
+}
+__global__ __launch_bounds__(1024) void level_panel_stream(Tree T, const int32_t *__restrict__ sns, double *__restrict__ fronts,
+                                                           int32_t *__restrict__ lperm, int k0, int32_t *__restrict__ pivs,
+                                                           double tiny, double repl, unsigned long long *__restrict__ stats) {
+    const FrontRef f = front_ref(T, sns, blockIdx.x, fronts, lperm);
+    if (k0 >= f.s) return;
+    const int nb = f.s - k0 < PNB ? f.s - k0 : PNB;
+    panel_factor_body(f.F, f.dim, f.s, k0, nb, pivs + (int64_t)blockIdx.x * NBB, tiny, repl, stats);
+}
+
+// the panel's interchanges on the columns outside it and on the row permutation, then U12 = L11^-1 A12 for this
+// thread's column (one thread per column outside the panel: blockIdx.x tiles of 256 columns, blockIdx.y = front)
+__global__ __launch_bounds__(256) void level_swaps_trsm(Tree T, const int32_t *__restrict__ sns, double *__restrict__ fronts,
+                                                        int32_t *__restrict__ lperm, int k0, const int32_t *__restrict__ pivs) {
+    const FrontRef f = front_ref(T, sns, blockIdx.y, fronts, lperm);
+    if (k0 >= f.s) return;
+    const int nb = f.s - k0 < PNB ? f.s - k0 : PNB;
+    const int dim = f.dim;
+    if ((int)blockIdx.x * 256 >= dim - nb + 1) return;
+    const int32_t *piv = pivs + (int64_t)blockIdx.y * NBB;
+    __shared__ double Ls[PNB][PNB + 1];
+    for (int idx = threadIdx.x; idx < nb * nb; idx += 256) {
+        const int r = idx % nb, q = idx / nb;
+        Ls[r][q] = f.F[(k0 + r) + (int64_t)(k0 + q) * dim];
+    }
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int outside = dim - nb;
+    if (t < outside) {
+        const int j = t < k0 ? t : t + nb;
+        double *col = f.F + (int64_t)j * dim;
+        for (int q = 0; q < nb; ++q) {
+            const int p = piv[q];
+            if (p != k0 + q) {
+                const double a = col[k0 + q];
+                col[k0 + q] = col[p];
+                col[p] = a;
+            }
+        }
+        if (j >= k0 + nb) {  // a column right of the panel: its rows k0 .. k0+nb-1 become U12
+            double u[PNB];
+#pragma unroll
+            for (int r = 0; r < PNB; ++r) u[r] = r < nb ? col[k0 + r] : 0.0;
+#pragma unroll
+            for (int r = 1; r < PNB; ++r)
+#pragma unroll
+                for (int q = 0; q < r; ++q)
+                    if (r < nb) u[r] = fma(-Ls[r][q], u[q], u[r]);
+#pragma unroll
+            for (int r = 0; r < PNB; ++r)
+                if (r < nb) col[k0 + r] = u[r];
+        }
+    } else if (t == outside) {
+        for (int q = 0; q < nb; ++q) {
+            const int p = piv[q];
+            if (p != k0 + q) {
+                const int32_t a = f.perm[k0 + q];
+                f.perm[k0 + q] = f.perm[p];
+                f.perm[p] = a;
+            }
+        }
+    }
+}
+
+// A22 -= L21 U12 of every front of the list: 64 x 64 tiles (blockIdx.x, blockIdx.y) of the trailing block, blockIdx.z =
+// front; 256 threads, a 4 x 4 micro-tile each (rows tx + 16 i: a wavefront reads whole 128-byte segments of a column)
+__global__ __launch_bounds__(256) void level_rank_update(Tree T, const int32_t *__restrict__ sns, double *__restrict__ fronts,
+                                                         int32_t *__restrict__ lperm, int k0) {
+    const FrontRef f = front_ref(T, sns, blockIdx.z, fronts, lperm);
+    if (k0 >= f.s) return;
+    const int nb = f.s - k0 < PNB ? f.s - k0 : PNB;
+    const int dim = f.dim, j0 = k0 + nb;
+    const int i0 = j0 + (int)blockIdx.x * 64, c0 = j0 + (int)blockIdx.y * 64;
+    if (i0 >= dim || c0 >= dim) return;
+    __shared__ double Lt[PNB][64 + 1], Ut[PNB][64 + 1];
+    for (int e = threadIdx.x; e < PNB * 64; e += 256) {
+        const int q = e / 64, r = e % 64;
+        Lt[q][r] = (q < nb && i0 + r < dim) ? f.F[(i0 + r) + (int64_t)(k0 + q) * dim] : 0.0;
+        Ut[q][r] = (q < nb && c0 + r < dim) ? f.F[(k0 + q) + (int64_t)(c0 + r) * dim] : 0.0;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = i0 + tx + 16 * ii, c = c0 + ty * 4 + jj;
+            acc[ii][jj] = (i < dim && c < dim) ? f.F[i + (int64_t)c * dim] : 0.0;
+        }
+#pragma unroll
+    for (int q = 0; q < PNB; ++q) {
+        double l[4], u[4];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) l[ii] = Lt[q][tx + 16 * ii];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) u[jj] = Ut[q][ty * 4 + jj];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = fma(-l[ii], u[jj], acc[ii][jj]);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = i0 + tx + 16 * ii, c = c0 + ty * 4 + jj;
+            if (i < dim && c < dim) f.F[i + (int64_t)c * dim] = acc[ii][jj];
+        }
 }
 
 // the panel's interchanges on the columns outside it (one thread per column, the nb swaps in order), and on
@@ -1032,6 +1190,7 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor, double tiny_thre
     const int max_lanes = !nodal_extra_streams_ok(h) ? 1 : (S->lanes < want_lanes ? S->lanes : want_lanes);  // (see api.hip)
     const bool fronts_in_lds = !(getenv("NODAL_DIRECT_FRONT_LDS") && atoi(getenv("NODAL_DIRECT_FRONT_LDS")) == 0);
     const bool panel_regs = !(getenv("NODAL_DIRECT_PANEL_REGS") && atoi(getenv("NODAL_DIRECT_PANEL_REGS")) == 0);
+    const bool batched = !(getenv("NODAL_DIRECT_BATCHED") && atoi(getenv("NODAL_DIRECT_BATCHED")) == 0);
     int64_t big_fronts = 0;
     for (int32_t l = 0; l < S->nlev; ++l) {
         const int32_t cnt = S->lvl_ptr[(size_t)l + 1] - S->lvl_ptr[(size_t)l];
@@ -1067,7 +1226,40 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor, double tiny_thre
                                                             S->stats.as<unsigned long long>());
         }
         NODAL_HIP_TRY(h, hipGetLastError());
-        // The wide fronts of a level are independent and each one's chain is a sequence of small launches (a
+        // The wide fronts of the level, all at once, panel step by panel step (see level_panel_regs): four launches per
+        // 16 pivot columns of the level's widest front.  (NODAL_DIRECT_BATCHED=0: round 4's chains, front after front.)
+        if (nbig > 0 && batched) {
+            const int32_t *bsns = sns + nsmall;
+            int max_s = 0, max_dim = 0;
+            for (int32_t q = 0; q < nbig; ++q) {
+                const int32_t t = S->h_lvl_sn[(size_t)S->lvl_ptr[(size_t)l] + nsmall + q];
+                max_s = std::max(max_s, S->h_start[(size_t)t + 1] - S->h_start[(size_t)t]);
+                max_dim = std::max(max_dim, S->h_dim[(size_t)t]);
+            }
+            NODAL_HIP_TRY(h, S->bigpiv.reserve((size_t)nbig * NBB * 4 + 64));
+            int32_t *pivs = S->bigpiv.as<int32_t>();
+            double *Fd = S->fronts.as<double>();
+            int32_t *pd = S->lperm.as<int32_t>();
+            unsigned long long *pst = S->stats.as<unsigned long long>();
+            level_iota<<<nbig, 256, 0, st>>>(T, bsns, Fd, pd);
+            for (int k0 = 0; k0 < max_s; k0 += PNB) {
+                const int prows = max_dim - k0;  // (the tallest panel of the step)
+                if (panel_regs && prows <= 512) level_panel_regs<2><<<nbig, 256, 0, st>>>(T, bsns, Fd, pd, k0, pivs, tiny, repl, pst);
+                else if (panel_regs && prows <= 1024) level_panel_regs<4><<<nbig, 256, 0, st>>>(T, bsns, Fd, pd, k0, pivs, tiny, repl, pst);
+                else if (panel_regs && prows <= 1536) level_panel_regs<6><<<nbig, 256, 0, st>>>(T, bsns, Fd, pd, k0, pivs, tiny, repl, pst);
+                else level_panel_stream<<<nbig, 1024, 0, st>>>(T, bsns, Fd, pd, k0, pivs, tiny, repl, pst);
+                level_swaps_trsm<<<dim3((unsigned)((max_dim + 255) / 256), (unsigned)nbig), 256, 0, st>>>(T, bsns, Fd, pd, k0, pivs);
+                const int rest = max_dim - k0 - 1;  // (at least: a front's last panel may be a single column)
+                if (rest > 0) {
+                    const unsigned tiles = (unsigned)((rest + 63) / 64);
+                    level_rank_update<<<dim3(tiles, tiles, (unsigned)nbig), 256, 0, st>>>(T, bsns, Fd, pd, k0);
+                }
+                NODAL_HIP_TRY(h, hipGetLastError());
+            }
+            big_fronts += nbig;
+            continue;
+        }
+        // (round 4) The wide fronts of a level are independent and each one's chain is a sequence of small launches (a
         // one-workgroup panel, its interchanges, a triangular solve, a thin GEMM): up to three of them run side by
         // side on streams of the factorisation's own (NODAL_DIRECT_LANES, four), forked and joined by events around the level.
         hipStream_t main_st = st;

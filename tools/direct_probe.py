@@ -9,6 +9,7 @@ from oracle import nodal_oracle as oracle
 
 def run(name, table, ref=True):
     h = _ffi.Handle(0)
+    h.set_option(_ffi.OPT_EXTRA_STREAMS, 1)  # (a handle that is used alone, like bench.py's)
     h.upload(table)
     h.assemble_symbolic()
     assert h.assemble_numeric()[0] == _ffi.OK
