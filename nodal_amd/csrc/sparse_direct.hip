@@ -300,7 +300,7 @@ __global__ __launch_bounds__(BS) void factor_fronts(Tree T, const int32_t *__res
 // the rest of the front, the U block row by a triangular solve over the columns, and the trailing update
 // A22 -= L21 U12 by the fp64 MFMA GEMM of gemm_f64.hip -- the one place of the sparse path where the matrix cores
 // have work (north_star: MFMA where G is dense enough to be a panel factorisation).
-constexpr int BIG_DIM = 192;  // (512 until round 5: the fronts between are stepped with the wide ones now)
+constexpr int BIG_DIM = 84;  // (512 until round 5; measured at cfg5(1000): 84 / 128 / 192 / 256 -> 30.3 / 31.6 / 33.9 / 34.0 ms per repeated solve)
 constexpr int NBB = 64;  // (64: the panel kernel -- one CU's bandwidth -- 694 us and the triangular solve 375 us per panel, its 64 values per thread spilling)
 
 __global__ __launch_bounds__(256) void iota_i32(int32_t *__restrict__ p, int n) {
@@ -1080,7 +1080,9 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor, double tiny_thre
             S->lvl_maxchildren.assign((size_t)S->nlev, 0);
             for (int32_t l = 0; l < S->nlev; ++l) {
                 auto b = sym.lvl_sn.begin() + sym.lvl_ptr[(size_t)l], e = sym.lvl_sn.begin() + sym.lvl_ptr[(size_t)l + 1];
-                auto mid = std::stable_partition(b, e, [&](int32_t t) { return S->h_dim[(size_t)t] <= BIG_DIM; });
+                // (NODAL_DIRECT_BIG_DIM: the front width above which a front is stepped with its level's wide ones)
+                static const int big_dim = getenv("NODAL_DIRECT_BIG_DIM") ? atoi(getenv("NODAL_DIRECT_BIG_DIM")) : BIG_DIM;
+                auto mid = std::stable_partition(b, e, [&](int32_t t) { return S->h_dim[(size_t)t] <= big_dim; });
                 S->lvl_small[(size_t)l] = (int32_t)(mid - b);
                 int32_t small_max = 0;
                 for (auto it = b; it != e; ++it) {
