@@ -789,17 +789,16 @@ int sparse_solve_pairs(nodal_ctx *h, int32_t npairs, const int32_t *ia, const in
     // nodal/equiv.py:31-37 admits resistors only) is no M-matrix: one sparse LU serves every pair, as SuperLU
     // serves the reference.
     const bool indefinite = !(h->B == 0 && h->passive_network);
-    // The factor-once route.  Measured on the 1e6-node grid (round 5): a factorisation 65 ms (its analysis --
-    // host work, kept per sparsity pattern -- 0.2 s more), a substitution for sixteen pairs 9.4 ms, i.e. 1.6 ms per pair
-    // with the refinement step against 0.93 ms per pair of the block iteration: on the networks the multigrid takes,
-    // the block iteration stays the default, and this route serves the ones it has no business with (indefinite:
-    // a non-positive resistance) -- sixteen pairs per substitution instead of one.  NODAL_PAIRS_DIRECT=1 forces it,
-    // =0 forbids it; NODAL_PAIRS_DIRECT_MIN=k takes it for sweeps of at least k pairs (4 k when the analysis is not
-    // at hand yet).
+    // The factor-once route.  Measured on the 1e6-node grid (round 5, DESIGN 3.5, tools/pairs_probe.py): a factorisation
+    // 27 ms (its analysis -- host work, kept per sparsity pattern -- 0.22 s more), two substitutions and a residual for
+    // sixteen pairs 11.3 ms, i.e. 0.71 ms per pair against 0.88-0.93 ms per pair of the block iteration: 1024 pairs 0.75 s
+    // against 0.90 s, 192 pairs 0.163 against 0.176 s.  So: sweeps of at least PAIRS_DIRECT_MIN (256) pairs when the
+    // analysis is at hand, eight times as many when it has to be made; always where the multigrid has no business
+    // (indefinite: a non-positive resistance).  NODAL_PAIRS_DIRECT=1 forces it, =0 forbids it.
     {
         const int forced = getenv("NODAL_PAIRS_DIRECT") ? atoi(getenv("NODAL_PAIRS_DIRECT")) : -1;  // (per call: tests switch it)
-        const int64_t min_pairs = getenv("NODAL_PAIRS_DIRECT_MIN") ? atoll(getenv("NODAL_PAIRS_DIRECT_MIN")) : (int64_t)1 << 40;
-        const bool worth = npairs >= (slu_analysis_kept(h) ? min_pairs : 4 * min_pairs);
+        const int64_t min_pairs = getenv("NODAL_PAIRS_DIRECT_MIN") ? atoll(getenv("NODAL_PAIRS_DIRECT_MIN")) : 256;
+        const bool worth = npairs >= (slu_analysis_kept(h) ? min_pairs : 8 * min_pairs);
         if (forced != 0 && (forced == 1 || indefinite || worth)) {
             bool taken = false;
             NODAL_TRY(sparse_solve_pairs_direct(h, npairs, ia, ib, res_dev, info, &taken));

@@ -62,6 +62,10 @@ struct SluState {
     // fronts wider than BIG_DIM are factored by a sequence of launches per front (big_front below): inside
     // every level's list they come last, lvl_small[l] = how many of the level's fronts take the batched kernel
     std::vector<int32_t> lvl_small, lvl_maxchildren, lvl_maxdim_all;
+    // the substitutions' own split (APPLY_BIG): the last lvl_abig[l] fronts of a level's list are wider than that and are
+    // substituted together, block step by block step; lvl_amax_s / lvl_amax_dim: their largest pivot count / width, and
+    // lvl_arest_dim: the widest of the others (it selects the one-workgroup kernel's size)
+    std::vector<int32_t> lvl_abig, lvl_amax_s, lvl_amax_dim, lvl_arest_dim;
     std::vector<int32_t> h_lvl_sn, h_start, h_dim;   // host copies: level lists, first pivot column, front width
     std::vector<int64_t> h_front_off;
     DevBuf bigpiv;                                     // pivot rows of the panels in flight (one set per lane)
@@ -71,9 +75,11 @@ struct SluState {
     int lanes = 1;
     // device copies of the symbolic part
     DevBuf rowof, colof, newrow;   // permuted position -> original row / column; original row -> position
+    DevBuf sn_of_row;              // supernode of every pivot position
     DevBuf sn_start, struct_ptr, struct_idx, front_off, vec_off, lvl_sn, child_ptr, child_idx, cmap, dest;
     // numeric part
     DevBuf fronts, vec, lperm, rs, cs, xb, stats;
+    DevBuf liperm;                 // inverse of lperm per front: where a front's row ends after the interchanges
     DevBuf blk_sn, blk_b0;         // the DB x DB diagonal blocks of all fronts' pivot parts (invert_diag_blocks)
     int64_t nblocks = 0;
     int vec_nr = 0;                // right-hand sides `vec` and `xb` are sized for
@@ -824,6 +830,16 @@ __global__ __launch_bounds__(64) void invert_diag_blocks(Tree T, int64_t nblocks
     }
 }
 
+// liperm[start + lperm[start + k]] = k for every front: the position a front's row takes after its interchanges
+__global__ __launch_bounds__(TB) void invert_perm(int64_t n, const int32_t *__restrict__ sn_of_row,
+                                                  const int32_t *__restrict__ sn_start, const int32_t *__restrict__ lperm,
+                                                  int32_t *__restrict__ liperm) {
+    for (int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x; k < n; k += (int64_t)gridDim.x * TB) {
+        const int32_t start = sn_start[sn_of_row[k]];
+        liperm[start + lperm[k]] = (int32_t)(k - start);
+    }
+}
+
 template <int NR> struct ColGroup { static constexpr int CW = NR >= 4 ? 4 : NR; static constexpr int CG = NR / CW; };
 
 // acc[0 .. CW) -= sum_k F[i + (c0 + k) dim] * Y[k][col0 ..]: the nb (<= DB) entries of row i in the column chunk c0,
@@ -848,20 +864,14 @@ __device__ __forceinline__ void chunk_update(const double *__restrict__ Frow, in
 
 // forward substitution of one level: v = [b'_S ; 0] + children's contributions, rows permuted like the
 // factorisation's, y_S = L11^-1 v_S, v_B -= L21 y_S.  y_S stays in v[0:s), the contribution in v[s:dim).
+// v = [b'_S ; 0] + the children's contributions, rows permuted like the factorisation's (the first part of a front's
+// forward substitution; ends with the workgroup in step)
 template <int BS, int NR>
-__global__ __launch_bounds__(BS) void forward_level(Tree T, const int32_t *__restrict__ sns,
-                                                    const double *__restrict__ fronts,
-                                                    const int32_t *__restrict__ lperm, const double *__restrict__ xb,
-                                                    double *__restrict__ vec) {
-    constexpr int CW = ColGroup<NR>::CW, CG = ColGroup<NR>::CG;
-    __shared__ double Y[DB][NR];       // the block's solved rows (zero rows behind a short last block)
-    __shared__ double Vb[DB][NR];      // ... before the multiplication by inv(L_bb)
-    __shared__ double Li[DB][DB + 1];  // inv(L_bb)
-    const int32_t t = sns[blockIdx.x];
+__device__ __forceinline__ void forward_gather(const Tree &T, int32_t t, const int32_t *__restrict__ lperm,
+                                               const double *__restrict__ xb, double *__restrict__ vec) {
     const int start = T.sn_start[t];
     const int s = T.sn_start[t + 1] - start;
     const int dim = s + (int)(T.struct_ptr[t + 1] - T.struct_ptr[t]);
-    const double *F = fronts + T.front_off[t];
     double *v = vec + T.vec_off[t] * NR;
     const int tid = threadIdx.x;
     for (int e = tid; e < dim * NR; e += BS) v[e] = e < s * NR ? xb[(int64_t)start * NR + e] : 0.0;
@@ -882,6 +892,27 @@ __global__ __launch_bounds__(BS) void forward_level(Tree T, const int32_t *__res
     __syncthreads();
     for (int e = tid; e < s * NR; e += BS) v[e] = tmp[e];
     __syncthreads();
+}
+
+// forward substitution of one level: v = [b'_S ; 0] + children's contributions, rows permuted like the
+// factorisation's, y_S = L11^-1 v_S, v_B -= L21 y_S.  y_S stays in v[0:s), the contribution in v[s:dim).
+template <int BS, int NR>
+__global__ __launch_bounds__(BS) void forward_level(Tree T, const int32_t *__restrict__ sns,
+                                                    const double *__restrict__ fronts,
+                                                    const int32_t *__restrict__ lperm, const double *__restrict__ xb,
+                                                    double *__restrict__ vec) {
+    constexpr int CW = ColGroup<NR>::CW, CG = ColGroup<NR>::CG;
+    __shared__ double Y[DB][NR];       // the block's solved rows (zero rows behind a short last block)
+    __shared__ double Vb[DB][NR];      // ... before the multiplication by inv(L_bb)
+    __shared__ double Li[DB][DB + 1];  // inv(L_bb)
+    const int32_t t = sns[blockIdx.x];
+    const int start = T.sn_start[t];
+    const int s = T.sn_start[t + 1] - start;
+    const int dim = s + (int)(T.struct_ptr[t + 1] - T.struct_ptr[t]);
+    const double *F = fronts + T.front_off[t];
+    double *v = vec + T.vec_off[t] * NR;
+    const int tid = threadIdx.x;
+    forward_gather<BS, NR>(T, t, lperm, xb, vec);
     for (int b0 = 0; b0 < s; b0 += DB) {
         const int nb = s - b0 < DB ? s - b0 : DB;
         // the block and its rows of v into LDS (coalesced), the product from there
@@ -980,6 +1011,179 @@ __global__ __launch_bounds__(BS) void backward_level(Tree T, const int32_t *__re
     for (int e = tid; e < s * NR; e += BS) xb[(int64_t)start * NR + e] = v[e];
 }
 
+// ---- the WIDE fronts of a level substituted together, block step by block step (round 5) --------------------------
+// One workgroup per front leaves a 1489-row front to one compute unit: 0.65 ms per sweep of each of the top levels with
+// sixteen right-hand sides.  Here step b0 of a level is ONE launch over (row tiles, fronts): every workgroup forms the
+// block's solved rows itself (a 32 x 32 product from LDS: cheaper than a launch of its own) and updates its tile of
+// the rows below (forward) / above (backward).  The solved rows go to the front's scratch rows (forward: read back by
+// the backward sweep) or straight into the solution (backward), never into rows another workgroup of the step reads.
+constexpr int APPLY_BIG = 256;  // fronts wider than this take the stepped form
+
+constexpr int GATHER_RT = 64;
+// v = [b'_S ; 0] + the children's contributions, every row written straight to the place the factorisation's row
+// interchanges give it (liperm): row tiles x fronts.  A workgroup owns the destination rows [r0, r0 + RT) and takes, child
+// after child (two children may add to one row: a fixed order), the child rows that land there.
+template <int NR>
+__global__ __launch_bounds__(256) void level_fwd_gather(Tree T, const int32_t *__restrict__ sns,
+                                                        const int32_t *__restrict__ liperm, const double *__restrict__ xb,
+                                                        double *__restrict__ vec) {
+    constexpr int RT = GATHER_RT;  // destination rows per workgroup
+    const int32_t t = sns[blockIdx.y];
+    const int start = T.sn_start[t];
+    const int s = T.sn_start[t + 1] - start;
+    const int dim = s + (int)(T.struct_ptr[t + 1] - T.struct_ptr[t]);
+    const int r0 = (int)blockIdx.x * RT;
+    if (r0 >= dim) return;
+    double *v = vec + T.vec_off[t] * NR;
+    const int32_t *ip = liperm + start;
+    const int tid = threadIdx.x;
+    // (a destination row below s holds the right-hand side of the source row that is interchanged into it)
+    for (int e = tid; e < RT * NR; e += 256)
+        if (r0 + e / NR < dim) v[(int64_t)r0 * NR + e] = 0.0;
+    __syncthreads();
+    for (int e = tid; e < s * NR; e += 256) {  // (s source rows: the ones that land in this tile)
+        const int pos = ip[e / NR];
+        if (pos >= r0 && pos < r0 + RT) v[(int64_t)pos * NR + e % NR] = xb[(int64_t)start * NR + e];
+    }
+    __syncthreads();
+    for (int32_t q = T.child_ptr[t]; q < T.child_ptr[t + 1]; ++q) {
+        const int32_t c = T.child_idx[q];
+        const int cs_ = T.sn_start[c + 1] - T.sn_start[c];
+        const int64_t cb = T.struct_ptr[c + 1] - T.struct_ptr[c];
+        const double *cv = vec + (T.vec_off[c] + cs_) * NR;
+        const int32_t *map = T.cmap + T.struct_ptr[c];
+        for (int64_t e = tid; e < cb * NR; e += 256) {
+            const int m = map[e / NR];
+            const int pos = m < s ? ip[m] : m;
+            if (pos >= r0 && pos < r0 + RT) v[(int64_t)pos * NR + e % NR] += cv[e];
+        }
+        __syncthreads();
+    }
+}
+
+template <int NR>
+__global__ __launch_bounds__(256) void level_fwd_step(Tree T, const int32_t *__restrict__ sns, const double *__restrict__ fronts,
+                                                      double *__restrict__ vec, int b0) {
+    constexpr int CW = ColGroup<NR>::CW, CG = ColGroup<NR>::CG, RT = 256 / CG;  // rows per workgroup
+    __shared__ double Y[DB][NR];
+    __shared__ double Vb[DB][NR];
+    __shared__ double Li[DB][DB + 1];
+    const int32_t t = sns[blockIdx.y];
+    const int s = T.sn_start[t + 1] - T.sn_start[t];
+    if (b0 >= s) return;
+    const int dim = s + (int)(T.struct_ptr[t + 1] - T.struct_ptr[t]);
+    const int nb = s - b0 < DB ? s - b0 : DB;
+    const int below = b0 + nb, rows = dim - below;
+    const int r0 = (int)blockIdx.x * RT;
+    if (blockIdx.x > 0 && r0 >= rows) return;
+    const double *F = fronts + T.front_off[t];
+    double *v = vec + T.vec_off[t] * NR;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < DB * DB; e += 256) {
+        const int r = e % DB, k = e / DB;
+        Li[r][k] = (r < nb && k < r) ? F[(b0 + r) + (int64_t)(b0 + k) * dim] : 0.0;
+    }
+    for (int e = tid; e < DB * NR; e += 256) Vb[e / NR][e % NR] = e < nb * NR ? v[(int64_t)b0 * NR + e] : 0.0;
+    __syncthreads();
+    double *ys = v + (int64_t)dim * NR;  // (the scratch rows: y_S of the whole front ends there)
+    for (int e = tid; e < DB * NR; e += 256) {
+        const int r = e / NR, c = e % NR;
+        double acc = Vb[r][c];
+#pragma unroll
+        for (int k = 0; k < DB; ++k) acc = fma(Li[r][k], Vb[k][c], acc);
+        Y[r][c] = acc;
+        if (blockIdx.x == 0 && r < nb) ys[(int64_t)(b0 + r) * NR + c] = acc;
+    }
+    __syncthreads();
+    const int i = below + r0 + tid % RT, g = tid / RT;
+    if (i < dim) {
+        double acc[CW];
+#pragma unroll
+        for (int jj = 0; jj < CW; ++jj) acc[jj] = v[(int64_t)i * NR + g * CW + jj];
+        chunk_update<NR, CW>(F + i + (int64_t)b0 * dim, dim, nb, Y, g * CW, acc);
+#pragma unroll
+        for (int jj = 0; jj < CW; ++jj) v[(int64_t)i * NR + g * CW + jj] = acc[jj];
+    }
+}
+
+// v_S = y_S - U12 x_B (y_S from the scratch rows, x_B from the ancestors' solution): row tiles x fronts
+template <int NR>
+__global__ __launch_bounds__(256) void level_bwd_u12(Tree T, const int32_t *__restrict__ sns, const double *__restrict__ fronts,
+                                                     const double *__restrict__ xb, double *__restrict__ vec) {
+    constexpr int CW = ColGroup<NR>::CW, CG = ColGroup<NR>::CG, RT = 256 / CG;
+    __shared__ double Y[DB][NR];
+    const int32_t t = sns[blockIdx.y];
+    const int s = T.sn_start[t + 1] - T.sn_start[t];
+    const int r0 = (int)blockIdx.x * RT;
+    if (r0 >= s) return;
+    const int dim = s + (int)(T.struct_ptr[t + 1] - T.struct_ptr[t]);
+    const double *F = fronts + T.front_off[t];
+    double *v = vec + T.vec_off[t] * NR;
+    const double *ys = v + (int64_t)dim * NR;
+    const int32_t *bidx = T.struct_idx + T.struct_ptr[t];
+    const int tid = threadIdx.x;
+    const int i = r0 + tid % RT, g = tid / RT;
+    double acc[CW];
+#pragma unroll
+    for (int jj = 0; jj < CW; ++jj) acc[jj] = i < s ? ys[(int64_t)i * NR + g * CW + jj] : 0.0;
+    for (int c0 = s; c0 < dim; c0 += DB) {
+        const int nb = dim - c0 < DB ? dim - c0 : DB;
+        __syncthreads();
+        for (int e = tid; e < DB * NR; e += 256)
+            Y[e / NR][e % NR] = e < nb * NR ? xb[(int64_t)bidx[c0 - s + e / NR] * NR + e % NR] : 0.0;
+        __syncthreads();
+        if (i < s) chunk_update<NR, CW>(F + i + (int64_t)c0 * dim, dim, nb, Y, g * CW, acc);
+    }
+    if (i < s) {
+#pragma unroll
+        for (int jj = 0; jj < CW; ++jj) v[(int64_t)i * NR + g * CW + jj] = acc[jj];
+    }
+}
+
+template <int NR>
+__global__ __launch_bounds__(256) void level_bwd_step(Tree T, const int32_t *__restrict__ sns, const double *__restrict__ fronts,
+                                                      double *__restrict__ xb, double *__restrict__ vec, int b0) {
+    constexpr int CW = ColGroup<NR>::CW, CG = ColGroup<NR>::CG, RT = 256 / CG;
+    __shared__ double Y[DB][NR];
+    __shared__ double Vb[DB][NR];
+    __shared__ double Ui[DB][DB + 1];
+    const int32_t t = sns[blockIdx.y];
+    const int start = T.sn_start[t];
+    const int s = T.sn_start[t + 1] - start;
+    if (b0 >= s) return;
+    const int r0 = (int)blockIdx.x * RT;
+    if (blockIdx.x > 0 && r0 >= b0) return;
+    const int dim = s + (int)(T.struct_ptr[t + 1] - T.struct_ptr[t]);
+    const int nb = s - b0 < DB ? s - b0 : DB;
+    const double *F = fronts + T.front_off[t];
+    double *v = vec + T.vec_off[t] * NR;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < DB * DB; e += 256) {
+        const int r = e % DB, k = e / DB;
+        Ui[r][k] = (k < nb && r <= k) ? F[(b0 + r) + (int64_t)(b0 + k) * dim] : 0.0;
+    }
+    for (int e = tid; e < DB * NR; e += 256) Vb[e / NR][e % NR] = e < nb * NR ? v[(int64_t)b0 * NR + e] : 0.0;
+    __syncthreads();
+    for (int e = tid; e < DB * NR; e += 256) {
+        const int r = e / NR, c = e % NR;
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < DB; ++k) acc = fma(Ui[r][k], Vb[k][c], acc);
+        Y[r][c] = acc;
+        if (blockIdx.x == 0 && r < nb) xb[(int64_t)(start + b0 + r) * NR + c] = acc;  // (the solution itself)
+    }
+    __syncthreads();
+    const int i = r0 + tid % RT, g = tid / RT;
+    if (i < b0) {
+        double acc[CW];
+#pragma unroll
+        for (int jj = 0; jj < CW; ++jj) acc[jj] = v[(int64_t)i * NR + g * CW + jj];
+        chunk_update<NR, CW>(F + i + (int64_t)b0 * dim, dim, nb, Y, g * CW, acc);
+#pragma unroll
+        for (int jj = 0; jj < CW; ++jj) v[(int64_t)i * NR + g * CW + jj] = acc[jj];
+    }
+}
+
 template <class T>
 int upload_vec(nodal_ctx *h, DevBuf &buf, const std::vector<T> &v) {
     NODAL_HIP_TRY(h, buf.reserve(v.size() * sizeof(T) + 64));
@@ -1017,7 +1221,7 @@ void slu_destroy(nodal_ctx *h) {
     if (!S) return;
     DevBuf *bufs[] = {&S->rowof, &S->colof, &S->newrow, &S->sn_start, &S->struct_ptr, &S->struct_idx, &S->front_off,
                       &S->vec_off, &S->lvl_sn, &S->child_ptr, &S->child_idx, &S->cmap, &S->dest, &S->fronts,
-                      &S->vec, &S->lperm, &S->rs, &S->cs, &S->xb, &S->stats, &S->bigpiv, &S->blk_sn, &S->blk_b0};
+                      &S->vec, &S->lperm, &S->rs, &S->cs, &S->xb, &S->stats, &S->bigpiv, &S->blk_sn, &S->blk_b0, &S->liperm, &S->sn_of_row};
     for (DevBuf *b : bufs) b->release();
     for (int k = 1; k < SluState::LANES; ++k)
         if (S->lane_st[k]) (void)hipStreamDestroy(S->lane_st[k]);
@@ -1077,6 +1281,7 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor, double tiny_thre
                 S->h_dim[(size_t)t] = (int32_t)((sym.sn_start[(size_t)t + 1] - sym.sn_start[(size_t)t]) +
                                                 (sym.struct_ptr[(size_t)t + 1] - sym.struct_ptr[(size_t)t]));
             S->lvl_small.assign((size_t)S->nlev, 0);
+            S->lvl_abig.clear(); S->lvl_amax_s.clear(); S->lvl_amax_dim.clear(); S->lvl_arest_dim.clear();
             S->lvl_maxchildren.assign((size_t)S->nlev, 0);
             for (int32_t l = 0; l < S->nlev; ++l) {
                 auto b = sym.lvl_sn.begin() + sym.lvl_ptr[(size_t)l], e = sym.lvl_sn.begin() + sym.lvl_ptr[(size_t)l + 1];
@@ -1084,6 +1289,19 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor, double tiny_thre
                 static const int big_dim = getenv("NODAL_DIRECT_BIG_DIM") ? atoi(getenv("NODAL_DIRECT_BIG_DIM")) : BIG_DIM;
                 auto mid = std::stable_partition(b, e, [&](int32_t t) { return S->h_dim[(size_t)t] <= big_dim; });
                 S->lvl_small[(size_t)l] = (int32_t)(mid - b);
+                auto amid = std::stable_partition(mid, e, [&](int32_t t) { return S->h_dim[(size_t)t] <= APPLY_BIG; });
+                int32_t am_s = 0, am_d = 0, rest_d = 0;
+                for (auto it = b; it != e; ++it) {
+                    if (it < amid) rest_d = std::max(rest_d, S->h_dim[(size_t)*it]);
+                    else {
+                        am_s = std::max(am_s, S->h_start[(size_t)*it + 1] - S->h_start[(size_t)*it]);
+                        am_d = std::max(am_d, S->h_dim[(size_t)*it]);
+                    }
+                }
+                S->lvl_abig.push_back((int32_t)(e - amid));
+                S->lvl_amax_s.push_back(am_s);
+                S->lvl_amax_dim.push_back(am_d);
+                S->lvl_arest_dim.push_back(rest_d);
                 int32_t small_max = 0;
                 for (auto it = b; it != e; ++it) {
                     if (it < mid) small_max = std::max(small_max, S->h_dim[(size_t)*it]);
@@ -1125,6 +1343,12 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor, double tiny_thre
         NODAL_TRY(upload_vec(h, S->child_idx, sym.child_idx));
         NODAL_TRY(upload_vec(h, S->cmap, sym.cmap));
         NODAL_TRY(upload_vec(h, S->dest, sym.dest));
+        {
+            std::vector<int32_t> sn_of_row((size_t)n);
+            for (int32_t t = 0; t < S->nsn; ++t)
+                for (int32_t k = S->h_start[(size_t)t]; k < S->h_start[(size_t)t + 1]; ++k) sn_of_row[(size_t)k] = t;
+            NODAL_TRY(upload_vec(h, S->sn_of_row, sn_of_row));
+        }
         NODAL_TRY(upload_vec(h, S->blk_sn, blk_sn));
         NODAL_TRY(upload_vec(h, S->blk_b0, blk_b0));
         NODAL_WAIT_STREAM(h, st);  // (the host vectors go out of scope)
@@ -1139,6 +1363,7 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor, double tiny_thre
     if (S->vec_nr < 1) S->vec_nr = 1;
     NODAL_HIP_TRY(h, S->vec.reserve((size_t)S->vec_doubles * 8 * S->vec_nr + 64));
     NODAL_HIP_TRY(h, S->lperm.reserve((size_t)n * 4 + 64));
+    NODAL_HIP_TRY(h, S->liperm.reserve((size_t)n * 4 + 64));
     NODAL_HIP_TRY(h, S->rs.reserve((size_t)n * 8 + 64));
     NODAL_HIP_TRY(h, S->cs.reserve((size_t)n * 8 + 64));
     NODAL_HIP_TRY(h, S->xb.reserve((size_t)n * 8 * S->vec_nr + 64));
@@ -1317,6 +1542,9 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor, double tiny_thre
                                                                 S->fronts.as<double>());
         NODAL_HIP_TRY(h, hipGetLastError());
     }
+    invert_perm<<<grid_for(n), TB, 0, st>>>(n, S->sn_of_row.as<int32_t>(), S->sn_start.as<int32_t>(), S->lperm.as<int32_t>(),
+                                           S->liperm.as<int32_t>());
+    NODAL_HIP_TRY(h, hipGetLastError());
     unsigned long long pert = 0;
     NODAL_TRY(nodal_read_words(h, &pert, S->stats.p, 8));
     S->perturbed = (int64_t)pert;
@@ -1340,30 +1568,54 @@ int slu_apply_nr(nodal_ctx *h, SluState *S, const double *r, double *z) {
         S->vec_nr = NR;
     }
     permute_rhs<<<grid_for(n * NR), TB, 0, st>>>(n, NR, S->rowof.as<int32_t>(), S->rs.as<double>(), r, S->xb.as<double>());
+    static const bool stepped = !(getenv("NODAL_DIRECT_APPLY_STEPPED") && atoi(getenv("NODAL_DIRECT_APPLY_STEPPED")) == 0);
+    constexpr int RT = 256 / ColGroup<NR>::CG;  // rows per workgroup of the stepped kernels
+    const double *Fd = S->fronts.as<double>();
+    double *xbd = S->xb.as<double>(), *vd = S->vec.as<double>();
+    const int32_t *pd = S->lperm.as<int32_t>();
     for (int32_t l = 0; l < S->nlev; ++l) {
         const int32_t cnt = S->lvl_ptr[(size_t)l + 1] - S->lvl_ptr[(size_t)l];
         const int32_t *sns = S->lvl_sn.as<int32_t>() + S->lvl_ptr[(size_t)l];
-        const int md = S->lvl_maxdim_all[(size_t)l];
-        if (md > 192)
-            forward_level<1024, NR><<<cnt, 1024, 0, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(),
-                                                          S->xb.as<double>(), S->vec.as<double>());
-        else if (md > 64 / (NR > 4 ? 4 : 1))
-            forward_level<256, NR><<<cnt, 256, 0, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(),
-                                                        S->xb.as<double>(), S->vec.as<double>());
-        else
-            forward_level<64, NR><<<cnt, 64, 0, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(),
-                                                      S->xb.as<double>(), S->vec.as<double>());
+        const int32_t nab = stepped ? S->lvl_abig[(size_t)l] : 0, rest = cnt - nab;
+        const int md = stepped ? S->lvl_arest_dim[(size_t)l] : S->lvl_maxdim_all[(size_t)l];
+        if (rest > 0) {
+            if (md > 192) forward_level<1024, NR><<<rest, 1024, 0, st>>>(T, sns, Fd, pd, xbd, vd);
+            else if (md > 64 / (NR > 4 ? 4 : 1)) forward_level<256, NR><<<rest, 256, 0, st>>>(T, sns, Fd, pd, xbd, vd);
+            else forward_level<64, NR><<<rest, 64, 0, st>>>(T, sns, Fd, pd, xbd, vd);
+        }
+        if (nab > 0) {  // the wide fronts of the level together (level_fwd_step)
+            const int32_t *bs = sns + rest;
+            const int ms = S->lvl_amax_s[(size_t)l], mdim = S->lvl_amax_dim[(size_t)l];
+            {
+                constexpr int GRT = GATHER_RT;
+                level_fwd_gather<NR><<<dim3((unsigned)((mdim + GRT - 1) / GRT), (unsigned)nab), 256, 0, st>>>(
+                    T, bs, S->liperm.as<int32_t>(), xbd, vd);
+            }
+            for (int b0 = 0; b0 < ms; b0 += DB) {
+                const int tiles = std::max(1, (mdim - b0 - 1 + RT - 1) / RT);
+                level_fwd_step<NR><<<dim3((unsigned)tiles, (unsigned)nab), 256, 0, st>>>(T, bs, Fd, vd, b0);
+            }
+        }
     }
     for (int32_t l = S->nlev - 1; l >= 0; --l) {
         const int32_t cnt = S->lvl_ptr[(size_t)l + 1] - S->lvl_ptr[(size_t)l];
         const int32_t *sns = S->lvl_sn.as<int32_t>() + S->lvl_ptr[(size_t)l];
-        const int md = S->lvl_maxdim_all[(size_t)l];
-        if (md > 192)
-            backward_level<1024, NR><<<cnt, 1024, 0, st>>>(T, sns, S->fronts.as<double>(), S->xb.as<double>(), S->vec.as<double>());
-        else if (md > 64 / (NR > 4 ? 4 : 1))
-            backward_level<256, NR><<<cnt, 256, 0, st>>>(T, sns, S->fronts.as<double>(), S->xb.as<double>(), S->vec.as<double>());
-        else
-            backward_level<64, NR><<<cnt, 64, 0, st>>>(T, sns, S->fronts.as<double>(), S->xb.as<double>(), S->vec.as<double>());
+        const int32_t nab = stepped ? S->lvl_abig[(size_t)l] : 0, rest = cnt - nab;
+        const int md = stepped ? S->lvl_arest_dim[(size_t)l] : S->lvl_maxdim_all[(size_t)l];
+        if (rest > 0) {
+            if (md > 192) backward_level<1024, NR><<<rest, 1024, 0, st>>>(T, sns, Fd, xbd, vd);
+            else if (md > 64 / (NR > 4 ? 4 : 1)) backward_level<256, NR><<<rest, 256, 0, st>>>(T, sns, Fd, xbd, vd);
+            else backward_level<64, NR><<<rest, 64, 0, st>>>(T, sns, Fd, xbd, vd);
+        }
+        if (nab > 0) {
+            const int32_t *bs = sns + rest;
+            const int ms = S->lvl_amax_s[(size_t)l];
+            level_bwd_u12<NR><<<dim3((unsigned)((ms + RT - 1) / RT), (unsigned)nab), 256, 0, st>>>(T, bs, Fd, xbd, vd);
+            for (int b0 = ((ms - 1) / DB) * DB; b0 >= 0; b0 -= DB) {
+                const int tiles = std::max(1, (b0 + RT - 1) / RT);
+                level_bwd_step<NR><<<dim3((unsigned)tiles, (unsigned)nab), 256, 0, st>>>(T, bs, Fd, xbd, vd, b0);
+            }
+        }
     }
     unpermute_solution<<<grid_for(n * NR), TB, 0, st>>>(n, NR, S->colof.as<int32_t>(), S->cs.as<double>(), S->xb.as<double>(), z);
     NODAL_HIP_TRY(h, hipGetLastError());
