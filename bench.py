@@ -429,12 +429,44 @@ def resistance_sweep_times(device, npairs=192):
         t0 = time.perf_counter()
         res, info = h.solve_pairs(ia, ib, False)
         secs.append(time.perf_counter() - t0)
+    # the factor-once route (csrc/sparse.hip sparse_solve_pairs_direct: one multifrontal LU, sixteen pairs per
+    # substitution + one refinement step), forced: automatic from 256 pairs on when the analysis is at hand
+    os.environ["NODAL_PAIRS_DIRECT"] = "1"
+    try:
+        dsecs = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            dres, dinfo = h.solve_pairs(ia, ib, False)
+            dsecs.append(time.perf_counter() - t0)
+        big = 1024
+        ja = rng.randint(0, table.K, size=big).astype(np.int32)
+        jb = rng.randint(-1, table.K, size=big).astype(np.int32)
+        jb[jb == ja] = -1
+        t0 = time.perf_counter()
+        _r, _i = h.solve_pairs(ja, jb, False)
+        dbig = time.perf_counter() - t0
+    finally:
+        del os.environ["NODAL_PAIRS_DIRECT"]
+    os.environ["NODAL_PAIRS_DIRECT"] = "0"
+    try:
+        t0 = time.perf_counter()
+        _r, _i = h.solve_pairs(ja, jb, False)
+        bbig = time.perf_counter() - t0
+    finally:
+        del os.environ["NODAL_PAIRS_DIRECT"]
     h.close()
+    agree = float(np.abs(dres - res).max() / np.abs(res).max())
     return {"workload": f"cfg3's network (grid(1000), 1e6 nodes), {npairs} random pairs, nodal_solve_pairs(dense = 0)",
             "first_s": secs[0], "repeated_s": secs[1], "ms_per_pair": secs[1] / npairs * 1e3, "info": int(info),
+            "factor_once": {"what": "the same pairs through one sparse LU + sixteen right-hand sides per substitution (forced)",
+                            "first_s_with_analysis": dsecs[0], "repeated_s_analysis_kept": dsecs[1],
+                            "ms_per_pair": dsecs[1] / npairs * 1e3, "info": int(dinfo),
+                            "max_relative_difference_to_block_iteration": agree,
+                            "pairs_1024_s": dbig, "pairs_1024_block_iteration_s": bbig},
             "note": "first_s includes the hierarchy setup and the growth of the block iteration's buffers; parity of "
                     "the block iteration with one solve per pair and with a sparse LU: tests/test_gpu_parity.py::"
-                    "test_block_iteration_matches_one_solve_per_pair"}
+                    "test_block_iteration_matches_one_solve_per_pair; of the factor-once route: tests/test_gpu_direct.py::"
+                    "test_factor_once_route_of_a_pair_sweep_matches_the_oracle"}
 
 
 def make_workload(name, rank, world, device, dist, per_step, force_collective=False):

@@ -1418,8 +1418,21 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor, double tiny_thre
     const bool fronts_in_lds = !(getenv("NODAL_DIRECT_FRONT_LDS") && atoi(getenv("NODAL_DIRECT_FRONT_LDS")) == 0);
     const bool panel_regs = !(getenv("NODAL_DIRECT_PANEL_REGS") && atoi(getenv("NODAL_DIRECT_PANEL_REGS")) == 0);
     const bool batched = !(getenv("NODAL_DIRECT_BATCHED") && atoi(getenv("NODAL_DIRECT_BATCHED")) == 0);
+    // NODAL_DIRECT_LEVELS=1: an event behind every level, and a table of times, flops and bytes per level on stderr
+    const bool level_table = getenv("NODAL_DIRECT_LEVELS") != nullptr;
+    std::vector<hipEvent_t> lev_ev;
+    if (level_table) {
+        lev_ev.resize((size_t)S->nlev + 1);
+        for (auto &e : lev_ev) NODAL_HIP_TRY(h, hipEventCreate(&e));
+        NODAL_HIP_TRY(h, hipEventRecord(lev_ev[0], st));
+    }
+    struct LevelEvents {  // (records the event of a level whatever way the loop body is left)
+        std::vector<hipEvent_t> &ev; hipStream_t st; size_t at; bool on;
+        ~LevelEvents() { if (on) (void)hipEventRecord(ev[at], st); }
+    };
     int64_t big_fronts = 0;
     for (int32_t l = 0; l < S->nlev; ++l) {
+        LevelEvents level_done{lev_ev, st, (size_t)l + 1, level_table};
         const int32_t cnt = S->lvl_ptr[(size_t)l + 1] - S->lvl_ptr[(size_t)l];
         const int32_t nsmall = S->lvl_small[(size_t)l], nbig = cnt - nsmall;
         const int32_t *sns = S->lvl_sn.as<int32_t>() + S->lvl_ptr[(size_t)l];
@@ -1535,6 +1548,34 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor, double tiny_thre
             NODAL_HIP_TRY(h, hipStreamWaitEvent(main_st, S->lane_ev[k], 0));
         }
         join.disarm();
+    }
+    if (level_table) {
+        NODAL_TRY(nodal_wait_stream(h, st, NODAL_SITE));
+        fprintf(stderr, "[direct] numeric factorisation by level of the assembly tree (leaves first): fronts, widest front / most pivot "
+                        "columns, time, flops of the partial LUs (2/3 (d^3 - (d - s)^3)) and their rate, bytes of the fronts "
+                        "(8 d^2, read and written once = the floor) and their rate\n");
+        double tot_ms = 0.0, tot_fl = 0.0, tot_by = 0.0;
+        for (int32_t l = 0; l < S->nlev; ++l) {
+            double fl = 0.0, by = 0.0;
+            int md = 0, ms_ = 0;
+            for (int32_t q = S->lvl_ptr[(size_t)l]; q < S->lvl_ptr[(size_t)l + 1]; ++q) {
+                const int32_t t = S->h_lvl_sn[(size_t)q];
+                const double d = S->h_dim[(size_t)t], sz = S->h_start[(size_t)t + 1] - S->h_start[(size_t)t];
+                fl += 2.0 / 3.0 * (d * d * d - (d - sz) * (d - sz) * (d - sz));
+                by += 16.0 * d * d;
+                md = std::max(md, (int)d);
+                ms_ = std::max(ms_, (int)sz);
+            }
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, lev_ev[(size_t)l], lev_ev[(size_t)l + 1]);
+            fprintf(stderr, "[direct]   level %2d: %6d fronts, widest %4d / %4d pivots  %8.3f ms  %9.3f GFLOP %8.2f TFLOP/s  %8.1f MB %7.1f GB/s\n",
+                    l, S->lvl_ptr[(size_t)l + 1] - S->lvl_ptr[(size_t)l], md, ms_, ms, fl * 1e-9, ms > 0 ? fl / ms * 1e-9 : 0.0,
+                    by * 1e-6, ms > 0 ? by / ms * 1e-6 : 0.0);
+            tot_ms += ms; tot_fl += fl; tot_by += by;
+        }
+        fprintf(stderr, "[direct]   all levels: %.3f ms, %.2f GFLOP (%.2f TFLOP/s), %.1f MB of fronts r+w (%.1f GB/s)\n", tot_ms,
+                tot_fl * 1e-9, tot_ms > 0 ? tot_fl / tot_ms * 1e-9 : 0.0, tot_by * 1e-6, tot_ms > 0 ? tot_by / tot_ms * 1e-6 : 0.0);
+        for (auto &e : lev_ev) (void)hipEventDestroy(e);
     }
     // the substitutions multiply by the diagonal blocks' inverses (see forward_level): in place, once per factorisation
     if (S->nblocks > 0) {
