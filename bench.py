@@ -221,6 +221,8 @@ class SingleCircuits:
             g = self.sc.latest()
             gathered_ok = bool(g.shape[0] == self.sc.world and np.isfinite(g).all() and
                                all(np.array_equal(g[r], g[self.sc.rank]) for r in range(g.shape[0])))
+        x = h.download_x()  # (the first one allocates its page-locked block: _ffi.host_empty recycles it from then on)
+        del x
         t0 = time.perf_counter()
         x = h.download_x()
         d2h_ms = (time.perf_counter() - t0) * 1e3
