@@ -201,6 +201,27 @@ def test_rccl_single_rank_gather():
     assert out["member3_normwise_error"] <= 1e-9
 
 
+@pytest.mark.gpu
+def test_rccl_single_rank_independent_circuits():
+    """The N > 1 headline path of bench.py on the one GPU of the box: ShardedCircuits with backend "nccl" (= RCCL),
+    world_size 1 -- nodal_run, nodal_x_device into alternating device send buffers, asynchronous all_gather_into_tensor
+    behind the next solve -- five different circuits, every gathered solution against the oracle (1e-9)."""
+    import json
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_circuits_child.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, child, str(port)], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    assert out["backend"] == "nccl" and out["world_size"] == 1 and out["circuits"] == 5
+    assert out["tensors_on_device"] and out["gathered_equals_own_solution"]
+    assert out["worst_normwise_error"] <= 1e-9
+
+
 # ---- independent circuits over the ranks (bench.py --gpus N: config 3 at every N) ----
 
 def _single_circuit_oracle(table):
