@@ -780,7 +780,13 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dist = None
+    saved_stdout = None
     if world > 1 or args.force_collective:
+        # rank 0 prints ONE JSON line on stdout: whatever the communication libraries print there when they start
+        # (RCCL's version banner, gloo's "connected to peers") goes to stderr instead
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
@@ -877,9 +883,14 @@ def main():
         also["sparse_direct"] = direct_route_times(local)
         also["resistance_sweep"] = resistance_sweep_times(local)
         out["also"] = also
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
+        os.dup2(2, 1)  # (the libraries may speak again when the group goes)
         dist.destroy_process_group()
 
 
