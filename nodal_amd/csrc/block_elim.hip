@@ -597,15 +597,27 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
 
     // A12 <- Q A12 for the block [J0, J1): columns [c0, c1) on stream st through scratch buf
     // (sym: buf is the block's panel V, column j of it <-> global column J1 + j, and it is kept)
+    // copied: the columns are in buf already (round 5: the first columns of the next block are copied, and their head
+    // transposed, on the strip's stream as soon as the strip is done -- off the chain)
     auto scale_cols = [&](hipStream_t st, const double *Qk, double *buf, int64_t J0, int64_t J1, int64_t c0,
-                          int64_t c1) -> int {
+                          int64_t c1, bool copied = false) -> int {
         if (c1 <= c0) return NODAL_OK;
         const int w = (int)(J1 - J0);
         if (sym) buf += (c0 - J1) * wmax;
-        copy_block<<<blocks_for(c1 - c0, 4), 256, 0, st>>>(A + c0 * lda + J0, lda, buf, wmax, w, c1 - c0);
-        NODAL_HIP_TRY(h, hipGetLastError());
+        if (!copied) {
+            copy_block<<<blocks_for(c1 - c0, 4), 256, 0, st>>>(A + c0 * lda + J0, lda, buf, wmax, w, c1 - c0);
+            NODAL_HIP_TRY(h, hipGetLastError());
+        }
         return gemm_f64(h, st, GEMM_SET, A + c0 * lda + J0, lda, Qk, wmax, buf, wmax, w, c1 - c0, w);
     };
+    auto copy_cols = [&](hipStream_t st, double *buf, int64_t J0, int64_t J1, int64_t c0, int64_t c1) -> int {
+        if (c1 <= c0) return NODAL_OK;
+        copy_block<<<blocks_for(c1 - c0, 4), 256, 0, st>>>(A + c0 * lda + J0, lda, buf + (c0 - J1) * wmax, wmax, (int)(J1 - J0), c1 - c0);
+        NODAL_HIP_TRY(h, hipGetLastError());
+        return NODAL_OK;
+    };
+    static const bool early_copy_env = !(getenv("NODAL_BI_EARLY_COPY") && atoi(getenv("NODAL_BI_EARLY_COPY")) == 0);
+    const bool early_copy = sym && early_copy_env;
     // sym: Lt(k) = (first w_next columns of V(k))^T, the rows J1:J2 of the never-formed block column k
     auto head_transpose = [&](hipStream_t st, int k) -> int {
         if (!sym || k + 2 > nb) return NODAL_OK;
@@ -616,8 +628,10 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
         return NODAL_OK;
     };
     // W(k)'s first columns: those the next two diagonal blocks (k + 1, k + 2) read
+    static const int first_blocks = getenv("NODAL_BI_FIRST_BLOCKS") ? atoi(getenv("NODAL_BI_FIRST_BLOCKS")) : 2;
     auto first_end = [&](int k) {
-        const int64_t e = bnd[k + 3 < nb ? k + 3 : nb];
+        const int to = k + 1 + (first_blocks < 1 ? 1 : (first_blocks > 2 ? 2 : first_blocks));
+        const int64_t e = bnd[to < nb ? to : nb];
         return e < ncols ? e : ncols;
     };
 
@@ -659,6 +673,10 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
         // s3: strip
         NODAL_TRY(gemm_sub_f64(h, s3, A + J2 * lda + J1, lda, Lhead, ldh, U + (J2 - J1) * lda, lda,
                                J2 - J1, ncols - J2, w));
+        if (early_copy) {  // V(k+1)'s first columns and its transposed head need the strip only: not the chain's business
+            NODAL_TRY(copy_cols(s3, V[(blk + 1) & 1], J1, J2, J2, first_end(blk + 1)));
+            NODAL_TRY(head_transpose(s3, blk + 1));
+        }
         NODAL_HIP_TRY(h, hipEventRecord(ev_strip, s3));
         // sg: rest
         if (J2 < n) {
@@ -682,8 +700,8 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
         } else ev_rest = nullptr;
         // W(k+1): the first columns on the critical stream, the wide remainder beside it
         NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_strip, 0));
-        NODAL_TRY(scale_cols(sp, Qn, sym ? V[(blk + 1) & 1] : S1, J1, J2, J2, first_end(blk + 1)));
-        NODAL_TRY(head_transpose(sp, blk + 1));
+        NODAL_TRY(scale_cols(sp, Qn, sym ? V[(blk + 1) & 1] : S1, J1, J2, J2, first_end(blk + 1), early_copy));
+        if (!early_copy) NODAL_TRY(head_transpose(sp, blk + 1));
         NODAL_HIP_TRY(h, hipEventRecord(ev_wfirst, sp));
         NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_q, 0));
         NODAL_TRY(scale_cols(s3, Qn, sym ? V[(blk + 1) & 1] : S, J1, J2, first_end(blk + 1), ncols));

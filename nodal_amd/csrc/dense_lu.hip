@@ -32,6 +32,7 @@
 // An exactly zero pivot sets info = column + 1 (LAPACK convention).
 #include <cstdlib>
 
+#include <chrono>
 #include "dense_common.h"
 
 namespace {
@@ -1040,6 +1041,7 @@ int dense_factor_solve(nodal_ctx *h, int32_t *info) {
 // columns) and leave the solutions in xout (column c at xout + c * ldx).  *info as
 // LAPACK dgesv.
 int dense_factor_solve_multi(nodal_ctx *h, int32_t nrhs, double *xout, int64_t ldx, int32_t *info) {
+    const auto t_start = std::chrono::steady_clock::now();
     NODAL_TRY(nodal_ensure_aux_streams(h));
     const int64_t n = h->n, lda = dense_lda(n), ncols = n + nrhs;
     hipStream_t st = h->stream;
@@ -1076,8 +1078,15 @@ int dense_factor_solve_multi(nodal_ctx *h, int32_t nrhs, double *xout, int64_t l
         j1 = j0;
     }
     NODAL_HIP_TRY(h, hipGetLastError());
+    static const bool trace_enq = getenv("NODAL_TRACE") != nullptr;
+    const auto t_enq = std::chrono::steady_clock::now();
     int32_t hinfo = 0;
     NODAL_TRY(nodal_read_words(h, &hinfo, dinfo, 4));
+    if (trace_enq)  // (is the host ahead of the device? a wait of ~0 means the launches are what takes the time)
+        fprintf(stderr, "[dense] n %lld: enqueued in %.2f ms (%llu launches of this thread so far), then waited %.2f ms for the device\n",
+                (long long)n, std::chrono::duration<double, std::milli>(t_enq - t_start).count(),
+                (unsigned long long)nodal_launches_noted(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq).count());
     *info = hinfo;
     tm.collect();
     return NODAL_OK;
