@@ -510,8 +510,10 @@ int build_lists(nodal_ctx *h, const E &en, int64_t nrows, int64_t *nent_out, int
     uint32_t *pos = reinterpret_cast<uint32_t *>(w + off_pos);
     NODAL_HIP_TRY(h, hipMemsetAsync(w, 0, off_scan, st));
 
-    {   // (NODAL_COUNT_LDS=0: one returning atomic per distinct row of an ITEM, round 3's kernel; the cross-check)
-        static const bool lds_count = !(getenv("NODAL_COUNT_LDS") && atoi(getenv("NODAL_COUNT_LDS")) == 0);
+    {   // (NODAL_COUNT_LDS=1: the rows of a tile aggregated in LDS first.  Measured at config 3, round 5: the symbolic phase
+        // 0.216 -> 0.241 ms -- the table's clear, three barriers and the LDS atomics of every tile cost more than the
+        // memory-side requests they save; off, kept as the cross-check and for hub-heavy tables)
+        static const bool lds_count = getenv("NODAL_COUNT_LDS") && atoi(getenv("NODAL_COUNT_LDS")) != 0;
         if (lds_count) count_rows_lds<E><<<grid_for(en.nitems), TB, 0, st>>>(en, rowstart, pos);
         else count_rows<E><<<grid_for(en.nitems), TB, 0, st>>>(en, rowstart, pos);
     }
