@@ -408,3 +408,21 @@ def test_factor_once_route_of_a_pair_sweep_matches_the_oracle(kind, monkeypatch)
             b[ib[q]] = -1.0
         want = b @ lu.solve(b)
         assert abs(res[q] - want) <= TOL * abs(want), (q, res[q], want)
+
+
+@pytest.mark.parametrize("nb", [16, 32, 48, 64])
+def test_front_by_front_chains_for_every_panel_width(nb, monkeypatch):
+    """Round 4's factorisation of the wide fronts -- one chain of launches per front, NODAL_DIRECT_BATCHED=0 -- is kept as
+    the cross-check of round 5's level-wide steps; its panel width is selectable (NODAL_DIRECT_NB) and its triangular
+    solve once gave wrong values in a width-templated form (advisor, round 4): every width against SuperLU, and against
+    the level-wide form's answer."""
+    table = gen.cfg5_table(130)
+    G, A = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(G.tocsr(), A, True)
+    x_new, info, _it, res = _direct(table)
+    assert info == 0 and normwise(x_new, xo) <= TOL
+    monkeypatch.setenv("NODAL_DIRECT_BATCHED", "0")
+    monkeypatch.setenv("NODAL_DIRECT_NB", str(nb))
+    x_old, info, _it, res = _direct(table)
+    assert info == 0 and res <= 1e-14
+    assert normwise(x_old, xo) <= TOL and normwise(x_old, x_new) <= 1e-12
