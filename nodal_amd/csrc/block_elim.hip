@@ -576,8 +576,16 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
     // workgroups no longer queue behind 58-us GEMM workgroups (14.37 -> 13.92 ms; 8 / 16 / 64 CUs: 14.15 /
     // 14.12 / 14.69).  NODAL_BI_MASKED=0: bulk updates on all CUs (the default until the symmetric form).
     static const bool full_mask = getenv("NODAL_BI_MASKED") != nullptr && atoi(getenv("NODAL_BI_MASKED")) == 0;
-    hipStream_t sp = h->stream, sg = full_mask ? h->stream3 : h->stream2;
-    hipStream_t s3 = full_mask ? h->stream2 : h->stream3;
+    // NODAL_BI_UNMASK_ROWS=r (round 5, measured, off): the bulk update on ALL compute units while more than r rows are
+    // left, on the masked stream afterwards (the two side streams swap roles at that block).  The idea -- the bulk update
+    // bounds the first two thirds of the solve and the mask costs it an eighth of the chip -- did not survive the
+    // measurement: config 2 13.65 ms without, 14.28 / 13.98 / 13.70 / 13.85 ms for r = 4000 / 5632 / 7000 / 8500: the chain's
+    // small kernels queueing behind 58-us GEMM workgroups cost more than the 32 CUs give, in every phase.
+    static const int64_t unmask_rows = getenv("NODAL_BI_UNMASK_ROWS") ? atoll(getenv("NODAL_BI_UNMASK_ROWS")) : 0;
+    const bool adaptive = !full_mask && unmask_rows > 0 && unmask_rows < n;
+    hipStream_t sp = h->stream, sg = (full_mask || adaptive) ? h->stream3 : h->stream2;
+    hipStream_t s3 = (full_mask || adaptive) ? h->stream2 : h->stream3;
+    bool swapped = false;
     hipEvent_t ev_wfirst = h->ev_bi[0], ev_strip = h->ev_bi[1], ev_wrest = h->ev_bi[2],
                ev_start = h->ev_bi[3], ev_done = h->ev_bi[4], ev_q = h->ev_bi[5], ev_rest = nullptr;
     const int nb = (int)bnd.size() - 1;
@@ -661,6 +669,13 @@ int factor_blockinv(nodal_ctx *h, double *A, int64_t n, int64_t lda, int64_t nco
         const double *Lhead = sym ? Lt[blk & 1] : L + J1;
         const int64_t ldh = sym ? wmax : lda;
         double *Qn = Q[(blk + 1) & 1];
+        if (adaptive && !swapped && n - J2 <= unmask_rows) {  // from here on the bulk update leaves CUs to the chain
+            std::swap(sg, s3);
+            swapped = true;
+            if (ev_rest) NODAL_HIP_TRY(h, hipStreamWaitEvent(sg, ev_rest, 0));  // (bulk updates stay in order)
+            // (the new strip stream did not scale W(k)'s wide part, nor transpose its head: ev_wrest lies behind both)
+            NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_wrest, 0));
+        }
         if (ev_rest) {  // block row k+1 was last written by the previous bulk update
             NODAL_HIP_TRY(h, hipStreamWaitEvent(sp, ev_rest, 0));
             NODAL_HIP_TRY(h, hipStreamWaitEvent(s3, ev_rest, 0));

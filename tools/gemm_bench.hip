@@ -23,13 +23,19 @@ int main(int argc, char **argv) {
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipEventRecord(e0, st);
         const int iters = 10;
-        for (int i = 0; i < iters; ++i) gemm_f64(h, st, mode, C, ld, A, ld, B, ld, M, N, K);
+        // mode 3: the symmetric block elimination's bulk update, C -= At^T B on the upper block triangle (At: the K x M
+        // panel above C, like B); the flops printed are the executed ones (the upper triangle, diagonal blocks whole)
+        for (int i = 0; i < iters; ++i) {
+            if (mode == 3) gemm_sub_tn_upper_f64(h, st, C, ld, B, ld, B, ld, M, N, K, 256);
+            else gemm_f64(h, st, mode, C, ld, A, ld, B, ld, M, N, K);
+        }
         (void)hipEventRecord(e1, st);
         (void)hipEventSynchronize(e1);
         float ms;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        printf("M=%lld N=%lld K=%lld: %.1f us/launch  %.2f TFLOP/s\n", (long long)M, (long long)N, (long long)K,
-               ms * 1e3 / iters, 2.0 * M * N * K * iters / ms / 1e9);
+        const double area = mode == 3 ? ((double)M * N - 0.5 * (double)M * ((double)M - 256.0)) : (double)M * N;
+        printf("M=%lld N=%lld K=%lld mode %d: %.1f us/launch  %.2f TFLOP/s\n", (long long)M, (long long)N, (long long)K, mode,
+               ms * 1e3 / iters, 2.0 * area * K * iters / ms / 1e9);
     }
     return 0;
 }
