@@ -366,19 +366,28 @@ def concurrent_throughput(name, device, streams, per_stream, reuse=False):
 
 
 def print_solution_seconds(device):
-    """str(Solution) of the 1e6-node grid (sorted() over 1e6 string names,
-    shortest-repr formatting of 1e6 doubles) -- the reference's output contract at scale."""
+    """str(Solution) of the 1e6-node grid (sorted() over 1e6 string names, shortest-repr
+    formatting of 1e6 doubles) -- the reference's output contract at scale, on the netlist as the command line gets it:
+    read from its file (the potentials' lines then come from libnodal_csv.so on the host threads).  Returns (seconds,
+    seconds of Netlist(path))."""
+    import tempfile
     import numpy as np
     from nodal_amd import generators as gen
     from nodal_amd.circuit import Solution
     from nodal_amd.netlist import Netlist
-    nl = Netlist.from_rows(gen.grid_rows(1000))
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        path = os.path.join(d, "grid1000.csv")
+        gen.write_csv(gen.grid_rows(1000), path)
+        Netlist(path)  # (pages the file and the tokenizer in)
+        t0 = time.perf_counter()
+        nl = Netlist(path)
+        read_s = time.perf_counter() - t0
     sol = Solution(np.linspace(0.0, 1.0, nl.nums["kcl"]), nl, [])
     t0 = time.perf_counter()
     text = str(sol)
     dt = time.perf_counter() - t0
     assert text.count("\n") == nl.nums["kcl"]
-    return dt
+    return dt, read_s
 
 
 def direct_route_times(device):
@@ -852,7 +861,7 @@ def main():
         out["concurrent"]["all"] = [{k: c[k] for k in ("streams", "symbolic_phases_kept", "circuits_per_sec")}
                                     for c in conc]
     if rank == 0 and world == 1 and name == "cfg3" and not args.no_also:
-        out["print_1e6_s"] = print_solution_seconds(local)
+        out["print_1e6_s"], out["netlist_read_1e6_s"] = print_solution_seconds(local)
     if world > 1 and name != "cfg4" and not args.no_also:
         # config 4 -- the value sweep that shards as one block system per rank, 128 members per GPU, gathered over
         # RCCL -- measured at every N beside the headline (every rank takes part; rank 0 reports)

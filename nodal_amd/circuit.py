@@ -237,10 +237,23 @@ class Solution:
         # lexicographic string order: reference nodal/nodal.py:422-434.  tolist() +
         # repr() gives the same digits as formatting np.float64 one by one, without a
         # numpy scalar object per line.
-        values = np.asarray(self.result, dtype=np.float64).tolist()
+        result = np.asarray(self.result, dtype=np.float64)
         lines = [f"Ground node: {self.ground}"]
-        nodenum = self.nodenum
-        lines += [f"e({name}) \t= {values[nodenum[name]]!r}" for name in sorted(nodenum)]
+        # a natively read netlist: the million "e(...)" lines by the host library, from the label blob (round 5; the
+        # same text, tests/test_frontend.py)
+        from . import fastparse
+        block = fastparse.native_potential_lines(self._netlist, result) if len(result) >= 20000 else None
+        values = None
+        if block is not None:
+            if block:
+                lines.append(block)
+        else:
+            values = result.tolist()
+            nodenum = self.nodenum
+            lines += [f"e({name}) \t= {values[nodenum[name]]!r}" for name in sorted(nodenum)]
         offset, anomnum = self.nums["kcl"], self.anomnum
-        lines += [f"i({name}) \t= {values[offset + anomnum[name]]!r}" for name in sorted(anomnum)]
+        if anomnum:
+            if values is None:
+                values = result.tolist()
+            lines += [f"i({name}) \t= {values[offset + anomnum[name]]!r}" for name in sorted(anomnum)]
         return "\n".join(lines)

@@ -514,3 +514,182 @@ int nodal_csv_parse(const char *buf, int64_t len, nodal_csv_result *out) {
 }
 
 }  // extern "C"
+
+// ---- Solution.__str__ at 1e6 nodes (reference nodal/nodal.py:422-434) ---------------------
+// The reference prints "e(name) \t= value" for the node names in sorted() order -- lexicographic STRING order, "10" < "2"
+// -- with str(np.float64), i.e. the shortest digits that round-trip, laid out by Python's repr rule.  At 1e6 nodes that
+// is a sort of a million strings and a million float formats: 0.55 s in Python, the largest item of the user-visible
+// path once the front end took 0.08 s.  Here: the labels (the tokenizer's blob, ids in first-appearance order) are
+// bucketed by their first two bytes, the buckets sorted on host threads (byte order = code-point order for UTF-8, which
+// is what Python's str comparison is), the lines formatted on threads into one buffer.
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+
+// repr(float) of Python 3 (float_repr_style 'short'): shortest round-trip digits; exponent form iff decpt <= -4 or
+// decpt > 16 (decpt: position of the decimal point relative to the digit string), "e-05" style exponents, ".0" appended
+// to integral values in fixed form.  Returns the number of characters written (buf holds at least 32).
+static int python_repr(double v, char *buf) {
+    if (std::isnan(v)) { memcpy(buf, "nan", 3); return 3; }
+    if (std::isinf(v)) { const char *s = v < 0 ? "-inf" : "inf"; const int n = v < 0 ? 4 : 3; memcpy(buf, s, (size_t)n); return n; }
+    char sci[40];
+    auto res = std::to_chars(sci, sci + sizeof sci, v, std::chars_format::scientific);  // [-]d[.ddd]e[+-]XX, shortest
+    const int len = (int)(res.ptr - sci);
+    int p = 0, o = 0;
+    if (sci[0] == '-') { buf[o++] = '-'; p = 1; }
+    char digits[24];
+    int nd = 0;
+    for (; p < len && sci[p] != 'e'; ++p)
+        if (sci[p] != '.') digits[nd++] = sci[p];
+    int e10 = 0;
+    {
+        ++p;  // 'e'
+        const bool neg = sci[p] == '-';
+        ++p;
+        for (; p < len; ++p) e10 = e10 * 10 + (sci[p] - '0');
+        if (neg) e10 = -e10;
+    }
+    while (nd > 1 && digits[nd - 1] == '0') --nd;  // (to_chars gives no trailing zeros; belt and braces)
+    const int decpt = e10 + 1;
+    if (decpt <= -4 || decpt > 16) {
+        buf[o++] = digits[0];
+        if (nd > 1) {
+            buf[o++] = '.';
+            memcpy(buf + o, digits + 1, (size_t)(nd - 1));
+            o += nd - 1;
+        }
+        buf[o++] = 'e';
+        int e = decpt - 1;
+        buf[o++] = e < 0 ? '-' : '+';
+        if (e < 0) e = -e;
+        char eb[8];
+        int ne = 0;
+        do { eb[ne++] = (char)('0' + e % 10); e /= 10; } while (e);
+        if (ne < 2) eb[ne++] = '0';
+        while (ne) buf[o++] = eb[--ne];
+        return o;
+    }
+    if (decpt <= 0) {
+        buf[o++] = '0';
+        buf[o++] = '.';
+        for (int z = 0; z < -decpt; ++z) buf[o++] = '0';
+        memcpy(buf + o, digits, (size_t)nd);
+        return o + nd;
+    }
+    if (decpt >= nd) {
+        memcpy(buf + o, digits, (size_t)nd);
+        o += nd;
+        for (int z = 0; z < decpt - nd; ++z) buf[o++] = '0';
+        buf[o++] = '.';
+        buf[o++] = '0';
+        return o;
+    }
+    memcpy(buf + o, digits, (size_t)decpt);
+    o += decpt;
+    buf[o++] = '.';
+    memcpy(buf + o, digits + decpt, (size_t)(nd - decpt));
+    return o + (nd - decpt);
+}
+
+extern "C" {
+
+// repr of one double (testing hook: the formatter against Python's own repr)
+int nodal_repr_double(double v, char *buf32) { return python_repr(v, buf32); }
+
+// "prefix" + name + ") \t= " + repr(values[index_of[k]]) for every label k with index_of[k] >= 0, the lines in sorted()
+// order of the names, joined by '\n' (no trailing newline).  labels: nlabels names joined by '\n'.  *out is malloc'ed
+// (nodal_csv_free_buffer).  Returns 0, or CSV_NO_MEMORY.
+int nodal_format_lines(const char *labels, int64_t labels_len, int64_t nlabels, const int64_t *index_of,
+                       const double *values, const char *prefix, char **out, int64_t *out_len) {
+    *out = nullptr;
+    *out_len = 0;
+    int threads = (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("NODAL_HOST_THREADS")) threads = atoi(e);
+    if (threads < 1) threads = 1;
+    if (threads > 32) threads = 32;
+    if (nlabels < 20000) threads = 1;
+    const size_t plen = strlen(prefix);
+    // label k = bytes [off[k], off[k + 1] - 1)
+    std::vector<int64_t> off((size_t)nlabels + 1);
+    {
+        int64_t k = 0, at = 0;
+        off[0] = 0;
+        while (k < nlabels) {
+            const char *nl = static_cast<const char *>(memchr(labels + at, '\n', (size_t)(labels_len - at)));
+            const int64_t end = nl ? nl - labels : labels_len;
+            off[(size_t)++k] = end + 1;
+            at = end + 1;
+            if (!nl) break;
+        }
+        if (k != nlabels) return CSV_FIELD_COUNT;
+    }
+    auto name_of = [&](int64_t k) { return std::string_view(labels + off[(size_t)k], (size_t)(off[(size_t)k + 1] - 1 - off[(size_t)k])); };
+    // buckets by the first two bytes (0 for a missing byte: a shorter name sorts first)
+    auto key_of = [&](int64_t k) {
+        const std::string_view s = name_of(k);
+        const unsigned b0 = s.size() > 0 ? (unsigned char)s[0] : 0u, b1 = s.size() > 1 ? (unsigned char)s[1] : 0u;
+        return (b0 << 8) | b1;
+    };
+    std::vector<int64_t> start(65537, 0);
+    std::vector<int32_t> order;
+    int64_t kept = 0;
+    for (int64_t k = 0; k < nlabels; ++k)
+        if (index_of[k] >= 0) {
+            ++start[(size_t)key_of(k) + 1];
+            ++kept;
+        }
+    for (size_t b = 0; b < 65536; ++b) start[b + 1] += start[b];
+    order.resize((size_t)kept);
+    {
+        std::vector<int64_t> fill(start.begin(), start.end() - 1);
+        for (int64_t k = 0; k < nlabels; ++k)
+            if (index_of[k] >= 0) order[(size_t)fill[(size_t)key_of(k)]++] = (int32_t)k;
+    }
+    std::vector<int> used;
+    for (int b = 0; b < 65536; ++b)
+        if (start[(size_t)b + 1] > start[(size_t)b] + 1) used.push_back(b);
+    parallel_for((int)used.size(), threads, [&](int u) {
+        const int b = used[(size_t)u];
+        std::sort(order.begin() + start[(size_t)b], order.begin() + start[(size_t)b + 1],
+                  [&](int32_t x, int32_t y) { return name_of(x) < name_of(y); });
+    });
+    // lines: ranges of the sorted order on the threads, sizes first
+    const int parts = threads > 1 ? 4 * threads : 1;
+    std::vector<int64_t> part_bytes((size_t)parts + 1, 0);
+    std::vector<std::vector<char>> chunks((size_t)parts);
+    parallel_for(parts, threads, [&](int q) {
+        const int64_t lo = kept * q / parts, hi = kept * (q + 1) / parts;
+        std::vector<char> &buf = chunks[(size_t)q];
+        buf.reserve((size_t)(hi - lo) * 40);
+        char num[40];
+        for (int64_t r = lo; r < hi; ++r) {
+            const int64_t k = order[(size_t)r];
+            const std::string_view nm = name_of(k);
+            const int nn = python_repr(values[index_of[k]], num);
+            const size_t need = plen + nm.size() + 5 + (size_t)nn + 1;
+            const size_t at = buf.size();
+            buf.resize(at + need);
+            char *w = buf.data() + at;
+            memcpy(w, prefix, plen); w += plen;
+            memcpy(w, nm.data(), nm.size()); w += nm.size();
+            memcpy(w, ") \t= ", 5); w += 5;
+            memcpy(w, num, (size_t)nn); w += nn;
+            *w = '\n';
+        }
+        part_bytes[(size_t)q + 1] = (int64_t)buf.size();
+    });
+    for (int q = 0; q < parts; ++q) part_bytes[(size_t)q + 1] += part_bytes[(size_t)q];
+    const int64_t total = part_bytes[(size_t)parts];
+    char *res = static_cast<char *>(malloc((size_t)total + 8));
+    if (!res) return CSV_NO_MEMORY;
+    parallel_for(parts, threads, [&](int q) {
+        if (!chunks[(size_t)q].empty()) memcpy(res + part_bytes[(size_t)q], chunks[(size_t)q].data(), chunks[(size_t)q].size());
+    });
+    *out = res;
+    *out_len = total ? total - 1 : 0;  // without the last separator
+    return CSV_OK;
+}
+
+void nodal_csv_free_buffer(char *p) { free(p); }
+
+}  // extern "C"

@@ -104,8 +104,44 @@ def _load_csv_lib():
         lib.nodal_csv_free.restype = None
         lib.nodal_csv_free.argtypes = [C.POINTER(Result)]
         lib.Result = Result
+        lib.nodal_repr_double.restype = C.c_int
+        lib.nodal_repr_double.argtypes = [C.c_double, C.c_char_p]
+        lib.nodal_format_lines.restype = C.c_int
+        lib.nodal_format_lines.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                           C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        lib.nodal_csv_free_buffer.restype = None
+        lib.nodal_csv_free_buffer.argtypes = [C.c_void_p]
         _csv_lib = lib
     return _csv_lib
+
+
+def native_potential_lines(netlist, values):
+    """The "e(name) \t= value" lines of Solution.__str__ (reference nodal/nodal.py:422-434: names in sorted() order,
+    values as str(np.float64) prints them) for a natively read netlist, made by libnodal_csv.so on the host threads from
+    the tokenizer's label blob; None when that does not apply (the caller formats them in Python)."""
+    d = netlist.__dict__
+    if not d.get("_fast") or "_labels_blob" not in d:
+        return None
+    if "nodenum" in d and len(d["nodenum"]) != d["_nlabels"] - 1:
+        return None  # (somebody changed the dict: its own contents are what counts)
+    lib = _load_csv_lib()
+    if not lib:
+        return None
+    import ctypes as C
+    index_of = np.ascontiguousarray(d["_node_index"][: d["_nlabels"]], dtype=np.int64)
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    if len(values) < d["_nlabels"] - 1:
+        return None
+    out, out_len = C.c_void_p(), C.c_int64(0)
+    blob = d["_labels_blob"]
+    status = lib.nodal_format_lines(blob, len(blob), d["_nlabels"], index_of.ctypes.data_as(C.POINTER(C.c_int64)),
+                                    values.ctypes.data_as(C.POINTER(C.c_double)), b"e(", C.byref(out), C.byref(out_len))
+    if status != 0:
+        return None
+    try:
+        return C.string_at(out, out_len.value).decode()
+    finally:
+        lib.nodal_csv_free_buffer(out)
 
 
 def _finish_fast(nl, name, type_names, value, nfields, acode, bcode, labels):

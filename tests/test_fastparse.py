@@ -225,3 +225,55 @@ def test_natively_read_netlist_builds_its_containers_on_demand(tmp_path, monkeyp
     import copy
     clone = copy.deepcopy(plain_fast)     # equivalent_resistance's first step
     assert clone.nodenum == plain_slow.nodenum and clone.component_keys == plain_slow.component_keys
+
+
+def test_native_repr_of_doubles_is_pythons(reader):
+    """csrc/fastcsv.cpp python_repr against repr(float) -- what str(np.float64) prints (reference nodal/nodal.py:427,432)
+    -- over magnitudes, signs, the fixed / exponent switch at 1e-4 and 1e16, integers, denormals, infinities, nan."""
+    if reader != "native":
+        pytest.skip("native library only")
+    import ctypes as C
+    import struct
+    lib = fastparse._load_csv_lib()
+    rng = random.Random(9)
+    cases = [0.0, -0.0, 1.0, -1.0, 0.1, 0.5, 1e-4, 9.999e-5, 1e-5, 123456.789, 1e15, 1e16, 9999999999999998.0,
+             12345678901234567.0, 1.2345678901234568e+17, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308,
+             float("inf"), float("-inf"), float("nan"), -1.9999999999999998, 8.872546346681101, 100.0, 1e22, 1e23,
+             0.30000000000000004, 2.0 ** 53, 2.0 ** 53 + 2, 1 / 3, 123.0, 0.001, 0.0001, 0.00001234]
+    for _ in range(40000):
+        kind = rng.random()
+        if kind < 0.4:
+            cases.append(struct.unpack("<d", struct.pack("<Q", rng.getrandbits(64)))[0])  # any bit pattern
+        elif kind < 0.7:
+            cases.append(rng.uniform(-10, 10) * 10.0 ** rng.randint(-20, 20))
+        elif kind < 0.85:
+            cases.append(float(rng.randint(-10 ** 17, 10 ** 17)))
+        else:
+            cases.append(round(rng.uniform(-1000, 1000), rng.randint(0, 6)))
+    buf = C.create_string_buffer(40)
+    for v in cases:
+        n_ = lib.nodal_repr_double(v, buf)
+        assert buf.raw[:n_].decode() == repr(v), (v, buf.raw[:n_])
+
+
+def test_native_solution_text_equals_the_python_text(tmp_path, monkeypatch, reader):
+    """str(Solution) of a natively read netlist: the potentials' lines come from libnodal_csv.so (sorted on host
+    threads from the label blob, formatted there); the text must be the one the Python loop makes -- names in sorted()
+    string order ("10" < "2"), shortest-repr values, -0.0, the ground left out (reference nodal/nodal.py:422-434)."""
+    if reader != "native":
+        pytest.skip("native library only")
+    from nodal_amd.circuit import Solution
+    rows = list(gen.grid_rows(150))  # 22 499 potentials: above the native path's threshold
+    _slow, fast = both(tmp_path, rows, monkeypatch)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(fast.nums["kcl"]) * 10.0 ** rng.integers(-8, 8, fast.nums["kcl"])
+    x[::97] = 0.0
+    x[5::101] = -0.0
+    x[7] = 1e16
+    x[8] = 1e-5
+    sol = Solution(x, fast, [])
+    native = str(sol)
+    assert "nodenum" not in fast.__dict__  # (the native path never built the dict)
+    monkeypatch.setattr(fastparse, "native_potential_lines", lambda nl, v: None)
+    assert str(sol) == native
+    assert native.startswith("Ground node: g\ne(1) \t= ") and native.count("\n") == fast.nums["kcl"]
