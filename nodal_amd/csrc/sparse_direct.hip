@@ -299,6 +299,171 @@ __global__ __launch_bounds__(BS) void factor_fronts(Tree T, const int32_t *__res
     }
 }
 
+// ---- small fronts, one WAVEFRONT each, the panel in registers (round 5) --------------------------------------------
+// factor_fronts<64, true> keeps the front in LDS and walks it with loops of LDS round trips: 80 us for a 60 x 60 leaf,
+// 3.4 ms for the 48 888 leaves of config 5's matrix.  Here the lane IS the row: the 16 columns of a panel live in the
+// lane's registers for the whole panel step (the pivot row travels by v_readlane -- the pivot's row number is uniform --,
+// the arg-max by wave shuffles, no barrier that means anything with one wave), and the lane's rows of L21 stay in
+// those registers for the rank-16 update of the trailing block, which reads U12 by broadcast from LDS.  The same
+// operations on the same values in the same order as factor_fronts: identical factors (NODAL_DIRECT_WAVE=0 keeps the
+// LDS kernel as the cross-check).  RPL: rows per lane (1: fronts of at most 64 rows; 2: of at most 128).
+__device__ __forceinline__ double lane_bcast(double v, int src) {  // src uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+template <int RPL>
+__global__ __launch_bounds__(64) void factor_fronts_wave(Tree T, const int32_t *__restrict__ sns, double *__restrict__ fronts,
+                                                         int32_t *__restrict__ lperm, double tiny, double repl,
+                                                         unsigned long long *__restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) double Fl[];
+    const int32_t t = sns[blockIdx.x];
+    const int s = T.sn_start[t + 1] - T.sn_start[t];
+    const int dim = s + (int)(T.struct_ptr[t + 1] - T.struct_ptr[t]);
+    double *Fg = fronts + T.front_off[t];
+    int32_t *perm = lperm + T.sn_start[t];
+    const int lane = threadIdx.x;
+    for (int e = lane; e < dim * dim; e += 64) Fl[e] = Fg[e];
+    for (int i = lane; i < s; i += 64) perm[i] = i;
+    __syncthreads();
+    for (int k0 = 0; k0 < s; k0 += NB) {
+        const int nb = s - k0 < NB ? s - k0 : NB;
+        double a[RPL][NB];
+        auto load_panel = [&]() {
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const int i = lane + 64 * r;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) a[r][c] = (i < dim && c < nb) ? Fl[i + (k0 + c) * dim] : 0.0;
+            }
+        };
+        auto store_panel = [&]() {
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const int i = lane + 64 * r;
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+                    if (i < dim && c < nb) Fl[i + (k0 + c) * dim] = a[r][c];
+            }
+        };
+        load_panel();
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            if (c < nb) {  // (uniform)
+                const int k = k0 + c;
+                // pivot search in column k among the fully summed rows k .. s-1 (first row of maximal |a|)
+                double best = -1.0;
+                int bi = k;
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) {
+                    const int i = lane + 64 * r;
+                    const double v = fabs(a[r][c]);
+                    if (i >= k && i < s && v > best) { best = v; bi = i; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double ov = __shfl_xor(best, off, 64);
+                    const int oi = __shfl_xor(bi, off, 64);
+                    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+                }
+                double d = lane_bcast(a[0][c], k & 63);
+                if (RPL > 1 && k >= 64) d = lane_bcast(a[RPL - 1][c], k & 63);
+                int p = bi;
+                double forced = 0.0;
+                if (!(best >= tiny)) {  // nothing usable in the pivot block: SuperLU_DIST's static-pivot rule
+                    forced = d < 0.0 ? -repl : repl;
+                    p = k;
+                    if (lane == 0) atomicAdd(stats, 1ull);
+                } else if (fabs(d) >= 0.25 * best) {
+                    p = k;  // (threshold pivoting: the diagonal stays when it is within a factor 4 of the best)
+                }
+                if (forced != 0.0) {
+#pragma unroll
+                    for (int r = 0; r < RPL; ++r)
+                        if (lane + 64 * r == k) a[r][c] = forced;
+                }
+                if (p != k) {  // (uniform; rare) the whole rows k and p change places: through LDS, every column
+                    store_panel();
+                    __syncthreads();
+                    for (int j = lane; j < dim; j += 64) {
+                        const double x = Fl[k + j * dim], y = Fl[p + j * dim];
+                        Fl[k + j * dim] = y;
+                        Fl[p + j * dim] = x;
+                    }
+                    if (lane == 0) {
+                        const int32_t tmp = perm[k];
+                        perm[k] = perm[p];
+                        perm[p] = tmp;
+                    }
+                    __syncthreads();
+                    load_panel();
+                }
+                // the pivot row (row k after the interchange), columns c .. nb-1 of the panel
+                double prow[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    prow[j] = 0.0;
+                    if (j >= c) {
+                        prow[j] = lane_bcast(a[0][j], k & 63);
+                        if (RPL > 1 && k >= 64) prow[j] = lane_bcast(a[RPL - 1][j], k & 63);
+                    }
+                }
+                const double rp = 1.0 / prow[c];
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) {
+                    const int i = lane + 64 * r;
+                    if (i > k && i < dim) {
+                        const double l = a[r][c] * rp;
+                        a[r][c] = l;
+#pragma unroll
+                        for (int j = 0; j < NB; ++j)
+                            if (j > c && j < nb) a[r][j] = fma(-l, prow[j], a[r][j]);
+                    }
+                }
+            }
+        }
+        store_panel();
+        __syncthreads();
+        const int j0 = k0 + nb;
+        if (j0 >= dim) break;
+        // U12 = L11^-1 A12: rows k0 .. j0-1 of the columns j >= j0, one lane per column
+        for (int j = j0 + lane; j < dim; j += 64) {
+            double u[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) u[r] = r < nb ? Fl[(k0 + r) + j * dim] : 0.0;
+#pragma unroll
+            for (int r = 1; r < NB; ++r)
+#pragma unroll
+                for (int q = 0; q < r; ++q)
+                    if (r < nb) u[r] = fma(-Fl[(k0 + r) + (k0 + q) * dim], u[q], u[r]);
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+                if (r < nb) Fl[(k0 + r) + j * dim] = u[r];
+        }
+        __syncthreads();
+        // trailing update: the lane's rows of L21 are in its registers, U12 by broadcast from LDS
+        for (int j = j0; j < dim; ++j) {
+            double u[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) u[q] = q < nb ? Fl[(k0 + q) + j * dim] : 0.0;
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const int i = lane + 64 * r;
+                if (i >= j0 && i < dim) {
+                    double acc = Fl[i + j * dim];
+#pragma unroll
+                    for (int q = 0; q < NB; ++q)
+                        if (q < nb) acc = fma(-a[r][q], u[q], acc);
+                    Fl[i + j * dim] = acc;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = lane; e < dim * dim; e += 64) Fg[e] = Fl[e];
+}
+
 // ---- fronts wider than BIG_DIM: one front, many workgroups ------------------------------------------------
 // A 1500-wide front holds 7e8 of the factorisation's flops and ONE workgroup needed 30-90 ms for it (a 2944-wide
 // front of a binary tree: 1.5 s).  Such fronts are factored panel by panel from the host: a single-workgroup
@@ -1452,7 +1617,14 @@ int slu_factor(nodal_ctx *h, int32_t *info, double tiny_factor, double tiny_thre
                 // barriers per column step next to free; round 5)
                 static const int lds_bs = getenv("NODAL_DIRECT_LDS_BS") ? atoi(getenv("NODAL_DIRECT_LDS_BS")) : 64;
                 const size_t lds = (size_t)S->lvl_maxdim[(size_t)l] * S->lvl_maxdim[(size_t)l] * 8;
-                if (lds_bs == 64)
+                const bool wave_fronts = !(getenv("NODAL_DIRECT_WAVE") && atoi(getenv("NODAL_DIRECT_WAVE")) == 0);
+                if (lds_bs == 64 && wave_fronts && S->lvl_maxdim[(size_t)l] <= 64)
+                    factor_fronts_wave<1><<<nsmall, 64, lds, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl,
+                                                                   S->stats.as<unsigned long long>());
+                else if (lds_bs == 64 && wave_fronts)
+                    factor_fronts_wave<2><<<nsmall, 64, lds, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl,
+                                                                   S->stats.as<unsigned long long>());
+                else if (lds_bs == 64)
                     factor_fronts<64, true><<<nsmall, 64, lds, st>>>(T, sns, S->fronts.as<double>(), S->lperm.as<int32_t>(), tiny, repl,
                                                                      S->stats.as<unsigned long long>());
                 else if (lds_bs == 128)

@@ -426,3 +426,18 @@ def test_front_by_front_chains_for_every_panel_width(nb, monkeypatch):
     x_old, info, _it, res = _direct(table)
     assert info == 0 and res <= 1e-14
     assert normwise(x_old, xo) <= TOL and normwise(x_old, x_new) <= 1e-12
+
+
+@pytest.mark.parametrize("name", ["cfg5(90)", "grid(60)", "grid + wires", "tree(3000)"])
+def test_wave_per_front_kernel_gives_the_factors_of_the_lds_kernel(name, monkeypatch):
+    """Round 5: the leaves and small separators are factored one WAVEFRONT per front with the panel in registers
+    (csrc/sparse_direct.hip factor_fronts_wave); the same pivots and the same operations in the same order as the in-LDS
+    kernel it replaces (NODAL_DIRECT_WAVE=0): the solutions must agree bit for bit."""
+    table = TABLES[name]()
+    monkeypatch.setenv("NODAL_DIRECT_WAVE", "1")
+    x_wave, info, _it, _res = _direct(table)
+    assert info == 0
+    monkeypatch.setenv("NODAL_DIRECT_WAVE", "0")
+    x_lds, info, _it, _res = _direct(table)
+    assert info == 0
+    assert np.array_equal(x_wave, x_lds)
