@@ -560,11 +560,13 @@ __device__ __forceinline__ void panel_factor_regs_body(double *__restrict__ F, i
                                                        unsigned long long *__restrict__ stats) {
     constexpr int BS = 256, NW = BS / 64;  // (256 threads: a budget of 256 registers each; 512 / 1024 threads leave 128 / 64 and spill)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ double red_v[NW];
-    __shared__ int red_i[NW];
-    __shared__ int piv_row;
-    __shared__ double prow[PNB], krow[PNB];
-    __shared__ double pivot_value;
+    // Two barriers per column (round 5; four before): every thread takes the pivot decision itself from the four waves'
+    // candidates -- no thread-0 step with a barrier behind it --, and the words a column hands round (candidates, row k,
+    // the pivot row) live in slots of the column's parity, so that column c + 1 writes nothing a slow thread of column c
+    // still reads (between a slot's two uses lie the two barriers of the column in between).
+    __shared__ double red_v[2][NW];
+    __shared__ int red_i[2][NW];
+    __shared__ double prow2[2][PNB], krow2[2][PNB];
     double a[RPT][PNB];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
@@ -576,6 +578,7 @@ __device__ __forceinline__ void panel_factor_regs_body(double *__restrict__ F, i
     for (int c = 0; c < PNB; ++c) {  // (fully unrolled: every index into a[][] is a constant -- registers, not scratch)
         if (c < nb) {                // (uniform over the workgroup)
         const int k = k0 + c;
+        double *prow = prow2[c & 1], *krow = krow2[c & 1];
         double best = -1.0;
         int bi = k;
 #pragma unroll
@@ -590,34 +593,35 @@ __device__ __forceinline__ void panel_factor_regs_body(double *__restrict__ F, i
             const int oi = __shfl_down(bi, off, 64);
             if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
         }
-        if (lane == 0) { red_v[wave] = best; red_i[wave] = bi; }
+        if (lane == 0) { red_v[c & 1][wave] = best; red_i[c & 1][wave] = bi; }
         // row k of the panel for whoever needs it (the diagonal for the pivot rule, the row for the interchange)
         if (tid == c) {  // (row k = k0 + c is thread c's first row)
 #pragma unroll
             for (int j = 0; j < PNB; ++j) krow[j] = a[0][j];
         }
         __syncthreads();
-        if (tid == 0) {
-            double bv = red_v[0];
-            int br = red_i[0];
-            for (int w = 1; w < NW; ++w)
-                if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < br)) { bv = red_v[w]; br = red_i[w]; }
+        int p;
+        double forced = 0.0;  // 0: the pivot is whatever row p holds
+        {
+            double bv = red_v[c & 1][0];
+            int br = red_i[c & 1][0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                const double wv = red_v[c & 1][w];
+                const int wi = red_i[c & 1][w];
+                if (wv > bv || (wv == bv && wi < br)) { bv = wv; br = wi; }
+            }
             const double d = krow[c];
-            double pv = 0.0;  // 0: the pivot is whatever row br holds
             if (!(bv >= tiny)) {
-                pv = d < 0.0 ? -repl : repl;
+                forced = d < 0.0 ? -repl : repl;
                 br = k;
-                atomicAdd(stats, 1ull);
+                if (tid == 0) atomicAdd(stats, 1ull);
             } else if (fabs(d) >= 0.25 * bv) {
                 br = k;
             }
-            piv_row = br;
-            pivot_value = pv;
-            piv[c] = br;
+            p = br;
+            if (tid == 0) piv[c] = br;
         }
-        __syncthreads();
-        const int p = piv_row;
-        const double forced = pivot_value;
         // the owner of row p publishes it
         {
             const int off = p - k0 - tid;  // row p is mine iff off = r * BS for some r < RPT
@@ -656,7 +660,6 @@ __device__ __forceinline__ void panel_factor_regs_body(double *__restrict__ F, i
                     if (j > c) a[r][j] = fma(-l, prow[j], a[r][j]);
             }
         }
-        __syncthreads();  // (prow / krow are rewritten by the next column)
         }
     }
 #pragma unroll
