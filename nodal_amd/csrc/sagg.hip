@@ -89,13 +89,16 @@ struct Ell {
     int64_t n = 0, ld = 0;
     int32_t width = 0;
     const int32_t *col = nullptr;
+    const int16_t *dcol = nullptr;  // fixed-width levels whose columns all lie within 32767 of their row: column - row
+                                    // (what the cycle's and the outer iteration's row kernels read instead of `col`)
     const double *val = nullptr;
     const float *valf = nullptr;  // the same values rounded to f32: what the preconditioner's sweeps read
     const int32_t *len = nullptr;
 };
 
 enum { ST_MAXLEN = 0, ST_GRADED = 1, ST_BADDIAG = 2, ST_OVERFLOW = 3, ST_NNZ = 4, ST_UNASSIGNED = 5,
-       ST_MAXR = 6, ST_NC = 7 /* aggregates of the level (the scan's total) */, ST_COUNT = 8 };
+       ST_MAXR = 6, ST_NC = 7 /* aggregates of the level (the scan's total) */,
+       ST_FARCOL = 8 /* level 0: some column lies further than 32767 from its row */, ST_COUNT = 9 };
 
 struct SLevel {
     int64_t n = 0, ld = 0, nc = 0;
@@ -104,6 +107,8 @@ struct SLevel {
     int32_t wfix = 0;        // > 0: every row is zero-padded to this many slots (unrolled row kernels)
     int64_t nnz = 0;
     DevBuf acol, aval, alen, dinv;
+    DevBuf adcol;            // int16 column - row per slot (d16)
+    bool d16 = false;
     DevBuf agg, pcol, pval;
     DevBuf rcol, rval, rlen;
     int64_t rld = 0;
@@ -114,6 +119,7 @@ struct SLevel {
         e.n = n; e.ld = ld; e.width = width;
         e.col = acol.as<int32_t>(); e.val = aval.as<double>(); e.len = alen.as<int32_t>();
         e.valf = avalf.as<float>();
+        e.dcol = d16 ? adcol.as<int16_t>() : nullptr;
         return e;
     }
     // (slots of ld doubles; a cyc_t vector uses the front of its slot)
@@ -216,7 +222,7 @@ struct SHierarchy {
         if (aux) (void)hipStreamDestroy(aux);
         for (SLevel *l : pool) {
             DevBuf *b[] = {&l->acol, &l->aval, &l->alen, &l->dinv, &l->agg, &l->pcol, &l->pval, &l->rcol,
-                           &l->rval, &l->rlen, &l->vec, &l->part, &l->gflag, &l->avalf, &l->pvalf, &l->rvalf};
+                           &l->rval, &l->rlen, &l->vec, &l->part, &l->gflag, &l->avalf, &l->pvalf, &l->rvalf, &l->adcol};
             for (DevBuf *x : b) x->release();
             delete l;
         }
@@ -272,13 +278,15 @@ __global__ __launch_bounds__(TB) void row_stats(int64_t n, const int32_t *__rest
                                                 bool general, unsigned long long *__restrict__ stats,
                                                 uint32_t *__restrict__ bstat) {
     int32_t mlen = 0;
-    uint32_t graded = 0, bad = 0;
+    uint32_t graded = 0, bad = 0, far = 0;
     for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
         const int32_t e0 = indptr[i], e1 = indptr[i + 1];
         mlen = max(mlen, e1 - e0);
         double d = 0.0, mx = 0.0, mn = 1e300;
         for (int32_t e = e0; e < e1; ++e) {
             const double v = data[e];
+            const int64_t dc = (int64_t)indices[e] - i;
+            if (dc > 32767 || dc < -32767) far = 1;
             if (indices[e] == (int32_t)i) d = v;
             else if (v != 0.0) {
                 mx = fmax(mx, fabs(v));
@@ -295,11 +303,13 @@ __global__ __launch_bounds__(TB) void row_stats(int64_t n, const int32_t *__rest
     atomicMax(&s_len, (unsigned)mlen);
     if (graded) atomicAdd(&s_graded, graded);
     if (bad) atomicOr(&s_bad, 1u);
+    if (far) atomicOr(&s_bad, 2u);
     __syncthreads();
     if (threadIdx.x == 0) {
         bstat[blockIdx.x] = s_len;
         bstat[BSTAT_MAX + blockIdx.x] = s_graded;
-        if (s_bad) atomicOr(&stats[ST_BADDIAG], 1ull);  // (rare)
+        if (s_bad & 1u) atomicOr(&stats[ST_BADDIAG], 1ull);  // (rare)
+        if (s_bad & 2u) stats[ST_FARCOL] = 1ull;             // (every writer stores the same word)
     }
 }
 
@@ -308,7 +318,8 @@ __global__ __launch_bounds__(TB) void csr_to_ell(int64_t n, int64_t ld, const in
                                                  const int32_t *__restrict__ indices,
                                                  const double *__restrict__ data, int32_t *__restrict__ col,
                                                  double *__restrict__ val, float *__restrict__ valf,
-                                                 int32_t *__restrict__ len, double *__restrict__ dinv, int32_t wpad) {
+                                                 int32_t *__restrict__ len, double *__restrict__ dinv, int32_t wpad,
+                                                 int16_t *__restrict__ dcol) {
     for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
         const int32_t e0 = indptr[i], e1 = indptr[i + 1];
         double d = 1.0;
@@ -316,12 +327,14 @@ __global__ __launch_bounds__(TB) void csr_to_ell(int64_t n, int64_t ld, const in
             const int32_t c = indices[e];
             const double v = data[e];
             col[(int64_t)(e - e0) * ld + i] = c;
+            if (dcol) dcol[(int64_t)(e - e0) * ld + i] = (int16_t)(c - (int32_t)i);
             val[(int64_t)(e - e0) * ld + i] = v;
             valf[(int64_t)(e - e0) * ld + i] = (float)v;
             if (c == (int32_t)i) d = v;
         }
         for (int32_t s = e1 - e0; s < wpad; ++s) {  // zero padding up to the fixed width
             col[(int64_t)s * ld + i] = (int32_t)i;
+            if (dcol) dcol[(int64_t)s * ld + i] = 0;
             val[(int64_t)s * ld + i] = 0.0;
             valf[(int64_t)s * ld + i] = 0.0f;
         }
@@ -1502,7 +1515,8 @@ int sagg_refresh(nodal_ctx *h, SHierarchy *H, const int32_t *indptr0, const int3
     }
     csr_to_ell<<<grid_for(n0), TB, 0, st>>>(n0, L0->ld, indptr0, indices0, data0, L0->acol.as<int32_t>(),
                                            L0->aval.as<double>(), L0->avalf.as<float>(),
-                                           L0->alen.as<int32_t>(), L0->dinv.as<double>(), L0->wfix);
+                                           L0->alen.as<int32_t>(), L0->dinv.as<double>(), L0->wfix,
+                                           L0->d16 ? L0->adcol.as<int16_t>() : nullptr);
     NODAL_HIP_TRY(h, hipGetLastError());
     for (int l = 0; l + 1 < H->nlev; ++l) {
         SLevel *L = H->pool[l], *C = H->pool[l + 1];
@@ -1655,9 +1669,16 @@ static int sagg_setup_csr_body(nodal_ctx *h, int64_t n0, int64_t nnz0, const int
     NODAL_HIP_TRY(h, L0->avalf.reserve((size_t)L0->width * L0->ld * 4 + 64));
     NODAL_HIP_TRY(h, L0->alen.reserve((size_t)L0->ld * 4 + 64));
     NODAL_HIP_TRY(h, L0->dinv.reserve((size_t)L0->ld * 8 + 64));
+    // Columns as 16-bit offsets from the row (NODAL_SA_D16=0: off): the three level-0 row kernels of an iteration read 10
+    // instead of 20 bytes of columns per row (W = 5); the same columns, hence the same sums, bit for bit.  Level 0 only
+    // (the other levels are latency-bound), fixed-width rows only, and only when every column is that close to its row.
+    static const bool d16_env = !(getenv("NODAL_SA_D16") && atoi(getenv("NODAL_SA_D16")) == 0);
+    L0->d16 = d16_env && L0->wfix > 0 && hs[ST_FARCOL] == 0;
+    if (L0->d16) NODAL_HIP_TRY(h, L0->adcol.reserve((size_t)L0->width * L0->ld * 2 + 64));
     csr_to_ell<<<grid_for(n0), TB, 0, st>>>(n0, L0->ld, indptr0, indices0, data0, L0->acol.as<int32_t>(),
                                            L0->aval.as<double>(), L0->avalf.as<float>(),
-                                           L0->alen.as<int32_t>(), L0->dinv.as<double>(), L0->wfix);
+                                           L0->alen.as<int32_t>(), L0->dinv.as<double>(), L0->wfix,
+                                           L0->d16 ? L0->adcol.as<int16_t>() : nullptr);
     NODAL_HIP_TRY(h, hipGetLastError());
 
     int l = 0;
@@ -2156,7 +2177,8 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
             const int64_t it_ref = rr_prev > 0.0 ? it_prev : 0;
             if (hs[F_RR] > 0.0 && hs[F_RR] < rr_ref && enqueued > it_ref) {
                 const double rate = log(hs[F_RR] / rr_ref) / (double)(enqueued - it_ref);  // < 0
-                next = (int)floor(0.75 * log(target / hs[F_RR]) / rate);
+                static const double look = getenv("NODAL_FCG_LOOK") ? atof(getenv("NODAL_FCG_LOOK")) : 0.75;
+                next = (int)floor(look * log(target / hs[F_RR]) / rate);
             }
             if (next > enqueued) next = (int)enqueued;  // (at most doubling: early rates are pessimistic)
             batch = next < 1 ? 1 : (next > 32 ? 32 : next);

@@ -49,10 +49,18 @@ __device__ __forceinline__ double ell_row_w(const Ell &A, const VT *__restrict__
     } else {
         int32_t c[W];
         double v[W];
+        if (A.dcol) {  // (uniform) columns as 16-bit offsets from the row
 #pragma unroll
-        for (int q = 0; q < W; ++q) {
-            c[q] = A.col[(int64_t)q * A.ld + i];
-            v[q] = (double)val[(int64_t)q * A.ld + i];
+            for (int q = 0; q < W; ++q) {
+                c[q] = (int32_t)i + (int32_t)A.dcol[(int64_t)q * A.ld + i];
+                v[q] = (double)val[(int64_t)q * A.ld + i];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                c[q] = A.col[(int64_t)q * A.ld + i];
+                v[q] = (double)val[(int64_t)q * A.ld + i];
+            }
         }
         double acc = 0.0;
 #pragma unroll
