@@ -665,6 +665,19 @@ __global__ __launch_bounds__(TB) void f_direction(const cyc_t *__restrict__ z, d
                                                   const double *__restrict__ part_rr, int nparts,
                                                   double *__restrict__ sc, int parity, int64_t n) {
     const int cur = parity & 1, prev = cur ^ 1;
+    // The vector operands of the thread's first FD_PRE rows are requested BEFORE the scalars and the partial sums are
+    // looked at: the reduction in front of the update is a dependent round trip and a barrier (~2 us of an 8-us
+    // kernel) during which nothing streamed.
+    constexpr int FD_PRE = 4;
+    const int64_t i0 = (int64_t)xcd_block() * TB + threadIdx.x, stride = (int64_t)gridDim.x * TB;
+    cyc_t zq[FD_PRE];  // (as loaded: a conversion here would wait for the load)
+    double pq[FD_PRE];
+#pragma unroll
+    for (int u = 0; u < FD_PRE; ++u) {
+        const int64_t i = i0 + u * stride, ii = i < n ? i : n - 1;  // (unconditional loads from a row of the vector)
+        zq[u] = z[ii];
+        pq[u] = p[ii];
+    }
     const int iter = (int)sc[F_ITNO + prev];
     if (blockIdx.x == 0 && threadIdx.x == 0) sc[F_ITNO + cur] = (double)(iter + 1);
     if (iter > 0 && sc[F_CONV + prev] != 0.0) {  // converged earlier: hand the flag on
@@ -687,7 +700,12 @@ __global__ __launch_bounds__(TB) void f_direction(const cyc_t *__restrict__ z, d
         if (converged) sc[F_ITERS] = (double)iter;
     }
     if (converged) return;  // uniform over the grid: every workgroup reduces the same partials
-    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB)
+#pragma unroll
+    for (int u = 0; u < FD_PRE; ++u) {
+        const int64_t i = i0 + u * stride;
+        if (i < n) p[i] = iter > 0 ? fma(beta, pq[u], (double)zq[u]) : (double)zq[u];
+    }
+    for (int64_t i = i0 + FD_PRE * stride; i < n; i += stride)
         p[i] = iter > 0 ? fma(beta, p[i], (double)z[i]) : (double)z[i];
 }
 
@@ -733,6 +751,19 @@ __global__ __launch_bounds__(TB) void f_update(double *__restrict__ x, double *_
                                                double *__restrict__ part_rr, double *__restrict__ sc, int iter,
                                                int64_t n) {
     const int cur = iter & 1;
+    // (operands of the thread's first rows requested before the scalars: see f_direction)
+    constexpr int FU_PRE = 4;
+    const int64_t i0 = (int64_t)xcd_block() * TB + threadIdx.x, stride = (int64_t)gridDim.x * TB;
+    double xq[FU_PRE], rq[FU_PRE], pq[FU_PRE], aq[FU_PRE], dq[FU_PRE];
+#pragma unroll
+    for (int u = 0; u < FU_PRE; ++u) {
+        const int64_t i = i0 + u * stride, ii = i < n ? i : n - 1;  // (unconditional loads from a row of the vectors)
+        xq[u] = x[ii];
+        rq[u] = r[ii];
+        pq[u] = p[ii];
+        aq[u] = Ap[ii];
+        dq[u] = dinv[ii];
+    }
     if (sc[F_CONV + cur] != 0.0) return;
     const double pap = reduce_partials(part_pap, nparts);
     const double rz = sc[F_RZ + cur];
@@ -743,11 +774,22 @@ __global__ __launch_bounds__(TB) void f_update(double *__restrict__ x, double *_
         if (bad) sc[F_FLAG] = 1.0;
     }
     double srr = 0.0;
-    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+#pragma unroll
+    for (int u = 0; u < FU_PRE; ++u) {
+        const int64_t i = i0 + u * stride;
+        if (i < n) {
+            x[i] = fma(alpha, pq[u], xq[u]);
+            const double ri = fma(-alpha, aq[u], rq[u]);
+            r[i] = ri;
+            x0[i] = (cyc_t)(OMEGA * dq[u] * ri);  // the next cycle's pre-smoothed iterate
+            srr = fma(ri, ri, srr);
+        }
+    }
+    for (int64_t i = i0 + FU_PRE * stride; i < n; i += stride) {
         x[i] = fma(alpha, p[i], x[i]);
         const double ri = fma(-alpha, Ap[i], r[i]);
         r[i] = ri;
-        x0[i] = (cyc_t)(OMEGA * dinv[i] * ri);  // the next cycle's pre-smoothed iterate
+        x0[i] = (cyc_t)(OMEGA * dinv[i] * ri);
         srr = fma(ri, ri, srr);
     }
     srr = block_sum(srr);
