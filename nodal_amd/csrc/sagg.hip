@@ -1132,7 +1132,8 @@ int width_class(int maxlen) {
 int choose_wfix(int maxlen, int64_t n, int64_t nnz, int pad_limit) {
     const int c = width_class(maxlen);
     if (c == 0 || c > pad_limit) return 0;
-    if ((double)c * (double)n <= 1.3 * (double)nnz || n <= 32768) return c;
+    static const double slack = getenv("NODAL_SA_PADSLACK") ? atof(getenv("NODAL_SA_PADSLACK")) : 1.3;
+    if ((double)c * (double)n <= slack * (double)nnz || n <= 32768) return c;
     return 0;
 }
 
@@ -1142,7 +1143,7 @@ SHierarchy *hierarchy_of(nodal_ctx *h) {
 }
 
 struct SolveBufs {
-    double *r, *p, *Ap, *part_rz, *part_zap, *part_rr, *part_pap, *sc;
+    double *r, *p, *p2, *Ap, *part_rz, *part_zap, *part_rr, *part_pap, *sc;
     cyc_t *z, *x0;
     int g0;  // grid of the level-0 kernels that produce / consume dot partials
 };
@@ -2011,7 +2012,7 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     }
 
     const size_t vec = align_up((size_t)n * 8);
-    NODAL_HIP_TRY(h, h->solver.reserve(5 * vec + 4 * MAX_PARTIALS * 8 + F_COUNT * 8 + 256));
+    NODAL_HIP_TRY(h, h->solver.reserve(6 * vec + 4 * MAX_PARTIALS * 8 + F_COUNT * 8 + 256));
     char *base = h->solver.as<char>();
     SolveBufs sb;
     sb.r = reinterpret_cast<double *>(base);
@@ -2019,7 +2020,8 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     sb.p = reinterpret_cast<double *>(base + 2 * vec);
     sb.Ap = reinterpret_cast<double *>(base + 3 * vec);
     sb.x0 = reinterpret_cast<cyc_t *>(base + 4 * vec);
-    sb.part_rz = reinterpret_cast<double *>(base + 5 * vec);
+    sb.p2 = reinterpret_cast<double *>(base + 5 * vec);  // the direction of the odd iterations (fused f_dir_spmv)
+    sb.part_rz = reinterpret_cast<double *>(base + 6 * vec);
     sb.part_zap = sb.part_rz + MAX_PARTIALS;
     sb.part_rr = sb.part_zap + MAX_PARTIALS;
     sb.part_pap = sb.part_rr + MAX_PARTIALS;
@@ -2054,9 +2056,30 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     double rr_prev = -1.0;
     int64_t it_prev = 0;
     int polls = 0;
+    static const bool fuse_dir_env = !(getenv("NODAL_SA_FUSE_DIR") && atoi(getenv("NODAL_SA_FUSE_DIR")) == 0);
+    const bool fuse_dir = fuse_dir_env && LPR_RAGGED == 1;
     // one outer iteration (the kernels take its parity only: see f_direction)
     auto iteration = [&](int it, bool timed) -> int {
         NODAL_TRY((cycle<double, cyc_t>(h, H, 0, sb.r, sb.x0, sb.z, &sb)));
+        if (fuse_dir) {  // direction and SpMV in one launch; the direction buffers swap with the parity
+            double *p_new = (it & 1) ? sb.p2 : sb.p;
+            const double *p_old = (it & 1) ? sb.p : sb.p2;
+            const unsigned tbf = TB;
+            if (timed) {
+                SAGG_DISPATCH_W(H->pool[0]->wfix, (hipExtLaunchKernelGGL((f_dir_spmv<W>), dim3(sb.g0), dim3(tbf), 0, st, e0, e1, 0,
+                                                                         A0, (const cyc_t *)sb.z, p_old, p_new, sb.Ap,
+                                                                         (const double *)sb.part_rz, (const double *)sb.part_zap,
+                                                                         (const double *)sb.part_rr, sb.g0, sb.part_pap, sb.sc,
+                                                                         it & 1)));
+            } else {
+                SAGG_DISPATCH_W(H->pool[0]->wfix, (f_dir_spmv<W><<<sb.g0, tbf, 0, st>>>(A0, sb.z, p_old, p_new, sb.Ap, sb.part_rz,
+                                                                                       sb.part_zap, sb.part_rr, sb.g0,
+                                                                                       sb.part_pap, sb.sc, it & 1)));
+            }
+            f_update<<<sb.g0, TB, 0, st>>>(x, sb.r, p_new, sb.Ap, sb.part_pap, sb.g0, dinv0, sb.x0, sb.part_rr, sb.sc, it & 1, n);
+            NODAL_HIP_TRY(h, hipGetLastError());
+            return NODAL_OK;
+        }
         f_direction<<<sb.g0, TB, 0, st>>>(sb.z, sb.p, sb.part_rz, sb.part_zap, sb.part_rr, sb.g0, sb.sc, it & 1, n);
         // one launch per poll batch is timed: start / stop events tied to the dispatch itself
         // (hipExtLaunchKernelGGL), i.e. the kernel's own duration as rocprofv3 reports it -- a pair
@@ -2191,6 +2214,7 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     *resid = hs[F_BB] > 0 ? sqrt(hs[F_RR] / hs[F_BB]) : 0.0;
     const SLevel *L0 = H->pool[0];
     h->kern_alg = 12.0 * (double)L0->nnz + 4.0 * (double)n + 16.0 * (double)n;
+    if (fuse_dir) h->kern_alg += 12.0 * (double)n;  // the timed launch also reads z (4) and writes the direction (8)
     if (trace)
         fprintf(stderr, "[sagg] %d iterations (%lld enqueued, %d polls), relative residual %.2e, status %d\n", *iters,
                 (long long)enqueued, polls, *resid, status);

@@ -69,6 +69,32 @@ __device__ __forceinline__ double ell_row_w(const Ell &A, const VT *__restrict__
     }
 }
 
+// the two halves of ell_row_w for W > 0, for kernels that request a row's slots before they know what to gather
+template <int W, class VT>
+__device__ __forceinline__ void ell_row_load(const Ell &A, const VT *__restrict__ val, int64_t i, int32_t (&c)[W > 0 ? W : 1],
+                                             VT (&v)[W > 0 ? W : 1]) {
+    if (A.dcol) {
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            c[q] = (int32_t)A.dcol[(int64_t)q * A.ld + i];  // (the offset: the row is added by ell_row_sum)
+            v[q] = val[(int64_t)q * A.ld + i];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            c[q] = A.col[(int64_t)q * A.ld + i] - (int32_t)i;
+            v[q] = val[(int64_t)q * A.ld + i];
+        }
+    }
+}
+template <int W, class VT, class XF>
+__device__ __forceinline__ double ell_row_sum(int64_t i, const int32_t (&c)[W > 0 ? W : 1], const VT (&v)[W > 0 ? W : 1], XF xf) {
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < W; ++q) acc = fma((double)v[q], xf((int32_t)i + c[q]), acc);
+    return acc;
+}
+
 #define SAGG_DISPATCH_W(w, CALL)                         \
     switch (w) {                                         \
     case 4: { constexpr int W = 4; CALL; } break;        \
@@ -740,6 +766,70 @@ __global__ __launch_bounds__(TB * RowLanes<W>::value) void f_spmv(Ell A, const d
         acc = fma(p[i], s, acc);
     }
     acc = block_sum<NT>(acc);
+    if (threadIdx.x == 0) part_pap[blockIdx.x] = acc;
+}
+
+// f_direction and f_spmv in ONE launch (NODAL_SA_FUSE_DIR=0: the two kernels): every workgroup forms beta from the
+// partials, the row sum gathers the NEW direction's entries  z[j] + beta p_old[j]  (the same fma as f_direction's: the
+// same bits) and the row's own entry is written to the OTHER direction buffer (p_old is still being gathered by the
+// neighbours' rows: the two buffers swap roles with the iteration's parity).  One launch floor (~4.5 us) and one pass
+// over p less per iteration; the scalars are written by workgroup 0 exactly as f_direction writes them.
+template <int W>
+__global__ __launch_bounds__(TB * RowLanes<W>::value) void f_dir_spmv(Ell A, const cyc_t *__restrict__ z,
+                                                 const double *__restrict__ p_old, double *__restrict__ p_new,
+                                                 double *__restrict__ Ap, const double *__restrict__ part_rz,
+                                                 const double *__restrict__ part_zap, const double *__restrict__ part_rr,
+                                                 int nparts, double *__restrict__ part_pap, double *__restrict__ sc,
+                                                 int parity) {
+    static_assert(RowLanes<W>::value == 1, "the reduction of the partials assumes TB threads");
+    const int cur = parity & 1, prev = cur ^ 1;
+    const int64_t i0 = (int64_t)xcd_block() * TB + threadIdx.x, stride = (int64_t)gridDim.x * TB;
+    // the first row's slots and the row's own entries are requested before the scalars and partials are looked at
+    int32_t c0[W > 0 ? W : 1];
+    double v0[W > 0 ? W : 1];
+    const int64_t ifirst = i0 < A.n ? i0 : A.n - 1;
+    if constexpr (W > 0) ell_row_load<W>(A, A.val, ifirst, c0, v0);
+    const cyc_t zfirst = z[ifirst];
+    const double pfirst = p_old[ifirst];
+    const int iter = (int)sc[F_ITNO + prev];
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc[F_ITNO + cur] = (double)(iter + 1);
+    if (iter > 0 && sc[F_CONV + prev] != 0.0) {  // converged earlier: hand the flag on
+        if (blockIdx.x == 0 && threadIdx.x == 0) sc[F_CONV + cur] = 1.0;
+        return;
+    }
+    double rz_new, zap, rr;
+    reduce_partials3(part_rz, part_zap, part_rr, nparts, rz_new, zap, rr);
+    const double rz_old = iter > 0 ? sc[F_RZ + prev] : 1.0;
+    const double beta = (iter > 0 && rz_old != 0.0) ? -sc[F_ALPHA + prev] * zap / rz_old : 0.0;
+    const double bb = iter == 0 ? rr : sc[F_BB];
+    const bool bad = !(rz_new >= 0.0) || !(rr == rr);  // preconditioner not positive / NaN
+    const bool converged = bb == 0.0 || rr <= sc[F_TOL2] * bb || bad;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc[F_RZ + cur] = rz_new;
+        sc[F_RR] = rr;
+        if (iter == 0) sc[F_BB] = rr;
+        if (bad) sc[F_FLAG] = 1.0;
+        sc[F_CONV + cur] = converged ? 1.0 : 0.0;
+        if (converged) sc[F_ITERS] = (double)iter;
+    }
+    if (converged) return;  // uniform over the grid: every workgroup reduces the same partials
+    const bool first = iter == 0;
+    auto pn = [&](int32_t j) { return first ? (double)z[j] : fma(beta, p_old[j], (double)z[j]); };
+    double acc = 0.0;
+    for (int64_t i = i0; i < A.n; i += stride) {
+        double s, pi;
+        if (W > 0 && i == i0) {
+            s = ell_row_sum<W>(i, c0, v0, pn);
+            pi = first ? (double)zfirst : fma(beta, pfirst, (double)zfirst);
+        } else {
+            s = ell_row_w<W>(A, A.val, i, 0, pn);
+            pi = pn((int32_t)i);
+        }
+        p_new[i] = pi;
+        Ap[i] = s;
+        acc = fma(pi, s, acc);
+    }
+    acc = block_sum<TB>(acc);
     if (threadIdx.x == 0) part_pap[blockIdx.x] = acc;
 }
 
