@@ -1352,6 +1352,147 @@ __global__ __launch_bounds__(256) void level_bwd_step(Tree T, const int32_t *__r
     }
 }
 
+// ---- super steps: SUPER_SB diagonal blocks (128 pivot columns) of every wide front of the level per launch -------
+// A block step is a launch of ~8 us whatever it moves (117 of them per sweep of config 5's factors).  Here a workgroup
+// solves the super block's rows ITSELF, sub-block after sub-block from LDS (the triangle inside the super block is
+// 64 KB of the front, read by every workgroup of the step: it stays in the L2), and then updates its tile of the rows
+// outside the super block with all of its columns at once: a quarter of the launches, the same sums in the same order
+// per row (sub-block after sub-block), hence the same bits as the block steps.
+constexpr int SUPER_SB = 4, SUPER_W = SUPER_SB * DB;
+
+template <int NR>
+__global__ __launch_bounds__(256) void level_fwd_super(Tree T, const int32_t *__restrict__ sns, const double *__restrict__ fronts,
+                                                       double *__restrict__ vec, int B0) {
+    constexpr int CW = ColGroup<NR>::CW, CG = ColGroup<NR>::CG, RT = 256 / CG;  // rows per workgroup
+    __shared__ double Y[SUPER_W][NR];   // the super block's solved rows
+    __shared__ double Vs[SUPER_W][NR];  // its rows of v, updated sub-block by sub-block
+    __shared__ double Li[DB][DB + 1];
+    const int32_t t = sns[blockIdx.y];
+    const int s = T.sn_start[t + 1] - T.sn_start[t];
+    if (B0 >= s) return;
+    const int dim = s + (int)(T.struct_ptr[t + 1] - T.struct_ptr[t]);
+    const int sw = s - B0 < SUPER_W ? s - B0 : SUPER_W;  // pivot columns of this super block
+    const int below = B0 + sw, rows = dim - below;
+    const int r0 = (int)blockIdx.x * RT;
+    if (blockIdx.x > 0 && r0 >= rows) return;
+    const double *F = fronts + T.front_off[t];
+    double *v = vec + T.vec_off[t] * NR;
+    double *ys = v + (int64_t)dim * NR;  // (the scratch rows: y_S of the whole front ends there)
+    const int tid = threadIdx.x;
+    for (int e = tid; e < SUPER_W * NR; e += 256) {
+        Vs[e / NR][e % NR] = e < sw * NR ? v[(int64_t)B0 * NR + e] : 0.0;
+        Y[e / NR][e % NR] = 0.0;
+    }
+    for (int k = 0; k * DB < sw; ++k) {
+        const int b0 = B0 + k * DB, nb = s - b0 < DB ? s - b0 : DB;
+        __syncthreads();
+        for (int e = tid; e < DB * DB; e += 256) {
+            const int r = e % DB, q = e / DB;
+            Li[r][q] = (r < nb && q < r) ? F[(b0 + r) + (int64_t)(b0 + q) * dim] : 0.0;
+        }
+        __syncthreads();
+        for (int e = tid; e < DB * NR; e += 256) {  // y_b = inv(L_bb) v_b (unit diagonal)
+            const int r = e / NR, c = e % NR;
+            double acc = Vs[k * DB + r][c];
+#pragma unroll
+            for (int q = 0; q < DB; ++q) acc = fma(Li[r][q], Vs[k * DB + q][c], acc);
+            Y[k * DB + r][c] = acc;
+            if (blockIdx.x == 0 && r < nb) ys[(int64_t)(b0 + r) * NR + c] = acc;
+        }
+        __syncthreads();
+        // the rows of the super block below this sub-block
+        const int ra = sw - (k + 1) * DB;
+        for (int e = tid; e < ra * CG; e += 256) {
+            const int il = (k + 1) * DB + e % ra, g = e / ra;
+            double acc[CW];
+#pragma unroll
+            for (int jj = 0; jj < CW; ++jj) acc[jj] = Vs[il][g * CW + jj];
+            chunk_update<NR, CW>(F + (B0 + il) + (int64_t)b0 * dim, dim, nb, (const double (*)[NR]) & Y[k * DB], g * CW, acc);
+#pragma unroll
+            for (int jj = 0; jj < CW; ++jj) Vs[il][g * CW + jj] = acc[jj];
+        }
+    }
+    __syncthreads();
+    const int i = below + r0 + tid % RT, g = tid / RT;
+    if (i < dim) {
+        double acc[CW];
+#pragma unroll
+        for (int jj = 0; jj < CW; ++jj) acc[jj] = v[(int64_t)i * NR + g * CW + jj];
+        for (int k = 0; k * DB < sw; ++k) {
+            const int b0 = B0 + k * DB, nb = s - b0 < DB ? s - b0 : DB;
+            chunk_update<NR, CW>(F + i + (int64_t)b0 * dim, dim, nb, (const double (*)[NR]) & Y[k * DB], g * CW, acc);
+        }
+#pragma unroll
+        for (int jj = 0; jj < CW; ++jj) v[(int64_t)i * NR + g * CW + jj] = acc[jj];
+    }
+}
+
+// backward: the super block [B0, B0 + sw) from its last sub-block up, then the rows above it
+template <int NR>
+__global__ __launch_bounds__(256) void level_bwd_super(Tree T, const int32_t *__restrict__ sns, const double *__restrict__ fronts,
+                                                       double *__restrict__ xb, double *__restrict__ vec, int B0) {
+    constexpr int CW = ColGroup<NR>::CW, CG = ColGroup<NR>::CG, RT = 256 / CG;
+    __shared__ double Y[SUPER_W][NR];
+    __shared__ double Vs[SUPER_W][NR];
+    __shared__ double Ui[DB][DB + 1];
+    const int32_t t = sns[blockIdx.y];
+    const int start = T.sn_start[t];
+    const int s = T.sn_start[t + 1] - start;
+    if (B0 >= s) return;
+    const int r0 = (int)blockIdx.x * RT;
+    if (blockIdx.x > 0 && r0 >= B0) return;
+    const int dim = s + (int)(T.struct_ptr[t + 1] - T.struct_ptr[t]);
+    const int sw = s - B0 < SUPER_W ? s - B0 : SUPER_W;
+    const double *F = fronts + T.front_off[t];
+    double *v = vec + T.vec_off[t] * NR;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < SUPER_W * NR; e += 256) {
+        Vs[e / NR][e % NR] = e < sw * NR ? v[(int64_t)B0 * NR + e] : 0.0;
+        Y[e / NR][e % NR] = 0.0;
+    }
+    for (int k = (sw - 1) / DB; k >= 0; --k) {
+        const int b0 = B0 + k * DB, nb = s - b0 < DB ? s - b0 : DB;
+        __syncthreads();
+        for (int e = tid; e < DB * DB; e += 256) {
+            const int r = e % DB, q = e / DB;
+            Ui[r][q] = (q < nb && r <= q) ? F[(b0 + r) + (int64_t)(b0 + q) * dim] : 0.0;
+        }
+        __syncthreads();
+        for (int e = tid; e < DB * NR; e += 256) {  // x_b = inv(U_bb) v_b
+            const int r = e / NR, c = e % NR;
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < DB; ++q) acc = fma(Ui[r][q], Vs[k * DB + q][c], acc);
+            Y[k * DB + r][c] = acc;
+            if (blockIdx.x == 0 && r < nb) xb[(int64_t)(start + b0 + r) * NR + c] = acc;  // (the solution itself)
+        }
+        __syncthreads();
+        const int ra = k * DB;  // the rows of the super block above this sub-block
+        for (int e = tid; e < ra * CG; e += 256) {
+            const int il = e % ra, g = e / ra;
+            double acc[CW];
+#pragma unroll
+            for (int jj = 0; jj < CW; ++jj) acc[jj] = Vs[il][g * CW + jj];
+            chunk_update<NR, CW>(F + (B0 + il) + (int64_t)b0 * dim, dim, nb, (const double (*)[NR]) & Y[k * DB], g * CW, acc);
+#pragma unroll
+            for (int jj = 0; jj < CW; ++jj) Vs[il][g * CW + jj] = acc[jj];
+        }
+    }
+    __syncthreads();
+    const int i = r0 + tid % RT, g = tid / RT;
+    if (i < B0) {
+        double acc[CW];
+#pragma unroll
+        for (int jj = 0; jj < CW; ++jj) acc[jj] = v[(int64_t)i * NR + g * CW + jj];
+        for (int k = (sw - 1) / DB; k >= 0; --k) {
+            const int b0 = B0 + k * DB, nb = s - b0 < DB ? s - b0 : DB;
+            chunk_update<NR, CW>(F + i + (int64_t)b0 * dim, dim, nb, (const double (*)[NR]) & Y[k * DB], g * CW, acc);
+        }
+#pragma unroll
+        for (int jj = 0; jj < CW; ++jj) v[(int64_t)i * NR + g * CW + jj] = acc[jj];
+    }
+}
+
 template <class T>
 int upload_vec(nodal_ctx *h, DevBuf &buf, const std::vector<T> &v) {
     NODAL_HIP_TRY(h, buf.reserve(v.size() * sizeof(T) + 64));
@@ -1785,6 +1926,7 @@ int slu_apply_nr(nodal_ctx *h, SluState *S, const double *r, double *z) {
     }
     permute_rhs<<<grid_for(n * NR), TB, 0, st>>>(n, NR, S->rowof.as<int32_t>(), S->rs.as<double>(), r, S->xb.as<double>());
     static const bool stepped = !(getenv("NODAL_DIRECT_APPLY_STEPPED") && atoi(getenv("NODAL_DIRECT_APPLY_STEPPED")) == 0);
+    static const bool super_steps = !(getenv("NODAL_DIRECT_SUPER") && atoi(getenv("NODAL_DIRECT_SUPER")) == 0);
     constexpr int RT = 256 / ColGroup<NR>::CG;  // rows per workgroup of the stepped kernels
     const double *Fd = S->fronts.as<double>();
     double *xbd = S->xb.as<double>(), *vd = S->vec.as<double>();
@@ -1807,9 +1949,16 @@ int slu_apply_nr(nodal_ctx *h, SluState *S, const double *r, double *z) {
                 level_fwd_gather<NR><<<dim3((unsigned)((mdim + GRT - 1) / GRT), (unsigned)nab), 256, 0, st>>>(
                     T, bs, S->liperm.as<int32_t>(), xbd, vd);
             }
-            for (int b0 = 0; b0 < ms; b0 += DB) {
-                const int tiles = std::max(1, (mdim - b0 - 1 + RT - 1) / RT);
-                level_fwd_step<NR><<<dim3((unsigned)tiles, (unsigned)nab), 256, 0, st>>>(T, bs, Fd, vd, b0);
+            if (super_steps) {
+                for (int b0 = 0; b0 < ms; b0 += SUPER_W) {
+                    const int tiles = std::max(1, (mdim - b0 - 1 + RT - 1) / RT);
+                    level_fwd_super<NR><<<dim3((unsigned)tiles, (unsigned)nab), 256, 0, st>>>(T, bs, Fd, vd, b0);
+                }
+            } else {
+                for (int b0 = 0; b0 < ms; b0 += DB) {
+                    const int tiles = std::max(1, (mdim - b0 - 1 + RT - 1) / RT);
+                    level_fwd_step<NR><<<dim3((unsigned)tiles, (unsigned)nab), 256, 0, st>>>(T, bs, Fd, vd, b0);
+                }
             }
         }
     }
@@ -1827,9 +1976,16 @@ int slu_apply_nr(nodal_ctx *h, SluState *S, const double *r, double *z) {
             const int32_t *bs = sns + rest;
             const int ms = S->lvl_amax_s[(size_t)l];
             level_bwd_u12<NR><<<dim3((unsigned)((ms + RT - 1) / RT), (unsigned)nab), 256, 0, st>>>(T, bs, Fd, xbd, vd);
-            for (int b0 = ((ms - 1) / DB) * DB; b0 >= 0; b0 -= DB) {
-                const int tiles = std::max(1, (b0 + RT - 1) / RT);
-                level_bwd_step<NR><<<dim3((unsigned)tiles, (unsigned)nab), 256, 0, st>>>(T, bs, Fd, xbd, vd, b0);
+            if (super_steps) {
+                for (int b0 = ((ms - 1) / SUPER_W) * SUPER_W; b0 >= 0; b0 -= SUPER_W) {
+                    const int tiles = std::max(1, (b0 + RT - 1) / RT);
+                    level_bwd_super<NR><<<dim3((unsigned)tiles, (unsigned)nab), 256, 0, st>>>(T, bs, Fd, xbd, vd, b0);
+                }
+            } else {
+                for (int b0 = ((ms - 1) / DB) * DB; b0 >= 0; b0 -= DB) {
+                    const int tiles = std::max(1, (b0 + RT - 1) / RT);
+                    level_bwd_step<NR><<<dim3((unsigned)tiles, (unsigned)nab), 256, 0, st>>>(T, bs, Fd, xbd, vd, b0);
+                }
             }
         }
     }
