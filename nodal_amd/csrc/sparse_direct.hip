@@ -1010,16 +1010,89 @@ __global__ __launch_bounds__(TB) void invert_perm(int64_t n, const int32_t *__re
 
 template <int NR> struct ColGroup { static constexpr int CW = NR >= 4 ? 4 : NR; static constexpr int CG = NR / CW; };
 
+// Staging into LDS without a memory round trip per element: a loop `dst[e] = test ? src[e] : 0` keeps its test as a
+// branch around the load and waits for every load before its LDS store (the level steps spent six dependent round
+// trips, 5 of their 8.6 us, filling Li and Vb).  Here every load is unconditional (the address of an element that is
+// not wanted is clamped to one that is), all of a thread's loads are requested first, and the stores follow.
+// inverse factor of the diagonal block at (b0, b0): LOWER: its strictly lower part (unit diagonal implied), else its
+// upper triangle with the diagonal; zeros elsewhere and beyond nb
+template <int BS, bool LOWER>
+__device__ __forceinline__ void stage_diag_block(const double *__restrict__ F, int64_t dim, int b0, int nb,
+                                                 double (*D)[DB + 1], int tid) {
+    constexpr int PER = (DB * DB + BS - 1) / BS;
+    double t[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = tid + u * BS, r = e % DB, k = (e / DB) % DB;
+        const bool in = e < DB * DB && (LOWER ? (r < nb && k < r) : (k < nb && r <= k));
+        t[u] = F[(b0 + (in ? r : 0)) + (int64_t)(b0 + (in ? k : 0)) * dim];
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = tid + u * BS, r = e % DB, k = (e / DB) % DB;
+        const bool in = e < DB * DB && (LOWER ? (r < nb && k < r) : (k < nb && r <= k));
+        if (e < DB * DB) D[r][k] = in ? t[u] : 0.0;
+    }
+}
+// ROWS x NR block of the interleaved vector starting at src (count = wanted rows * NR elements; zeros behind them)
+template <int BS, int NR, int ROWS>
+__device__ __forceinline__ void stage_rows(const double *__restrict__ src, int count, double (*dst)[NR], int tid) {
+    constexpr int PER = (ROWS * NR + BS - 1) / BS;
+    double t[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = tid + u * BS;
+        t[u] = src[e < count ? e : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = tid + u * BS;
+        if (e < ROWS * NR) dst[e / NR][e % NR] = e < count ? t[u] : 0.0;
+    }
+}
+// the chunk of x_B behind the boundary indices bidx[0 .. nb): rows of the ancestors' solution xb (two dependent loads
+// per element, all of a thread's in flight together)
+template <int BS, int NR>
+__device__ __forceinline__ void stage_boundary(const double *__restrict__ xb, const int32_t *__restrict__ bidx, int nb,
+                                               double (*Y)[NR], int tid) {
+    constexpr int PER = (DB * NR + BS - 1) / BS;
+    int32_t bi[PER];
+    double t[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = tid + u * BS;
+        bi[u] = bidx[e < nb * NR ? e / NR : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = tid + u * BS;
+        t[u] = xb[(int64_t)bi[u] * NR + e % NR];
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = tid + u * BS;
+        if (e < DB * NR) Y[e / NR][e % NR] = e < nb * NR ? t[u] : 0.0;
+    }
+}
+
 // acc[0 .. CW) -= sum_k F[i + (c0 + k) dim] * Y[k][col0 ..]: the nb (<= DB) entries of row i in the column chunk c0,
 // ALL requested before the first is used -- one round trip to memory per chunk, not one per entry (a loop that
 // loads, multiplies and loads again took 1.1 ms per sweep of a 1489-row front).  Y: the chunk's vector rows, in LDS.
-template <int NR, int CW>
+// UNCOND (the kernels of the wide fronts): a short last chunk is read with clamped, unconditional loads too (the tests
+// of the other form stay branches around the loads, one round trip each; the small fronts' kernels keep that form: most
+// of their chunks are short and other workgroups hide the round trips)
+template <int NR, int CW, bool UNCOND = false>
 __device__ __forceinline__ void chunk_update(const double *__restrict__ Frow, int64_t dim, int nb, const double (*Y)[NR],
                                              int col0, double (&acc)[CW]) {
     double l[DB];
     if (nb == DB) {
 #pragma unroll
         for (int k = 0; k < DB; ++k) l[k] = Frow[(int64_t)k * dim];
+    } else if (UNCOND) {
+#pragma unroll
+        for (int k = 0; k < DB; ++k) l[k] = Frow[(int64_t)(k < nb ? k : 0) * dim];  // (nb >= 1)
+#pragma unroll
+        for (int k = 0; k < DB; ++k) l[k] = k < nb ? l[k] : 0.0;
     } else {
 #pragma unroll
         for (int k = 0; k < DB; ++k) l[k] = k < nb ? Frow[(int64_t)k * dim] : 0.0;
@@ -1042,6 +1115,9 @@ __device__ __forceinline__ void forward_gather(const Tree &T, int32_t t, const i
     const int dim = s + (int)(T.struct_ptr[t + 1] - T.struct_ptr[t]);
     double *v = vec + T.vec_off[t] * NR;
     const int tid = threadIdx.x;
+    // (plain loops: this runs with one workgroup per front on levels of thousands of small fronts, where more
+    // workgroups in flight hide the round trips better than more loads per thread -- batching them was measured: 149 ->
+    // 197 us per level launch)
     for (int e = tid; e < dim * NR; e += BS) v[e] = e < s * NR ? xb[(int64_t)start * NR + e] : 0.0;
     __syncthreads();
     for (int32_t q = T.child_ptr[t]; q < T.child_ptr[t + 1]; ++q) {
@@ -1084,6 +1160,8 @@ __global__ __launch_bounds__(BS) void forward_level(Tree T, const int32_t *__res
     for (int b0 = 0; b0 < s; b0 += DB) {
         const int nb = s - b0 < DB ? s - b0 : DB;
         // the block and its rows of v into LDS (coalesced), the product from there
+        // (plain loops here and in backward_level: levels of thousands of small fronts, mostly with a handful of pivot
+        // columns -- the tests skip most of the loads, and other workgroups hide the round trips of the rest)
         for (int e = tid; e < DB * DB; e += BS) {
             const int r = e % DB, k = e / DB;
             Li[r][k] = (r < nb && k < r) ? F[(b0 + r) + (int64_t)(b0 + k) * dim] : 0.0;
@@ -1247,11 +1325,8 @@ __global__ __launch_bounds__(256) void level_fwd_step(Tree T, const int32_t *__r
     const double *F = fronts + T.front_off[t];
     double *v = vec + T.vec_off[t] * NR;
     const int tid = threadIdx.x;
-    for (int e = tid; e < DB * DB; e += 256) {
-        const int r = e % DB, k = e / DB;
-        Li[r][k] = (r < nb && k < r) ? F[(b0 + r) + (int64_t)(b0 + k) * dim] : 0.0;
-    }
-    for (int e = tid; e < DB * NR; e += 256) Vb[e / NR][e % NR] = e < nb * NR ? v[(int64_t)b0 * NR + e] : 0.0;
+    stage_diag_block<256, true>(F, dim, b0, nb, Li, tid);
+    stage_rows<256, NR, DB>(v + (int64_t)b0 * NR, nb * NR, Vb, tid);
     __syncthreads();
     double *ys = v + (int64_t)dim * NR;  // (the scratch rows: y_S of the whole front ends there)
     for (int e = tid; e < DB * NR; e += 256) {
@@ -1268,7 +1343,7 @@ __global__ __launch_bounds__(256) void level_fwd_step(Tree T, const int32_t *__r
         double acc[CW];
 #pragma unroll
         for (int jj = 0; jj < CW; ++jj) acc[jj] = v[(int64_t)i * NR + g * CW + jj];
-        chunk_update<NR, CW>(F + i + (int64_t)b0 * dim, dim, nb, Y, g * CW, acc);
+        chunk_update<NR, CW, true>(F + i + (int64_t)b0 * dim, dim, nb, Y, g * CW, acc);
 #pragma unroll
         for (int jj = 0; jj < CW; ++jj) v[(int64_t)i * NR + g * CW + jj] = acc[jj];
     }
@@ -1297,10 +1372,9 @@ __global__ __launch_bounds__(256) void level_bwd_u12(Tree T, const int32_t *__re
     for (int c0 = s; c0 < dim; c0 += DB) {
         const int nb = dim - c0 < DB ? dim - c0 : DB;
         __syncthreads();
-        for (int e = tid; e < DB * NR; e += 256)
-            Y[e / NR][e % NR] = e < nb * NR ? xb[(int64_t)bidx[c0 - s + e / NR] * NR + e % NR] : 0.0;
+        stage_boundary<256, NR>(xb, bidx + (c0 - s), nb, Y, tid);
         __syncthreads();
-        if (i < s) chunk_update<NR, CW>(F + i + (int64_t)c0 * dim, dim, nb, Y, g * CW, acc);
+        if (i < s) chunk_update<NR, CW, true>(F + i + (int64_t)c0 * dim, dim, nb, Y, g * CW, acc);
     }
     if (i < s) {
 #pragma unroll
@@ -1326,11 +1400,8 @@ __global__ __launch_bounds__(256) void level_bwd_step(Tree T, const int32_t *__r
     const double *F = fronts + T.front_off[t];
     double *v = vec + T.vec_off[t] * NR;
     const int tid = threadIdx.x;
-    for (int e = tid; e < DB * DB; e += 256) {
-        const int r = e % DB, k = e / DB;
-        Ui[r][k] = (k < nb && r <= k) ? F[(b0 + r) + (int64_t)(b0 + k) * dim] : 0.0;
-    }
-    for (int e = tid; e < DB * NR; e += 256) Vb[e / NR][e % NR] = e < nb * NR ? v[(int64_t)b0 * NR + e] : 0.0;
+    stage_diag_block<256, false>(F, dim, b0, nb, Ui, tid);
+    stage_rows<256, NR, DB>(v + (int64_t)b0 * NR, nb * NR, Vb, tid);
     __syncthreads();
     for (int e = tid; e < DB * NR; e += 256) {
         const int r = e / NR, c = e % NR;
@@ -1346,7 +1417,7 @@ __global__ __launch_bounds__(256) void level_bwd_step(Tree T, const int32_t *__r
         double acc[CW];
 #pragma unroll
         for (int jj = 0; jj < CW; ++jj) acc[jj] = v[(int64_t)i * NR + g * CW + jj];
-        chunk_update<NR, CW>(F + i + (int64_t)b0 * dim, dim, nb, Y, g * CW, acc);
+        chunk_update<NR, CW, true>(F + i + (int64_t)b0 * dim, dim, nb, Y, g * CW, acc);
 #pragma unroll
         for (int jj = 0; jj < CW; ++jj) v[(int64_t)i * NR + g * CW + jj] = acc[jj];
     }
@@ -1379,17 +1450,12 @@ __global__ __launch_bounds__(256) void level_fwd_super(Tree T, const int32_t *__
     double *v = vec + T.vec_off[t] * NR;
     double *ys = v + (int64_t)dim * NR;  // (the scratch rows: y_S of the whole front ends there)
     const int tid = threadIdx.x;
-    for (int e = tid; e < SUPER_W * NR; e += 256) {
-        Vs[e / NR][e % NR] = e < sw * NR ? v[(int64_t)B0 * NR + e] : 0.0;
-        Y[e / NR][e % NR] = 0.0;
-    }
+    stage_rows<256, NR, SUPER_W>(v + (int64_t)B0 * NR, sw * NR, Vs, tid);
+    for (int e = tid; e < SUPER_W * NR; e += 256) Y[e / NR][e % NR] = 0.0;
     for (int k = 0; k * DB < sw; ++k) {
         const int b0 = B0 + k * DB, nb = s - b0 < DB ? s - b0 : DB;
         __syncthreads();
-        for (int e = tid; e < DB * DB; e += 256) {
-            const int r = e % DB, q = e / DB;
-            Li[r][q] = (r < nb && q < r) ? F[(b0 + r) + (int64_t)(b0 + q) * dim] : 0.0;
-        }
+        stage_diag_block<256, true>(F, dim, b0, nb, Li, tid);
         __syncthreads();
         for (int e = tid; e < DB * NR; e += 256) {  // y_b = inv(L_bb) v_b (unit diagonal)
             const int r = e / NR, c = e % NR;
@@ -1407,7 +1473,7 @@ __global__ __launch_bounds__(256) void level_fwd_super(Tree T, const int32_t *__
             double acc[CW];
 #pragma unroll
             for (int jj = 0; jj < CW; ++jj) acc[jj] = Vs[il][g * CW + jj];
-            chunk_update<NR, CW>(F + (B0 + il) + (int64_t)b0 * dim, dim, nb, (const double (*)[NR]) & Y[k * DB], g * CW, acc);
+            chunk_update<NR, CW, true>(F + (B0 + il) + (int64_t)b0 * dim, dim, nb, (const double (*)[NR]) & Y[k * DB], g * CW, acc);
 #pragma unroll
             for (int jj = 0; jj < CW; ++jj) Vs[il][g * CW + jj] = acc[jj];
         }
@@ -1420,7 +1486,7 @@ __global__ __launch_bounds__(256) void level_fwd_super(Tree T, const int32_t *__
         for (int jj = 0; jj < CW; ++jj) acc[jj] = v[(int64_t)i * NR + g * CW + jj];
         for (int k = 0; k * DB < sw; ++k) {
             const int b0 = B0 + k * DB, nb = s - b0 < DB ? s - b0 : DB;
-            chunk_update<NR, CW>(F + i + (int64_t)b0 * dim, dim, nb, (const double (*)[NR]) & Y[k * DB], g * CW, acc);
+            chunk_update<NR, CW, true>(F + i + (int64_t)b0 * dim, dim, nb, (const double (*)[NR]) & Y[k * DB], g * CW, acc);
         }
 #pragma unroll
         for (int jj = 0; jj < CW; ++jj) v[(int64_t)i * NR + g * CW + jj] = acc[jj];
@@ -1446,17 +1512,12 @@ __global__ __launch_bounds__(256) void level_bwd_super(Tree T, const int32_t *__
     const double *F = fronts + T.front_off[t];
     double *v = vec + T.vec_off[t] * NR;
     const int tid = threadIdx.x;
-    for (int e = tid; e < SUPER_W * NR; e += 256) {
-        Vs[e / NR][e % NR] = e < sw * NR ? v[(int64_t)B0 * NR + e] : 0.0;
-        Y[e / NR][e % NR] = 0.0;
-    }
+    stage_rows<256, NR, SUPER_W>(v + (int64_t)B0 * NR, sw * NR, Vs, tid);
+    for (int e = tid; e < SUPER_W * NR; e += 256) Y[e / NR][e % NR] = 0.0;
     for (int k = (sw - 1) / DB; k >= 0; --k) {
         const int b0 = B0 + k * DB, nb = s - b0 < DB ? s - b0 : DB;
         __syncthreads();
-        for (int e = tid; e < DB * DB; e += 256) {
-            const int r = e % DB, q = e / DB;
-            Ui[r][q] = (q < nb && r <= q) ? F[(b0 + r) + (int64_t)(b0 + q) * dim] : 0.0;
-        }
+        stage_diag_block<256, false>(F, dim, b0, nb, Ui, tid);
         __syncthreads();
         for (int e = tid; e < DB * NR; e += 256) {  // x_b = inv(U_bb) v_b
             const int r = e / NR, c = e % NR;
@@ -1473,7 +1534,7 @@ __global__ __launch_bounds__(256) void level_bwd_super(Tree T, const int32_t *__
             double acc[CW];
 #pragma unroll
             for (int jj = 0; jj < CW; ++jj) acc[jj] = Vs[il][g * CW + jj];
-            chunk_update<NR, CW>(F + (B0 + il) + (int64_t)b0 * dim, dim, nb, (const double (*)[NR]) & Y[k * DB], g * CW, acc);
+            chunk_update<NR, CW, true>(F + (B0 + il) + (int64_t)b0 * dim, dim, nb, (const double (*)[NR]) & Y[k * DB], g * CW, acc);
 #pragma unroll
             for (int jj = 0; jj < CW; ++jj) Vs[il][g * CW + jj] = acc[jj];
         }
@@ -1486,7 +1547,7 @@ __global__ __launch_bounds__(256) void level_bwd_super(Tree T, const int32_t *__
         for (int jj = 0; jj < CW; ++jj) acc[jj] = v[(int64_t)i * NR + g * CW + jj];
         for (int k = (sw - 1) / DB; k >= 0; --k) {
             const int b0 = B0 + k * DB, nb = s - b0 < DB ? s - b0 : DB;
-            chunk_update<NR, CW>(F + i + (int64_t)b0 * dim, dim, nb, (const double (*)[NR]) & Y[k * DB], g * CW, acc);
+            chunk_update<NR, CW, true>(F + i + (int64_t)b0 * dim, dim, nb, (const double (*)[NR]) & Y[k * DB], g * CW, acc);
         }
 #pragma unroll
         for (int jj = 0; jj < CW; ++jj) v[(int64_t)i * NR + g * CW + jj] = acc[jj];
