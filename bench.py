@@ -616,8 +616,8 @@ DOMINANT_SPARSE_KERNEL = {
     # The solve is ~900 launches and no kernel holds more than 9 % of it (profiles/r02_*_kernel_stats.txt);
     # the largest class by bytes is the pass over the level-0 matrix: the Krylov SpMV timed here and
     # the two smoother passes (k_smooth_residual<5>, k_post<5, true>) that read the same ELL arrays.
-    "cfg3": "f_spmv<5>: fp64 ELL SpMV of the flexible CG on the 1e6-node level (sagg_cycle.h)",
-    "cfg4": "f_spmv<5>: fp64 ELL SpMV of the flexible CG on the block-diagonal fine level (sagg_cycle.h)",
+    "cfg3": "f_dir_spmv<5>: direction update + fp64 ELL SpMV of the flexible CG on the 1e6-node level (sagg_cycle.h)",
+    "cfg4": "f_dir_spmv<5>: direction update + fp64 ELL SpMV of the flexible CG on the block-diagonal fine level (sagg_cycle.h)",
     "cfg5": "k_ell_spmv<W>: fp64 ELL SpMV of FGMRES on the presolved system (sagg_cycle.h)",
 }
 

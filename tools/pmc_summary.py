@@ -20,8 +20,8 @@ import sys
 
 DOMINANT = {  # workload -> (kernel name regex, minimum grid size in threads)
     "cfg2": (r"gemm_sub_kernel<0", 200000),  # (<0>: C -= A B; <0, true, true>: the symmetric C -= A^T B)
-    "cfg3": (r"f_spmv<", 200000),
-    "cfg4": (r"f_spmv<", 200000),
+    "cfg3": (r"f_(dir_)?spmv<", 200000),
+    "cfg4": (r"f_(dir_)?spmv<", 200000),
     "cfg5": (r"k_ell_spmv<", 200000),
 }
 

@@ -12,8 +12,8 @@ level-0 passes: rows x bytes per row of what the kernel reads and writes (DESIGN
 import glob, json, sqlite3, sys
 
 W0 = 5  # padded ELL width of the grid's level 0
-_F32ROW = W0 * 8          # col i32 + val f32 per slot
-_F64ROW = W0 * 12
+_F32ROW = W0 * 6          # column offset i16 (round 5: Ell::dcol) + val f32 per slot
+_F64ROW = W0 * 10
 # bytes per level-0 row of each pass (reads + writes; the outer iteration's vectors x, r, p, Ap are f64, the
 # vectors inside the cycle -- x0, the cycle's residual, xp, z -- f32 since round 4: csrc/sagg.hip, cyc_t)
 LEVEL0_BYTES = {
@@ -22,6 +22,7 @@ LEVEL0_BYTES = {
     "k_prolong": 4 * 8 + 4 + 4 + 8 / 7.0,                # P (col + f32 val) x 4, x, xp, coarse gathers
     "k_post": _F32ROW + 8 + 4 + 4 + 4 + 8 + 8,           # A, b (f64), xp gather + own, out (z), u (Ap, f64), dinv
     "f_spmv": _F64ROW + 8 + 8 + 8,                       # A (f64), p gather + own, Ap
+    "f_dir_spmv": _F64ROW + 8 + 4 + 8 + 8,               # A (f64), p_old and z gathered, the new direction, Ap
     "f_direction": 4 + 8 + 8,                            # z, p, p
     "f_update": 8 * 4 + 8 * 2 + 4 + 8,                   # x r p Ap in, x r out, x0 out, dinv
     "f_init": 8 * 2 + 8 * 3 + 4,
@@ -48,7 +49,7 @@ def class_of(nm, grid_threads, wg_threads, n):
     if any(base.startswith(p) for p in SETUP_NAMES):
         return "hierarchy_setup", base
     if base in LEVEL0_BYTES and (wgs >= big or nm.startswith(base + "<%d" % W0) or
-                                 base in ("f_spmv", "f_direction", "f_update", "f_init")):
+                                 base in ("f_spmv", "f_dir_spmv", "f_direction", "f_update", "f_init")):
         return "level0_passes", base
     if base.startswith("k_") or base.startswith("f_"):
         return "coarse_levels", base
