@@ -1672,9 +1672,10 @@ static int sagg_setup_csr_body(nodal_ctx *h, int64_t n0, int64_t nnz0, const int
     NODAL_HIP_TRY(h, L0->dinv.reserve((size_t)L0->ld * 8 + 64));
     // Columns as 16-bit offsets from the row (NODAL_SA_D16=0: off): the three level-0 row kernels of an iteration read 10
     // instead of 20 bytes of columns per row (W = 5); the same columns, hence the same sums, bit for bit.  Level 0 only
-    // (the other levels are latency-bound), fixed-width rows only, and only when every column is that close to its row.
+    // (the other levels are latency-bound), rows of fixed width or with their lengths (config 5's reduced system), and
+    // only when every column is that close to its row.
     static const bool d16_env = !(getenv("NODAL_SA_D16") && atoi(getenv("NODAL_SA_D16")) == 0);
-    L0->d16 = d16_env && L0->wfix > 0 && hs[ST_FARCOL] == 0;
+    L0->d16 = d16_env && hs[ST_FARCOL] == 0;
     if (L0->d16) NODAL_HIP_TRY(h, L0->adcol.reserve((size_t)L0->width * L0->ld * 2 + 64));
     csr_to_ell<<<grid_for(n0), TB, 0, st>>>(n0, L0->ld, indptr0, indices0, data0, L0->acol.as<int32_t>(),
                                            L0->aval.as<double>(), L0->avalf.as<float>(),

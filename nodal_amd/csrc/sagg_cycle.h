@@ -22,13 +22,24 @@ __device__ __forceinline__ double ell_row_lanes(const Ell &A, const VT *__restri
     for (int32_t s0 = sub; s0 < len; s0 += LPR_RAGGED * Q) {
         int32_t c[Q];
         double v[Q];
+        if (A.dcol) {  // (uniform) columns as 16-bit offsets from the row
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const bool ok = s0 + q * LPR_RAGGED < len;  // (a slot past the end re-reads the lane's first one)
-            const int64_t at = (int64_t)(ok ? s0 + q * LPR_RAGGED : s0) * A.ld + i;
-            c[q] = A.col[at];
-            const VT loaded = val[at];  // (unconditional: `at` is always a slot of the row)
-            v[q] = ok ? (double)loaded : 0.0;
+            for (int q = 0; q < Q; ++q) {
+                const bool ok = s0 + q * LPR_RAGGED < len;
+                const int64_t at = (int64_t)(ok ? s0 + q * LPR_RAGGED : s0) * A.ld + i;
+                c[q] = (int32_t)i + (int32_t)A.dcol[at];
+                const VT loaded = val[at];
+                v[q] = ok ? (double)loaded : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const bool ok = s0 + q * LPR_RAGGED < len;  // (a slot past the end re-reads the lane's first one)
+                const int64_t at = (int64_t)(ok ? s0 + q * LPR_RAGGED : s0) * A.ld + i;
+                c[q] = A.col[at];
+                const VT loaded = val[at];  // (unconditional: `at` is always a slot of the row)
+                v[q] = ok ? (double)loaded : 0.0;
+            }
         }
 #pragma unroll
         for (int q = 0; q < Q; ++q) acc = fma(v[q], xf(c[q]), acc);
