@@ -1497,6 +1497,28 @@ def test_reused_handle_with_every_scratch_buffer_poisoned():
     assert r.returncode == 0 and "poison child ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+def test_schedule_variants_give_identical_bits():
+    """Round 5's variants that claim to change the schedule only -- level-0 columns as 16-bit offsets from the row
+    (csrc/sagg.hip, Ell::dcol), the direction update inside the outer SpMV's launch (f_dir_spmv, csrc/sagg_cycle.h), the
+    direct route's super steps (level_fwd_super / level_bwd_super, csrc/sparse_direct.hip) -- against the forms they
+    replace: a child process per setting (the switches are read once per process) solves the same systems through the
+    smoothed-aggregation FCG, the presolved FGMRES, the direct route with one and with sixteen right-hand sides, and
+    prints a SHA-256 over every solution's bytes.  The digests must be EQUAL (reference call replaced:
+    nodal/nodal.py:325, whose answer does not depend on a schedule either)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for name, extra in (("default", {}), ("no d16", {"NODAL_SA_D16": "0"}), ("two launches", {"NODAL_SA_FUSE_DIR": "0"}),
+                        ("block steps", {"NODAL_DIRECT_SUPER": "0"})):
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "variant_child.py")], env=dict(os.environ, **extra),
+                           cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "variant digest" in r.stdout, (name, r.stdout[-2000:], r.stderr[-2000:])
+        digests[name] = r.stdout.split("variant digest")[1].split()[0]
+    assert len(set(digests.values())) == 1, digests
+
+
 @pytest.mark.parametrize("kind", ["grid", "cfg5", "hub", "random", "zero resistance", "collision"])
 def test_stream_fold_matches_the_per_entry_fold(kind, monkeypatch):
     """The numeric fold in north_star's shape (csrc/stamp.hip fold_matrix_stream: a workgroup streams a contiguous
