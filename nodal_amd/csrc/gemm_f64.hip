@@ -47,20 +47,8 @@ template <int MODE, bool TA = false, bool UPPER = false>
 __global__ __launch_bounds__(NT, 2) void gemm_sub_kernel(double *__restrict__ C, int64_t ldc,
                                                          const double *__restrict__ A, int64_t lda,
                                                          const double *__restrict__ B, int64_t ldb,
-                                                         int M, int N, int K, int band = BM, int stagger_ticks = 0) {
+                                                         int M, int N, int K, int band = BM) {
     constexpr int LA = TA ? LDB_S : LDA_S;  // (transposing writes of the A image want the odd stride too)
-    // Every tile of a launch does the same work, so the workgroups of a round run in lockstep: all on the matrix cores,
-    // then all in the epilogue, where the read-modify-write of C is bound by the memory (128 MB per round of 512
-    // tiles: ~26 us during which the matrix cores idle -- measured: launch time = a + b K with a = the C traffic at
-    // 5 TB/s).  The workgroups of the FIRST round start `stagger_ticks` (of the 100 MHz wall clock) apart in four
-    // phases; the later ones inherit the offsets with the slots they take over.
-    if (stagger_ticks > 0 && blockIdx.x < 512u) {
-        const unsigned ph = ((blockIdx.x >> 3) ^ (blockIdx.x >> 8)) & 3u;
-        if (ph) {
-            const long long until = (long long)wall_clock64() + (long long)ph * stagger_ticks;
-            while ((long long)wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
-        }
-    }
     __shared__ double As[2][BK][LA];
     __shared__ double Bs[2][BK][LDB_S];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -336,14 +324,6 @@ __global__ __launch_bounds__(256) void gemm_small_pair_kernel(GemmProblem p0, Ge
 
 }  // namespace
 
-// ticks (10 ns) between the four start phases of a launch's first round: a quarter of a tile's time
-static int stagger_for(int64_t tiles, int64_t K) {
-    static const int mode = getenv("NODAL_GEMM_STAGGER") ? atoi(getenv("NODAL_GEMM_STAGGER")) : 0;
-    if (mode <= 0 || tiles < 1024) return 0;  // (two rounds at least)
-    const double tile_us = 0.257 * (double)K + 26.0;
-    return (int)(tile_us * 100.0 / 4.0 * (mode / 100.0));  // mode = percent of the quarter period
-}
-
 // C (op)= A * B on `stream`.  All matrices column-major, device pointers.
 int gemm_f64(nodal_ctx *h, hipStream_t stream, int mode, double *C, int64_t ldc, const double *A,
              int64_t lda, const double *B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
@@ -361,8 +341,7 @@ int gemm_f64(nodal_ctx *h, hipStream_t stream, int mode, double *C, int64_t ldc,
     }
     dim3 grid((unsigned)(((M + BM - 1) / BM) * ((N + BN - 1) / BN)));
     if (mode == GEMM_SUB)
-        gemm_sub_kernel<GEMM_SUB><<<grid, NT, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K, BM,
-                                                           stagger_for(grid.x, K));
+        gemm_sub_kernel<GEMM_SUB><<<grid, NT, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
     else if (mode == GEMM_SET)
         gemm_sub_kernel<GEMM_SET><<<grid, NT, 0, stream>>>(C, ldc, A, lda, B, ldb, (int)M, (int)N, (int)K);
     else
@@ -378,9 +357,7 @@ int gemm_sub_tn_upper_f64(nodal_ctx *h, hipStream_t stream, double *C, int64_t l
     if (M <= 0 || N <= 0 || K <= 0) return NODAL_OK;
     if (band < BM || band % BM) return nodal_fail(h, NODAL_E_INVALID, "gemm_sub_tn_upper: band must be a multiple of 128");
     dim3 grid((unsigned)(((M + BM - 1) / BM) * ((N + BN - 1) / BN)));
-    const int64_t tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
-    gemm_sub_kernel<GEMM_SUB, true, true><<<grid, NT, 0, stream>>>(C, ldc, At, ldat, B, ldb, (int)M, (int)N, (int)K, band,
-                                                                   stagger_for(tm * tn - tm * (tm - 1) / 2, K));
+    gemm_sub_kernel<GEMM_SUB, true, true><<<grid, NT, 0, stream>>>(C, ldc, At, ldat, B, ldb, (int)M, (int)N, (int)K, band);
     NODAL_HIP_TRY(h, hipGetLastError());
     return NODAL_OK;
 }
