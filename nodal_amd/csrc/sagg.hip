@@ -57,7 +57,14 @@ constexpr int DOT_BLOCKS = 1024;   // partial sums per dot product of the K-cycl
 #define NODAL_SA_OMEGA 0.85
 #endif
 constexpr double OMEGA = NODAL_SA_OMEGA;      // damped-Jacobi smoother
-constexpr double OMEGA_P = 2.0 / 3.0;         // prolongator smoothing (rho(D^-1 A) <= 2 for an M-matrix)
+// Prolongator smoothing weight (rho(D^-1 A) <= 2 for an M-matrix: anything below 1 damps).  The textbook 4 / (3 rho) = 2/3
+// is for the untruncated P; with P cut to four entries per row and the rest lumped, a little more smoothing pays: on the
+// 1e6-node grid 0.70 / 0.75 / 0.80 take 27 outer iterations, 0.72 and 0.85 take 28, 2/3 took 29 (A/B/A/B on one box: 8.36
+// -> 7.99 ms); grids of other sizes, the batches, config 5, 3-D, wires, contrast and anisotropic grids keep their counts at
+// 0.70, and the block systems keep their five levels (from 0.75 on a 64 x 19 600 batch coarsens to six).
+// NODAL_SA_OMEGA_P=w: another weight (tools/shape_probe.py, tools/topologies.py under it).
+constexpr double OMEGA_P = 0.70;
+constexpr double OMEGA_P_COARSE = 0.70;  // (levels >= 1)
 // Vectors inside the cycle (the preconditioner: residuals, corrections and smoothing iterates of every level outside
 // the tail, the start iterate w D^-1 r and the result z) are kept in f32 like the cycle's copies of A, P and R: the
 // outer iterations are flexible ones and their own vectors (x, r, p, Ap; the Krylov basis of the general path) and
@@ -521,7 +528,7 @@ __global__ __launch_bounds__(TB) void assign_far(Ell A, const int32_t *__restric
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(TB) void build_P(Ell A, const double *__restrict__ dinv,
                                               const int32_t *__restrict__ agg, int32_t *__restrict__ pcol,
-                                              double *__restrict__ pval, float *__restrict__ pvalf) {
+                                              double *__restrict__ pval, float *__restrict__ pvalf, double omega_p) {
     for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
         int32_t c[PW];
         double v[PW];
@@ -530,7 +537,7 @@ __global__ __launch_bounds__(TB) void build_P(Ell A, const double *__restrict__ 
         const int32_t own = agg[i];
         c[0] = own;
         v[0] = 1.0;
-        const double wd = OMEGA_P * dinv[i];
+        const double wd = omega_p * dinv[i];
         const int32_t l = A.len[i];
         for (int32_t s = 0; s < l; ++s) {
             const int32_t J = agg[A.col[(int64_t)s * A.ld + i]];
@@ -1209,6 +1216,22 @@ int galerkin_product(nodal_ctx *h, SHierarchy *H, int l, hipEvent_t r_ready = nu
 
 // one aggregation + transfer operators + Galerkin product: level l -> l + 1.
 // *stop: the level cannot be coarsened (every node is its own aggregate).
+// (NODAL_SA_OMEGA_P="w0" or "w0,w1": the weight of level 0 and of the coarse levels)
+double omega_p(int level) {
+    static double w[2] = {-1.0, -1.0};
+    if (w[0] < 0.0) {
+        double a = OMEGA_P, b = OMEGA_P_COARSE;
+        if (const char *e = getenv("NODAL_SA_OMEGA_P")) {
+            a = atof(e);
+            const char *c = strchr(e, ',');
+            b = c ? atof(c + 1) : a;
+        }
+        w[1] = b > 0.0 && b < 1.2 ? b : OMEGA_P_COARSE;
+        w[0] = a > 0.0 && a < 1.0 ? a : OMEGA_P;
+    }
+    return w[level > 0 ? 1 : 0];
+}
+
 int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool *declined, bool *stop) {
     hipStream_t st = h->stream;
     SLevel *L = H->level(l);
@@ -1266,7 +1289,7 @@ int build_level(nodal_ctx *h, SHierarchy *H, int l, unsigned long long *hs, bool
     assign_near<<<g, TB, 0, st>>>(A, T, flag, id, H->agg1.as<int32_t>());
     assign_far<<<g, TB, 0, st>>>(A, H->agg1.as<int32_t>(), L->agg.as<int32_t>(), dstats + (size_t)l * ST_COUNT);
     build_P<<<g, TB, 0, st>>>(A, L->dinv.as<double>(), L->agg.as<int32_t>(), L->pcol.as<int32_t>(),
-                             L->pval.as<double>(), L->pvalf.as<float>());
+                             L->pval.as<double>(), L->pvalf.as<float>(), omega_p(l));
     NODAL_HIP_TRY(h, hipGetLastError());
     NODAL_WAIT_EVENT(h, H->ev_copy, st);  // (the copies, not the three kernels behind them)
     if (trace_mis) {
@@ -1524,7 +1547,7 @@ int sagg_refresh(nodal_ctx *h, SHierarchy *H, const int32_t *indptr0, const int3
         Ell A = L->A();
         A.width = L->maxlen;
         build_P<<<grid_for(L->n), TB, 0, st>>>(A, L->dinv.as<double>(), L->agg.as<int32_t>(), L->pcol.as<int32_t>(),
-                                              L->pval.as<double>(), L->pvalf.as<float>());
+                                              L->pval.as<double>(), L->pvalf.as<float>(), omega_p(l));
         // (R's values on the hierarchy's other stream while this one computes A P: see build_level)
         const bool forked = H->aux != nullptr && nodal_extra_streams_ok(h) &&
                             !(getenv("NODAL_SA_FORK") && atoi(getenv("NODAL_SA_FORK")) == 0);

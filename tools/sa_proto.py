@@ -13,7 +13,7 @@ import numpy as np
 import scipy.sparse as sp
 
 OMEGA = 0.85
-OMEGA_P = 2.0 / 3.0
+OMEGA_P = 0.70  # (csrc/sagg.hip; 2/3 until the end of round 5)
 PW = 4
 MIS_ROUNDS = 6
 TAIL_MAX_N = 1024
