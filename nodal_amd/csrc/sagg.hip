@@ -64,7 +64,12 @@ constexpr double OMEGA = NODAL_SA_OMEGA;      // damped-Jacobi smoother
 // 0.70, and the block systems keep their five levels (from 0.75 on a 64 x 19 600 batch coarsens to six).
 // NODAL_SA_OMEGA_P=w: another weight (tools/shape_probe.py, tools/topologies.py under it).
 constexpr double OMEGA_P = 0.70;
-constexpr double OMEGA_P_COARSE = 0.70;  // (levels >= 1)
+// Levels >= 1: the Galerkin operators of a smoothed hierarchy have rho(D^-1 A) ~ 1.4-1.6, not 2 (power iterations on
+// the CPU prototype: 1.93 / 1.41 / 1.49 / 1.59 for the levels of the 1e6-node grid), so the textbook 4 / (3 rho) is
+// 0.83-0.95 there, and the weight of level 0 was too timid for them: 0.80 / 0.90 / 1.00 on the coarse levels all take the
+// 1e6-node grid from 27 to 26 outer iterations (grid(562) and grid(1200) 27 -> 26, the random-valued grid 30 -> 29),
+// nothing else moves (batches, config 5, 3-D, wires, contrast, anisotropy: same counts, same levels).
+constexpr double OMEGA_P_COARSE = 0.85;
 // Vectors inside the cycle (the preconditioner: residuals, corrections and smoothing iterates of every level outside
 // the tail, the start iterate w D^-1 r and the result z) are kept in f32 like the cycle's copies of A, P and R: the
 // outer iterations are flexible ones and their own vectors (x, r, p, Ap; the Krylov basis of the general path) and
