@@ -13,7 +13,8 @@ import numpy as np
 import scipy.sparse as sp
 
 OMEGA = 0.85
-OMEGA_P = 0.70  # (csrc/sagg.hip; 2/3 until the end of round 5)
+OMEGA_P = 0.70  # level 0 (csrc/sagg.hip; 2/3 until the end of round 5); the device uses 0.85 on the coarse levels:
+# pass omega_p per level to build_P to mirror that (see tools/experiments/README.md)
 PW = 4
 MIS_ROUNDS = 6
 TAIL_MAX_N = 1024
