@@ -164,6 +164,13 @@ struct SHierarchy {
     int tail = -1;          // first level inside the tail kernel
     bool ready = false;
     bool kcycle = true;          // two inner FCG steps at the first coarse level
+    // The coefficients of those two steps hardly move from one outer iteration to the next (the coarse correction of an
+    // aggregation hierarchy is too small by the same factor every time): the flexible-CG driver calibrates them in its
+    // first iterations and every fourth one after, and the cycles in between use the mean of the last three samples --
+    // three launches fewer (sagg_fcg_solve).  kfrozen: this cycle uses the frozen ones; kslot / kcount: where an adaptive
+    // cycle's sample goes (-1: nowhere -- every caller but that driver).
+    bool kfrozen = false;
+    int kslot = -1, kcount = 0;
     int klevels = 1;             // ... at the first `klevels` coarse levels (NODAL_SA_KLEVELS)
     int nu[3] = {1, 1, 2};       // Jacobi sweeps before and after the coarse correction: level 0 / 1 / deeper.
                                  // Two on the small levels outside the tail cost eight 4-us launches per iteration and
@@ -1789,7 +1796,7 @@ static int sagg_setup_csr_body(nodal_ctx *h, int64_t n0, int64_t nnz0, const int
     for (int k = 0; k < H->nlev; ++k) {
         SLevel *L = H->pool[k];
         NODAL_HIP_TRY(h, L->vec.reserve((size_t)V_COUNT * L->ld * 8 + 256));
-        NODAL_HIP_TRY(h, L->part.reserve(5 * DOT_BLOCKS * 8 + 256));
+        NODAL_HIP_TRY(h, L->part.reserve(5 * DOT_BLOCKS * 8 + 512));  // (+ s1, s2, the frozen triple, a ring of samples)
     }
     NODAL_TRY(build_tail(h, H, hs));
 
@@ -1913,21 +1920,34 @@ int cycle(nodal_ctx *h, SHierarchy *H, int l, const TBV *b, const cyc_t *x0, TOU
             const unsigned gd = grid_for(nc, DOT_BLOCKS);  // (grid-stride beyond DOT_BLOCKS x TB rows)
             const unsigned tbc = C->wfix ? TB : TB * LPR_RAGGED;
             nparts = (int)gd;
-            NODAL_TRY((cycle<cyc_t, cyc_t>(h, H, l + 1, rc, x0c, c1, nullptr)));
-            SAGG_DISPATCH_W(C->wfix, (k_spmv_dots<W><<<gd, tbc, 0, st>>>(Ac, c1, v1, rc, nullptr, part + 0 * DOT_BLOCKS,
-                                                                        part + 1 * DOT_BLOCKS, nullptr)));
-            k_second_residual<<<grid_for(nc), TB, 0, st>>>(nc, rc, v1, part, nparts, r2, C->dinv.as<double>(), x0c);
-            NODAL_HIP_TRY(h, hipGetLastError());
-            NODAL_TRY((cycle<cyc_t, cyc_t>(h, H, l + 1, r2, x0c, c2, nullptr)));
-            SAGG_DISPATCH_W(C->wfix, (k_spmv_dots<W><<<gd, tbc, 0, st>>>(Ac, c2, v2, v1, r2, part + 3 * DOT_BLOCKS,
-                                                                        part + 2 * DOT_BLOCKS, part + 4 * DOT_BLOCKS)));
-            NODAL_HIP_TRY(h, hipGetLastError());
+            double *cf = part + 5 * DOT_BLOCKS;  // s1, s2 | frozen s1, s2, t | ring of samples (k_kcoef)
+            if (H->kfrozen && l == 0) {
+                // between two calibrations: the coefficients of the last adaptive cycles, no dot products -- the first
+                // SpMV and the second residual in one launch, no second SpMV, no k_kcoef
+                NODAL_TRY((cycle<cyc_t, cyc_t>(h, H, l + 1, rc, x0c, c1, nullptr)));
+                SAGG_DISPATCH_W(C->wfix, (k_spmv_resid<W><<<gd, tbc, 0, st>>>(Ac, c1, rc, cf + 3, r2, C->dinv.as<double>(), x0c)));
+                NODAL_HIP_TRY(h, hipGetLastError());
+                NODAL_TRY((cycle<cyc_t, cyc_t>(h, H, l + 1, r2, x0c, c2, nullptr)));
+                coef = cf + 3;
+                nparts = 0;
+            } else {
+                NODAL_TRY((cycle<cyc_t, cyc_t>(h, H, l + 1, rc, x0c, c1, nullptr)));
+                SAGG_DISPATCH_W(C->wfix, (k_spmv_dots<W><<<gd, tbc, 0, st>>>(Ac, c1, v1, rc, nullptr, part + 0 * DOT_BLOCKS,
+                                                                            part + 1 * DOT_BLOCKS, nullptr)));
+                k_second_residual<<<grid_for(nc), TB, 0, st>>>(nc, rc, v1, part, nparts, r2, C->dinv.as<double>(), x0c);
+                NODAL_HIP_TRY(h, hipGetLastError());
+                NODAL_TRY((cycle<cyc_t, cyc_t>(h, H, l + 1, r2, x0c, c2, nullptr)));
+                SAGG_DISPATCH_W(C->wfix, (k_spmv_dots<W><<<gd, tbc, 0, st>>>(Ac, c2, v2, v1, r2, part + 3 * DOT_BLOCKS,
+                                                                            part + 2 * DOT_BLOCKS, part + 4 * DOT_BLOCKS)));
+                NODAL_HIP_TRY(h, hipGetLastError());
+            }
         } else {
             NODAL_TRY((cycle<cyc_t, cyc_t>(h, H, l + 1, rc, x0c, c1, nullptr)));
         }
         if (nparts) {  // s1, s2 once, instead of five reductions in every workgroup of the prolongation
             double *cf = C->part.as<double>() + 5 * DOT_BLOCKS;
-            k_kcoef<<<1, 320, 0, st>>>(C->part.as<double>(), nparts, cf);
+            const bool sample = l == 0 && H->kslot >= 0;
+            k_kcoef<<<1, 320, 0, st>>>(C->part.as<double>(), nparts, cf, sample ? H->kslot : -1, sample ? H->kcount : 0);
             coef = cf;
         }
         k_prolong<cyc_t><<<grid_for(n), TB, 0, st>>>(n, L->ld, L->pcol.as<int32_t>(), L->pvalf.as<float>(), x, c1, c2, coef,
@@ -2088,7 +2108,29 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     static const bool fuse_dir_env = !(getenv("NODAL_SA_FUSE_DIR") && atoi(getenv("NODAL_SA_FUSE_DIR")) == 0);
     const bool fuse_dir = fuse_dir_env && LPR_RAGGED == 1;
     // one outer iteration (the kernels take its parity only: see f_direction)
+    // K-cycle coefficients (SHierarchy::kfrozen): adaptive in the first four iterations and in every fourth one after,
+    // frozen (the mean of the last three samples; the first two iterations' are not taken: they run high) in between.
+    // The schedule depends on the iteration number alone: the same launches every time.  NODAL_SA_KFREEZE=0: adaptive
+    // throughout (also under a replayed graph, whose launches are fixed).
+    static const bool kfreeze_env = !(getenv("NODAL_SA_KFREEZE") && atoi(getenv("NODAL_SA_KFREEZE")) == 0);
+    static const bool graphs_env = getenv("NODAL_SA_GRAPH") && atoi(getenv("NODAL_SA_GRAPH")) != 0;
+    const bool kfreeze = kfreeze_env && !graphs_env;
+    int ksamples = 0;
     auto iteration = [&](int it, bool timed) -> int {
+        if (kfreeze) {
+            const bool adaptive = it < 4 || (it & 3) == 0;
+            H->kfrozen = !adaptive && ksamples > 0;
+            H->kslot = -1;
+            if (!H->kfrozen && it >= 2) {
+                H->kslot = ksamples % 3;
+                ++ksamples;
+                H->kcount = ksamples < 3 ? ksamples : 3;
+            }
+        }
+        struct KReset {  // (whatever way this iteration is left: the hierarchy's other users run adaptive cycles)
+            SHierarchy *H;
+            ~KReset() { H->kfrozen = false; H->kslot = -1; }
+        } kreset{H};
         NODAL_TRY((cycle<double, cyc_t>(h, H, 0, sb.r, sb.x0, sb.z, &sb)));
         if (fuse_dir) {  // direction and SpMV in one launch; the direction buffers swap with the parity
             double *p_new = (it & 1) ? sb.p2 : sb.p;

@@ -247,7 +247,11 @@ __device__ __forceinline__ KCoef kcycle_coefficients(const double *__restrict__ 
 }
 
 // s1, s2 of the K-cycle, once per cycle: one workgroup of five wavefronts, one per dot product
-__global__ __launch_bounds__(320) void k_kcoef(const double *__restrict__ part, int nparts, double *__restrict__ coef) {
+// coef[0..1] = s1, s2 of this cycle.  slot >= 0: the sample (s1, s2, t = alpha1 / rho1) also goes to slot `slot` of a ring
+// of three behind them, and coef[3..5] = the mean of the ring's first `count` slots -- the FROZEN coefficients the
+// cycles between two calibrations use (sagg.hip, cycle(): k_spmv_resid + k_prolong with coef + 3).
+__global__ __launch_bounds__(320) void k_kcoef(const double *__restrict__ part, int nparts, double *__restrict__ coef,
+                                               int slot, int count) {
     __shared__ double d[5];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double s = 0.0;
@@ -269,6 +273,41 @@ __global__ __launch_bounds__(320) void k_kcoef(const double *__restrict__ part, 
         }
         coef[0] = s1;
         coef[1] = s2;
+        if (slot >= 0) {
+            double *ring = coef + 6;
+            ring[3 * slot + 0] = s1;
+            ring[3 * slot + 1] = s2;
+            ring[3 * slot + 2] = rho1 > 0.0 ? alpha1 / rho1 : 0.0;
+            double m0 = 0.0, m1 = 0.0, m2 = 0.0;
+            for (int q = 0; q < count; ++q) {  // (slot `slot` is among them: count = min(samples so far, 3))
+                m0 += ring[3 * q + 0];
+                m1 += ring[3 * q + 1];
+                m2 += ring[3 * q + 2];
+            }
+            coef[3] = m0 / count;
+            coef[4] = m1 / count;
+            coef[5] = m2 / count;
+        }
+    }
+}
+
+// r2 = rc - t A c1 with a FROZEN t (frz[2]) and the start iterate of the second visit: the first k_spmv_dots and
+// k_second_residual of an adaptive cycle in one launch, no dot products
+template <int W>
+__global__ __launch_bounds__(TB * RowLanes<W>::value) void k_spmv_resid(Ell A, const cyc_t *__restrict__ c,
+                                                   const cyc_t *__restrict__ rc, const double *__restrict__ frz,
+                                                   cyc_t *__restrict__ r2, const double *__restrict__ dinv,
+                                                   cyc_t *__restrict__ x0) {
+    constexpr int LPR = RowLanes<W>::value, NT = TB * LPR;
+    const int sub = threadIdx.x & (LPR - 1);
+    const double t = frz[2];
+    for (int64_t tt = (int64_t)xcd_block() * NT + threadIdx.x; tt / LPR < A.n; tt += (int64_t)gridDim.x * NT) {
+        const int64_t i = tt / LPR;
+        const double sd = ell_row_w<W>(A, A.valf, i, sub, [&](int32_t j) { return (double)c[j]; });
+        if (sub != 0) continue;
+        const double v = fma(-t, (double)(cyc_t)sd, (double)rc[i]);  // (A c1 rounded like the stored v1 of the adaptive cycle)
+        r2[i] = (cyc_t)v;
+        x0[i] = (cyc_t)(OMEGA * dinv[i] * v);
     }
 }
 
