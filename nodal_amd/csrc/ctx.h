@@ -411,7 +411,7 @@ int sagg_setup_csr(nodal_ctx *h, int64_t n, int64_t nnz, const int32_t *indptr, 
 typedef float nodal_cyc_t;  // vectors inside the multigrid cycle (csrc/sagg.hip: cyc_t)
 // x0_ready: the caller's last kernel already left the cycle's start iterate w D^-1 r (sagg_x0_slot) -- the launch that
 // computes it is skipped
-int sagg_apply(nodal_ctx *h, const double *r, double *z, bool x0_ready = false);
+int sagg_apply(nodal_ctx *h, const double *r, double *z, bool x0_ready = false, int it = -1);
 // where a producer of r can leave the start iterate of the next sagg_apply: x0[i] = (nodal_cyc_t)(omega * dinv[i] * r[i]),
 // i < n0.  false: no hierarchy.
 bool sagg_x0_slot(nodal_ctx *h, const double **dinv, nodal_cyc_t **x0, int64_t *n0, double *omega);

@@ -170,7 +170,7 @@ struct SHierarchy {
     // three launches fewer (sagg_fcg_solve).  kfrozen: this cycle uses the frozen ones; kslot / kcount: where an adaptive
     // cycle's sample goes (-1: nowhere -- every caller but that driver).
     bool kfrozen = false;
-    int kslot = -1, kcount = 0;
+    int kslot = -1, kcount = 0, ksamples = 0;
     int klevels = 1;             // ... at the first `klevels` coarse levels (NODAL_SA_KLEVELS)
     int nu[3] = {1, 1, 2};       // Jacobi sweeps before and after the coarse correction: level 0 / 1 / deeper.
                                  // Two on the small levels outside the tail cost eight 4-us launches per iteration and
@@ -1871,6 +1871,26 @@ int last_level(nodal_ctx *h, SHierarchy *H, int l, const double *b, double *out)
     return NODAL_OK;
 }
 
+// K-cycle coefficients of outer iteration `it` of a flexible Krylov method (it == 0 starts a solve): adaptive in the
+// first four iterations and in every fourth one after, frozen -- the mean of the last three samples; the first two
+// iterations' are not taken: they run high -- in between.  The schedule depends on `it` alone: the same launches every
+// time.  it < 0: an adaptive cycle that leaves no sample (every other caller).
+void kcycle_schedule(SHierarchy *H, int it) {
+    static const bool on = !(getenv("NODAL_SA_KFREEZE") && atoi(getenv("NODAL_SA_KFREEZE")) == 0);
+    H->kfrozen = false;
+    H->kslot = -1;
+    if (!on || it < 0) return;
+    if (it == 0) H->ksamples = 0;
+    const bool adaptive = it < 4 || (it & 3) == 0;
+    if (!adaptive && H->ksamples > 0) {
+        H->kfrozen = true;
+    } else if (it >= 2) {
+        H->kslot = H->ksamples % 3;
+        ++H->ksamples;
+        H->kcount = H->ksamples < 3 ? H->ksamples : 3;
+    }
+}
+
 // One cycle of level l (never a last level: the hierarchy has two levels at least and the tail starts at level 1
 // or below).  TBV: type of the right-hand side (f64 from the outer iteration at level 0, cyc_t inside); TOUT: of the
 // result (cyc_t; f64 when the general path's FGMRES takes it as a Krylov vector).
@@ -2003,14 +2023,20 @@ bool sagg_x0_slot(nodal_ctx *h, const double **dinv, nodal_cyc_t **x0, int64_t *
     *omega = OMEGA;
     return true;
 }
-int sagg_apply(nodal_ctx *h, const double *r, double *z, bool x0_ready) {
+// it >= 0: the cycle is the preconditioner of iteration `it` of a FLEXIBLE method (FGMRES: sparse_general.hip), which
+// may calibrate and freeze the K-cycle's coefficients like sagg_fcg_solve does (kcycle_schedule)
+int sagg_apply(nodal_ctx *h, const double *r, double *z, bool x0_ready, int it) {
     SHierarchy *H = static_cast<SHierarchy *>(h->sagg);
     if (!H || !H->ready) return nodal_fail(h, NODAL_E_INVALID, "sagg_setup_csr not called");
     SLevel *L0 = H->pool[0];
     cyc_t *x0 = L0->v<cyc_t>(V_X);
     if (!x0_ready) k_x0<<<grid_for(L0->n), TB, 0, h->stream>>>(L0->n, L0->dinv.as<double>(), r, x0);
     NODAL_HIP_TRY(h, hipGetLastError());
-    return cycle<double, double>(h, H, 0, r, x0, z, nullptr);
+    kcycle_schedule(H, it);
+    const int rc = cycle<double, double>(h, H, 0, r, x0, z, nullptr);
+    H->kfrozen = false;
+    H->kslot = -1;
+    return rc;
 }
 
 // y = A x with the level-0 ELL copy of the matrix the hierarchy was built on
@@ -2108,25 +2134,10 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     static const bool fuse_dir_env = !(getenv("NODAL_SA_FUSE_DIR") && atoi(getenv("NODAL_SA_FUSE_DIR")) == 0);
     const bool fuse_dir = fuse_dir_env && LPR_RAGGED == 1;
     // one outer iteration (the kernels take its parity only: see f_direction)
-    // K-cycle coefficients (SHierarchy::kfrozen): adaptive in the first four iterations and in every fourth one after,
-    // frozen (the mean of the last three samples; the first two iterations' are not taken: they run high) in between.
-    // The schedule depends on the iteration number alone: the same launches every time.  NODAL_SA_KFREEZE=0: adaptive
-    // throughout (also under a replayed graph, whose launches are fixed).
-    static const bool kfreeze_env = !(getenv("NODAL_SA_KFREEZE") && atoi(getenv("NODAL_SA_KFREEZE")) == 0);
+    // K-cycle coefficients calibrated, then frozen (kcycle_schedule; not under a replayed graph, whose launches are fixed)
     static const bool graphs_env = getenv("NODAL_SA_GRAPH") && atoi(getenv("NODAL_SA_GRAPH")) != 0;
-    const bool kfreeze = kfreeze_env && !graphs_env;
-    int ksamples = 0;
     auto iteration = [&](int it, bool timed) -> int {
-        if (kfreeze) {
-            const bool adaptive = it < 4 || (it & 3) == 0;
-            H->kfrozen = !adaptive && ksamples > 0;
-            H->kslot = -1;
-            if (!H->kfrozen && it >= 2) {
-                H->kslot = ksamples % 3;
-                ++ksamples;
-                H->kcount = ksamples < 3 ? ksamples : 3;
-            }
-        }
+        kcycle_schedule(H, graphs_env ? -1 : it);
         struct KReset {  // (whatever way this iteration is left: the hierarchy's other users run adaptive cycles)
             SHierarchy *H;
             ~KReset() { H->kfrozen = false; H->kslot = -1; }

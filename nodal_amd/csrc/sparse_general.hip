@@ -656,7 +656,7 @@ int general_impl(nodal_ctx *h, const double *b, double *x, int32_t *info, int32_
                 // z_j = M^-1 v_j
                 if (j == 0) nodal_nan_probe(h, vj, n, "fgmres v0");
                 if (direct) NODAL_TRY(slu_apply(h, vj, zj));
-                else if (use_sa) NODAL_TRY(sagg_apply(h, vj, zj, j > 0 && x0_slot != nullptr));
+                else if (use_sa) NODAL_TRY(sagg_apply(h, vj, zj, j > 0 && x0_slot != nullptr, cyc == 0 ? j : -1));
                 else NODAL_TRY(amg_apply(h, vj, zj));
                 if (j == 0) nodal_nan_probe(h, zj, K, "fgmres z0 (node block)");
                 if (n > K) {
