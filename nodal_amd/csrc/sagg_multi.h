@@ -231,7 +231,11 @@ __global__ __launch_bounds__(TB) void m_second_residual(int64_t n, const cyc_t *
 }
 
 // K-cycle coefficients per column from the totals: first [rho1, alpha1, -] then second [beta, gamma, alpha2]
-__global__ void m_kcoef(const double *__restrict__ tot1, const double *__restrict__ tot2, double *__restrict__ coef) {
+// slot >= 0: the column's sample (s1, s2, t) also goes to slot `slot` of a ring of three, and the mean of the ring's
+// first `count` slots to the FROZEN coefficients (fs: [MK][2], ft: [MK]) the cycles between two calibrations use
+// (sagg.hip: kcycle_schedule; m_spmv_resid below)
+__global__ void m_kcoef(const double *__restrict__ tot1, const double *__restrict__ tot2, double *__restrict__ coef,
+                        int slot, int count) {
     const int y = threadIdx.x;
     if (y >= MK) return;
     const double rho1 = tot1[y], alpha1 = tot1[MK + y];
@@ -248,6 +252,41 @@ __global__ void m_kcoef(const double *__restrict__ tot1, const double *__restric
     }
     coef[y * 2] = s1;
     coef[y * 2 + 1] = s2;
+    if (slot >= 0) {
+        double *fs = coef + 2 * MK, *ft = fs + 2 * MK, *ring = ft + MK;  // (behind the coefficients: MLevel::tot)
+        double *mine = ring + ((int64_t)slot * MK + y) * 3;
+        mine[0] = s1;
+        mine[1] = s2;
+        mine[2] = rho1 > 0.0 ? alpha1 / rho1 : 0.0;
+        double m0 = 0.0, m1 = 0.0, m2 = 0.0;
+        for (int q = 0; q < count; ++q) {
+            const double *e = ring + ((int64_t)q * MK + y) * 3;
+            m0 += e[0];
+            m1 += e[1];
+            m2 += e[2];
+        }
+        fs[y * 2] = m0 / count;
+        fs[y * 2 + 1] = m1 / count;
+        ft[y] = m2 / count;
+    }
+}
+
+// r2 = rc - t A c1 with the column's FROZEN t and the start iterate of the second visit: m_spmv_dots, m_reduce_kernel
+// and m_second_residual of an adaptive cycle in one launch, no dot products
+template <int W>
+__global__ __launch_bounds__(TB) void m_spmv_resid(Ell A, const cyc_t *__restrict__ c, const cyc_t *__restrict__ rc,
+                                                   const double *__restrict__ ft, cyc_t *__restrict__ r2,
+                                                   const double *__restrict__ dinv, cyc_t *__restrict__ x0, bool f32) {
+    const int64_t total = A.n * MK;
+    for (int64_t t = (int64_t)xcd_block() * TB + threadIdx.x; t < total; t += (int64_t)gridDim.x * TB) {
+        const int64_t i = t >> MK_SHIFT;
+        const int y = (int)(t & (MK - 1));
+        const double sd = f32 ? ell_row_w<W>(A, A.valf, i, 0, [&](int32_t j) { return (double)c[(int64_t)j * MK + y]; })
+                              : ell_row_w<W>(A, A.val, i, 0, [&](int32_t j) { return (double)c[(int64_t)j * MK + y]; });
+        const double v = fma(-ft[y], (double)(cyc_t)sd, (double)rc[t]);
+        r2[t] = (cyc_t)v;
+        x0[t] = (cyc_t)(OMEGA * dinv[i] * v);
+    }
 }
 
 __global__ __launch_bounds__(TB) void m_coarsest(int64_t n, const double *__restrict__ inv,
@@ -516,19 +555,31 @@ int m_cycle(nodal_ctx *h, SHierarchy *H, const MBufs &M, int l, const TBV *b, co
             const unsigned gd = mgrid(nc, MDOT);
             double *part1 = MC.part, *part2 = MC.part + (int64_t)3 * MDOT * MK;
             double *tot1 = MC.tot, *tot2 = MC.tot + 3 * MK, *cf = MC.tot + 6 * MK;
-            NODAL_TRY(m_cycle<cyc_t>(h, H, M, l + 1, rc, x0c, c1, false));
-            // [0] c1.v1 (rho1), [1] c1.rc (alpha1)
-            SAGG_DISPATCH_W(C->wfix, (m_spmv_dots<W><<<gd, TB, 0, st>>>(Ac, c1, v1, rc, nullptr, part1, MDOT, cf32)));
-            m_reduce_kernel<<<2, MR, 0, st>>>(part1, MDOT, (int)gd, tot1);
-            m_second_residual<<<mgrid(nc), TB, 0, st>>>(nc, rc, v1, tot1, r2, C->dinv.as<double>(), x0c);
-            NODAL_HIP_TRY(h, hipGetLastError());
-            NODAL_TRY(m_cycle<cyc_t>(h, H, M, l + 1, r2, x0c, c2, false));
-            // [0] c2.v2 (beta), [1] c2.v1 (gamma), [2] c2.r2 (alpha2)
-            SAGG_DISPATCH_W(C->wfix, (m_spmv_dots<W><<<gd, TB, 0, st>>>(Ac, c2, v2, v1, r2, part2, MDOT, cf32)));
-            m_reduce_kernel<<<3, MR, 0, st>>>(part2, MDOT, (int)gd, tot2);
-            m_kcoef<<<1, 64, 0, st>>>(tot1, tot2, cf);
-            NODAL_HIP_TRY(h, hipGetLastError());
-            coef = cf;
+            double *fs = cf + 2 * MK, *ft = fs + 2 * MK;  // the frozen coefficients (m_kcoef)
+            if (H->kfrozen && l == 0) {
+                // between two calibrations (sagg.hip, kcycle_schedule): six launches fewer
+                NODAL_TRY(m_cycle<cyc_t>(h, H, M, l + 1, rc, x0c, c1, false));
+                SAGG_DISPATCH_W(C->wfix, (m_spmv_resid<W><<<mgrid(nc), TB, 0, st>>>(Ac, c1, rc, ft, r2, C->dinv.as<double>(), x0c,
+                                                                                   cf32)));
+                NODAL_HIP_TRY(h, hipGetLastError());
+                NODAL_TRY(m_cycle<cyc_t>(h, H, M, l + 1, r2, x0c, c2, false));
+                coef = fs;
+            } else {
+                const bool sample = l == 0 && H->kslot >= 0;
+                NODAL_TRY(m_cycle<cyc_t>(h, H, M, l + 1, rc, x0c, c1, false));
+                // [0] c1.v1 (rho1), [1] c1.rc (alpha1)
+                SAGG_DISPATCH_W(C->wfix, (m_spmv_dots<W><<<gd, TB, 0, st>>>(Ac, c1, v1, rc, nullptr, part1, MDOT, cf32)));
+                m_reduce_kernel<<<2, MR, 0, st>>>(part1, MDOT, (int)gd, tot1);
+                m_second_residual<<<mgrid(nc), TB, 0, st>>>(nc, rc, v1, tot1, r2, C->dinv.as<double>(), x0c);
+                NODAL_HIP_TRY(h, hipGetLastError());
+                NODAL_TRY(m_cycle<cyc_t>(h, H, M, l + 1, r2, x0c, c2, false));
+                // [0] c2.v2 (beta), [1] c2.v1 (gamma), [2] c2.r2 (alpha2)
+                SAGG_DISPATCH_W(C->wfix, (m_spmv_dots<W><<<gd, TB, 0, st>>>(Ac, c2, v2, v1, r2, part2, MDOT, cf32)));
+                m_reduce_kernel<<<3, MR, 0, st>>>(part2, MDOT, (int)gd, tot2);
+                m_kcoef<<<1, 64, 0, st>>>(tot1, tot2, cf, sample ? H->kslot : -1, sample ? H->kcount : 0);
+                NODAL_HIP_TRY(h, hipGetLastError());
+                coef = cf;
+            }
         } else {
             NODAL_TRY(m_cycle<cyc_t>(h, H, M, l + 1, rc, x0c, c1, false));
         }
@@ -573,7 +624,7 @@ int sagg_fcg_solve_pairs_block(nodal_ctx *h, int32_t count, const int32_t *ia_ho
     for (int l = 0; l <= last_outside && l < H->nlev; ++l) {
         o_vec[l] = take((size_t)V_COUNT * H->pool[l]->ld * MK * 8);
         o_part[l] = take((size_t)6 * MDOT * MK * 8);
-        o_tot[l] = take((size_t)8 * MK * 8);
+        o_tot[l] = take((size_t)(8 + 3 + 9) * MK * 8);  // totals, coefficients | frozen (s1, s2), frozen t | ring of samples
     }
     const size_t o_outer = take((size_t)6 * n * MK * 8 + 6 * 256);
     const size_t o_opart = take((size_t)5 * MPARTS * MK * 8);
@@ -621,7 +672,11 @@ int sagg_fcg_solve_pairs_block(nodal_ctx *h, int32_t count, const int32_t *ia_ho
     NODAL_HIP_TRY(h, hipGetLastError());
 
     auto iteration = [&](int it) -> int {
-        NODAL_TRY(m_cycle<double>(h, H, M, 0, M.r, M.x0, M.z, true));  // leaves z.r, z.Ap partials in part[0..1]
+        kcycle_schedule(H, it);  // (the K-cycle's coefficients, per column: calibrated, then frozen -- sagg.hip)
+        const int mrc = m_cycle<double>(h, H, M, 0, M.r, M.x0, M.z, true);  // leaves z.r, z.Ap partials in part[0..1]
+        H->kfrozen = false;
+        H->kslot = -1;
+        NODAL_TRY(mrc);
         m_reduce_kernel<<<4, MR, 0, st>>>(M.part, MPARTS, M.g0, M.tot);  // [0] z.r [1] z.Ap [2] r.r [3] x.r
         m_direction<<<M.g0, TB, 0, st>>>(M.z, M.p, M.tot, M.sc, it & 1, n, functional);
         SAGG_DISPATCH_W(L0->wfix, (m_spmv<W><<<M.g0, TB, 0, st>>>(A0, M.p, M.Ap, part_pap, MPARTS, M.sc, it & 1)));
