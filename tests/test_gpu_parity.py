@@ -1519,6 +1519,39 @@ def test_schedule_variants_give_identical_bits():
     assert len(set(digests.values())) == 1, digests
 
 
+def test_frozen_kcycle_coefficients_keep_the_iteration_count():
+    """csrc/sagg.hip kcycle_schedule: the flexible Krylov drivers calibrate the K-cycle's three coefficients in their first
+    iterations and every fourth one, and use the mean of the last three samples in between (three launches fewer).  Against
+    the adaptive cycle in every iteration (NODAL_SA_KFREEZE=0; the switch is read once per process: a child each): the same
+    outer iteration count within one, info 0, and solutions that agree far inside the parity bar -- on a grid through the
+    flexible CG and on config 5's pattern through the presolved FGMRES (reference call replaced: nodal/nodal.py:325)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from nodal_amd import _ffi, generators as gen\n"
+        "for table in (gen.grid_table(400), gen.cfg5_table(300)):\n"
+        "    h = _ffi.Handle(0); h.upload(table); info = h.run(False); x = h.download_x(); it = h.solve_info()[0]\n"
+        "    print('RESULT', info, it, repr(float(np.abs(x).max())), repr(float(x[x.size // 3])), repr(float(x[-1])))\n"
+        "    h.close()\n" % root)
+    out = {}
+    for name, extra in (("frozen", {}), ("adaptive", {"NODAL_SA_KFREEZE": "0"})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), cwd=root, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stdout[-2000:], r.stderr[-2000:])
+        out[name] = [line.split()[1:] for line in r.stdout.splitlines() if line.startswith("RESULT")]
+        assert len(out[name]) == 2, (name, r.stdout[-2000:])
+    for a, b in zip(out["frozen"], out["adaptive"]):
+        assert a[0] == "0" and b[0] == "0"
+        assert abs(int(a[1]) - int(b[1])) <= 1, (a, b)
+        scale = float(b[2])
+        for u, v in zip(a[2:], b[2:]):
+            assert abs(float(u) - float(v)) <= 1e-10 * scale, (a, b)
+
+
 @pytest.mark.parametrize("kind", ["grid", "cfg5", "hub", "random", "zero resistance", "collision"])
 def test_stream_fold_matches_the_per_entry_fold(kind, monkeypatch):
     """The numeric fold in north_star's shape (csrc/stamp.hip fold_matrix_stream: a workgroup streams a contiguous
