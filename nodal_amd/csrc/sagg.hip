@@ -383,17 +383,32 @@ __global__ __launch_bounds__(TB) void mis_init(int64_t n, uint32_t *__restrict__
         T[i] = (1u << 30) | hash30((uint32_t)i);
 }
 
+// max of v over the neighbours of row i: eight slots at a time, their columns requested together, then the eight
+// gathers (a slot past the row's end re-reads the row's first one: the maximum does not mind) -- two dependent round
+// trips per eight entries instead of per entry; the coarse levels' rows of 10-27 entries made these kernels 6-8 us
+template <int NB>
+__device__ __forceinline__ uint32_t nbr_max_batch(const Ell &A, const uint32_t *__restrict__ v, int64_t i, int32_t l, int32_t s0,
+                                                  uint32_t best) {
+    int32_t c[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) c[u] = A.col[(int64_t)(s0 + u < l ? s0 + u : 0) * A.ld + i];
+    uint32_t t[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) t[u] = v[c[u]];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) best = t[u] > best ? t[u] : best;
+    return best;
+}
+__device__ __forceinline__ uint32_t nbr_max(const Ell &A, const uint32_t *__restrict__ v, int64_t i, int32_t l, uint32_t best) {
+    if (l <= 5) return nbr_max_batch<5>(A, v, i, l, 0, best);  // (level 0 of a grid: bound by the memory, no surplus loads)
+    for (int32_t s0 = 0; s0 < l; s0 += 8) best = nbr_max_batch<8>(A, v, i, l, s0, best);
+    return best;
+}
+
 // m[i] = max of v over the closed neighbourhood of i
 __global__ __launch_bounds__(TB) void mis_max(Ell A, const uint32_t *__restrict__ v, uint32_t *__restrict__ m) {
-    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
-        uint32_t best = v[i];
-        const int32_t l = A.len[i];
-        for (int32_t s = 0; s < l; ++s) {
-            const uint32_t t = v[A.col[(int64_t)s * A.ld + i]];
-            best = t > best ? t : best;
-        }
-        m[i] = best;
-    }
+    for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB)
+        m[i] = nbr_max(A, v, i, A.len[i], v[i]);
 }
 
 // second neighbour-max + state update: an undecided node that is the maximum of its distance-2
@@ -403,12 +418,7 @@ __global__ __launch_bounds__(TB) void mis_update(Ell A, uint32_t *__restrict__ T
     for (int64_t i = (int64_t)xcd_block() * TB + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * TB) {
         const uint32_t own = T[i];
         if ((own >> 30) != 1) continue;
-        uint32_t best = m1[i];
-        const int32_t l = A.len[i];
-        for (int32_t s = 0; s < l; ++s) {
-            const uint32_t t = m1[A.col[(int64_t)s * A.ld + i]];
-            best = t > best ? t : best;
-        }
+        const uint32_t best = nbr_max(A, m1, i, A.len[i], m1[i]);
         if (best == own) T[i] = own | (2u << 30);
         else if ((best >> 30) == 3) T[i] = 0;
     }
@@ -810,36 +820,54 @@ __global__ __launch_bounds__(64) void ap_rows_lds(Ell A, const int32_t *__restri
         int cnt = 0;
         if (i < A.n) {
             const int32_t l = A.len[i];
-            for (int32_t s = 0; s < l; ++s) {
-                const int32_t k = A.col[(int64_t)s * A.ld + i];
-                const double a = A.val[(int64_t)s * A.ld + i];
-                int32_t J[PW];
-                double pp[PW];
+            // Four entries of the row at a time: their columns and values, then the four P rows they name, are
+            // requested together (unconditional loads: a slot past the row's end re-reads the row's first one and is
+            // skipped below) -- two dependent round trips per four entries instead of per entry (a row of 27 entries on
+            // a level of a few hundred rows was 54 dependent round trips: 33-54 us of pure latency per launch); the
+            // products go into the table in the same (A slot, P slot) order: the same sums.
+            constexpr int AB = 4;
+            for (int32_t s0 = 0; s0 < l; s0 += AB) {
+                int32_t kk[AB];
+                double aa[AB];
 #pragma unroll
-                for (int sp = 0; sp < PW; ++sp) {
-                    J[sp] = pcol[(int64_t)sp * A.ld + k];
-                    pp[sp] = pval[(int64_t)sp * A.ld + k];
+                for (int u = 0; u < AB; ++u) {
+                    const int32_t su = s0 + u < l ? s0 + u : 0;
+                    kk[u] = A.col[(int64_t)su * A.ld + i];
+                    aa[u] = A.val[(int64_t)su * A.ld + i];
                 }
+                int32_t J[AB][PW];
+                double pp[AB][PW];
 #pragma unroll
-                for (int sp = 0; sp < PW; ++sp) {
-                    if (J[sp] < 0) continue;
-                    const double t = a * pp[sp];
-                    uint32_t slot = ((uint32_t)J[sp] * 2654435761u) >> 16 & (APW - 1);
-                    bool placed = false;
-                    for (int probe = 0; probe < APW && !placed; ++probe) {
-                        const int32_t c = tc[slot * 64 + lane];
-                        if (c == J[sp]) {
-                            tv[slot * 64 + lane] += t;
-                            placed = true;
-                        } else if (c < 0) {
-                            tc[slot * 64 + lane] = J[sp];
-                            tv[slot * 64 + lane] = t;
-                            ++cnt;
-                            placed = true;
-                        }
-                        slot = (slot + 1) & (APW - 1);
+                for (int u = 0; u < AB; ++u)
+#pragma unroll
+                    for (int sp = 0; sp < PW; ++sp) {
+                        J[u][sp] = pcol[(int64_t)sp * A.ld + kk[u]];
+                        pp[u][sp] = pval[(int64_t)sp * A.ld + kk[u]];
                     }
-                    if (!placed) overflow = true;
+#pragma unroll
+                for (int u = 0; u < AB; ++u) {
+                    if (s0 + u >= l) continue;
+#pragma unroll
+                    for (int sp = 0; sp < PW; ++sp) {
+                        if (J[u][sp] < 0) continue;
+                        const double t = aa[u] * pp[u][sp];
+                        uint32_t slot = ((uint32_t)J[u][sp] * 2654435761u) >> 16 & (APW - 1);
+                        bool placed = false;
+                        for (int probe = 0; probe < APW && !placed; ++probe) {
+                            const int32_t c = tc[slot * 64 + lane];
+                            if (c == J[u][sp]) {
+                                tv[slot * 64 + lane] += t;
+                                placed = true;
+                            } else if (c < 0) {
+                                tc[slot * 64 + lane] = J[u][sp];
+                                tv[slot * 64 + lane] = t;
+                                ++cnt;
+                                placed = true;
+                            }
+                            slot = (slot + 1) & (APW - 1);
+                        }
+                        if (!placed) overflow = true;
+                    }
                 }
             }
             int o = 0;
