@@ -30,6 +30,7 @@
 #include <hip/hip_ext.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "group.h"
 
@@ -513,12 +514,29 @@ __global__ __launch_bounds__(TB) void assign_near(Ell A, const uint32_t *__restr
         else {
             uint32_t best = 0;
             const int32_t l = A.len[i];
-            for (int32_t s = 0; s < l; ++s) {
-                const int32_t j = A.col[(int64_t)s * A.ld + i];
-                if (j == (int32_t)i || !flag[j]) continue;
-                const uint32_t t = T[j] | (3u << 30);
-                if (t > best) { best = t; a = (int32_t)id[j]; }
-            }
+            // (slots in batches, their columns requested together, then what the columns name: see nbr_max; the
+            // candidates are looked at in slot order, as the entry-by-entry loop did)
+            auto batch = [&](auto NBc, int32_t s0) {
+                constexpr int NB = decltype(NBc)::value;
+                int32_t c[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) c[u] = A.col[(int64_t)(s0 + u < l ? s0 + u : 0) * A.ld + i];
+                uint32_t fl[NB], tt[NB], idd[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    fl[u] = flag[c[u]];
+                    tt[u] = T[c[u]];
+                    idd[u] = id[c[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    if (s0 + u >= l || c[u] == (int32_t)i || !fl[u]) continue;
+                    const uint32_t t = tt[u] | (3u << 30);
+                    if (t > best) { best = t; a = (int32_t)idd[u]; }
+                }
+            };
+            if (l <= 5) batch(std::integral_constant<int, 5>{}, 0);
+            else for (int32_t s0 = 0; s0 < l; s0 += 8) batch(std::integral_constant<int, 8>{}, s0);
         }
         agg1[i] = a;
     }
@@ -532,13 +550,27 @@ __global__ __launch_bounds__(TB) void assign_far(Ell A, const int32_t *__restric
         if (a < 0) {
             double bw = -1.0;
             const int32_t l = A.len[i];
-            for (int32_t s = 0; s < l; ++s) {
-                const int32_t j = A.col[(int64_t)s * A.ld + i];
-                const int32_t aj = agg1[j];
-                if (j == (int32_t)i || aj < 0) continue;
-                const double w = fabs(A.val[(int64_t)s * A.ld + i]);
-                if (w > bw) { bw = w; a = aj; }
-            }
+            auto batch = [&](auto NBc, int32_t s0) {  // (as in assign_near)
+                constexpr int NB = decltype(NBc)::value;
+                int32_t c[NB];
+                double w[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int64_t at = (int64_t)(s0 + u < l ? s0 + u : 0) * A.ld + i;
+                    c[u] = A.col[at];
+                    w[u] = fabs(A.val[at]);
+                }
+                int32_t aj[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) aj[u] = agg1[c[u]];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    if (s0 + u >= l || c[u] == (int32_t)i || aj[u] < 0) continue;
+                    if (w[u] > bw) { bw = w[u]; a = aj[u]; }
+                }
+            };
+            if (l <= 5) batch(std::integral_constant<int, 5>{}, 0);
+            else for (int32_t s0 = 0; s0 < l; s0 += 8) batch(std::integral_constant<int, 8>{}, s0);
             if (a < 0) stats[ST_UNASSIGNED] = 1;  // benign race
         }
         agg[i] = a;
