@@ -126,6 +126,7 @@ __device__ __forceinline__ double rcp_f64(double p) {
     ip = fma(fma(-p, ip, 1.0), ip, ip);
     return fma(fma(-p, ip, 1.0), ip, ip);
 }
+#include "gj16_wave.h"
 
 __global__ __launch_bounds__(1024) void gj128_mfma(const double *__restrict__ src, int64_t lds_, int m,
                                                     double *__restrict__ dst, int64_t ldd,
@@ -267,42 +268,10 @@ __global__ __launch_bounds__(1024) void gj128_mfma(const double *__restrict__ sr
 // The column panel is double-buffered (step q+1 publishes it while slower waves still read step q's).
 constexpr int GJ16_LDS = (16 * 128 + 16 * RP_S + 2 * 16 * CP_S + 16 * 17) * 8;
 
-// In-wave inverse of the 16 x 16 block held as a[t] = P[lane & 15][4 t + (lane >> 4)]: block
-// Gauss-Jordan with 2 x 2 pivots (eight steps: the pivot block, its two rows and the lane's two
-// column entries travel by wave shuffles, one reciprocal -- of the 2 x 2 determinant -- per step).
-// With scalar pivots the sixteen dependent shuffle -> reciprocal -> update chains took 3.4 us, more
-// than everything else in an outer step together.
-__device__ __forceinline__ void gj16_in_wave(double (&a)[4], int lane, int32_t *__restrict__ dinfo, int first) {
-    const int r = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int k = 0; k < 16; k += 2) {
-        const int kj = k >> 2, kl = k & 3;  // columns k, k + 1: register kj of lane groups kl, kl + 1 (compile-time)
-        const double p00 = __shfl(a[kj], k + 16 * kl, 64), p01 = __shfl(a[kj], k + 16 * (kl + 1), 64);
-        const double p10 = __shfl(a[kj], k + 1 + 16 * kl, 64), p11 = __shfl(a[kj], k + 1 + 16 * (kl + 1), 64);
-        const double f0 = __shfl(a[kj], r + 16 * kl, 64), f1 = __shfl(a[kj], r + 16 * (kl + 1), 64);
-        double r0[4], r1[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            r0[t] = __shfl(a[t], k + 16 * g, 64);
-            r1[t] = __shfl(a[t], k + 1 + 16 * g, 64);
-        }
-        const double det = fma(p00, p11, -p01 * p10);
-        if (lane == 0 && !(det != 0.0 && det == det) && *dinfo == 0)
-            *dinfo = first + k + ((p00 != 0.0 && p00 == p00) ? 2 : 1);  // (the column a scalar elimination stops at)
-        const double id = rcp_f64(det);
-        const double i00 = p11 * id, i01 = -p01 * id, i10 = -p10 * id, i11 = p00 * id;
-        const double m0 = -fma(f0, i00, f1 * i10), m1 = -fma(f0, i01, f1 * i11);  // -[f0 f1] P2^-1
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const bool c0 = t == kj && g == kl, c1 = t == kj && g == kl + 1;  // my column is k / k + 1
-            const double n0 = fma(i00, r0[t], i01 * r1[t]), n1 = fma(i10, r0[t], i11 * r1[t]);
-            const double rowk = c0 ? i00 : (c1 ? i01 : n0), rowk1 = c0 ? i10 : (c1 ? i11 : n1);
-            const double other = c0 ? m0 : (c1 ? m1 : fma(m0, r0[t], fma(m1, r1[t], a[t])));
-            a[t] = r == k ? rowk : (r == k + 1 ? rowk1 : other);
-        }
-    }
-}
-
+// In-wave inverse of the 16 x 16 pivot block: gj16_wave.h (two forms with the same arithmetic: lane exchanges by
+// ds_bpermute, or -- DPP -- by v_readlane and DPP row broadcasts: 4 instead of 28 trips through the LDS crossbar per
+// 2 x 2 step on the critical path of an outer step; NODAL_GJ_DPP=0 selects the former).
+template <bool DPP>
 __global__ __launch_bounds__(1024) void gj128_mfma16(const double *__restrict__ src, int64_t lds_, int m,
                                                       double *__restrict__ dst, int64_t ldd,
                                                       int32_t *__restrict__ dinfo, int base) {
@@ -324,7 +293,8 @@ __global__ __launch_bounds__(1024) void gj128_mfma16(const double *__restrict__ 
     }
     if (wave == 0) {  // the first pivot block
         double a[4] = {acc0[0], acc0[1], acc0[2], acc0[3]};
-        gj16_in_wave(a, lane, dinfo, base);
+        if (DPP) gj16_in_wave(a, lane, dinfo, base);
+        else gj16_in_wave_bperm(a, lane, dinfo, base);
 #pragma unroll
         for (int j = 0; j < 4; ++j) pinv[lr][4 * j + lc] = a[j];
     }
@@ -402,7 +372,8 @@ __global__ __launch_bounds__(1024) void gj128_mfma16(const double *__restrict__ 
             double a[4];
             if (((q + 1) & 1) == 0) { a[0] = acc0[0]; a[1] = acc0[1]; a[2] = acc0[2]; a[3] = acc0[3]; }
             else { a[0] = acc1[4]; a[1] = acc1[5]; a[2] = acc1[6]; a[3] = acc1[7]; }
-            gj16_in_wave(a, lane, dinfo, base + k0 + 16);
+            if (DPP) gj16_in_wave(a, lane, dinfo, base + k0 + 16);
+            else gj16_in_wave_bperm(a, lane, dinfo, base + k0 + 16);
             // (pinv of this step was last read before the barrier above)
 #pragma unroll
             for (int j = 0; j < 4; ++j) pinv[lr][4 * j + lc] = a[j];
@@ -529,11 +500,15 @@ int invert_diag(nodal_ctx *h, hipStream_t sp, double *D, int64_t lda, int w, dou
             static std::atomic<bool> lds_allowed[64];  // per device: the attribute belongs to the device's code object
             const int dev = h->device >= 0 && h->device < 64 ? h->device : 0;
             if (!lds_allowed[dev].load(std::memory_order_acquire)) {
-                NODAL_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(gj128_mfma16),
+                NODAL_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(gj128_mfma16<true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, GJ16_LDS));
+                NODAL_HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(gj128_mfma16<false>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, GJ16_LDS));
                 lds_allowed[dev].store(true, std::memory_order_release);
             }
-            gj128_mfma16<<<1, 1024, GJ16_LDS, sp>>>(D, lda, w, Q, ldq, dinfo, base);
+            static const bool gj_dpp = !(getenv("NODAL_GJ_DPP") && atoi(getenv("NODAL_GJ_DPP")) == 0);
+            if (gj_dpp) gj128_mfma16<true><<<1, 1024, GJ16_LDS, sp>>>(D, lda, w, Q, ldq, dinfo, base);
+            else gj128_mfma16<false><<<1, 1024, GJ16_LDS, sp>>>(D, lda, w, Q, ldq, dinfo, base);
         }
         NODAL_HIP_TRY(h, hipGetLastError());
         return NODAL_OK;
