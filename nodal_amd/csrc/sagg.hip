@@ -173,12 +173,18 @@ struct SHierarchy {
     bool kfrozen = false;
     int kslot = -1, kcount = 0, ksamples = 0;
     int klevels = 1;             // ... at the first `klevels` coarse levels (NODAL_SA_KLEVELS)
-    int nu[3] = {1, 1, 2};       // Jacobi sweeps before and after the coarse correction: level 0 / 1 / deeper.
+    int nu[3] = {2, 1, 2};       // Jacobi sweeps before and after the coarse correction: level 0 / 1 / deeper.
                                  // Two on the small levels outside the tail cost eight 4-us launches per iteration and
                                  // make the count independent of where the level sizes fall: grid(1600) / grid(2000),
                                  // whose 1050- / 1600-row level just misses the tail, 39 / 40 -> 31 iterations; grid(1000)
-                                 // 30 -> 28 at the same time; the 128-member batch 32 -> 29.  (NODAL_SA_NU=212: 28
-                                 // iterations on the 1e6-node grid too, but 16.9 instead of 14.9 ms.)
+                                 // 30 -> 28 at the same time; the 128-member batch 32 -> 29.
+                                 // Two at LEVEL 0 since round 5's third session (one until then: in round 2 a level-0
+                                 // pass was 18 us and "212" cost 16.9 against 14.9 ms): a pass is 10 us now (f32 cycle
+                                 // vectors, 16-bit columns) and an iteration is mostly its 22 coarse-level launches, so
+                                 // two more level-0 passes (207 -> 227 us per iteration) for 26 -> 21 iterations on the
+                                 // 1e6-node grid pay: config 3 7.40 -> 6.81 ms, the 128-member batch 29 -> 22 iterations,
+                                 // grid(100) .. grid(1600) 8-18 % faster, grid(2000) 2 % slower (NODAL_SA_NU=112: one).
+                                 // Two at level 1 as well ("222") is slower (22 iterations, 7.6 ms).
     bool dense_coarsest = true;  // last level: dense inverse; false: nothing but isolated nodes (diagonal)
     DevBuf tail_stamps, tail_image, apcol, apval, aplen, bstat;
     DevBuf mvec;  // vectors, partials and scalars of the block iteration (sagg_multi.h)
