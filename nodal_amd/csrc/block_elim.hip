@@ -718,10 +718,12 @@ int dense_block_elimination(nodal_ctx *h, double *A, int64_t n, int64_t lda, int
     // Block widths.  While the bulk update of a block is long (many rows left) K = 512 updates run at
     // 43 instead of 38 TFLOP/s (two K = 256 launches read and write C twice); narrow blocks keep
     // the inverse chain short where it is the longer of the two.  NODAL_BI_WIDTH=256 / 512 forces
-    // one width; NODAL_BI_SWITCH the number of rows left at which the width drops to 256.
+    // one width; NODAL_BI_SWITCH the number of rows left at which the width drops to 256 (5632 until round 5's third
+    // session; re-scanned after the chain of a 256-block went from 245 to 198 us: 3584 / 4096 / 4608 / 5120 / 5632 / 6656 /
+    // 7680 rows: 12.91 / 12.89 / 12.83 / 13.00 / 13.02 / 13.18 / 13.66 ms for config 2 on one box; grid(80) .. grid(140) 0.3-2 % faster).
     std::vector<int64_t> bnd;
     {
-        int64_t sw = 5632;
+        int64_t sw = 4608;
         if (const char *e = getenv("NODAL_BI_SWITCH")) sw = atoll(e);
         // below sw2 rows left the chain of small kernels is far longer than the bulk update: 128-wide blocks need
         // ONE Gauss-Jordan inversion each instead of the 2 x 2 Schur formula's two inversions + four products
