@@ -1979,6 +1979,11 @@ int cycle(nodal_ctx *h, SHierarchy *H, int l, const TBV *b, const cyc_t *x0, TOU
         SAGG_DISPATCH_W(L->wfix, (k_post<W, false, TBV, cyc_t><<<g, tb, 0, st>>>(A, dinv, b, x0, x1, nullptr, nullptr, nullptr)));
         x = x1;
     }
+    if (nu >= 3) {  // third (NODAL_SA_NU experiments): into the slot the post-smoothing uses once x is no longer read
+        cyc_t *x2 = L->v<cyc_t>(V_T);
+        SAGG_DISPATCH_W(L->wfix, (k_post<W, false, TBV, cyc_t><<<g, tb, 0, st>>>(A, dinv, b, x, x2, nullptr, nullptr, nullptr)));
+        x = x2;
+    }
     SAGG_DISPATCH_W(L->wfix, (k_smooth_residual<W, TBV><<<g, tb, 0, st>>>(A, b, x, r)));
     const bool last = l + 1 == H->tail || l + 1 == H->nlev - 1;
     const double *coef = nullptr;
@@ -2044,6 +2049,11 @@ int cycle(nodal_ctx *h, SHierarchy *H, int l, const TBV *b, const cyc_t *x0, TOU
         cyc_t *mid = L->v<cyc_t>(V_T);
         SAGG_DISPATCH_W(L->wfix, (k_post<W, false, TBV, cyc_t><<<g, tb, 0, st>>>(A, dinv, b, cur, mid, nullptr, nullptr, nullptr)));
         cur = mid;
+    }
+    if (nu >= 3) {  // second of three
+        cyc_t *mid2 = L->v<cyc_t>(V_X1);
+        SAGG_DISPATCH_W(L->wfix, (k_post<W, false, TBV, cyc_t><<<g, tb, 0, st>>>(A, dinv, b, cur, mid2, nullptr, nullptr, nullptr)));
+        cur = mid2;
     }
     if (sb) {
         SAGG_DISPATCH_W(L->wfix, (k_post<W, true, TBV, TOUT><<<g, tb, 0, st>>>(A, dinv, b, cur, out, sb->Ap, sb->part_rz,
@@ -2149,7 +2159,7 @@ int sagg_fcg_solve(nodal_ctx *h, const double *b, bool do_setup, int32_t *info, 
     H->kcycle = kc != 0;
     H->klevels = getenv("NODAL_SA_KLEVELS") ? atoi(getenv("NODAL_SA_KLEVELS")) : 1;
     if (const char *e = getenv("NODAL_SA_NU")) {  // e.g. "212": sweeps at level 0, level 1, deeper levels
-        for (int k = 0; k < 3 && e[k] >= '1' && e[k] <= '2'; ++k) H->nu[k] = e[k] - '0';
+        for (int k = 0; k < 3 && e[k] >= '1' && e[k] <= '3'; ++k) H->nu[k] = e[k] - '0';
     }
 
     const size_t vec = align_up((size_t)n * 8);
