@@ -314,6 +314,38 @@ def test_multigrid_path_on_small_networks(side):
     h.close()
 
 
+@pytest.mark.parametrize("nu", ["112", "212", "312", "323", "133"])
+def test_multigrid_sweep_counts_change_the_iteration_count_not_the_solution(nu, monkeypatch):
+    """NODAL_SA_NU: Jacobi sweeps per side at level 0 / level 1 / deeper levels (1-3 each; the default is 212).
+    Every choice is a symmetric preconditioner of the same flexible CG: the same solution as SuperLU, and more
+    sweeps at level 0 never cost iterations."""
+    from nodal_amd import generators as gen
+    from oracle import nodal_oracle as oracle
+    table = gen.grid_table(150)
+    G, A = oracle.assemble_fast(table)
+    xo, _ = oracle.solve(G.tocsr(), A, True)
+
+    def solve(env):
+        if env is None:
+            monkeypatch.delenv("NODAL_SA_NU", raising=False)
+        else:
+            monkeypatch.setenv("NODAL_SA_NU", env)
+        h = _ffi.Handle(0)
+        h.upload(table)
+        h.assemble_symbolic()
+        assert h.assemble_numeric()[0] == _ffi.OK
+        x, info, iters, relres = h.solve_sparse(method=_ffi.SPARSE_PCG)
+        assert info == 0 and iters > 0 and h.residual() <= 1e-12
+        h.close()
+        return x, iters
+
+    x, iters = solve(nu)
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    x1, iters1 = solve("112")
+    if nu[0] > "1" and nu[1:] == "12":
+        assert iters < iters1
+
+
 def _chainlike_table(kind):
     from nodal_amd import generators as gen
     return {"ladder": lambda: gen.ladder_table(30000),
